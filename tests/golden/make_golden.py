@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE itself (run in the build
+container only; the reference never travels and is never copied).
+
+Sources of truth:
+  * oracle/_ref/libumpc_ref.so — the reference's own C (template/uprightmpc2/*.c)
+    compiled in place by oracle/Makefile, driven through ctypes (oracle/refbind.py);
+  * the reference's pure-numpy Python (template/genqp.py, template_controllers.py,
+    uprightmpc2.py, flight_tasks.py), imported from /root/reference/template with
+    EMPTY placeholder modules for the three imports that are absent here and are
+    never called on these code paths (`osqp`, `progressbar`, and `uprightmpc2py`
+    whose `UprightMPC2C` is replaced by the ctypes wrapper of the compiled C).
+
+Outputs are DATA only (inputs + expected outputs).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+
+import refbind  # noqa: E402
+
+REF_T = "/root/reference/template"
+
+
+def rand_rot(rng, tilt):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_rotvec(rng.normal(size=3) * tilt).as_matrix()
+
+
+def gen_inputs(rng, n):
+    ins = []
+    for k in range(n):
+        p0 = rng.normal(size=3) * 5.0
+        R0 = rand_rot(rng, 0.4)
+        dq0 = np.hstack((rng.normal(size=3) * 0.05, rng.normal(size=3) * 0.01))
+        pdes = p0 + rng.normal(size=3) * 3.0
+        dpdes = rng.normal(size=3) * 0.02
+        sdes = np.array([0, 0, 1.0]) if k % 3 else rand_rot(rng, 0.3)[:, 2]
+        aT0 = -1.0 if k % 5 else float(rng.uniform(0, 0.02))
+        ins.append((p0, R0, dq0, pdes, dpdes, sdes, aT0))
+    return ins
+
+
+def structure():
+    r = refbind.RefUMPC()
+    d = {k: r.iarr(v) for k, v in dict(
+        perm="linsys_solver_P", A_p="Adata_p", A_i="Adata_i", K_p="linsys_solver_KKT_p",
+        K_i="linsys_solver_KKT_i", PtoKKT="linsys_solver_PtoKKT", AtoKKT="linsys_solver_AtoKKT",
+        rhotoKKT="linsys_solver_rhotoKKT", etree="linsys_solver_etree", Lnz="linsys_solver_Lnz",
+        L_p="linsys_solver_L_p", L_i="linsys_solver_L_i", constr_type0="work_constr_type").items()}
+    d["A_x0"] = r.farr("Adata_x")
+    d["P_x0"] = r.farr("Pdata_x")
+    d["K_x0"] = r.farr("linsys_solver_KKT_x")
+    d["l0"], d["u0"], d["q0"] = r.farr("ldata"), r.farr("udata"), r.farr("qdata")
+    s = r.scaling()
+    d["D0"], d["E0"], d["c0"] = s["D"], s["E"], s["c"]
+    d["rho_vec0"] = r.farr("work_rho_vec")
+    d["Ax_idx"] = r.struct_vectors()[5]
+    np.savez_compressed(os.path.join(HERE, "structure.npz"), **d)
+    print("structure.npz: nnzA=%d nnzKKT=%d nnzL=%d" % (len(d["A_i"]), len(d["K_i"]), len(d["L_i"])))
+
+
+def sequence(seed, n, maxIter, fname, full_every=1):
+    """One controller from the pristine workspace through n calls (F1/F2)."""
+    rng = np.random.default_rng(seed)
+    r = refbind.RefUMPC(maxIter=maxIter)
+    rec = {k: [] for k in ("p0 R0 dq0 pdes dpdes sdes actualT0 pre_x pre_y pre_z pre_T0 pre_E3 "
+                           "l u q Px Ax c D E rho_vec constr_type Lx Dinv x y z sol_x sol_y uquad accdes "
+                           "status pri_res dua_res T0 ret").split()}
+    for (p0, R0, dq0, pdes, dpdes, sdes, aT0) in gen_inputs(rng, n):
+        x, y, z = r.iterates()
+        rec["pre_x"].append(x); rec["pre_y"].append(y); rec["pre_z"].append(z)
+        rec["pre_T0"].append(np.float32(r.up.T0))
+        rec["pre_E3"].append(r.scaling()["E"][36:39])
+        uq, ac = r.update(p0, R0, dq0, pdes, dpdes, sdes, aT0)
+        for k, v in zip(("p0", "R0", "dq0", "pdes", "dpdes", "sdes"), (p0, R0, dq0, pdes, dpdes, sdes)):
+            rec[k].append(np.asarray(v, np.float32))
+        rec["actualT0"].append(np.float32(aT0))
+        l, u, q, Px, Ax, _ = r.struct_vectors()
+        s = r.scaling()
+        info = r.info()
+        x, y, z = r.iterates()
+        for k, v in dict(l=l, u=u, q=q, Px=Px, Ax=Ax, c=s["c"], D=s["D"], E=s["E"],
+                         rho_vec=r.farr("work_rho_vec"), constr_type=r.iarr("work_constr_type"),
+                         Lx=r.farr("linsys_solver_L_x"), Dinv=r.farr("linsys_solver_Dinv"),
+                         x=x, y=y, z=z, sol_x=r.farr("xsolution"), sol_y=r.farr("ysolution"),
+                         uquad=uq, accdes=ac, status=np.int32(info["status_val"]),
+                         pri_res=info["pri_res"], dua_res=info["dua_res"], T0=np.float32(r.up.T0),
+                         ret=np.int32(r.ret)).items():
+            rec[k].append(v)
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out["maxIter"] = np.int32(maxIter)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    st, cnt = np.unique(out["status"], return_counts=True)
+    print(fname, "calls", n, "status histogram", dict(zip(st.tolist(), cnt.tolist())))
+
+
+def import_reference_python():
+    for name in ("osqp", "progressbar", "uprightmpc2py"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["uprightmpc2py"].UprightMPC2C = object  # only the name is imported
+    sys.path.insert(0, REF_T)
+    import genqp, template_controllers, flight_tasks, uprightmpc2  # noqa
+    return genqp, template_controllers, flight_tasks, uprightmpc2
+
+
+class _CtrlForHarness:
+    """What template/uprightmpc2.py:139 calls: mdl.update(p, Rb, dq, pdes, dpdes, sdes)."""
+
+    def __init__(self):
+        self.r = refbind.RefUMPC()
+        self.calls = []
+
+    def update(self, p, Rb, dq, pdes, dpdes, sdes, actualT0=-1.0):
+        self.calls.append((np.array(p), np.array(Rb), np.array(dq)))
+        uq, ac = self.r.update(p, Rb, dq, pdes, dpdes, sdes, actualT0)
+        self.status = getattr(self, "status", []) + [self.r.info()["status_val"]]
+        return uq.astype(np.float64), ac.astype(np.float64)
+
+
+def closed_loop(mods):
+    genqp, tc, ft, um2 = mods
+    ctrl = _CtrlForHarness()
+    log = um2.controlTest(ctrl, 500, useMPC=True, hlInterval=5, showPlots=False)
+    fire = np.nonzero(np.any(log["accdes"] != 0, axis=1))[0]
+    y = log["y"].copy()
+    err, eff = um2.logMetric({k: (v.copy() if hasattr(v, "copy") else v) for k, v in log.items()})
+    np.savez_compressed(os.path.join(HERE, "closed_loop_hover.npz"), t=log["t"], y=y, u=log["u"],
+                        accdes=log["accdes"], pdes=log["pdes"], fire=fire.astype(np.int32),
+                        ncalls=np.int32(len(ctrl.calls)), status=np.array(ctrl.status, np.int32),
+                        metric=np.array([err, eff]))
+    print("closed_loop_hover.npz: %d substeps, %d fires (first %d), final p=%s metric=(%.4f, %.4f)"
+          % (len(log["t"]), len(ctrl.calls), fire[0], np.round(y[-1, :3], 4), err, eff))
+
+
+def assembly_fp64(mods):
+    """F4: the pure-Python fp64 assembly for the inputs of sequence A (pins the
+    '#OK' identities of template_controllers.py:321-326)."""
+    genqp, tc, ft, um2 = mods
+    seq = np.load(os.path.join(HERE, "seq_iter50.npz"))
+    N, ny, nu = 3, 6, 3
+    nx, nc = N * (2 * ny + nu), 2 * N * ny + N
+    A, P = tc.initConstraint(N, nx, nc)
+    Ibi = np.diag(1 / genqp.Ib.diagonal())
+    ws, wds, wpr, wvr, wpf, wvf, wthrust, wmom = 1e1, 1e3, 1, 1e3, 5, 2e3, 1e-1, 1e-2
+    Wts = [np.hstack((np.full(3, wpr), np.full(3, ws))), np.hstack((np.full(3, wpf), np.full(3, ws))),
+           np.hstack((np.full(3, wvr), np.full(3, wds))), np.hstack((np.full(3, wvf), np.full(3, wds))),
+           np.hstack((wthrust, np.full(2, wmom)))]
+    out = {k: [] for k in "l u q Px Adata Axidx".split()}
+    n = 64
+    for k in range(n):
+        R0 = seq["R0"][k].astype(np.float64)
+        dq0 = seq["dq0"][k].astype(np.float64)
+        T0 = float(seq["actualT0"][k]) if seq["actualT0"][k] >= 0 else float(seq["pre_T0"][k])
+        s0 = R0[:, 2].copy()
+        Btau = (-R0 @ tc.e3h @ Ibi)[:, :2]
+        ds0 = -R0 @ tc.e3h @ dq0[3:6]
+        y0 = np.hstack((seq["p0"][k].astype(np.float64), s0))
+        dy0 = np.hstack((dq0[:3], ds0))
+        ydes = np.hstack((seq["pdes"][k], seq["sdes"][k])).astype(np.float64)
+        dydes = np.hstack((seq["dpdes"][k].astype(np.float64), 0, 0, 0))
+        A, l, u, Axidx = tc.updateConstraint(N, A, 5.0, T0, [s0] * N, [Btau] * N, y0, dy0, 9.81e-3, 2 * 9.81e-3)
+        Pdata, q = tc.updateObjective(N, *Wts, ydes, dydes)
+        for key, v in zip(out, (l, u, q, Pdata, A.data.copy(), Axidx)):
+            out[key].append(np.array(v))
+    np.savez_compressed(os.path.join(HERE, "assembly_fp64.npz"), n=np.int32(n),
+                        A_indices=A.indices, A_indptr=A.indptr, **{k: np.stack(v) for k, v in out.items()})
+    print("assembly_fp64.npz:", n, "cases; A.nnz =", A.nnz)
+
+
+def plant(mods):
+    genqp = mods[0]
+    rng = np.random.default_rng(5)
+    rec = {k: [] for k in "p R dq u dt p2 R2 dq2".split()}
+    for k in range(128):
+        p = rng.normal(size=3) * 10
+        R = rand_rot(rng, 1.0)
+        dq = np.hstack((rng.normal(size=3) * 0.2, rng.normal(size=3) * (0.05 if k % 4 else 1e-5)))
+        u = np.array([rng.uniform(0, 0.02), rng.normal() * 50, rng.normal() * 50])
+        dt = [0.2, 0.1, 1.0, 5.0][k % 4]
+        p2, R2, dq2 = genqp.quadrotorNLDyn(p, R, dq, u, dt)
+        for key, v in zip(rec, (p, R, dq, u, dt, p2, R2, dq2)):
+            rec[key].append(np.asarray(v, np.float64))
+    np.savez_compressed(os.path.join(HERE, "plant.npz"), **{k: np.stack(v) for k, v in rec.items()})
+    print("plant.npz: 128 cases")
+
+
+def tasks(mods):
+    ft = mods[2]
+    ts = np.linspace(0, 1200, 49)
+    p0 = np.array([1.0, -2.0, 3.0])
+    out = {}
+    for name, fn, kw in (("hover", ft.helix, dict(trajAmp=0, trajFreq=0, dz=0.1, useY=False)),
+                         ("helix", ft.helix, dict(trajAmp=80, trajFreq=1, dz=0.15, useY=True)),
+                         ("straightAcc", ft.straightAcc, {}), ("flip", ft.flip, {}), ("perch", ft.perch, {})):
+        out[name] = np.stack([np.hstack(fn(t, p0, **kw)) for t in ts])
+    np.savez_compressed(os.path.join(HERE, "flight_tasks.npz"), t=ts, p0=p0, **out)
+    print("flight_tasks.npz")
+
+
+if __name__ == "__main__":
+    assert refbind.available(), "build oracle/_ref first: make -C oracle ref"
+    structure()
+    sequence(20201117, 256, 50, "seq_iter50.npz")
+    for k in (1, 2, 10):
+        sequence(20201117 + k, 24, k, "seq_iter%d.npz" % k)
+    mods = import_reference_python()
+    closed_loop(mods)
+    assembly_fp64(mods)
+    plant(mods)
+    tasks(mods)

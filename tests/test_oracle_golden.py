@@ -1,0 +1,205 @@
+"""Pins the CPU oracle (oracle/umpc_oracle.c) against golden vectors generated
+from the reference itself (tests/golden/make_golden.py). CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def _replay(o, seq, k):
+    return o.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k],
+                    seq["sdes"][k], float(seq["actualT0"][k]))
+
+
+def test_symbolic_structure_matches_reference(oracle_built, structure):
+    """form_KKT + symperm + etree restatement == workspace.c tables."""
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"])
+    for k in ("A_p", "A_i", "K_p", "K_i", "PtoKKT", "AtoKKT", "rhotoKKT", "etree", "Lnz", "L_p", "Ax_idx"):
+        assert np.array_equal(o.get(k), structure[k]), k
+    assert np.array_equal(o.get("A_x"), structure["A_x0"])
+    assert np.array_equal(o.get("K_x"), structure["K_x0"])
+    assert np.array_equal(o.get("rho_vec"), structure["rho_vec0"])
+    assert len(structure["A_i"]) == 111  # template_controllers.py:113
+    assert len(structure["L_i"]) == 213 and len(structure["K_i"]) == 195
+
+
+@pytest.mark.parametrize("fname", ["seq_iter50.npz", "seq_iter1.npz", "seq_iter2.npz", "seq_iter10.npz"])
+def test_fp32_oracle_is_bit_identical_to_reference(oracle_built, structure, fname):
+    """Same ADMM iterate after the same number of iterations from the same warm
+    start, BIT FOR BIT, over a 256-call sequence starting at the pristine
+    workspace (covers the first-call constraint-type flip, F2)."""
+    seq = golden(fname)
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"], maxIter=int(seq["maxIter"]))
+    for k in range(len(seq["p0"])):
+        assert np.array_equal(o.get("x"), seq["pre_x"][k])
+        uq, ac = _replay(o, seq, k)
+        for name, mine in (("l", "l_new"), ("u", "u_new"), ("q", "q_new"), ("Px", "Px_data"), ("Ax", "Ax_data"),
+                           ("c", "c"), ("D", "D"), ("E", "E"), ("rho_vec", "rho_vec"),
+                           ("constr_type", "constr_type"), ("Lx", "L_x"), ("Dinv", "Ddinv"),
+                           ("x", "x"), ("y", "y"), ("z", "z"), ("sol_x", "sol_x"), ("sol_y", "sol_y"),
+                           ("pri_res", "pri_res"), ("dua_res", "dua_res"), ("T0", "T0")):
+            assert np.array_equal(np.ravel(o.get(mine)), np.ravel(seq[name][k])), (k, name)
+        assert np.array_equal(uq, seq["uquad"][k]) and np.array_equal(ac, seq["accdes"][k])
+        assert int(o.get("status_val")[0]) == int(seq["status"][k])
+        assert o.ret == int(seq["ret"][k])
+    assert np.array_equal(o.get("L_i"), structure["L_i"])
+
+
+def test_canonical_mode_tracks_faithful_mode(oracle_built, structure):
+    """The HIP kernel restarts from raw data every call (canonical mode) instead
+    of unscale -> patch -> rescale. Starting every call from the reference's own
+    pre-call state, the two differ only by round-off of that round trip."""
+    seq = golden("seq_iter50.npz")
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"])
+    o.set_canonical(True)
+    worst_u0 = worst_tau = worst_acc = 0.0
+    for k in range(len(seq["p0"])):
+        o.set_iterates(seq["pre_x"][k], seq["pre_y"][k], seq["pre_z"][k])
+        o.set_T0(float(seq["pre_T0"][k]))
+        o.set_canonical(True, seq["pre_E3"][k])
+        uq, ac = _replay(o, seq, k)
+        assert np.array_equal(o.get("constr_type"), seq["constr_type"][k])
+        worst_u0 = max(worst_u0, abs(uq[0] - seq["uquad"][k][0]))
+        worst_tau = max(worst_tau, np.max(np.abs(uq[1:] - seq["uquad"][k][1:]) /
+                                          np.maximum(1.0, np.abs(seq["uquad"][k][1:]))))
+        worst_acc = max(worst_acc, np.max(np.abs(ac - seq["accdes"][k])))
+    # stated fp32 tolerance of the path: 3e-5 thrust, max(2e-2,1e-3|u|) moments, 3e-5 accdes.
+    # (On these vectors the fp32 REFERENCE itself is 0.9e-5 / 3.4e-3 / 0.9e-5 away from the
+    # same algorithm in fp64 -- test_fp64_oracle_tracks_fp32_reference -- so 3e-5 is ~3x the
+    # reference's own rounding error.)
+    assert worst_u0 < 3e-5 and worst_tau < 2e-2 and worst_acc < 3e-5, (worst_u0, worst_tau, worst_acc)
+
+
+def test_fp64_oracle_tracks_fp32_reference(oracle_built, structure):
+    """fp64 build of the same restatement vs the fp32 reference at equal
+    iteration count from equal state: the fp32<->fp64 band of SURVEY 8c."""
+    seq = golden("seq_iter50.npz")
+    o = oracle_built.Oracle(np.float64, perm=structure["perm"])
+    o.set_canonical(True)
+    bad = 0
+    for k in range(len(seq["p0"])):
+        o.set_iterates(seq["pre_x"][k], seq["pre_y"][k], seq["pre_z"][k])
+        o.set_T0(float(seq["pre_T0"][k]))
+        o.set_canonical(True, seq["pre_E3"][k])
+        uq, ac = _replay(o, seq, k)
+        ref = seq["uquad"][k]
+        ok = (abs(uq[0] - ref[0]) <= 3e-5 and
+              np.all(np.abs(uq[1:] - ref[1:]) <= np.maximum(2e-2, 1e-3 * np.abs(ref[1:]))) and
+              np.all(np.abs(ac - seq["accdes"][k]) <= 3e-5))
+        bad += (not ok)
+    assert bad == 0, bad
+
+
+def test_assembly_fp64_identities(oracle_built, structure):
+    """template_controllers.py:321-326 '#OK' identities: C assembly == Python
+    fp64 assembly (l,u,q,Px,Ax by index) up to fp32 rounding; Axidx equal."""
+    asm = golden("assembly_fp64.npz")
+    seq = golden("seq_iter50.npz")
+    assert np.array_equal(asm["A_indices"], structure["A_i"]) and np.array_equal(asm["A_indptr"], structure["A_p"])
+    for k in range(int(asm["n"])):
+        assert np.array_equal(asm["Axidx"][k], structure["Ax_idx"])
+        np.testing.assert_allclose(seq["l"][k], asm["l"][k], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(seq["u"][k], asm["u"][k], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(seq["q"][k], asm["q"][k], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(seq["Px"][k], asm["Px"][k], rtol=1e-6)
+        np.testing.assert_allclose(seq["Ax"][k], asm["Adata"][k][structure["Ax_idx"]], rtol=2e-6, atol=1e-9)
+    # and the fp64 oracle assembles the same numbers
+    o = oracle_built.Oracle(np.float64, perm=structure["perm"])
+    for k in range(int(asm["n"])):
+        o.set_T0(float(seq["pre_T0"][k]))
+        _replay(o, seq, k)
+        np.testing.assert_allclose(o.get("l_new"), asm["l"][k], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(o.get("q_new"), asm["q"][k], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(o.get("Ax_data"), asm["Adata"][k][structure["Ax_idx"]], rtol=1e-6, atol=1e-9)
+        o.set_T0(0.0)
+
+
+def test_dynamics_constraint_known_answer(oracle_built, structure):
+    """UprightMPC2.testDyn (template_controllers.py:204-208): an open-loop
+    rollout x satisfies (A x - l)[:36] ~ 0 for the assembled A, l."""
+    o = oracle_built.Oracle(np.float64, perm=structure["perm"])
+    seq = golden("seq_iter50.npz")
+    rng = np.random.default_rng(3)
+    for k in range(8):
+        o.set_T0(0.013)
+        _replay(o, seq, k) if seq["actualT0"][k] < 0 else None
+        if seq["actualT0"][k] >= 0:
+            continue
+        # rebuild raw A from structure + Ax_data
+        A = np.zeros((39, 45))
+        Ax = structure["A_x0"].astype(np.float64).copy()
+        Ax[structure["Ax_idx"]] = o.get("Ax_data")
+        for j in range(45):
+            for p in range(structure["A_p"][j], structure["A_p"][j + 1]):
+                A[structure["A_i"][p], j] = Ax[p]
+        l = o.get("l_new")
+        dt, T0, g = 5.0, 0.013, 9.81e-3
+        R0 = seq["R0"][k].astype(np.float64)
+        s0 = R0[:, 2]
+        e3h = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 0.0]])
+        Btau = (-R0 @ e3h @ np.diag(1 / np.array([3333., 3333., 1000.])))[:, :2]
+        y = np.hstack((seq["p0"][k], s0)).astype(np.float64)
+        dy = np.hstack((seq["dq0"][k][:3], -R0 @ e3h @ seq["dq0"][k][3:6])).astype(np.float64)
+        us = rng.random((3, 3))
+        ys, dys = [], []
+        for i in range(3):  # openLoopX, template_controllers.py:145-167
+            A0y = np.hstack((T0 * y[3:], np.zeros(3)))
+            B0u = np.hstack((s0 * us[i, 0], Btau @ us[i, 1:]))
+            dyn = dy + dt * (A0y + B0u + np.array([0, 0, -g, 0, 0, 0]))
+            yn = y + dt * dy
+            ys.append(yn + dt * dyn); dys.append(dyn)
+            y, dy = yn, dyn
+        x = np.hstack((np.ravel(ys), np.ravel(dys), np.ravel(us)))
+        assert np.max(np.abs((A @ x - l)[:36])) < 1e-9
+
+
+def test_plant_step_matches_reference_python(oracle_built):
+    """quadrotorNLDyn (template/genqp.py:32-41, scipy expm) vs closed-form step."""
+    g = golden("plant.npz")
+    L = oracle_built.lib(np.float32)
+    for k in range(len(g["p"])):
+        p2, R2, dq2 = oracle_built.plant_step_d(L, g["p"][k], g["R"][k], g["dq"][k], g["u"][k], float(g["dt"][k]))
+        np.testing.assert_allclose(p2, g["p2"][k], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(R2, g["R2"][k], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(dq2, g["dq2"][k], rtol=1e-13, atol=1e-15)
+
+
+def test_closed_loop_hover_reproduces_reference_harness(oracle_built, structure):
+    """controlTest(mdl, 500, hlInterval=5) (template/uprightmpc2.py:87-159) with the
+    reference C controller: fp32 controller + fp64 plant, fires at the recorded
+    (float-jittered, 25/26) substeps. The oracle reproduces the whole 2500-substep
+    log and the logMetric pair."""
+    g = golden("closed_loop_hover.npz")
+    from scipy.spatial.transform import Rotation
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"])
+    L = oracle_built.lib(np.float32)
+    p = np.zeros(3); R = Rotation.from_euler("xyz", [0.5, -0.5, 0]).as_matrix(); dq = np.zeros(6); dq[0] = 0.1
+    uquad = np.zeros(3)
+    fire = set(g["fire"].tolist())
+    assert len(fire) == 96 and min(fire) == 26
+    Y = np.zeros_like(g["y"]); U = np.zeros_like(g["u"])
+    for ti in range(len(g["t"])):
+        if ti in fire:
+            uq, ac = o.update(p, R, dq, np.zeros(3), np.zeros(3), [0, 0, 1])
+            uquad = uq.astype(np.float64)
+            np.testing.assert_allclose(ac, g["accdes"][ti], rtol=1e-4, atol=1e-7)
+        uquad[1:] = np.clip(uquad[1:], -100, 100)
+        p, R, dq = oracle_built.plant_step_d(L, p, R, dq, uquad, 0.2)
+        Y[ti] = np.hstack((p, R[:, 2], dq)); U[ti] = uquad
+    np.testing.assert_allclose(Y, g["y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(U, g["u"], rtol=1e-5, atol=1e-6)
+    err = np.mean(np.sum(Y[:, :3] ** 2, axis=1)); eff = np.mean(np.sum(U[:, 1:3] ** 2, axis=1))
+    np.testing.assert_allclose([err, eff], g["metric"], rtol=1e-5)
+    assert np.linalg.norm(Y[-1, :3]) < 0.02 and abs(Y[-1, 5] - 1) < 1e-4  # hover converges to origin, upright
+
+
+@pytest.mark.skipif(not __import__("refbind").available(), reason="reference not present (GPU box)")
+def test_live_reference_matches_fixture(structure):
+    """When /root/reference is mounted: the live reference build still produces the committed vectors."""
+    import refbind
+    seq = golden("seq_iter50.npz")
+    r = refbind.RefUMPC()
+    for k in range(32):
+        uq, ac = r.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k],
+                          seq["sdes"][k], float(seq["actualT0"][k]))
+        assert np.array_equal(uq, seq["uquad"][k]) and np.array_equal(ac, seq["accdes"][k])
