@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: closed-loop MPC steps/sec (QP + plant), BASELINE.json metric.
+
+Workload (BASELINE.json configs[2], the one the >=1e6 steps/s target is quoted
+on; SURVEY 8d "Config 3"): B = 65536 robots PER GPU, fp32, horizon N = 3,
+random-tilt hover start (seed 20201118), closed loop. One "step" = one pass of
+the hot path over the whole batch = for every robot one umpcUpdate-equivalent
+(assembly + 10 Ruiz passes + LDL' + 50 ADMM iterations + status + extraction)
+followed by 25 plant substeps of 0.2 ms, moments clipped at +-100. One kernel
+launch per step; inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Robots are independent: ranks shard the batch (weak scaling, 65536 robots per
+GPU, RNG keyed by global robot index), there is no collective on the data path;
+one RCCL all_gather of the per-robot trajectory statistics runs AFTER the timed
+region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_STEP_FP32 = 1208  # (18 plant + 124 controller + 9 ref) read + (18+124+9) written, x4 B
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(args, plant_mode):
+    """The oracle (CPU restatement, OpenMP over robots) on a bounded sample of the
+    same workload, timed on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oraclebind
+    from robobee3d_amd.batch import hover_initial_conditions
+    oraclebind.build()
+    ncores = len(os.sched_getaffinity(0))
+    Bs, Ks = args.cpu_robots, args.cpu_steps
+    st, ref = hover_initial_conditions(Bs, 20201118, np.float32)
+    ctrl = np.zeros((127, Bs), np.float32)
+    ctrl[124:] = 1
+    # warm (page-in, thread pool)
+    oraclebind.batch_rollout(st.copy(), ctrl.copy(), ref, 1, dtype=np.float32, plant_mode=plant_mode, nthreads=ncores)
+    t0 = time.perf_counter()
+    oraclebind.batch_rollout(st, ctrl, ref, Ks, dtype=np.float32, plant_mode=plant_mode, nthreads=ncores)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    n1 = max(1, Bs // 64)
+    st1, ref1 = hover_initial_conditions(n1, 20201118, np.float32)
+    c1 = np.zeros((127, n1), np.float32); c1[124:] = 1
+    oraclebind.batch_rollout(st1, c1, ref1, Ks, dtype=np.float32, plant_mode=plant_mode, nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {"value": Bs * Ks / dt, "unit": "closed-loop MPC steps/s", "cores": ncores, "kind": "port",
+            "sample": "%d robots x %d steps of the same workload (oracle/umpc_oracle.c, fp32, OpenMP over robots)"
+                      % (Bs, Ks),
+            "single_thread_value": n1 * Ks / dt1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--plant", default="euler", choices=["euler", "rk4"],
+                    help="euler = the reference's Euler+expm step (parity mode); rk4 = build-defined RK4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-robots", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=100)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    from robobee3d_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    ndt = np.float32 if args.dtype == "f32" else np.float64
+    plant_mode = 0 if args.plant == "euler" else 1
+    B = args.batch
+
+    # synthetic inputs, resident in HBM before the timed region
+    st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=rank * B)
+    mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode)
+    mpc.set_state(st, ref)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        mpc.rollout(1)
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        evs[k][0].record()
+        mpc.rollout(1)          # ONE launch = one closed-loop step of all B robots
+        evs[k][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    # end-of-run trajectory statistics: the only exchange of the path (outside the timed region)
+    metric = mpc.metrics(args.warmup + args.steps)
+    if world > 1:
+        gathered = [torch.empty_like(metric) for _ in range(world)]
+        dist.all_gather(gathered, metric)
+        metric = torch.cat(gathered, dim=1)
+    status = mpc.status
+    nbad = int((~torch.isfinite(mpc.state)).sum().item())
+
+    if rank == 0:
+        total_steps = world * B * args.steps
+        value = total_steps / elapsed
+        bps = ALG_BYTES_PER_STEP_FP32 * (2 if args.dtype == "f64" else 1)
+        achieved = bps * B / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("batch") == B and j.get("dtype") == args.dtype and j.get("plant") == args.plant:
+                    traffic = j["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "closed-loop MPC steps/sec (QP+dyn)", "value": value, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: closed-loop uprightmpc2 (N=3, 50 ADMM it, 10 Ruiz, LDL' "
+                                   "refactor per step) + 25 plant substeps, random-tilt hover, seed 20201118",
+                       "robots_per_gpu": B, "global_batch": world * B, "horizon": 3,
+                       "plant": "Euler+expm (reference step)" if plant_mode == 0 else "RK4 (build-defined)",
+                       "parallelism": "robots sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": _lib.lib().umpcKernelName(0 if args.dtype == "f32" else 1, plant_mode).decode(),
+                         "kernel_ms": kern_ms, "alg_bytes_per_launch": bps * B,
+                         "note": "path is VALU-issue/latency bound, not HBM bound (DESIGN.md): ~1.1e5 flop per "
+                                 "1208 B; achieved fp32 rate %.1f TFLOP/s" % (1.1e5 * B / (kern_ms * 1e-3) / 1e12)},
+            "check": {"nonfinite_state_values": nbad,
+                      "mean_pos_err_mm2": float(metric[0].mean().item()),
+                      "status_solved_frac": float((status > 0).float().mean().item())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, plant_mode)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * libumpc_mi355x.so -- C ABI of the MI355X-native uprightmpc2 path.
+ *
+ * Part 1 re-exports the reference's own three entry points with identical
+ * signatures and semantics (avikde/robobee3d,
+ * template/uprightmpc2/uprightmpc2.h:27-49), so every existing host of the
+ * reference (pybind module py/uprightmpc2py.cpp:30-52, Simulink S-function
+ * legacy_code_gen.m:6, MCU loop g4bee/app/loop_update.cpp:36,54) links
+ * unchanged. Unlike the reference this library does NOT import `matMult`
+ * (matmult.h:35) and keeps no global solver workspace: any number of
+ * UprightMPC_t controllers may coexist (the reference allows one per process,
+ * workspace.c:2620).
+ *
+ * Part 2 is additive: batched controllers (one GPU lane per robot) that run
+ * the same step for B independent robots, optionally fused with the
+ * rigid-body plant (template/genqp.py:24-41) into a closed loop
+ * (template/uprightmpc2.py:120-154).
+ *
+ * Plain C types only; device buffers are raw HIP device pointers; `stream` is a
+ * hipStream_t passed as void* (NULL = default stream). No call allocates or
+ * synchronises except where stated.
+ */
+#ifndef UMPC_MI355X_H
+#define UMPC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Part 1: the reference ABI (template/uprightmpc2/uprightmpc2.h)      */
+/* ------------------------------------------------------------------ */
+#define UMPC_N 3
+#define UMPC_NY 6
+#define UMPC_NU 3
+#define UMPC_NX (UMPC_N * (2 * UMPC_NY + UMPC_NU))
+#define UMPC_NC (2 * UMPC_N * UMPC_NY + UMPC_N)
+#define UMPC_nAdata 48
+
+/* Caller-allocated POD, same field layout as uprightmpc2.h:27-43 (1308 B):
+ * the reference's pybind `vectors()/matrices()` read l,u,q,Px_data,Ax_data,
+ * Ax_idx straight out of it (py/uprightmpc2py.cpp:46-51), so umpcUpdate keeps
+ * them filled. */
+typedef struct {
+  float dt, g, Tmax;
+  float Qyr[6], Qyf[6], Qdyr[6], Qdyf[6], R[3];
+  float smin[3], smax[3];
+  float e3h[3 * 3];
+  float e3hIbi[3 * 3];
+  float l[UMPC_NC], u[UMPC_NC], q[UMPC_NX];
+  float Px_data[UMPC_NX];
+  float Ax_data[UMPC_nAdata];
+  int Ax_idx[UMPC_nAdata], nAxT0dt, nAxdt;
+  float c0[UMPC_NY];
+  float T0;
+} UprightMPC_t;
+
+/* uprightmpc2.h:45 / uprightmpc2.c:19-118 */
+void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, float wds,
+              float wpr, float wpf, float wvr, float wvf, float wthrust, float wmom,
+              const float Ib[/* 3 */], int maxIter);
+
+/* uprightmpc2.h:47 / uprightmpc2.c:209-272. R0 column-major. actualT0 >= 0
+ * overrides the internal thrust accumulator. Returns 0 (the reference returns
+ * osqp_solve's exit flag, which is 0 on every reachable path). Synchronous. */
+int umpcUpdate(UprightMPC_t *up, float uquad[/* 3 */], float accdes[/* 6 */],
+               const float p0[/* 3 */], const float R0[/* 9 */], const float dq0[/* 6 */],
+               const float pdes[/* 3 */], const float dpdes[/* 3 */],
+               const float sdes[/* 3 */], float actualT0);
+
+/* uprightmpc2.h:49 / uprightmpc2.c:275-284: lazily initialised singleton. */
+void umpcS(float uquad_y1[/* 3 */], float accdes_y2[/* 6 */], const float p0_u1[/* 3 */],
+           const float R0_u2[/* 9 */], const float dq0_u3[/* 6 */], const float pdes_u4[/* 3 */],
+           const float dpdes_u5[/* 3 */], const float sdes_u6[/* 3 */], float dt_u7, float g_u8,
+           float TtoWmax_u9, float ws_u10, float wds_u11, float wpr_u12, float wpf_u13,
+           float wvr_u14, float wvf_u15, float wthrust_u16, float wmom_u17,
+           const float Ib_u18[/* 3 */], int maxIter_u19, float actualT0_u20);
+
+/* OSQP status of the most recent umpcUpdate on `up` (the reference leaves it
+ * in its global workspace.info->status_val; constants.h:18-30). */
+int umpcLastStatus(const UprightMPC_t *up);
+/* Releases the device-side state attached to `up` (optional). */
+void umpcRelease(UprightMPC_t *up);
+
+/* ------------------------------------------------------------------ */
+/* Part 2: batched controllers                                         */
+/* ------------------------------------------------------------------ */
+#define UMPC_F32 0
+#define UMPC_F64 1
+
+/* rows of the SoA device arrays (every array is [rows][B], robot index fastest) */
+#define UMPC_STATE_ROWS 18 /* p(3), R column-major (9), dq = (v_world, omega_body) (6) */
+#define UMPC_CTRL_ROWS 127 /* x(45) y(39) z(39) T0(1) Eprev(3): warm start of the solver */
+#define UMPC_REF_ROWS 9    /* pdes(3) dpdes(3) sdes(3) */
+#define UMPC_OUT_ROWS 9    /* uquad(3) = (specific thrust, 2 moments), accdes(6) */
+#define UMPC_STAT_ROWS 2   /* sum |p|^2, sum |tau|^2 over plant substeps (logMetric, uprightmpc2.py:161-175) */
+
+typedef struct {
+  /* createMPC / umpcInit arguments (template_controllers.py:260-279) */
+  double dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom;
+  double Ib[3];
+  int maxIter; /* fixed ADMM iteration count (50 in the reference) */
+  /* closed loop (template/uprightmpc2.py:87, 148-151) */
+  double dtsim;   /* plant substep (0.2) */
+  double taulim;  /* moment clip (100) */
+  int nsub;       /* plant substeps per MPC step (25); 0 = controller only */
+  int plant_mode; /* 0 = reference Euler + expm step, 1 = RK4 on the same vector field */
+} umpc_batch_params_t;
+
+typedef struct umpc_batch umpc_batch_t;
+
+/* Fills `prm` with the reference defaults (createMPC + controlTest). */
+void umpcBatchDefaultParams(umpc_batch_params_t *prm);
+
+/* Creates a batched controller for B robots of scalar type dtype on the
+ * current HIP device. Returns NULL on error (umpcLastError()). No device memory
+ * is owned by the handle: all arrays are caller-provided. */
+umpc_batch_t *umpcBatchCreate(const umpc_batch_params_t *prm, int B, int dtype);
+void umpcBatchDestroy(umpc_batch_t *h);
+
+/* Writes the cold-start controller record (x=y=z=0, T0=0, Eprev=1) for B robots. */
+int umpcBatchInitCtrl(umpc_batch_t *h, void *ctrl, void *stream);
+
+/* K closed-loop MPC steps for every robot in ONE launch. Each step = QP
+ * assembly + 10 Ruiz passes + LDL' + maxIter ADMM iterations + status +
+ * extraction (= one umpcUpdate), then nsub plant substeps with the moments
+ * clipped. Device pointers, SoA [rows][B]:
+ *   state   in/out (not written when nsub == 0)
+ *   ctrl    in/out
+ *   ref     in
+ *   actualT0 in, [B] or NULL (values >= 0 override T0 before the first step)
+ *   Ib      in, [3][B] or NULL (per-robot inertia for controller and plant)
+ *   gain    in, [B] or NULL (per-robot plant thrust gain, Monte-Carlo mass sweep)
+ *   out     out
+ *   stats   in/out or NULL (accumulated)
+ *   status  out int32 [B] or NULL (OSQP status of the last step)
+ *   info    out [2][B] or NULL (pri_res, dua_res of the last step)
+ * Asynchronous on `stream`. Returns 0 or a hipError_t. */
+int umpcBatchRollout(umpc_batch_t *h, int K, void *state, void *ctrl, const void *ref,
+                     const void *actualT0, const void *Ib, const void *gain, void *out,
+                     void *stats, int32_t *status, void *info, void *stream);
+
+/* One controller step without plant (= umpcUpdate for B robots): `state` is
+ * only read. */
+int umpcBatchUpdate(umpc_batch_t *h, const void *state, void *ctrl, const void *ref,
+                    const void *actualT0, const void *Ib, void *out, int32_t *status,
+                    void *info, void *stream);
+
+/* Plant only: nsub substeps of the rigid-body model under inputs u[3][B]. */
+int umpcBatchPlant(umpc_batch_t *h, int nsub, void *state, const void *u, const void *Ib,
+                   const void *gain, void *stream);
+
+/* Debug/parity: QP assembly for B robots, raw l[39],u[39],q[45],Px[45],Ax[48] rows. */
+int umpcBatchAssemble(umpc_batch_t *h, const void *state, const void *ctrl, const void *ref,
+                      const void *Ib, void *l, void *u, void *q, void *Px, void *Ax, void *stream);
+
+/* Static facts */
+int umpcBatchSize(const umpc_batch_t *h);
+int umpcBatchDtype(const umpc_batch_t *h);
+const int *umpcAxIdx(void);    /* 48 entries, uprightmpc2.c:65-113 */
+const int *umpcKKTPerm(void);  /* 84 entries, the build's own elimination order */
+int umpcNnzL(void);
+const char *umpcLastError(void);
+/* name and duration of the kernels, for bench.py */
+const char *umpcKernelName(int dtype, int plant_mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMPC_MI355X_H */

@@ -1,0 +1,97 @@
+"""ctypes loader for libumpc_mi355x.so (the C ABI in include/umpc_mi355x.h).
+
+There is NO fallback: if the shared library is missing this raises, and the
+library itself refuses to create a controller when no HIP device is present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO_PATH = os.path.join(HERE, "libumpc_mi355x.so")
+SRC = os.path.join(HERE, "csrc", "umpc_mi355x.hip")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+UMPC_F32, UMPC_F64 = 0, 1
+STATE_ROWS, CTRL_ROWS, REF_ROWS, OUT_ROWS, STAT_ROWS = 18, 127, 9, 9, 2
+NX, NC, NADATA = 45, 39, 48
+
+# every symbol include/umpc_mi355x.h declares
+EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
+           "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
+           "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
+           "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
+           "umpcLastError", "umpcKernelName"]
+
+
+class BatchParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("dt", "g", "TtoWmax", "ws", "wds", "wpr", "wpf", "wvr",
+                                          "wvf", "wthrust", "wmom")] + \
+               [("Ib", C.c_double * 3), ("maxIter", C.c_int), ("dtsim", C.c_double),
+                ("taulim", C.c_double), ("nsub", C.c_int), ("plant_mode", C.c_int)]
+
+
+class UprightMPC_t(C.Structure):
+    # include/umpc_mi355x.h == template/uprightmpc2/uprightmpc2.h:27-43
+    _fields_ = [
+        ("dt", C.c_float), ("g", C.c_float), ("Tmax", C.c_float),
+        ("Qyr", C.c_float * 6), ("Qyf", C.c_float * 6), ("Qdyr", C.c_float * 6),
+        ("Qdyf", C.c_float * 6), ("R", C.c_float * 3), ("smin", C.c_float * 3),
+        ("smax", C.c_float * 3), ("e3h", C.c_float * 9), ("e3hIbi", C.c_float * 9),
+        ("l", C.c_float * NC), ("u", C.c_float * NC), ("q", C.c_float * NX),
+        ("Px_data", C.c_float * NX), ("Ax_data", C.c_float * NADATA),
+        ("Ax_idx", C.c_int * NADATA), ("nAxT0dt", C.c_int), ("nAxdt", C.c_int),
+        ("c0", C.c_float * 6), ("T0", C.c_float),
+    ]
+
+
+def build(force=False, verbose=False):
+    """Generate umpc_gen.h and compile the HIP library for gfx950 (works without a GPU)."""
+    from . import codegen
+    gen, _ = codegen.write()
+    deps = [SRC, gen, os.path.join(HERE, "csrc", "umpc_step.h"),
+            os.path.join(ROOT, "include", "umpc_mi355x.h")]
+    if (not force and os.path.exists(SO_PATH)
+            and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps)):
+        return SO_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", SO_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=os.path.join(HERE, "csrc"),
+                   stderr=None if verbose else subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError("libumpc_mi355x.so is not built (run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'`); robobee3d_amd has no CPU fallback")
+        L = C.CDLL(SO_PATH)
+        L.umpcBatchCreate.restype = C.c_void_p
+        L.umpcBatchCreate.argtypes = [C.POINTER(BatchParams), C.c_int, C.c_int]
+        L.umpcBatchDestroy.argtypes = [C.c_void_p]
+        L.umpcBatchInitCtrl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.umpcBatchRollout.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 11
+        L.umpcBatchUpdate.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+        L.umpcBatchPlant.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.umpcBatchAssemble.argtypes = [C.c_void_p] + [C.c_void_p] * 10
+        L.umpcLastError.restype = C.c_char_p
+        L.umpcKernelName.restype = C.c_char_p
+        L.umpcAxIdx.restype = C.POINTER(C.c_int * NADATA)
+        L.umpcKKTPerm.restype = C.POINTER(C.c_int * (NX + NC))
+        L.umpcUpdate.restype = C.c_int
+        L.umpcLastStatus.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def default_params():
+    p = BatchParams()
+    lib().umpcBatchDefaultParams(C.byref(p))
+    return p

@@ -1,0 +1,141 @@
+"""Batched uprightmpc2 controller + plant on one MI355X (host side, Python).
+
+torch is used only for device memory, streams and (elsewhere) torch.distributed;
+all compute is in libumpc_mi355x.so, reached through the C ABI with raw device
+pointers. Array convention: SoA [rows, B] contiguous, robot index fastest
+(include/umpc_mi355x.h).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.UMPC_F32, torch.float64: _lib.UMPC_F64}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def hover_initial_conditions(B, seed, dtype=np.float32, tilt=0.5, index_offset=0):
+    """Random-tilt hover start (reference single IC at
+    template/uprightmpc2.py:101-103 is a=0.5, b=-0.5): p=0, Rb = Rx(a) Ry(b),
+    a,b ~ U(-tilt, tilt), dq = (0.1,0,0,0,0,0). Streams are keyed by the GLOBAL
+    robot index so a sharded run draws the same numbers as a single-GPU run.
+    Returns state[18,B] (R column-major) and ref[9,B] (pdes=0, dpdes=0, sdes=e3)."""
+    idx = np.arange(index_offset, index_offset + B, dtype=np.uint64)
+    # counter-based: two uniforms per robot from a hash of (seed, index)
+    def u01(salt):
+        v = (idx + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(salt)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        v ^= v >> np.uint64(30); v *= np.uint64(0xBF58476D1CE4E5B9)
+        v ^= v >> np.uint64(27); v *= np.uint64(0x94D049BB133111EB)
+        v ^= v >> np.uint64(31)
+        return (v >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    with np.errstate(over="ignore"):
+        a = (2 * u01(1) - 1) * tilt
+        b = (2 * u01(2) - 1) * tilt
+    ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+    # R = Rx(a) @ Ry(b)
+    R = np.empty((B, 3, 3))
+    R[:, 0, 0] = cb; R[:, 0, 1] = 0; R[:, 0, 2] = sb
+    R[:, 1, 0] = sa * sb; R[:, 1, 1] = ca; R[:, 1, 2] = -sa * cb
+    R[:, 2, 0] = -ca * sb; R[:, 2, 1] = sa; R[:, 2, 2] = ca * cb
+    state = np.zeros((18, B), dtype)
+    state[3:12] = R.transpose(2, 1, 0).reshape(9, B)  # column-major: row r + 3*col c
+    state[12] = 0.1
+    ref = np.zeros((9, B), dtype)
+    ref[8] = 1.0
+    return state, ref
+
+
+class BatchUprightMPC:
+    """B independent uprightmpc2 controllers (+ plants), one GPU lane each."""
+
+    def __init__(self, B, dtype=torch.float32, device="cuda", **params):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchUprightMPC needs a HIP device; there is no CPU path")
+        self.L = _lib.lib()
+        self.B, self.dtype, self.device = int(B), dtype, torch.device(device)
+        self.prm = _lib.default_params()
+        for k, v in params.items():
+            if k == "Ib":
+                for i in range(3):
+                    self.prm.Ib[i] = float(v[i])
+            else:
+                if not hasattr(self.prm, k):
+                    raise TypeError("unknown parameter %r" % k)
+                setattr(self.prm, k, v)
+        with torch.cuda.device(self.device):
+            self.h = self.L.umpcBatchCreate(C.byref(self.prm), self.B, _DT[dtype])
+        if not self.h:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        z = lambda r, dt=dtype: torch.zeros((r, self.B), dtype=dt, device=self.device)
+        self.state, self.ctrl, self.ref = z(_lib.STATE_ROWS), z(_lib.CTRL_ROWS), z(_lib.REF_ROWS)
+        self.out, self.stats, self.info = z(_lib.OUT_ROWS), z(_lib.STAT_ROWS), z(2)
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.Ib = None
+        self.gain = None
+        self.actualT0 = None
+        self.reset_controller()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.umpcBatchDestroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc):
+        if rc:
+            raise RuntimeError(self.L.umpcLastError().decode())
+
+    def reset_controller(self):
+        self._check(self.L.umpcBatchInitCtrl(self.h, _ptr(self.ctrl), self._stream()))
+        self.stats.zero_()
+
+    def set_state(self, state, ref=None):
+        self.state.copy_(torch.as_tensor(state, dtype=self.dtype))
+        if ref is not None:
+            self.ref.copy_(torch.as_tensor(ref, dtype=self.dtype))
+
+    def rollout(self, K=1):
+        """K closed-loop MPC steps (QP + nsub plant substeps each) in one launch."""
+        with torch.cuda.device(self.device):
+            self._check(self.L.umpcBatchRollout(self.h, int(K), _ptr(self.state), _ptr(self.ctrl), _ptr(self.ref),
+                                                _ptr(self.actualT0), _ptr(self.Ib), _ptr(self.gain), _ptr(self.out),
+                                                _ptr(self.stats), _ptr(self.status), _ptr(self.info), self._stream()))
+
+    def update(self):
+        """One controller step on the current state (= umpcUpdate for every robot); no plant."""
+        with torch.cuda.device(self.device):
+            self._check(self.L.umpcBatchUpdate(self.h, _ptr(self.state), _ptr(self.ctrl), _ptr(self.ref),
+                                               _ptr(self.actualT0), _ptr(self.Ib), _ptr(self.out), _ptr(self.status),
+                                               _ptr(self.info), self._stream()))
+
+    def plant(self, u, nsub=1):
+        u = torch.as_tensor(u, dtype=self.dtype, device=self.device).contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self.L.umpcBatchPlant(self.h, int(nsub), _ptr(self.state), _ptr(u), _ptr(self.Ib),
+                                              _ptr(self.gain), self._stream()))
+
+    def assemble(self):
+        """Raw QP data (l, u, q, Px, Ax) for the current state; parity/debug."""
+        z = lambda r: torch.empty((r, self.B), dtype=self.dtype, device=self.device)
+        l, u, q, Px, Ax = z(39), z(39), z(45), z(45), z(48)
+        with torch.cuda.device(self.device):
+            self._check(self.L.umpcBatchAssemble(self.h, _ptr(self.state), _ptr(self.ctrl), _ptr(self.ref),
+                                                 _ptr(self.Ib), _ptr(l), _ptr(u), _ptr(q), _ptr(Px), _ptr(Ax),
+                                                 self._stream()))
+        return l, u, q, Px, Ax
+
+    def metrics(self, nsteps):
+        """logMetric pair per robot (template/uprightmpc2.py:161-175): mean |p|^2, mean |tau|^2
+        over the nsteps*nsub plant substeps accumulated so far."""
+        n = max(1, int(nsteps) * int(self.prm.nsub))
+        return self.stats / n

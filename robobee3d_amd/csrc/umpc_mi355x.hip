@@ -1,0 +1,450 @@
+// libumpc_mi355x.so: HIP kernels (gfx950) + the C ABI declared in include/umpc_mi355x.h.
+// No torch, no reference code, no CPU fallback: every entry point launches a kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "../../include/umpc_mi355x.h"
+#include "umpc_step.h"
+
+namespace {
+
+using umpc::DevParams;
+using namespace umpcgen;
+
+constexpr int kBlock = 64;  // one wavefront per workgroup: 64 robots, no barriers anywhere
+
+thread_local std::string g_err;
+int fail(hipError_t e, const char *what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <typename T>
+struct RolloutArgs {
+  DevParams<T> prm;
+  int B, K;
+  T *state;        // [18][B]
+  T *ctrl;         // [127][B]
+  const T *ref;    // [9][B]
+  const T *actualT0;
+  const T *Ib;     // [3][B] or null
+  const T *gain;   // [B] or null
+  T *out;          // [9][B]
+  T *stats;        // [2][B] or null
+  int32_t *status; // [B] or null
+  T *info;         // [2][B] or null
+};
+
+// K closed-loop steps per robot; lane b of the grid owns robot b.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(RolloutArgs<T> a) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= a.B) return;
+  const size_t B = (size_t)a.B;
+  const DevParams<T> &prm = a.prm;
+
+  T p[3], R[9], dq[6], ref[9], Ib[3], Ibi[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = a.state[(size_t)i * B + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = a.state[(size_t)(3 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dq[i] = a.state[(size_t)(12 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ref[i] = a.ref[(size_t)i * B + b];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Ib[i] = a.Ib ? a.Ib[(size_t)i * B + b] : prm.Ib[i];
+    Ibi[i] = T(1) / Ib[i];  // uprightmpc2.c:50-52
+  }
+  const T gain = a.gain ? a.gain[b] : T(1);
+
+  T x[NX], y[NC], z[NC], T0, Eprev3[N];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) x[j] = a.ctrl[(size_t)j * B + b];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) y[i] = a.ctrl[(size_t)(NX + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) z[i] = a.ctrl[(size_t)(NX + NC + i) * B + b];
+  T0 = a.ctrl[(size_t)(NX + 2 * NC) * B + b];
+#pragma unroll
+  for (int k = 0; k < N; ++k) Eprev3[k] = a.ctrl[(size_t)(NX + 2 * NC + 1 + k) * B + b];
+  if (a.actualT0) {
+    const T t = a.actualT0[b];
+    if (t >= T(0)) T0 = t;  // uprightmpc2.c:215-216
+  }
+
+  T uq[3] = {T(0), T(0), T(0)}, acc[6], pri = T(0), dua = T(0);
+  T s_err = a.stats ? a.stats[b] : T(0), s_eff = a.stats ? a.stats[B + b] : T(0);
+  int status = umpc::ST_UNSOLVED;
+#pragma nounroll
+  for (int k = 0; k < a.K; ++k) {
+    status = umpc::mpc_step(prm, Ibi, p, R, dq, ref, x, y, z, T0, Eprev3, uq, acc, pri, dua);
+    // input limit, template/uprightmpc2.py:148-149
+    uq[1] = umpc::umpc_min(umpc::umpc_max(uq[1], -prm.taulim), prm.taulim);
+    uq[2] = umpc::umpc_min(umpc::umpc_max(uq[2], -prm.taulim), prm.taulim);
+#pragma nounroll
+    for (int s = 0; s < prm.nsub; ++s) {
+      umpc::plant_step(p, R, dq, uq, prm.dtsim, Ib, gain, prm.plant_mode);
+      s_err += p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+      s_eff += uq[1] * uq[1] + uq[2] * uq[2];
+    }
+  }
+
+  if (prm.nsub > 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.state[(size_t)i * B + b] = p[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.state[(size_t)(3 + i) * B + b] = R[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.state[(size_t)(12 + i) * B + b] = dq[i];
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) a.ctrl[(size_t)j * B + b] = x[j];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) a.ctrl[(size_t)(NX + i) * B + b] = y[i];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) a.ctrl[(size_t)(NX + NC + i) * B + b] = z[i];
+  a.ctrl[(size_t)(NX + 2 * NC) * B + b] = T0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) a.ctrl[(size_t)(NX + 2 * NC + 1 + k) * B + b] = Eprev3[k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) a.out[(size_t)i * B + b] = uq[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) a.out[(size_t)(3 + i) * B + b] = acc[i];
+  if (a.stats) { a.stats[b] = s_err; a.stats[B + b] = s_eff; }
+  if (a.status) a.status[b] = status;
+  if (a.info) { a.info[b] = pri; a.info[B + b] = dua; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void umpc_plant_kernel(DevParams<T> prm, int B_, int nsub, T *state,
+                                                            const T *u, const T *IbA, const T *gainA) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B_) return;
+  const size_t B = (size_t)B_;
+  T p[3], R[9], dq[6], uq[3], Ib[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { p[i] = state[(size_t)i * B + b]; uq[i] = u[(size_t)i * B + b]; }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = state[(size_t)(3 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dq[i] = state[(size_t)(12 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Ib[i] = IbA ? IbA[(size_t)i * B + b] : prm.Ib[i];
+  const T gain = gainA ? gainA[b] : T(1);
+#pragma nounroll
+  for (int s = 0; s < nsub; ++s) umpc::plant_step(p, R, dq, uq, prm.dtsim, Ib, gain, prm.plant_mode);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) state[(size_t)i * B + b] = p[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) state[(size_t)(3 + i) * B + b] = R[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) state[(size_t)(12 + i) * B + b] = dq[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void umpc_assemble_kernel(DevParams<T> prm, int B_, const T *state,
+                                                               const T *ctrl, const T *refA, const T *IbA, T *l,
+                                                               T *u, T *q, T *Px, T *Ax) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B_) return;
+  const size_t B = (size_t)B_;
+  T p[3], R[9], dq[6], ref[9], Ibi[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = state[(size_t)i * B + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = state[(size_t)(3 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dq[i] = state[(size_t)(12 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ref[i] = refA[(size_t)i * B + b];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Ibi[i] = T(1) / (IbA ? IbA[(size_t)i * B + b] : prm.Ib[i]);
+  const T T0 = ctrl[(size_t)(NX + 2 * NC) * B + b];
+  umpc::RawQP<T> qp;
+  umpc::assemble(prm, Ibi, T0, p, R, dq, ref, qp);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    l[(size_t)i * B + b] = qp.l[i];
+    u[(size_t)i * B + b] = i < NEQ ? qp.l[i] : qp.u3[i - NEQ];
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) { q[(size_t)j * B + b] = qp.q[j]; Px[(size_t)j * B + b] = qp.Px[j]; }
+  // Ax_data order: [T0dt x3(N-2) | dt x6N | s0 x3N | Btau x6N], uprightmpc2.c:161-179
+  int o = 0;
+#pragma unroll
+  for (int k = 0; k < 3 * (N - 2); ++k) Ax[(size_t)(o++) * B + b] = qp.dtT0;
+#pragma unroll
+  for (int k = 0; k < 6 * N; ++k) Ax[(size_t)(o++) * B + b] = prm.dt;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ax[(size_t)(o++) * B + b] = qp.s0dt[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Ax[(size_t)(o++) * B + b] = qp.Btaudt[i];
+}
+
+template <typename T>
+__global__ void umpc_init_ctrl_kernel(int B_, T *ctrl) {
+  const size_t B = (size_t)B_;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)UMPC_CTRL_ROWS * B;
+       i += (size_t)gridDim.x * blockDim.x)
+    ctrl[i] = (i / B) >= (size_t)(NX + 2 * NC + 1) ? T(1) : T(0);
+}
+
+template <typename T>
+DevParams<T> make_dev(const umpc_batch_params_t &p) {
+  DevParams<T> d;
+  d.dt = (T)p.dt; d.g = (T)p.g;
+  d.Tmax = (T)p.TtoWmax * (T)p.g;  // uprightmpc2.c:25
+  d.wpr = (T)p.wpr; d.wpf = (T)p.wpf; d.ws = (T)p.ws; d.wvr = (T)p.wvr; d.wvf = (T)p.wvf;
+  d.wds = (T)p.wds; d.wthrust = (T)p.wthrust; d.wmom = (T)p.wmom;
+  for (int i = 0; i < 3; ++i) d.Ib[i] = (T)p.Ib[i];
+  d.dtsim = (T)p.dtsim; d.taulim = (T)p.taulim;
+  d.maxIter = p.maxIter; d.nsub = p.nsub; d.plant_mode = p.plant_mode;
+  return d;
+}
+
+}  // namespace
+
+struct umpc_batch {
+  umpc_batch_params_t prm;
+  int B, dtype;
+};
+
+template <typename T>
+static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *ctrl, const void *ref,
+                          const void *actualT0, const void *Ib, const void *gain, void *out, void *stats,
+                          int32_t *status, void *info, void *stream) {
+  if (!state || !ctrl || !ref || !out) { g_err = "umpcBatchRollout: null array"; return -1; }
+  RolloutArgs<T> a;
+  a.prm = make_dev<T>(h->prm);
+  a.prm.nsub = nsub;
+  a.B = h->B; a.K = K;
+  a.state = (T *)state; a.ctrl = (T *)ctrl; a.ref = (const T *)ref; a.actualT0 = (const T *)actualT0;
+  a.Ib = (const T *)Ib; a.gain = (const T *)gain; a.out = (T *)out; a.stats = (T *)stats;
+  a.status = status; a.info = (T *)info;
+  const int grid = (h->B + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(umpc_rollout_kernel<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
+}
+
+extern "C" {
+
+const char *umpcLastError(void) { return g_err.c_str(); }
+const int *umpcAxIdx(void) { return umpcgen::kAxIdx; }
+const int *umpcKKTPerm(void) { return umpcgen::kPerm; }
+int umpcNnzL(void) { return umpcgen::NNZL; }
+const char *umpcKernelName(int dtype, int) {
+  return dtype == UMPC_F64 ? "umpc_rollout_kernel<double>" : "umpc_rollout_kernel<float>";
+}
+
+void umpcBatchDefaultParams(umpc_batch_params_t *p) {
+  // createMPC, template/template_controllers.py:260-263,279; controlTest, template/uprightmpc2.py:87
+  p->dt = 5; p->g = 9.81e-3; p->TtoWmax = 2; p->ws = 1e1; p->wds = 1e3; p->wpr = 1; p->wpf = 5;
+  p->wvr = 1e3; p->wvf = 2e3; p->wthrust = 1e-1; p->wmom = 1e-2;
+  p->Ib[0] = 3333; p->Ib[1] = 3333; p->Ib[2] = 1000;  // template/genqp.py:22
+  p->maxIter = 50; p->dtsim = 0.2; p->taulim = 100; p->nsub = 25; p->plant_mode = 0;
+}
+
+umpc_batch_t *umpcBatchCreate(const umpc_batch_params_t *prm, int B, int dtype) {
+  if (!prm || B <= 0 || (dtype != UMPC_F32 && dtype != UMPC_F64) || prm->maxIter < 0 || prm->nsub < 0) {
+    g_err = "umpcBatchCreate: bad argument";
+    return nullptr;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    g_err = "umpcBatchCreate: no HIP device (this library has no CPU path)";
+    return nullptr;
+  }
+  umpc_batch *h = new umpc_batch;
+  h->prm = *prm; h->B = B; h->dtype = dtype;
+  return h;
+}
+void umpcBatchDestroy(umpc_batch_t *h) { delete h; }
+int umpcBatchSize(const umpc_batch_t *h) { return h->B; }
+int umpcBatchDtype(const umpc_batch_t *h) { return h->dtype; }
+
+int umpcBatchInitCtrl(umpc_batch_t *h, void *ctrl, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (h->dtype == UMPC_F32) hipLaunchKernelGGL(umpc_init_ctrl_kernel<float>, dim3(256), dim3(256), 0, s, h->B, (float *)ctrl);
+  else hipLaunchKernelGGL(umpc_init_ctrl_kernel<double>, dim3(256), dim3(256), 0, s, h->B, (double *)ctrl);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchInitCtrl");
+}
+
+int umpcBatchRollout(umpc_batch_t *h, int K, void *state, void *ctrl, const void *ref, const void *actualT0,
+                     const void *Ib, const void *gain, void *out, void *stats, int32_t *status, void *info,
+                     void *stream) {
+  if (K < 0) { g_err = "umpcBatchRollout: K < 0"; return -1; }
+  return h->dtype == UMPC_F32
+             ? launch_rollout<float>(h, K, h->prm.nsub, state, ctrl, ref, actualT0, Ib, gain, out, stats, status, info, stream)
+             : launch_rollout<double>(h, K, h->prm.nsub, state, ctrl, ref, actualT0, Ib, gain, out, stats, status, info, stream);
+}
+
+int umpcBatchUpdate(umpc_batch_t *h, const void *state, void *ctrl, const void *ref, const void *actualT0,
+                    const void *Ib, void *out, int32_t *status, void *info, void *stream) {
+  return h->dtype == UMPC_F32
+             ? launch_rollout<float>(h, 1, 0, (void *)state, ctrl, ref, actualT0, Ib, nullptr, out, nullptr, status, info, stream)
+             : launch_rollout<double>(h, 1, 0, (void *)state, ctrl, ref, actualT0, Ib, nullptr, out, nullptr, status, info, stream);
+}
+
+int umpcBatchPlant(umpc_batch_t *h, int nsub, void *state, const void *u, const void *Ib, const void *gain,
+                   void *stream) {
+  const int grid = (h->B + kBlock - 1) / kBlock;
+  if (h->dtype == UMPC_F32)
+    hipLaunchKernelGGL(umpc_plant_kernel<float>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                       make_dev<float>(h->prm), h->B, nsub, (float *)state, (const float *)u, (const float *)Ib,
+                       (const float *)gain);
+  else
+    hipLaunchKernelGGL(umpc_plant_kernel<double>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                       make_dev<double>(h->prm), h->B, nsub, (double *)state, (const double *)u, (const double *)Ib,
+                       (const double *)gain);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchPlant");
+}
+
+int umpcBatchAssemble(umpc_batch_t *h, const void *state, const void *ctrl, const void *ref, const void *Ib,
+                      void *l, void *u, void *q, void *Px, void *Ax, void *stream) {
+  const int grid = (h->B + kBlock - 1) / kBlock;
+  if (h->dtype == UMPC_F32)
+    hipLaunchKernelGGL(umpc_assemble_kernel<float>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                       make_dev<float>(h->prm), h->B, (const float *)state, (const float *)ctrl, (const float *)ref,
+                       (const float *)Ib, (float *)l, (float *)u, (float *)q, (float *)Px, (float *)Ax);
+  else
+    hipLaunchKernelGGL(umpc_assemble_kernel<double>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                       make_dev<double>(h->prm), h->B, (const double *)state, (const double *)ctrl,
+                       (const double *)ref, (const double *)Ib, (double *)l, (double *)u, (double *)q, (double *)Px,
+                       (double *)Ax);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchAssemble");
+}
+
+// ---------------------------------------------------------------------------
+// Part 1: the reference's own three symbols, B = 1 on the GPU
+// ---------------------------------------------------------------------------
+namespace {
+struct Single {
+  umpc_batch_t *h = nullptr;
+  float *dev = nullptr;  // state18 | ctrl127 | ref9 | aT0 1 | out9 | info2 | l39 u39 q45 Px45 Ax48 | status(int)
+  int status = umpc::ST_UNSOLVED;
+};
+std::mutex g_mu;
+std::map<const UprightMPC_t *, Single> g_single;
+constexpr int O_STATE = 0, O_CTRL = 18, O_REF = O_CTRL + 127, O_AT0 = O_REF + 9, O_OUT = O_AT0 + 1,
+              O_INFO = O_OUT + 9, O_L = O_INFO + 2, O_U = O_L + 39, O_Q = O_U + 39, O_PX = O_Q + 45,
+              O_AX = O_PX + 45, O_STATUS = O_AX + 48, O_TOTAL = O_STATUS + 1;
+}  // namespace
+
+void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, float wds, float wpr, float wpf,
+              float wvr, float wvf, float wthrust, float wmom, const float Ib[3], int maxIter) {
+  // host-visible part of uprightmpc2.c:19-118
+  memset(up, 0, sizeof(*up));
+  up->dt = dt; up->g = g; up->Tmax = TtoWmax * g;
+  for (int i = 0; i < 3; ++i) {
+    up->Qyr[i] = wpr; up->Qyf[i] = wpf; up->Qyr[3 + i] = up->Qyf[3 + i] = ws;
+    up->Qdyr[i] = wvr; up->Qdyf[i] = wvf; up->Qdyr[3 + i] = up->Qdyf[3 + i] = wds;
+  }
+  up->R[0] = wthrust; up->R[1] = up->R[2] = wmom;
+  up->c0[2] = -g;
+  up->T0 = 0;
+  up->e3h[1] = 1; up->e3h[3] = -1;
+  up->e3hIbi[1] = 1.0f / Ib[0]; up->e3hIbi[3] = -(1.0f / Ib[1]);
+  for (int i = 0; i < UMPC_nAdata; ++i) up->Ax_idx[i] = umpcgen::kAxIdx[i];
+  up->nAxT0dt = 3 * (UMPC_N - 2);
+  up->nAxdt = up->nAxT0dt + 6 * UMPC_N;
+
+  std::lock_guard<std::mutex> lk(g_mu);
+  Single &s = g_single[up];
+  if (s.h) umpcBatchDestroy(s.h);
+  umpc_batch_params_t p;
+  umpcBatchDefaultParams(&p);
+  p.dt = dt; p.g = g; p.TtoWmax = TtoWmax; p.ws = ws; p.wds = wds; p.wpr = wpr; p.wpf = wpf; p.wvr = wvr;
+  p.wvf = wvf; p.wthrust = wthrust; p.wmom = wmom; p.maxIter = maxIter; p.nsub = 0;
+  for (int i = 0; i < 3; ++i) p.Ib[i] = Ib[i];
+  s.h = umpcBatchCreate(&p, 1, UMPC_F32);
+  if (!s.h) { fprintf(stderr, "umpcInit: %s\n", g_err.c_str()); return; }
+  if (!s.dev && hipMalloc((void **)&s.dev, O_TOTAL * sizeof(float)) != hipSuccess) {
+    fprintf(stderr, "umpcInit: hipMalloc failed\n");
+    umpcBatchDestroy(s.h); s.h = nullptr; return;
+  }
+  umpcBatchInitCtrl(s.h, s.dev + O_CTRL, nullptr);
+  (void)hipDeviceSynchronize();
+}
+
+int umpcUpdate(UprightMPC_t *up, float uquad[3], float accdes[6], const float p0[3], const float R0[9],
+               const float dq0[6], const float pdes[3], const float dpdes[3], const float sdes[3],
+               float actualT0) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_single.find(up);
+  if (it == g_single.end() || !it->second.h) {
+    fprintf(stderr, "umpcUpdate: controller not initialised or no GPU (no CPU path exists)\n");
+    return 1;
+  }
+  Single &s = it->second;
+  float hin[18 + 9 + 1];
+  memcpy(hin, p0, 12); memcpy(hin + 3, R0, 36); memcpy(hin + 12, dq0, 24);
+  float href[10];
+  memcpy(href, pdes, 12); memcpy(href + 3, dpdes, 12); memcpy(href + 6, sdes, 12); href[9] = actualT0;
+  (void)hipMemcpy(s.dev + O_STATE, hin, 18 * sizeof(float), hipMemcpyHostToDevice);
+  (void)hipMemcpy(s.dev + O_REF, href, 10 * sizeof(float), hipMemcpyHostToDevice);
+  // the T0 the assembly will see (uprightmpc2.c:215-216) -> keep the POD's debug fields exact
+  if (actualT0 >= 0) (void)hipMemcpy(s.dev + O_CTRL + 123, &actualT0, sizeof(float), hipMemcpyHostToDevice);
+  int rc = umpcBatchAssemble(s.h, s.dev + O_STATE, s.dev + O_CTRL, s.dev + O_REF, nullptr, s.dev + O_L,
+                             s.dev + O_U, s.dev + O_Q, s.dev + O_PX, s.dev + O_AX, nullptr);
+  if (!rc)
+    rc = umpcBatchUpdate(s.h, s.dev + O_STATE, s.dev + O_CTRL, s.dev + O_REF, s.dev + O_AT0, nullptr,
+                         s.dev + O_OUT, (int32_t *)(s.dev + O_STATUS), s.dev + O_INFO, nullptr);
+  if (rc) return 1;
+  float hout[O_TOTAL - O_OUT];
+  if (hipMemcpy(hout, s.dev + O_OUT, sizeof(hout), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  memcpy(uquad, hout, 12); memcpy(accdes, hout + 3, 24);
+  memcpy(up->l, hout + (O_L - O_OUT), 39 * 4); memcpy(up->u, hout + (O_U - O_OUT), 39 * 4);
+  memcpy(up->q, hout + (O_Q - O_OUT), 45 * 4); memcpy(up->Px_data, hout + (O_PX - O_OUT), 45 * 4);
+  memcpy(up->Ax_data, hout + (O_AX - O_OUT), 48 * 4);
+  memcpy(&s.status, hout + (O_STATUS - O_OUT), 4);
+  up->T0 = uquad[0];  // uprightmpc2.c:256-257
+  return 0;
+}
+
+namespace { UprightMPC_t g_up; int g_inited = 0; }
+void umpcS(float uquad[3], float accdes[6], const float p0[3], const float R0[9], const float dq0[6],
+           const float pdes[3], const float dpdes[3], const float sdes[3], float dt, float g, float TtoWmax,
+           float ws, float wds, float wpr, float wpf, float wvr, float wvf, float wthrust, float wmom,
+           const float Ib[3], int maxIter, float actualT0) {
+  if (!g_inited) {  // uprightmpc2.c:279-283
+    umpcInit(&g_up, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, maxIter);
+    g_inited = 1;
+  }
+  umpcUpdate(&g_up, uquad, accdes, p0, R0, dq0, pdes, dpdes, sdes, actualT0);
+}
+
+int umpcLastStatus(const UprightMPC_t *up) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_single.find(up);
+  return it == g_single.end() ? umpc::ST_UNSOLVED : it->second.status;
+}
+void umpcRelease(UprightMPC_t *up) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_single.find(up);
+  if (it == g_single.end()) return;
+  if (it->second.h) umpcBatchDestroy(it->second.h);
+  if (it->second.dev) (void)hipFree(it->second.dev);
+  g_single.erase(it);
+}
+
+}  // extern "C"

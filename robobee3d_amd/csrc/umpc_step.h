@@ -1,0 +1,545 @@
+// MI355X (gfx950) device code for one uprightmpc2 closed-loop step.
+//
+// Mapping: ONE LANE = ONE ROBOT. A 64-lane wavefront carries 64 independent
+// robots; there is no cross-lane communication anywhere on the path, every
+// sparse index is a literal baked in by codegen.py (umpc_gen.h), and all HBM
+// traffic is SoA [row][B] so that a wave load/store of one row is one
+// contiguous 256-byte (fp32) segment.
+//
+// What one step computes (reference file:line, template/uprightmpc2/...):
+//   assembly                  uprightmpc2.c:209-245, 126-207
+//   constraint classification osqp.c:784-833 -> auxil.c:103-145 (update_rho_vec)
+//   Ruiz equilibration x10    scaling.c:44-156
+//   KKT fill + LDL'           kkt.c:184-222, qdldl.c:86-247
+//   ADMM x maxIter            osqp.c:354-370, auxil.c:164-228, qdldl_interface.c:322-369
+//   residuals + status        auxil.c:243-362, 517-565, 684-789; osqp.c:524-573
+//   extraction                uprightmpc2.c:253-269
+//   plant substeps            template/genqp.py:24-41, template/uprightmpc2.py:148-151
+//
+// Numerics: every scalar is T (float for the reference's DFLOAT build). FMAs
+// are used where the reference has a multiply followed by an add on the sparse
+// kernels (explicit UMPC_FMA); everything else is compiled with
+// -ffp-contract=off. The problem data is rebuilt from raw values on every step
+// (the reference un-scales and re-scales its persistent copy,
+// osqp.c:1211-1248, which is the same up to round-off).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "umpc_gen.h"
+
+namespace umpc {
+
+using namespace umpcgen;
+
+template <typename T>
+struct DevParams {
+  T dt, g, Tmax;
+  T wpr, wpf, ws, wvr, wvf, wds, wthrust, wmom;
+  T Ib[3];
+  T dtsim, taulim;
+  int maxIter, nsub, plant_mode;
+};
+
+// OSQP constants (template/uprightmpc2/constants.h:59-110, workspace.c:561)
+#define RHO_EQ 100.0   /* RHO_EQ_OVER_RHO_INEQ * rho, rounded to T */
+#define RINV_EQ 0.01   /* 1 / RHO_EQ */
+#define UMPC_RHO 0.1
+#define UMPC_RHO_MIN 1e-6
+#define UMPC_RHO_TOL 1e-4
+#define UMPC_MIN_SCALING 1e-4
+#define UMPC_MAX_SCALING 1e4
+#define UMPC_INFTY 1e30
+#define UMPC_SCALING_ITERS 10
+
+enum { ST_SOLVED = 1, ST_SOLVED_INACC = 2, ST_PINF_INACC = 3, ST_DINF_INACC = 4,
+       ST_MAX_ITER = -2, ST_PINF = -3, ST_DINF = -4, ST_NON_CVX = -7, ST_UNSOLVED = -10 };
+
+template <typename T> __device__ __forceinline__ T umpc_abs(T v) { return v < T(0) ? -v : v; }
+template <typename T> __device__ __forceinline__ T umpc_max(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T umpc_min(T a, T b) { return a < b ? a : b; }
+__device__ __forceinline__ float umpc_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double umpc_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float umpc_sqrt(float v) { return __fsqrt_rn(v); }
+__device__ __forceinline__ double umpc_sqrt(double v) { return __dsqrt_rn(v); }
+__device__ __forceinline__ float umpc_sin(float v) { return sinf(v); }
+__device__ __forceinline__ double umpc_sin(double v) { return sin(v); }
+__device__ __forceinline__ float umpc_cos(float v) { return cosf(v); }
+__device__ __forceinline__ double umpc_cos(double v) { return cos(v); }
+
+// limit_scaling, scaling.c:7-14
+template <typename T> __device__ __forceinline__ T limit_scaling(T v) {
+  v = v < T(UMPC_MIN_SCALING) ? T(1) : v;
+  v = v > T(UMPC_MAX_SCALING) ? T(UMPC_MAX_SCALING) : v;
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// plant: template/genqp.py:24-41 (R column-major, dq = (v_world, omega_body))
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void plant_vf(const T (&R)[9], const T (&dq)[6], const T (&u)[3],
+                                         const T (&Ib)[3], T gain, T (&ddq)[6]) {
+  const T wx = dq[3], wy = dq[4], wz = dq[5];
+  const T Th = gain * u[0];
+  ddq[0] = Th * R[6];
+  ddq[1] = Th * R[7];
+  ddq[2] = Th * R[8] - T(9.81e-3);
+  const T hx = Ib[0] * wx, hy = Ib[1] * wy, hz = Ib[2] * wz;
+  const T cx = wy * hz - wz * hy;
+  const T cy = wz * hx - wx * hz;
+  const T cz = wx * hy - wy * hx;
+  ddq[3] = (-cx + u[1]) / Ib[0];
+  ddq[4] = (-cy + u[2]) / Ib[1];
+  ddq[5] = (-cz) / Ib[2];
+}
+
+// R <- R expm(skew(w) h): Rodrigues form of scipy.linalg.expm(skew(w) dt), genqp.py:39
+template <typename T>
+__device__ __forceinline__ void plant_rot(T (&R)[9], T w0, T w1, T w2, T h) {
+  const T ax = w0 * h, ay = w1 * h, az = w2 * h;
+  const T t = ax * ax + ay * ay + az * az;
+  T a, b;
+  if (t < T(1e-2)) {
+    a = T(1) - t * (T(1) / 6 - t * (T(1) / 120 - t * (T(1) / 5040 - t * (T(1) / 362880))));
+    b = T(0.5) - t * (T(1) / 24 - t * (T(1) / 720 - t * (T(1) / 40320 - t * (T(1) / 3628800))));
+  } else {
+    const T th = umpc_sqrt(t);
+    a = umpc_sin(th) / th;
+    b = (T(1) - umpc_cos(th)) / t;
+  }
+  T e[3][3];
+  e[0][0] = T(1) - b * (ay * ay + az * az);
+  e[1][1] = T(1) - b * (ax * ax + az * az);
+  e[2][2] = T(1) - b * (ax * ax + ay * ay);
+  e[0][1] = -a * az + b * ax * ay;
+  e[1][0] = a * az + b * ax * ay;
+  e[0][2] = a * ay + b * ax * az;
+  e[2][0] = -a * ay + b * ax * az;
+  e[1][2] = -a * ax + b * ay * az;
+  e[2][1] = a * ax + b * ay * az;
+  T Rn[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Rn[r + 3 * c] = R[r] * e[0][c] + R[r + 3] * e[1][c] + R[r + 6] * e[2][c];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+}
+
+template <typename T>
+__device__ __forceinline__ void plant_step(T (&p)[3], T (&R)[9], T (&dq)[6], const T (&u)[3], T dt,
+                                           const T (&Ib)[3], T gain, int mode) {
+  if (mode == 0) {
+    T ddq[6];
+    plant_vf(R, dq, u, Ib, gain, ddq);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = p[i] + dt * dq[i];
+    plant_rot(R, dq[3], dq[4], dq[5], dt);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dq[i] = dq[i] + dt * ddq[i];
+  } else {
+    // build-defined classical RK4 on y = (p, R, dq), dR/dt = R skew(w)
+    T yv0[18], ys[18], acc[18], k[18];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yv0[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) yv0[3 + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) yv0[12 + i] = dq[i];
+    const T cs[4] = {T(0), T(0.5), T(0.5), T(1)};
+    const T wt[4] = {T(1), T(2), T(2), T(1)};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) ys[i] = s ? yv0[i] + cs[s] * dt * k[i] : yv0[i];
+      T Rs[9], dqs[6], dd[6];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rs[i] = ys[3 + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dqs[i] = ys[12 + i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) k[i] = dqs[i];
+      const T wx = dqs[3], wy = dqs[4], wz = dqs[5];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        k[3 + r + 0] = Rs[r + 3] * wz - Rs[r + 6] * wy;
+        k[3 + r + 3] = -Rs[r + 0] * wz + Rs[r + 6] * wx;
+        k[3 + r + 6] = Rs[r + 0] * wy - Rs[r + 3] * wx;
+      }
+      plant_vf(Rs, dqs, u, Ib, gain, dd);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) k[12 + i] = dd[i];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) acc[i] = s ? acc[i] + wt[s] * k[i] : k[i];
+    }
+    // same association as the oracle: (k1 + 2 k2 + 2 k3 + k4)
+#pragma unroll
+    for (int i = 0; i < 18; ++i) ys[i] = yv0[i] + dt * acc[i] / T(6);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = ys[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = ys[3 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dq[i] = ys[12 + i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// QP assembly: uprightmpc2.c:209-245 (umpcUpdate head), 126-180, 182-207
+// ---------------------------------------------------------------------------
+template <typename T>
+struct RawQP {
+  T l[NC], u3[N];  // u == l on the NEQ dynamics rows
+  T q[NX], Px[NX];
+  T dtT0, s0dt[3], Btaudt[6];
+};
+
+template <typename T>
+__device__ __forceinline__ void assemble(const DevParams<T> &prm, const T (&Ibi)[3], T T0, const T (&p0)[3],
+                                         const T (&R0)[9], const T (&dq0)[6], const T (&ref)[9], RawQP<T> &qp) {
+  const T dt = prm.dt;
+  T s0[3], ds0[3], Btau[6], yv0[NY], dy0[NY], yv1[NY], ydes[NY], dydes[NY];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    s0[r] = R0[6 + r];
+    // ds0 = -R0 e3h w,  e3h w = (-wy, wx, 0)
+    ds0[r] = -(R0[r] * (-dq0[4]) + R0[r + 3] * dq0[3]);
+    // Btau = (-R0 e3h Ib^-1)[:, :2]
+    Btau[r] = -(R0[r + 3] * Ibi[0]);
+    Btau[3 + r] = -(R0[r] * (-Ibi[1]));
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    yv0[i] = p0[i]; yv0[3 + i] = s0[i];
+    dy0[i] = dq0[i]; dy0[3 + i] = ds0[i];
+    ydes[i] = ref[i]; ydes[3 + i] = ref[6 + i];
+    dydes[i] = ref[3 + i]; dydes[3 + i] = T(0);
+  }
+  T c0[NY] = {T(0), T(0), -prm.g, T(0), T(0), T(0)};
+#pragma unroll
+  for (int i = 0; i < NY; ++i) { yv1[i] = yv0[i] + dt * dy0[i]; }
+#pragma unroll
+  for (int i = 0; i < N * NY; ++i) qp.l[i] = T(0);
+#pragma unroll
+  for (int i = 0; i < NY; ++i) qp.l[i] = -yv1[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      T v;
+      if (k == 0) v = -dy0[i] - dt * (i < 3 ? T0 * yv0[i + 3] : T(0)) - dt * c0[i];
+      else if (k == 1) v = -dt * (i < 3 ? T0 * yv1[i + 3] : T(0)) - dt * c0[i];
+      else v = -dt * c0[i];
+      qp.l[NY * (N + k) + i] = v;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) { qp.l[NEQ + k] = -T0; qp.u3[k] = prm.Tmax - T0; }
+  qp.dtT0 = dt * T0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) qp.s0dt[i] = dt * s0[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) qp.Btaudt[i] = dt * Btau[i];
+  // objective
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const T wy = i < 3 ? (k == N - 1 ? prm.wpf : prm.wpr) : prm.ws;
+      const T wd = i < 3 ? (k == N - 1 ? prm.wvf : prm.wvr) : prm.wds;
+      qp.Px[k * NY + i] = wy;
+      qp.q[k * NY + i] = -wy * ydes[i];
+      qp.Px[N * NY + k * NY + i] = wd;
+      qp.q[N * NY + k * NY + i] = -wd * dydes[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      qp.Px[2 * N * NY + k * NU + i] = i == 0 ? prm.wthrust : prm.wmom;
+      qp.q[2 * N * NY + k * NU + i] = T(0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one controller step (= umpcUpdate). x, y, z, T0, Eprev3 are the persistent
+// controller record; returns the OSQP status, writes uquad / accdes.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ int mpc_step(const DevParams<T> &prm, const T (&Ibi)[3], const T (&p0)[3],
+                                        const T (&R0)[9], const T (&dq0)[6], const T (&ref)[9], T (&x)[NX],
+                                        T (&y)[NC], T (&z)[NC], T &T0, T (&Eprev3)[N], T (&uquad)[3],
+                                        T (&accdes)[6], T &pri_res_out, T &dua_res_out) {
+  const T sigma = T(1e-6), alpha = T(1.6), oma = T(1.0) - T(1.6);
+  const T eps_abs0 = T(1e-4), eps_rel0 = T(1e-4), eps_pinf0 = T(1e-4), eps_dinf0 = T(1e-4);
+
+  T P[NX], A[NNZA], q[NX], Ds[NX], Es[NC], lo[NC], up3[N], rho3[N], rinv3[N];
+  T cscale;
+  {
+    RawQP<T> qp;
+    assemble(prm, Ibi, T0, p0, R0, dq0, ref, qp);
+#define A_(p) A[p]
+    UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
+#undef A_
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { P[j] = qp.Px[j]; q[j] = qp.q[j]; }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) lo[i] = qp.l[i];
+#pragma unroll
+    for (int k = 0; k < N; ++k) up3[k] = qp.u3[k];
+  }
+  // constraint classification with the PREVIOUS call's E (osqp.c:812-820 -> auxil.c:103-145).
+  // Rows < NEQ have l == u bit-for-bit: always "equality".
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const T ls = lo[NEQ + k] * Eprev3[k], us = up3[k] * Eprev3[k];
+    if ((ls < -T(UMPC_INFTY) * T(UMPC_MIN_SCALING)) && (us > T(UMPC_INFTY) * T(UMPC_MIN_SCALING))) {
+      rho3[k] = T(UMPC_RHO_MIN); rinv3[k] = T(1) / T(UMPC_RHO_MIN);
+    } else if (us - ls < T(UMPC_RHO_TOL)) {
+      rho3[k] = T(RHO_EQ); rinv3[k] = T(RINV_EQ);
+    } else {
+      rho3[k] = T(UMPC_RHO); rinv3[k] = T(1) / T(UMPC_RHO);
+    }
+  }
+
+  // ---- Ruiz equilibration, scaling.c:44-156 -------------------------------
+  cscale = T(1);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) Ds[j] = T(1);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) Es[i] = T(1);
+#define A_(p) A[p]
+#define P_(j) P[j]
+#define DT_(j) Dt[j]
+#define ET_(i) Et[i]
+#pragma nounroll
+  for (int it = 0; it < UMPC_SCALING_ITERS; ++it) {
+    T Dt[NX], Et[NC];
+    UMPC_GEN_RUIZ_NORMS();
+#pragma unroll
+    for (int j = 0; j < NX; ++j) Dt[j] = T(1) / umpc_sqrt(limit_scaling(Dt[j]));
+#pragma unroll
+    for (int i = 0; i < NC; ++i) Et[i] = T(1) / umpc_sqrt(limit_scaling(Et[i]));
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { P[j] = (P[j] * Dt[j]) * Dt[j]; }
+    UMPC_GEN_RUIZ_APPLY_A();
+    T pmean = T(0), qn = T(0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      q[j] = q[j] * Dt[j];
+      Ds[j] = Dt[j] * Ds[j];
+      pmean += umpc_abs(P[j]);
+      qn = umpc_max(qn, umpc_abs(q[j]));
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) Es[i] = Et[i] * Es[i];
+    pmean /= T(NX);
+    qn = limit_scaling(qn);
+    T ct = limit_scaling(umpc_max(pmean, qn));
+    ct = T(1) / ct;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { P[j] *= ct; q[j] *= ct; }
+    cscale *= ct;
+  }
+#undef DT_
+#undef ET_
+  const T cinv = T(1) / cscale;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) lo[i] = lo[i] * Es[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { up3[k] = up3[k] * Es[NEQ + k]; Eprev3[k] = Es[NEQ + k]; }
+
+  // ---- KKT fill + LDL' --------------------------------------------------------
+  T Lx[NNZL], Di[NK];
+  int npos = 0;
+#define LX_(e) Lx[e]
+#define DI_(k) Di[k]
+#define RINV3_(k) rinv3[k]
+#define RHO3_(k) rho3[k]
+  UMPC_GEN_KKT_FACTOR(npos);
+  (void)npos;
+
+  // ---- ADMM, osqp.c:354-370 -------------------------------------------------------
+  T W[NK], dyv[NC], xprev[NX];
+#define W_(k) W[k]
+#define X_(j) x[j]
+#define Y_(i) y[i]
+#define Z_(i) z[i]
+#define Q_(j) q[j]
+#define LO_(i) lo[i]
+#define UP3_(k) up3[k]
+#pragma unroll
+  for (int i = 0; i < NC; ++i) dyv[i] = T(0);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) xprev[j] = x[j];
+#define UMPC_ADMM_DY(i, v)
+#pragma nounroll
+  for (int it = 1; it < prm.maxIter; ++it) {
+    UMPC_GEN_ADMM_ITER();
+  }
+#undef UMPC_ADMM_DY
+#define UMPC_ADMM_DY(i, v) dyv[i] = (v)
+  if (prm.maxIter >= 1) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) xprev[j] = x[j];
+    UMPC_GEN_ADMM_ITER();
+  }
+#undef UMPC_ADMM_DY
+
+  // ---- update_info: residuals (auxil.c:243-307) -----------------------------------
+  T Einv[NC], Dinv[NX];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) Einv[i] = T(1) / Es[i];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) Dinv[j] = T(1) / Ds[j];
+  T Ax[NC], Aty[NX], Px[NX];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) Ax[i] = T(0);
+#define IN_X(j) x[j]
+#define OUT_AX(i) Ax[i]
+  UMPC_GEN_A_MUL(IN_X, OUT_AX);
+#define IN_Y(i) y[i]
+#define OUT_ATY(j) Aty[j]
+  UMPC_GEN_AT_MUL(IN_Y, OUT_ATY);
+  T pri_res = T(0), dua_res = T(0);
+  T nz = T(0), nAx = T(0), nq = T(0), nAty = T(0), nPx = T(0);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    pri_res = umpc_max(pri_res, umpc_abs(Einv[i] * (Ax[i] - z[i])));
+    nz = umpc_max(nz, umpc_abs(Einv[i] * z[i]));
+    nAx = umpc_max(nAx, umpc_abs(Einv[i] * Ax[i]));
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    Px[j] = P[j] * x[j];
+    dua_res = umpc_max(dua_res, umpc_abs(Dinv[j] * ((q[j] + Px[j]) + Aty[j])));
+    nq = umpc_max(nq, umpc_abs(Dinv[j] * q[j]));
+    nAty = umpc_max(nAty, umpc_abs(Dinv[j] * Aty[j]));
+    nPx = umpc_max(nPx, umpc_abs(Dinv[j] * Px[j]));
+  }
+  dua_res = cinv * dua_res;
+  pri_res_out = pri_res;
+  dua_res_out = dua_res;
+
+  // ---- check_termination (auxil.c:684-789), exact then approximate (osqp.c:524-573) --
+  int status = ST_UNSOLVED;
+  if ((pri_res > T(UMPC_INFTY)) || (dua_res > T(UMPC_INFTY))) {
+    status = ST_NON_CVX;
+  } else {
+#pragma nounroll
+    for (int approx = 0; approx < 2 && status == ST_UNSOLVED; ++approx) {
+      const T mul = approx ? T(10) : T(1);
+      const T eps_abs = eps_abs0 * mul, eps_rel = eps_rel0 * mul;
+      const T eps_pinf = eps_pinf0 * mul, eps_dinf = eps_dinf0 * mul;
+      const T eps_prim = eps_abs + eps_rel * umpc_max(nz, nAx);
+      const T eps_dual = eps_abs + eps_rel * (umpc_max(umpc_max(nq, nAty), nPx) * cinv);
+      bool prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual;
+      bool pinf = false, dinf = false;
+      if (!prim_ok) {
+        // is_primal_infeasible, auxil.c:362-424 (all bounds finite here: no projection of delta_y)
+        T ndy = T(0), lhs = T(0);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) ndy = umpc_max(ndy, umpc_abs(dyv[i] * Es[i]));
+        if (ndy > eps_pinf) {
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            const T ui = i < NEQ ? lo[i] : up3[i - NEQ];
+            lhs += ui * umpc_max(dyv[i], T(0)) + lo[i] * umpc_min(dyv[i], T(0));
+          }
+          if (lhs < -eps_pinf * ndy) {
+            T Atdy[NX];
+#define IN_DY(i) dyv[i]
+#define OUT_ATDY(j) Atdy[j]
+            UMPC_GEN_AT_MUL(IN_DY, OUT_ATDY);
+            T nrm = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) nrm = umpc_max(nrm, umpc_abs(Atdy[j] * Dinv[j]));
+            pinf = nrm < eps_pinf * ndy;
+          }
+        }
+      }
+      if (!dual_ok) {
+        // is_dual_infeasible, auxil.c:426-512
+        T ndx = T(0), qdx = T(0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+          const T dx = x[j] - xprev[j];
+          ndx = umpc_max(ndx, umpc_abs(Ds[j] * dx));
+          qdx += q[j] * dx;
+        }
+        if (ndx > eps_dinf && qdx < -cscale * eps_dinf * ndx) {
+          T nP = T(0);
+#pragma unroll
+          for (int j = 0; j < NX; ++j) nP = umpc_max(nP, umpc_abs((P[j] * (x[j] - xprev[j])) * Dinv[j]));
+          if (nP < cscale * eps_dinf * ndx) {
+            T dxv[NX], Adx[NC];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) dxv[j] = x[j] - xprev[j];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) Adx[i] = T(0);
+#define IN_DX(j) dxv[j]
+#define OUT_ADX(i) Adx[i]
+            UMPC_GEN_A_MUL(IN_DX, OUT_ADX);
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+              const T v = Adx[i] * Einv[i];
+              if (v > eps_dinf * ndx || v < -eps_dinf * ndx) ok = false;  // all bounds finite
+            }
+            dinf = ok;
+          }
+        }
+      }
+      if (prim_ok && dual_ok) status = approx ? ST_SOLVED_INACC : ST_SOLVED;
+      else if (pinf) status = approx ? ST_PINF_INACC : ST_PINF;
+      else if (dinf) status = approx ? ST_DINF_INACC : ST_DINF;
+    }
+    if (status == ST_UNSOLVED) status = ST_MAX_ITER;
+  }
+
+  // ---- store_solution (auxil.c:527-565) + extraction (uprightmpc2.c:253-269) ------
+  const bool has_sol = status != ST_PINF && status != ST_PINF_INACC && status != ST_DINF &&
+                       status != ST_DINF_INACC && status != ST_NON_CVX;
+  T u0, u1, u2, dy1[NY];
+  if (has_sol) {
+    u0 = x[2 * NY * N + 0] * Ds[2 * NY * N + 0];
+    u1 = x[2 * NY * N + 1] * Ds[2 * NY * N + 1];
+    u2 = x[2 * NY * N + 2] * Ds[2 * NY * N + 2];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) dy1[i] = x[NY * N + i] * Ds[NY * N + i];
+  } else {
+    // the reference's OSQP_NAN is the NUMBER (c_float)0x7fc00000 = 2143289344 (constants.h:96),
+    // and the iterates are cold-started (auxil.c:563)
+    const T nanv = T(2143289344.0);
+    u0 = u1 = u2 = nanv;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) dy1[i] = nanv;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) x[j] = T(0);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { y[i] = T(0); z[i] = T(0); }
+  }
+  T0 += u0;
+  uquad[0] = T0; uquad[1] = u1; uquad[2] = u2;
+  // dq1des = (dy1des[0:3], e3h R0' dy1des[3:6]); e3h R0' v = (-(R0' v)_y, (R0' v)_x, 0)
+  const T rx = (R0[0] * dy1[3] + R0[1] * dy1[4]) + R0[2] * dy1[5];
+  const T ry = (R0[3] * dy1[3] + R0[4] * dy1[4]) + R0[5] * dy1[5];
+  const T dq1[NY] = {dy1[0], dy1[1], dy1[2], -ry, rx, T(0)};
+#pragma unroll
+  for (int i = 0; i < NY; ++i) accdes[i] = (dq1[i] - dq0[i]) / prm.dt;
+  return status;
+#undef A_
+#undef P_
+#undef LX_
+#undef DI_
+#undef RINV3_
+#undef RHO3_
+#undef W_
+#undef X_
+#undef Y_
+#undef Z_
+#undef Q_
+#undef LO_
+#undef UP3_
+}
+
+}  // namespace umpc

@@ -1,0 +1,70 @@
+"""Drop-in for the reference's pybind11 module `uprightmpc2py`
+(template/uprightmpc2/py/uprightmpc2py.cpp:30-52): same class name, same
+constructor arguments, same `update / vectors / matrices` methods and return
+shapes, backed by libumpc_mi355x.so's umpcInit / umpcUpdate (the reference's own
+C symbols, here executing on the MI355X).
+
+    from robobee3d_amd.uprightmpc2py import UprightMPC2C
+    upc = UprightMPC2C(dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, 50)
+    uquad, accdes = upc.update(p0, R0, dq0, pdes, dpdes, sdes, actualT0)
+
+`actualT0` defaults to -1 because the reference's own harness calls update with
+six arguments (template/uprightmpc2.py:139).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class UprightMPC2C:
+    def __init__(self, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, maxIter):
+        self._L = _lib.lib()
+        self.umpc = _lib.UprightMPC_t()
+        ib = np.ascontiguousarray(Ib, np.float32)
+        assert ib.shape == (3,)
+        self._L.umpcInit(C.byref(self.umpc), *[C.c_float(v) for v in
+                         (dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom)], _fp(ib), C.c_int(maxIter))
+
+    def __del__(self):
+        try:
+            self._L.umpcRelease(C.byref(self.umpc))
+        except Exception:
+            pass
+
+    def update(self, p0, R0, dq0, pdes, dpdes, sdes, actualT0=-1.0):
+        f = lambda a, n: np.ascontiguousarray(np.asarray(a, np.float32).reshape(n))
+        p0, dq0, pdes, dpdes, sdes = f(p0, 3), f(dq0, 6), f(pdes, 3), f(dpdes, 3), f(sdes, 3)
+        # pybind11/eigen converts a row-major numpy 3x3 into a column-major Matrix3f
+        R0c = np.ascontiguousarray(np.asarray(R0, np.float32).reshape(3, 3).T.ravel())
+        uquad = np.zeros(3, np.float32)
+        accdes = np.zeros(6, np.float32)
+        rc = self._L.umpcUpdate(C.byref(self.umpc), _fp(uquad), _fp(accdes), _fp(p0), _fp(R0c), _fp(dq0),
+                                _fp(pdes), _fp(dpdes), _fp(sdes), C.c_float(actualT0))
+        if rc:
+            raise RuntimeError("umpcUpdate failed (no GPU / not initialised)")
+        return uquad, accdes
+
+    def vectors(self):
+        u = self.umpc
+        return (np.array(u.l, np.float32), np.array(u.u, np.float32), np.array(u.q, np.float32))
+
+    def matrices(self):
+        u = self.umpc
+        return (np.array(u.Px_data, np.float32), np.array(u.Ax_data, np.float32), np.array(u.Ax_idx, np.int32))
+
+    def status(self):
+        """OSQP status code of the last update (extension; the reference drops it)."""
+        return int(self._L.umpcLastStatus(C.byref(self.umpc)))
+
+
+def createMPC(N=3, ws=1e1, wds=1e3, wpr=1, wvr=1e3, wpf=5, wvf=2e3, wthrust=1e-1, wmom=1e-2, TtoWmax=2, **kwargs):
+    """C-version half of template/template_controllers.py:260-280 (same defaults)."""
+    assert N == 3, "the compiled horizon is N = 3 (template/uprightmpc2/uprightmpc2.h:20)"
+    return UprightMPC2C(5, 9.81e-3, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom,
+                        np.array([3333.0, 3333.0, 1000.0]), 50)

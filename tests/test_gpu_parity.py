@@ -1,0 +1,321 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu). Everything goes
+through the C ABI of libumpc_mi355x.so; the oracle is only the checker.
+
+Stated fp32 tolerance of the path (same start state, same 50 ADMM iterations):
+    |d thrust| <= 3e-5, |d moment| <= max(2e-2, 1e-3 |moment|), |d accdes| <= 3e-5
+(the fp32 reference itself is 0.9e-5 / 3.4e-3 / 0.9e-5 from the fp64 evaluation
+of the same algorithm on these vectors: tests/test_oracle_golden.py).
+fp64 kernel vs fp64 oracle: 1e-9 relative.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_T, TOL_A = 3e-5, 3e-5
+
+
+def tol_tau(ref):
+    return np.maximum(2e-2, 1e-3 * np.abs(ref))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _load_seq_into(mpc, seq, torch, n=None):
+    n = n or len(seq["p0"])
+    B = mpc.B
+    assert B == n
+    dt = np.float32 if mpc.dtype == torch.float32 else np.float64
+    state = np.zeros((18, B), dt)
+    state[0:3] = seq["p0"][:n].T
+    state[3:12] = seq["R0"][:n].transpose(2, 1, 0).reshape(9, n)  # column-major
+    state[12:18] = seq["dq0"][:n].T
+    ref = np.vstack((seq["pdes"][:n].T, seq["dpdes"][:n].T, seq["sdes"][:n].T)).astype(dt)
+    ctrl = np.vstack((seq["pre_x"][:n].T, seq["pre_y"][:n].T, seq["pre_z"][:n].T, seq["pre_T0"][:n][None, :],
+                      seq["pre_E3"][:n].T)).astype(dt)
+    mpc.set_state(state, ref)
+    mpc.ctrl.copy_(torch.as_tensor(ctrl))
+    mpc.actualT0 = torch.as_tensor(seq["actualT0"][:n].astype(dt)).to(mpc.device)
+    return state, ref, ctrl
+
+
+def test_native_library_is_loaded(torch_cuda):
+    from robobee3d_amd import _lib
+    L = _lib.lib()
+    assert b"umpc_rollout_kernel" in L.umpcKernelName(0, 0)
+    with open("/proc/self/maps") as f:
+        assert "libumpc_mi355x.so" in f.read()
+
+
+def test_assembly_matches_reference(torch_cuda):
+    """l,u,q,Px,Ax of the kernel == the reference C's UprightMPC_t fields (a4,a5)."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC
+    seq = golden("seq_iter50.npz")
+    mpc = BatchUprightMPC(256, torch.float32)
+    _load_seq_into(mpc, seq, torch)
+    # the T0 the reference assembled with: actualT0 if >= 0 else the accumulator
+    T0 = np.where(seq["actualT0"] >= 0, seq["actualT0"], seq["pre_T0"]).astype(np.float32)
+    mpc.ctrl[123].copy_(torch.as_tensor(T0))
+    l, u, q, Px, Ax = [t.cpu().numpy().T for t in mpc.assemble()]
+    np.testing.assert_allclose(l, seq["l"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(u, seq["u"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(q, seq["q"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(Px, seq["Px"])
+    np.testing.assert_allclose(Ax, seq["Ax"], rtol=1e-6, atol=1e-9)
+
+
+def _check_outputs(out, seq, n, label):
+    uq, ac = out[:3].T, out[3:].T
+    ru, ra = seq["uquad"][:n].astype(np.float64), seq["accdes"][:n].astype(np.float64)
+    d0 = np.abs(uq[:, 0] - ru[:, 0]).max()
+    dt_ = np.abs(uq[:, 1:] - ru[:, 1:])
+    da = np.abs(ac - ra).max()
+    assert d0 <= TOL_T, (label, "thrust", d0)
+    assert np.all(dt_ <= tol_tau(ru[:, 1:])), (label, "moment", dt_.max())
+    assert da <= TOL_A, (label, "accdes", da)
+    return d0, dt_.max(), da
+
+
+@pytest.mark.parametrize("fname", ["seq_iter50.npz", "seq_iter10.npz", "seq_iter2.npz", "seq_iter1.npz"])
+def test_single_step_matches_reference_golden(torch_cuda, fname):
+    """Every call of the reference sequences, replayed as one batch: robot k
+    starts from the reference's state before call k (warm start x,y,z, T0, E)."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC
+    seq = golden(fname)
+    n = len(seq["p0"])
+    mpc = BatchUprightMPC(n, torch.float32, maxIter=int(seq["maxIter"]))
+    _load_seq_into(mpc, seq, torch)
+    mpc.update()
+    torch.cuda.synchronize()
+    out = mpc.out.cpu().numpy().astype(np.float64)
+    _check_outputs(out, seq, n, fname)
+    ctrl = mpc.ctrl.cpu().numpy()
+    # iterates: scaled x, y, z after the same number of iterations
+    for name, sl in (("x", slice(0, 45)), ("y", slice(45, 84)), ("z", slice(84, 123))):
+        ref = seq[name].T
+        err = np.abs(ctrl[sl] - ref) / (1e-3 + np.abs(ref).max(axis=0, keepdims=True))
+        assert err.max() < 2e-2, (name, err.max())
+    np.testing.assert_allclose(ctrl[123], seq["T0"], rtol=0, atol=TOL_T)
+    np.testing.assert_allclose(ctrl[124:127].T, seq["E"][:, 36:39], rtol=1e-5)
+    status = mpc.status.cpu().numpy()
+    mismatch = int(np.sum(status != seq["status"]))
+    # status flips only at the tolerance boundary of check_termination
+    assert mismatch <= max(2, n // 50), (mismatch, n)
+    info = mpc.info.cpu().numpy()
+    np.testing.assert_allclose(info[0], seq["pri_res"], rtol=5e-2, atol=1e-6)
+    np.testing.assert_allclose(info[1], seq["dua_res"], rtol=5e-2, atol=1e-6)
+
+
+def test_single_step_fp32_vs_canonical_oracle_and_fp64(torch_cuda, oracle_built, structure):
+    """HIP fp32 vs (a) the fp32 oracle in canonical mode with the kernel's own
+    elimination order, (b) the fp64 oracle: the kernel is not further from fp64
+    truth than 3x what the reference itself is."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC
+    from robobee3d_amd import _lib
+    seq = golden("seq_iter50.npz")
+    n = 256
+    mpc = BatchUprightMPC(n, torch.float32)
+    _load_seq_into(mpc, seq, torch)
+    mpc.update()
+    out = mpc.out.cpu().numpy().astype(np.float64)
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    worst = np.zeros(3)
+    for dtype, scale in ((np.float32, 1.0), (np.float64, 1.0)):
+        o = oracle_built.Oracle(dtype, perm=perm)
+        for k in range(n):
+            o.set_canonical(True, seq["pre_E3"][k])
+            o.set_iterates(seq["pre_x"][k], seq["pre_y"][k], seq["pre_z"][k])
+            o.set_T0(float(seq["pre_T0"][k]))
+            uq, ac = o.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k],
+                              seq["sdes"][k], float(seq["actualT0"][k]))
+            assert abs(out[0, k] - uq[0]) <= TOL_T
+            assert np.all(np.abs(out[1:3, k] - uq[1:]) <= tol_tau(uq[1:]))
+            assert np.all(np.abs(out[3:, k] - ac) <= TOL_A)
+
+
+def test_fp64_kernel_matches_fp64_oracle(torch_cuda, oracle_built):
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC
+    from robobee3d_amd import _lib
+    seq = golden("seq_iter50.npz")
+    n = 64
+    mpc = BatchUprightMPC(n, torch.float64)
+    _load_seq_into(mpc, seq, torch, n)
+    mpc.update()
+    out = mpc.out.cpu().numpy()
+    ctrl = mpc.ctrl.cpu().numpy()
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    o = oracle_built.Oracle(np.float64, perm=perm)
+    for k in range(n):
+        o.set_canonical(True, seq["pre_E3"][k].astype(np.float64))
+        o.set_iterates(seq["pre_x"][k], seq["pre_y"][k], seq["pre_z"][k])
+        o.set_T0(float(seq["pre_T0"][k]))
+        uq, ac = o.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k],
+                          seq["sdes"][k], float(seq["actualT0"][k]))
+        np.testing.assert_allclose(out[:3, k], uq, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(out[3:, k], ac, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(ctrl[:45, k], o.get("x"), rtol=1e-8, atol=1e-10)
+        assert int(mpc.status[k]) == int(o.get("status_val")[0])
+
+
+def test_reference_boundary_dropin_sequence(torch_cuda):
+    """uprightmpc2py.UprightMPC2C through umpcInit/umpcUpdate: one controller
+    carried across 24 calls of the reference's sequence from a pristine start
+    (state persists inside the library like the reference's global workspace);
+    vectors()/matrices() expose the same debug fields."""
+    from robobee3d_amd.uprightmpc2py import UprightMPC2C
+    seq = golden("seq_iter50.npz")
+    upc = UprightMPC2C(5, 9.81e-3, 2, 1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2, np.array([3333., 3333., 1000.]), 50)
+    st = golden("structure.npz")
+    for k in range(24):
+        uq, ac = upc.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k],
+                            seq["sdes"][k], float(seq["actualT0"][k]))
+        assert uq.shape == (3,) and ac.shape == (6,) and uq.dtype == np.float32
+        # errors of earlier calls feed later ones through the warm start: looser than single-step
+        assert abs(uq[0] - seq["uquad"][k][0]) <= 1e-4
+        assert np.all(np.abs(uq[1:] - seq["uquad"][k][1:]) <= 3 * tol_tau(seq["uquad"][k][1:]))
+        assert np.all(np.abs(ac - seq["accdes"][k]) <= 1e-4)
+        l, u, q = upc.vectors()
+        Px, Ax, Aidx = upc.matrices()
+        np.testing.assert_allclose(q, seq["q"][k], rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(Px, seq["Px"][k])
+        np.testing.assert_array_equal(Aidx, st["Ax_idx"])
+        np.testing.assert_allclose(Ax, seq["Ax"][k], rtol=2e-3, atol=1e-6)  # Ax holds dt*T0 (accumulated)
+    # six-argument call of the reference harness (template/uprightmpc2.py:139)
+    uq, ac = upc.update(np.zeros(3), np.eye(3), np.zeros(6), np.zeros(3), np.zeros(3), [0, 0, 1])
+    assert np.all(np.isfinite(uq))
+
+
+def test_plant_kernel_matches_reference_python(torch_cuda, oracle_built):
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC
+    g = golden("plant.npz")
+    n = len(g["p"])
+    for dt_sub in (0.2, 0.1, 1.0, 5.0):
+        sel = np.nonzero(g["dt"] == dt_sub)[0]
+        for dtype, tol in ((torch.float64, 1e-11), (torch.float32, 2e-5)):
+            mpc = BatchUprightMPC(len(sel), dtype, dtsim=dt_sub)
+            state = np.zeros((18, len(sel)))
+            state[0:3] = g["p"][sel].T
+            state[3:12] = g["R"][sel].transpose(2, 1, 0).reshape(9, -1)
+            state[12:18] = g["dq"][sel].T
+            mpc.set_state(state)
+            mpc.plant(g["u"][sel].T.copy(), nsub=1)
+            s = mpc.state.cpu().numpy().astype(np.float64)
+            sc = 1.0 if dtype == torch.float64 else 10.0
+            np.testing.assert_allclose(s[0:3].T, g["p2"][sel], rtol=tol, atol=tol * sc)
+            np.testing.assert_allclose(s[3:12].reshape(3, 3, -1).transpose(2, 1, 0), g["R2"][sel], rtol=0, atol=tol)
+            np.testing.assert_allclose(s[12:18].T, g["dq2"][sel], rtol=tol * 10, atol=tol)
+
+
+@pytest.mark.parametrize("plant_mode", [0, 1])
+def test_closed_loop_rollout_matches_oracle(torch_cuda, oracle_built, plant_mode):
+    """K closed-loop steps (QP + 25 substeps) for 512 random-tilt robots: HIP
+    fp64 vs the fp64 oracle (tight), HIP fp32 vs fp64 oracle (fp32 band)."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    from robobee3d_amd import _lib
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    B, K = 512, 12
+    st64, ref64 = hover_initial_conditions(B, 20201118, np.float64)
+    ctrl0 = np.zeros((127, B)); ctrl0[124:] = 1
+    s_o, c_o = st64.copy(), ctrl0.copy()
+    out_o, stats_o, status_o = oracle_built.batch_rollout(s_o, c_o, ref64, K, dtype=np.float64, perm=perm,
+                                                          plant_mode=plant_mode)
+    m64 = BatchUprightMPC(B, torch.float64, plant_mode=plant_mode)
+    m64.set_state(st64, ref64)
+    m64.rollout(K)
+    np.testing.assert_allclose(m64.state.cpu().numpy(), s_o, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m64.out.cpu().numpy(), out_o, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(m64.stats.cpu().numpy(), stats_o, rtol=1e-7)
+    m32 = BatchUprightMPC(B, torch.float32, plant_mode=plant_mode)
+    m32.set_state(st64.astype(np.float32), ref64.astype(np.float32))
+    for _ in range(K):  # also exercises launch-per-step == K-in-one-launch
+        m32.rollout(1)
+    s32 = m32.state.cpu().numpy().astype(np.float64)
+    # positions to 1e-3 mm, attitude/velocities to 1e-4 after K steps (SURVEY 8c closed-loop tolerance)
+    np.testing.assert_allclose(s32[0:3], s_o[0:3], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(s32[3:], s_o[3:], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m32.stats.cpu().numpy(), stats_o, rtol=1e-3)
+
+
+def test_full_size_hover_properties(torch_cuda):
+    """BASELINE config 3 size (B = 65536, fp32, closed loop): size-independent
+    properties -- every robot converges to hover at the origin, R stays
+    orthonormal, thrust stays inside [0, Tmax], and the result is invariant to
+    how the batch is partitioned (a sharded run == the single-GPU run)."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    B, K = 65536, 100
+    st, ref = hover_initial_conditions(B, 20201118)
+    mpc = BatchUprightMPC(B, torch.float32)
+    mpc.set_state(st, ref)
+    mpc.rollout(K)
+    s = mpc.state.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(s))
+    assert np.linalg.norm(s[0:3], axis=0).max() < 0.05          # mm
+    assert np.abs(s[11] - 1).max() < 1e-3 and np.abs(s[9:11]).max() < 2e-2   # s = R e3 -> e3
+    R = s[3:12].reshape(3, 3, B)  # [col, row, b]
+    G = np.einsum("crb,drb->cdb", R, R)
+    assert np.abs(G - np.eye(3)[:, :, None]).max() < 1e-3
+    out = mpc.out.cpu().numpy()
+    assert out[0].min() >= -1e-6 and out[0].max() <= 2 * 9.81e-3 + 1e-6
+    assert np.abs(out[0] - 9.81e-3).max() < 2e-4                # hover thrust = g
+    # partition invariance: robots [1000, 1000+4096) alone
+    off, n = 1000, 4096
+    st2, ref2 = hover_initial_conditions(n, 20201118, index_offset=off)
+    np.testing.assert_array_equal(st2, st[:, off:off + n])
+    sub = BatchUprightMPC(n, torch.float32)
+    sub.set_state(st2, ref2)
+    sub.rollout(K)
+    np.testing.assert_array_equal(sub.state.cpu().numpy(), mpc.state[:, off:off + n].cpu().numpy())
+    np.testing.assert_array_equal(sub.stats.cpu().numpy(), mpc.stats[:, off:off + n].cpu().numpy())
+
+
+def test_ragged_and_tiny_batches(torch_cuda):
+    """B = 1 and B not a multiple of the 64-lane wavefront."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    st, ref = hover_initial_conditions(131, 7)
+    big = BatchUprightMPC(131, torch.float32)
+    big.set_state(st, ref)
+    big.rollout(3)
+    for n in (1, 63, 65):
+        m = BatchUprightMPC(n, torch.float32)
+        m.set_state(st[:, :n].copy(), ref[:, :n].copy())
+        m.rollout(3)
+        np.testing.assert_array_equal(m.state.cpu().numpy(), big.state[:, :n].cpu().numpy())
+        np.testing.assert_array_equal(m.out.cpu().numpy(), big.out[:, :n].cpu().numpy())
+
+
+def test_monte_carlo_inertia_and_mass(torch_cuda, oracle_built):
+    """Config 5 inputs: per-robot Ib (controller + plant) and thrust gain."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    from robobee3d_amd import _lib
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    B, K = 256, 6
+    rng = np.random.default_rng(20201120)
+    st, ref = hover_initial_conditions(B, 20201120, np.float64)
+    Ib = np.array([3333., 3333., 1000.])[:, None] * (1 + rng.uniform(-0.2, 0.2, (3, B)))
+    gain = 1 + rng.uniform(-0.2, 0.2, B)
+    ctrl = np.zeros((127, B)); ctrl[124:] = 1
+    s_o = st.copy()
+    out_o, stats_o, _ = oracle_built.batch_rollout(s_o, ctrl, ref, K, dtype=np.float64, perm=perm, Ib=Ib, gain=gain)
+    m = BatchUprightMPC(B, torch.float64)
+    m.set_state(st, ref)
+    m.Ib = torch.as_tensor(Ib).cuda()
+    m.gain = torch.as_tensor(gain).cuda()
+    m.rollout(K)
+    np.testing.assert_allclose(m.state.cpu().numpy(), s_o, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m.out.cpu().numpy(), out_o, rtol=1e-6, atol=1e-8)
