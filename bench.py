@@ -39,7 +39,8 @@ def cpu_baseline(args, plant_mode):
     import oraclebind
     from robobee3d_amd.batch import hover_initial_conditions
     oraclebind.build()
-    ncores = len(os.sched_getaffinity(0))
+    # the one-GPU box exposes every host thread but grants a 16-CPU share: use that many threads
+    ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("UMPC_CPU_THREADS", "16")))
     Bs, Ks = args.cpu_robots, args.cpu_steps
     st, ref = hover_initial_conditions(Bs, 20201118, np.float32)
     ctrl = np.zeros((127, Bs), np.float32)

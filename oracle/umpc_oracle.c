@@ -955,11 +955,12 @@ void umpc_oracle_batch_rollout(const umpc_oracle_params_t *prm, const int *perm,
       real s_err = stats ? stats[b] : 0, s_eff = stats ? stats[(size_t)B + b] : 0;
       for (int k = 0; k < K; ++k) {
         umpc_oracle_update(o, uq, acc, p, R, dq, &rf[0], &rf[3], &rf[6], (real)-1);
-        for (int i = 1; i < 3; ++i) uq[i] = c_min(c_max(uq[i], -prm->taulim), prm->taulim);
+        real uc[3] = {uq[0], c_min(c_max(uq[1], -prm->taulim), prm->taulim),
+                      c_min(c_max(uq[2], -prm->taulim), prm->taulim)};
         for (int s = 0; s < prm->nsub; ++s) {
-          plant_step_r(p, R, dq, uq, prm->dtsim, ib, gain, prm->plant_mode);
+          plant_step_r(p, R, dq, uc, prm->dtsim, ib, gain, prm->plant_mode);
           s_err += p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
-          s_eff += uq[1] * uq[1] + uq[2] * uq[2];
+          s_eff += uc[1] * uc[1] + uc[2] * uc[2];
         }
       }
       for (int i = 0; i < 3; ++i) state[(size_t)i * B + b] = p[i];

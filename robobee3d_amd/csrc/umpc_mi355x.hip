@@ -28,102 +28,19 @@ int fail(hipError_t e, const char *what) {
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
+// K closed-loop steps per robot; lane b of the grid owns robot b. One wavefront per
+// workgroup (no barriers, no cross-lane traffic); fp32 keeps q and 1/D of the factor in LDS
+// (33 float4 per lane = 33,792 B per workgroup -> 4 workgroups = 4 waves per CU, one per SIMD).
 template <typename T>
-struct RolloutArgs {
-  DevParams<T> prm;
-  int B, K;
-  T *state;        // [18][B]
-  T *ctrl;         // [127][B]
-  const T *ref;    // [9][B]
-  const T *actualT0;
-  const T *Ib;     // [3][B] or null
-  const T *gain;   // [B] or null
-  T *out;          // [9][B]
-  T *stats;        // [2][B] or null
-  int32_t *status; // [B] or null
-  T *info;         // [2][B] or null
-};
-
-// K closed-loop steps per robot; lane b of the grid owns robot b.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(RolloutArgs<T> a) {
+__global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a, int K, const T *actualT0) {
+  constexpr bool kLds = sizeof(T) == 4;
+  __shared__ float4 lds[kLds ? (umpc::HOT_WORDS / 4) * kBlock : 1];
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= a.B) return;
-  const size_t B = (size_t)a.B;
-  const DevParams<T> &prm = a.prm;
-
-  T p[3], R[9], dq[6], ref[9], Ib[3], Ibi[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) p[i] = a.state[(size_t)i * B + b];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = a.state[(size_t)(3 + i) * B + b];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) dq[i] = a.state[(size_t)(12 + i) * B + b];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) ref[i] = a.ref[(size_t)i * B + b];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    Ib[i] = a.Ib ? a.Ib[(size_t)i * B + b] : prm.Ib[i];
-    Ibi[i] = T(1) / Ib[i];  // uprightmpc2.c:50-52
-  }
-  const T gain = a.gain ? a.gain[b] : T(1);
-
-  T x[NX], y[NC], z[NC], T0, Eprev3[N];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) x[j] = a.ctrl[(size_t)j * B + b];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) y[i] = a.ctrl[(size_t)(NX + i) * B + b];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) z[i] = a.ctrl[(size_t)(NX + NC + i) * B + b];
-  T0 = a.ctrl[(size_t)(NX + 2 * NC) * B + b];
-#pragma unroll
-  for (int k = 0; k < N; ++k) Eprev3[k] = a.ctrl[(size_t)(NX + 2 * NC + 1 + k) * B + b];
-  if (a.actualT0) {
-    const T t = a.actualT0[b];
-    if (t >= T(0)) T0 = t;  // uprightmpc2.c:215-216
-  }
-
-  T uq[3] = {T(0), T(0), T(0)}, acc[6], pri = T(0), dua = T(0);
-  T s_err = a.stats ? a.stats[b] : T(0), s_eff = a.stats ? a.stats[B + b] : T(0);
-  int status = umpc::ST_UNSOLVED;
+  umpc::Hot<T, kLds> hot;
+  if constexpr (kLds) hot.base = reinterpret_cast<T *>(lds) + 4 * threadIdx.x;
 #pragma nounroll
-  for (int k = 0; k < a.K; ++k) {
-    status = umpc::mpc_step(prm, Ibi, p, R, dq, ref, x, y, z, T0, Eprev3, uq, acc, pri, dua);
-    // input limit, template/uprightmpc2.py:148-149
-    uq[1] = umpc::umpc_min(umpc::umpc_max(uq[1], -prm.taulim), prm.taulim);
-    uq[2] = umpc::umpc_min(umpc::umpc_max(uq[2], -prm.taulim), prm.taulim);
-#pragma nounroll
-    for (int s = 0; s < prm.nsub; ++s) {
-      umpc::plant_step(p, R, dq, uq, prm.dtsim, Ib, gain, prm.plant_mode);
-      s_err += p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
-      s_eff += uq[1] * uq[1] + uq[2] * uq[2];
-    }
-  }
-
-  if (prm.nsub > 0) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) a.state[(size_t)i * B + b] = p[i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) a.state[(size_t)(3 + i) * B + b] = R[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) a.state[(size_t)(12 + i) * B + b] = dq[i];
-  }
-#pragma unroll
-  for (int j = 0; j < NX; ++j) a.ctrl[(size_t)j * B + b] = x[j];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) a.ctrl[(size_t)(NX + i) * B + b] = y[i];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) a.ctrl[(size_t)(NX + NC + i) * B + b] = z[i];
-  a.ctrl[(size_t)(NX + 2 * NC) * B + b] = T0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) a.ctrl[(size_t)(NX + 2 * NC + 1 + k) * B + b] = Eprev3[k];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) a.out[(size_t)i * B + b] = uq[i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) a.out[(size_t)(3 + i) * B + b] = acc[i];
-  if (a.stats) { a.stats[b] = s_err; a.stats[B + b] = s_eff; }
-  if (a.status) a.status[b] = status;
-  if (a.info) { a.info[b] = pri; a.info[B + b] = dua; }
+  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kLds>(a, b, hot, k == 0, actualT0);
 }
 
 template <typename T>
@@ -222,6 +139,7 @@ DevParams<T> make_dev(const umpc_batch_params_t &p) {
 struct umpc_batch {
   umpc_batch_params_t prm;
   int B, dtype;
+  void *ws;  // [WS_ROWS][B] scratch the step parks Ruiz scalings / x_prev / delta_y in
 };
 
 template <typename T>
@@ -229,15 +147,16 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
                           const void *actualT0, const void *Ib, const void *gain, void *out, void *stats,
                           int32_t *status, void *info, void *stream) {
   if (!state || !ctrl || !ref || !out) { g_err = "umpcBatchRollout: null array"; return -1; }
-  RolloutArgs<T> a;
+  umpc::StepIO<T> a;
   a.prm = make_dev<T>(h->prm);
   a.prm.nsub = nsub;
-  a.B = h->B; a.K = K;
-  a.state = (T *)state; a.ctrl = (T *)ctrl; a.ref = (const T *)ref; a.actualT0 = (const T *)actualT0;
-  a.Ib = (const T *)Ib; a.gain = (const T *)gain; a.out = (T *)out; a.stats = (T *)stats;
+  a.B = h->B;
+  a.state = (T *)state; a.ctrl = (T *)ctrl; a.ref = (const T *)ref;
+  a.Ib = (const T *)Ib; a.gain = (const T *)gain; a.ws = (T *)h->ws; a.out = (T *)out; a.stats = (T *)stats;
   a.status = status; a.info = (T *)info;
   const int grid = (h->B + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(umpc_rollout_kernel<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(umpc_rollout_kernel<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
+                     (const T *)actualT0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
 }
@@ -272,10 +191,16 @@ umpc_batch_t *umpcBatchCreate(const umpc_batch_params_t *prm, int B, int dtype) 
     return nullptr;
   }
   umpc_batch *h = new umpc_batch;
-  h->prm = *prm; h->B = B; h->dtype = dtype;
+  h->prm = *prm; h->B = B; h->dtype = dtype; h->ws = nullptr;
+  e = hipMalloc(&h->ws, (size_t)umpc::WS_ROWS * (size_t)B * (dtype == UMPC_F64 ? 8 : 4));
+  if (e != hipSuccess) { fail(e, "umpcBatchCreate: workspace"); delete h; return nullptr; }
   return h;
 }
-void umpcBatchDestroy(umpc_batch_t *h) { delete h; }
+void umpcBatchDestroy(umpc_batch_t *h) {
+  if (!h) return;
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+}
 int umpcBatchSize(const umpc_batch_t *h) { return h->B; }
 int umpcBatchDtype(const umpc_batch_t *h) { return h->dtype; }
 

@@ -55,8 +55,18 @@ enum { ST_SOLVED = 1, ST_SOLVED_INACC = 2, ST_PINF_INACC = 3, ST_DINF_INACC = 4,
        ST_MAX_ITER = -2, ST_PINF = -3, ST_DINF = -4, ST_NON_CVX = -7, ST_UNSOLVED = -10 };
 
 template <typename T> __device__ __forceinline__ T umpc_abs(T v) { return v < T(0) ? -v : v; }
-template <typename T> __device__ __forceinline__ T umpc_max(T a, T b) { return a > b ? a : b; }
-template <typename T> __device__ __forceinline__ T umpc_min(T a, T b) { return a < b ? a : b; }
+// max/min of non-NaN values (c_max / c_min of glob_opts.h:95-99): one v_max / v_min
+__device__ __forceinline__ float umpc_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float umpc_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double umpc_max(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double umpc_min(double a, double b) { return __builtin_fmin(a, b); }
+// 1/sqrt(v): the reference does sqrtf then 1.0f/ (two roundings, scaling.c:98-103). fp32 uses the
+// hardware v_rsq_f32 (1 ulp, one quarter-rate instruction instead of ~20); fp64 keeps sqrt + divide.
+__device__ __forceinline__ float umpc_rsqrt(float v) { return __builtin_amdgcn_rsqf(v); }
+__device__ __forceinline__ double umpc_rsqrt(double v) { return 1.0 / __dsqrt_rn(v); }
+// 1/v where only residual NORMS consume the result
+__device__ __forceinline__ float umpc_rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ double umpc_rcp_fast(double v) { return 1.0 / v; }
 __device__ __forceinline__ float umpc_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double umpc_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float umpc_sqrt(float v) { return __fsqrt_rn(v); }
@@ -68,9 +78,7 @@ __device__ __forceinline__ double umpc_cos(double v) { return cos(v); }
 
 // limit_scaling, scaling.c:7-14
 template <typename T> __device__ __forceinline__ T limit_scaling(T v) {
-  v = v < T(UMPC_MIN_SCALING) ? T(1) : v;
-  v = v > T(UMPC_MAX_SCALING) ? T(UMPC_MAX_SCALING) : v;
-  return v;
+  return v < T(UMPC_MIN_SCALING) ? T(1) : umpc_min(v, T(UMPC_MAX_SCALING));
 }
 
 // ---------------------------------------------------------------------------
@@ -261,242 +269,395 @@ __device__ __forceinline__ void assemble(const DevParams<T> &prm, const T (&Ibi)
 }
 
 // ---------------------------------------------------------------------------
-// one controller step (= umpcUpdate). x, y, z, T0, Eprev3 are the persistent
-// controller record; returns the OSQP status, writes uquad / accdes.
+// Where the per-robot working set lives (one lane = one robot, one wave per SIMD):
+//
+//   ADMM-loop residents            words   home
+//   L (strict lower factor)         213    registers (VGPR/AGPR, compiler-allocated)
+//   W (KKT rhs / solution)           84    registers
+//   x, y, z                         123    registers
+//   thrust-row bounds / rho          12    registers
+//   q (scaled linear cost)           45    LDS  (fp32)   float4-interleaved per lane
+//   1/D of the factor                84    LDS  (fp32)
+//   -------------------------------------
+//   Ruiz D, E, c; x_prev, delta_y   169    parked in the HBM workspace across the loop
+//   P, A (scaled)                   156    dead after the factorisation; re-derived from
+//                                          the raw entries and D, E, c for the residuals
+//
+// 512 registers + 160 LDS words per lane is everything a CU can give a lane at
+// one wave per SIMD; the loop needs ~560 words, so q and 1/D (read-only inside
+// the loop, one ds_read_b128 per four words) go to LDS and everything that is
+// not touched by the loop leaves the chip. fp64 has no such budget (2x words):
+// it keeps the same code and lets the compiler spill.
 // ---------------------------------------------------------------------------
+constexpr int HOT_Q = 0, HOT_DI = 48, HOT_WORDS = 132;  // 33 float4 per lane
+constexpr int WS_DS = 0, WS_ES = WS_DS + NX, WS_C = WS_ES + NC, WS_XPREV = WS_C + 1, WS_DY = WS_XPREV + NX,
+              WS_ROWS = WS_DY + NC;  // 169
+
+template <typename T, bool LDS> struct Hot;
+template <typename T> struct Hot<T, false> {
+  T v[HOT_WORDS];
+  __device__ __forceinline__ T &at(int w) { return v[w]; }
+};
+template <typename T> struct Hot<T, true> {
+  T *base;  // = lds + 4 * lane
+  __device__ __forceinline__ T &at(int w) { return base[(w >> 2) * 256 + (w & 3)]; }
+};
+
 template <typename T>
-__device__ __forceinline__ int mpc_step(const DevParams<T> &prm, const T (&Ibi)[3], const T (&p0)[3],
-                                        const T (&R0)[9], const T (&dq0)[6], const T (&ref)[9], T (&x)[NX],
-                                        T (&y)[NC], T (&z)[NC], T &T0, T (&Eprev3)[N], T (&uquad)[3],
-                                        T (&accdes)[6], T &pri_res_out, T &dua_res_out) {
+struct StepIO {
+  DevParams<T> prm;
+  int B;
+  T *state;        // [18][B]
+  T *ctrl;         // [127][B]
+  const T *ref;    // [9][B]
+  const T *Ib;     // [3][B] or null
+  const T *gain;   // [B] or null
+  T *ws;           // [WS_ROWS][B] workspace
+  T *out;          // [9][B]
+  T *stats;        // [2][B] or null
+  int32_t *status; // [B] or null
+  T *info;         // [2][B] or null
+};
+
+// One closed-loop step of robot b: controller step (= umpcUpdate) + nsub plant substeps.
+// Everything persistent round-trips through the SoA arrays, so K steps in one launch and K
+// launches of one step are the same computation.
+template <typename T, bool LDS>
+__device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, Hot<T, LDS> &hot, const bool first_step,
+                                                 const T *actualT0) {
+  const size_t B = (size_t)a.B;
+  const DevParams<T> &prm = a.prm;
   const T sigma = T(1e-6), alpha = T(1.6), oma = T(1.0) - T(1.6);
   const T eps_abs0 = T(1e-4), eps_rel0 = T(1e-4), eps_pinf0 = T(1e-4), eps_dinf0 = T(1e-4);
-
-  T P[NX], A[NNZA], q[NX], Ds[NX], Es[NC], lo[NC], up3[N], rho3[N], rinv3[N];
-  T cscale;
-  {
-    RawQP<T> qp;
-    assemble(prm, Ibi, T0, p0, R0, dq0, ref, qp);
-#define A_(p) A[p]
-    UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
-#undef A_
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { P[j] = qp.Px[j]; q[j] = qp.q[j]; }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) lo[i] = qp.l[i];
-#pragma unroll
-    for (int k = 0; k < N; ++k) up3[k] = qp.u3[k];
-  }
-  // constraint classification with the PREVIOUS call's E (osqp.c:812-820 -> auxil.c:103-145).
-  // Rows < NEQ have l == u bit-for-bit: always "equality".
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const T ls = lo[NEQ + k] * Eprev3[k], us = up3[k] * Eprev3[k];
-    if ((ls < -T(UMPC_INFTY) * T(UMPC_MIN_SCALING)) && (us > T(UMPC_INFTY) * T(UMPC_MIN_SCALING))) {
-      rho3[k] = T(UMPC_RHO_MIN); rinv3[k] = T(1) / T(UMPC_RHO_MIN);
-    } else if (us - ls < T(UMPC_RHO_TOL)) {
-      rho3[k] = T(RHO_EQ); rinv3[k] = T(RINV_EQ);
-    } else {
-      rho3[k] = T(UMPC_RHO); rinv3[k] = T(1) / T(UMPC_RHO);
-    }
-  }
-
-  // ---- Ruiz equilibration, scaling.c:44-156 -------------------------------
-  cscale = T(1);
-#pragma unroll
-  for (int j = 0; j < NX; ++j) Ds[j] = T(1);
-#pragma unroll
-  for (int i = 0; i < NC; ++i) Es[i] = T(1);
-#define A_(p) A[p]
-#define P_(j) P[j]
-#define DT_(j) Dt[j]
-#define ET_(i) Et[i]
-#pragma nounroll
-  for (int it = 0; it < UMPC_SCALING_ITERS; ++it) {
-    T Dt[NX], Et[NC];
-    UMPC_GEN_RUIZ_NORMS();
-#pragma unroll
-    for (int j = 0; j < NX; ++j) Dt[j] = T(1) / umpc_sqrt(limit_scaling(Dt[j]));
-#pragma unroll
-    for (int i = 0; i < NC; ++i) Et[i] = T(1) / umpc_sqrt(limit_scaling(Et[i]));
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { P[j] = (P[j] * Dt[j]) * Dt[j]; }
-    UMPC_GEN_RUIZ_APPLY_A();
-    T pmean = T(0), qn = T(0);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      q[j] = q[j] * Dt[j];
-      Ds[j] = Dt[j] * Ds[j];
-      pmean += umpc_abs(P[j]);
-      qn = umpc_max(qn, umpc_abs(q[j]));
-    }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) Es[i] = Et[i] * Es[i];
-    pmean /= T(NX);
-    qn = limit_scaling(qn);
-    T ct = limit_scaling(umpc_max(pmean, qn));
-    ct = T(1) / ct;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { P[j] *= ct; q[j] *= ct; }
-    cscale *= ct;
-  }
-#undef DT_
-#undef ET_
-  const T cinv = T(1) / cscale;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) lo[i] = lo[i] * Es[i];
-#pragma unroll
-  for (int k = 0; k < N; ++k) { up3[k] = up3[k] * Es[NEQ + k]; Eprev3[k] = Es[NEQ + k]; }
-
-  // ---- KKT fill + LDL' --------------------------------------------------------
-  T Lx[NNZL], Di[NK];
-  int npos = 0;
+  // Row pointers are wave-uniform (SGPR) and the robot index is a 32-bit lane offset. `bb` is
+  // laundered through an empty asm at every phase boundary so that the compiler re-derives the
+  // (cheap) addresses instead of keeping ~400 precomputed 64-bit pointers alive across the loop.
+  unsigned bb = (unsigned)b;
+// scheduling fence: nothing (in particular no LDS read) is moved across it
+#define UMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define UMPC_PHASE_FENCE() asm volatile("" : "+v"(bb)::"memory")
+#define GLD(arr, row) ((arr) + (size_t)(row) * B)[bb]
+#define Q_(j) hot.at(HOT_Q + (j))
+#define DI_(k) hot.at(HOT_DI + (k))
 #define LX_(e) Lx[e]
-#define DI_(k) Di[k]
 #define RINV3_(k) rinv3[k]
 #define RHO3_(k) rho3[k]
-  UMPC_GEN_KKT_FACTOR(npos);
-  (void)npos;
-
-  // ---- ADMM, osqp.c:354-370 -------------------------------------------------------
-  T W[NK], dyv[NC], xprev[NX];
+#define LO3_(k) lo3[k]
+#define UP3_(k) up3[k]
 #define W_(k) W[k]
 #define X_(j) x[j]
 #define Y_(i) y[i]
 #define Z_(i) z[i]
-#define Q_(j) q[j]
-#define LO_(i) lo[i]
-#define UP3_(k) up3[k]
+
+  T Lx[NNZL];
+  T lo[NEQ];  // scaled bounds of the dynamics rows; consumed by the first ADMM iteration
+  T lo3[N], up3[N], rho3[N], rinv3[N], Eprev3[N];
+  T T0 = GLD(a.ctrl, NX + 2 * NC);
+  if (first_step && actualT0) {
+    const T t = actualT0[bb];
+    if (t >= T(0)) T0 = t;  // uprightmpc2.c:215-216
+  }
+  T Ibi[3];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) dyv[i] = T(0);
+  for (int i = 0; i < 3; ++i) Ibi[i] = T(1) / (a.Ib ? GLD(a.Ib, i) : prm.Ib[i]);  // uprightmpc2.c:50-52
+
+  // =========================== phase A: assemble, equilibrate, factor ===========================
+  UMPC_PHASE_FENCE();
+  {
+    T p0[3], R0[9], dq0[6], ref[9];
 #pragma unroll
-  for (int j = 0; j < NX; ++j) xprev[j] = x[j];
+    for (int i = 0; i < 3; ++i) p0[i] = GLD(a.state, i);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R0[i] = GLD(a.state, 3 + i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dq0[i] = GLD(a.state, 12 + i);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ref[i] = GLD(a.ref, i);
+#pragma unroll
+    for (int k = 0; k < N; ++k) Eprev3[k] = GLD(a.ctrl, NX + 2 * NC + 1 + k);
+
+    T P[NX], A[NNZA], q[NX], Ds[NX], Es[NC], lraw[NC];
+    {
+      RawQP<T> qp;
+      assemble(prm, Ibi, T0, p0, R0, dq0, ref, qp);
+#define A_(p) A[p]
+      UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) { P[j] = qp.Px[j]; q[j] = qp.q[j]; }
+#pragma unroll
+      for (int i = 0; i < NC; ++i) lraw[i] = qp.l[i];
+#pragma unroll
+      for (int k = 0; k < N; ++k) up3[k] = qp.u3[k];
+    }
+    // constraint classification with the PREVIOUS call's E (osqp.c:812-820 -> auxil.c:103-145).
+    // Rows < NEQ have l == u bit-for-bit: always "equality".
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const T ls = lraw[NEQ + k] * Eprev3[k], us = up3[k] * Eprev3[k];
+      if ((ls < -T(UMPC_INFTY) * T(UMPC_MIN_SCALING)) && (us > T(UMPC_INFTY) * T(UMPC_MIN_SCALING))) {
+        rho3[k] = T(UMPC_RHO_MIN); rinv3[k] = T(1) / T(UMPC_RHO_MIN);
+      } else if (us - ls < T(UMPC_RHO_TOL)) {
+        rho3[k] = T(RHO_EQ); rinv3[k] = T(RINV_EQ);
+      } else {
+        rho3[k] = T(UMPC_RHO); rinv3[k] = T(1) / T(UMPC_RHO);
+      }
+    }
+    // ---- Ruiz equilibration, scaling.c:44-156 ----
+    T cscale = T(1);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) Ds[j] = T(1);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) Es[i] = T(1);
+#define P_(j) P[j]
+#define DT_(j) Dt[j]
+#define ET_(i) Et[i]
+#pragma nounroll
+    for (int it = 0; it < UMPC_SCALING_ITERS; ++it) {
+      T Dt[NX], Et[NC];
+      UMPC_GEN_RUIZ_NORMS();
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Dt[j] = umpc_rsqrt(limit_scaling(Dt[j]));
+#pragma unroll
+      for (int i = 0; i < NC; ++i) Et[i] = umpc_rsqrt(limit_scaling(Et[i]));
+#pragma unroll
+      for (int j = 0; j < NX; ++j) P[j] = (P[j] * Dt[j]) * Dt[j];
+      UMPC_GEN_RUIZ_APPLY_A();
+      T pmean = T(0), qn = T(0);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        q[j] = q[j] * Dt[j];
+        Ds[j] = Dt[j] * Ds[j];
+        pmean += umpc_abs(P[j]);
+        qn = umpc_max(qn, umpc_abs(q[j]));
+      }
+#pragma unroll
+      for (int i = 0; i < NC; ++i) Es[i] = Et[i] * Es[i];
+      pmean /= T(NX);
+      qn = limit_scaling(qn);
+      T ct = limit_scaling(umpc_max(pmean, qn));
+      ct = T(1) / ct;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) { P[j] *= ct; q[j] *= ct; }
+      cscale *= ct;
+    }
+#undef DT_
+#undef ET_
+    // park what the loop does not touch; hand q to its loop home
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { GLD(a.ws, WS_DS + j) = Ds[j]; Q_(j) = q[j]; }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) GLD(a.ws, WS_ES + i) = Es[i];
+    GLD(a.ws, WS_C) = cscale;
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) lo[i] = lraw[i] * Es[i];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      lo3[k] = lraw[NEQ + k] * Es[NEQ + k];
+      up3[k] = up3[k] * Es[NEQ + k];
+      Eprev3[k] = Es[NEQ + k];
+    }
+    // ---- KKT fill + LDL', kkt.c:184-222 + qdldl.c:86-247 ----
+    int npos = 0;
+    UMPC_GEN_KKT_FACTOR(npos);
+    (void)npos;
+#undef A_
+#undef P_
+  }
+
+  // =========================== phase B: ADMM, osqp.c:354-370 ===========================
+  UMPC_PHASE_FENCE();
+  T x[NX], y[NC], z[NC];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) x[j] = GLD(a.ctrl, j);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) y[i] = GLD(a.ctrl, NX + i);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) z[i] = GLD(a.ctrl, NX + NC + i);
+  {
+    T W[NK];
+    // x_prev / delta_y of the LAST iteration feed the infeasibility tests (auxil.c:362-512)
+#define UMPC_CAPTURE_X() _Pragma("unroll") for (int j = 0; j < NX; ++j) GLD(a.ws, WS_XPREV + j) = x[j]
+    if (prm.maxIter >= 1) {
+      // first iteration: z_prev is the warm start; afterwards z == l == u on the dynamics rows
+      UMPC_CAPTURE_X();
+#define LOEQ_(i) lo[i]
+#define UMPC_ADMM_DY(i, v) GLD(a.ws, WS_DY + (i)) = (v)
+      UMPC_GEN_ADMM_ITER();
+#undef LOEQ_
+#undef UMPC_ADMM_DY
+    } else {
+      UMPC_CAPTURE_X();
+#pragma unroll
+      for (int i = 0; i < NC; ++i) GLD(a.ws, WS_DY + i) = T(0);
+    }
+#define LOEQ_(i) z[i]
 #define UMPC_ADMM_DY(i, v)
 #pragma nounroll
-  for (int it = 1; it < prm.maxIter; ++it) {
-    UMPC_GEN_ADMM_ITER();
-  }
+    for (int it = 2; it < prm.maxIter; ++it) {
+      // keep the LDS-resident q and 1/D in LDS: without this the (loop-invariant) ds_reads are
+      // hoisted into 129 registers and the factor spills to scratch instead
+      asm volatile("" ::: "memory");
+      UMPC_GEN_ADMM_ITER();
+    }
 #undef UMPC_ADMM_DY
-#define UMPC_ADMM_DY(i, v) dyv[i] = (v)
-  if (prm.maxIter >= 1) {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) xprev[j] = x[j];
-    UMPC_GEN_ADMM_ITER();
-  }
+#define UMPC_ADMM_DY(i, v) GLD(a.ws, WS_DY + (i)) = (v)
+    if (prm.maxIter >= 2) {
+      UMPC_PHASE_FENCE();
+      UMPC_CAPTURE_X();
+      UMPC_GEN_ADMM_ITER();
+    }
 #undef UMPC_ADMM_DY
+#undef LOEQ_
+  }
 
-  // ---- update_info: residuals (auxil.c:243-307) -----------------------------------
-  T Einv[NC], Dinv[NX];
+  // =========================== phase C: residuals, status, extraction, plant ===========================
+  UMPC_PHASE_FENCE();
+  T p0[3], R0[9], dq0[6];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) Einv[i] = T(1) / Es[i];
+  for (int i = 0; i < 3; ++i) p0[i] = GLD(a.state, i);
 #pragma unroll
-  for (int j = 0; j < NX; ++j) Dinv[j] = T(1) / Ds[j];
-  T Ax[NC], Aty[NX], Px[NX];
+  for (int i = 0; i < 9; ++i) R0[i] = GLD(a.state, 3 + i);
 #pragma unroll
-  for (int i = 0; i < NC; ++i) Ax[i] = T(0);
+  for (int i = 0; i < 6; ++i) dq0[i] = GLD(a.state, 12 + i);
+  int status = ST_UNSOLVED;
+  T pri_res = T(0), dua_res = T(0);
+  T Ds[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) Ds[j] = GLD(a.ws, WS_DS + j);
+  {
+    T Es[NC], A[NNZA], P[NX];
+    const T cscale = GLD(a.ws, WS_C);
+    const T cinv = T(1) / cscale;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) Es[i] = GLD(a.ws, WS_ES + i);
+    {
+      // scaled P, A again: raw entries times the final D, E, c (the factorisation consumed the originals)
+      T ref[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ref[i] = GLD(a.ref, i);
+      RawQP<T> qp;
+      assemble(prm, Ibi, T0, p0, R0, dq0, ref, qp);
+#define A_(p) A[p]
+#define DT_(j) Ds[j]
+#define ET_(i) Es[i]
+      UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
+      UMPC_GEN_RUIZ_APPLY_A();
+#undef DT_
+#undef ET_
+#pragma unroll
+      for (int j = 0; j < NX; ++j) P[j] = ((qp.Px[j] * Ds[j]) * Ds[j]) * cscale;
+    }
+    // ---- update_info: residuals (auxil.c:243-307) ----
+    T Ax[NC], Aty[NX];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) Ax[i] = T(0);
 #define IN_X(j) x[j]
 #define OUT_AX(i) Ax[i]
-  UMPC_GEN_A_MUL(IN_X, OUT_AX);
+    UMPC_GEN_A_MUL(IN_X, OUT_AX);
 #define IN_Y(i) y[i]
 #define OUT_ATY(j) Aty[j]
-  UMPC_GEN_AT_MUL(IN_Y, OUT_ATY);
-  T pri_res = T(0), dua_res = T(0);
-  T nz = T(0), nAx = T(0), nq = T(0), nAty = T(0), nPx = T(0);
+    UMPC_GEN_AT_MUL(IN_Y, OUT_ATY);
+    T nz = T(0), nAx = T(0), nq = T(0), nAty = T(0), nPx = T(0);
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    pri_res = umpc_max(pri_res, umpc_abs(Einv[i] * (Ax[i] - z[i])));
-    nz = umpc_max(nz, umpc_abs(Einv[i] * z[i]));
-    nAx = umpc_max(nAx, umpc_abs(Einv[i] * Ax[i]));
-  }
+    for (int i = 0; i < NC; ++i) {
+      const T einv = umpc_rcp_fast(Es[i]);
+      pri_res = umpc_max(pri_res, umpc_abs(einv * (Ax[i] - z[i])));
+      nz = umpc_max(nz, umpc_abs(einv * z[i]));
+      nAx = umpc_max(nAx, umpc_abs(einv * Ax[i]));
+    }
 #pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    Px[j] = P[j] * x[j];
-    dua_res = umpc_max(dua_res, umpc_abs(Dinv[j] * ((q[j] + Px[j]) + Aty[j])));
-    nq = umpc_max(nq, umpc_abs(Dinv[j] * q[j]));
-    nAty = umpc_max(nAty, umpc_abs(Dinv[j] * Aty[j]));
-    nPx = umpc_max(nPx, umpc_abs(Dinv[j] * Px[j]));
-  }
-  dua_res = cinv * dua_res;
-  pri_res_out = pri_res;
-  dua_res_out = dua_res;
+    for (int j = 0; j < NX; ++j) {
+      const T dinv = umpc_rcp_fast(Ds[j]);
+      const T Pxj = P[j] * x[j];
+      dua_res = umpc_max(dua_res, umpc_abs(dinv * ((Q_(j) + Pxj) + Aty[j])));
+      nq = umpc_max(nq, umpc_abs(dinv * Q_(j)));
+      nAty = umpc_max(nAty, umpc_abs(dinv * Aty[j]));
+      nPx = umpc_max(nPx, umpc_abs(dinv * Pxj));
+    }
+    dua_res = cinv * dua_res;
 
-  // ---- check_termination (auxil.c:684-789), exact then approximate (osqp.c:524-573) --
-  int status = ST_UNSOLVED;
-  if ((pri_res > T(UMPC_INFTY)) || (dua_res > T(UMPC_INFTY))) {
-    status = ST_NON_CVX;
-  } else {
+    // ---- check_termination (auxil.c:684-789), exact then approximate (osqp.c:524-573) ----
+    if ((pri_res > T(UMPC_INFTY)) || (dua_res > T(UMPC_INFTY))) {
+      status = ST_NON_CVX;
+    } else {
 #pragma nounroll
-    for (int approx = 0; approx < 2 && status == ST_UNSOLVED; ++approx) {
-      const T mul = approx ? T(10) : T(1);
-      const T eps_abs = eps_abs0 * mul, eps_rel = eps_rel0 * mul;
-      const T eps_pinf = eps_pinf0 * mul, eps_dinf = eps_dinf0 * mul;
-      const T eps_prim = eps_abs + eps_rel * umpc_max(nz, nAx);
-      const T eps_dual = eps_abs + eps_rel * (umpc_max(umpc_max(nq, nAty), nPx) * cinv);
-      bool prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual;
-      bool pinf = false, dinf = false;
-      if (!prim_ok) {
-        // is_primal_infeasible, auxil.c:362-424 (all bounds finite here: no projection of delta_y)
-        T ndy = T(0), lhs = T(0);
+      for (int approx = 0; approx < 2 && status == ST_UNSOLVED; ++approx) {
+        const T mul = approx ? T(10) : T(1);
+        const T eps_abs = eps_abs0 * mul, eps_rel = eps_rel0 * mul;
+        const T eps_pinf = eps_pinf0 * mul, eps_dinf = eps_dinf0 * mul;
+        const T eps_prim = eps_abs + eps_rel * umpc_max(nz, nAx);
+        const T eps_dual = eps_abs + eps_rel * (umpc_max(umpc_max(nq, nAty), nPx) * cinv);
+        const bool prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual;
+        bool pinf = false, dinf = false;
+        if (!prim_ok) {
+          // is_primal_infeasible, auxil.c:362-424 (all bounds finite here: no projection of delta_y)
+          T dyv[NC];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) ndy = umpc_max(ndy, umpc_abs(dyv[i] * Es[i]));
-        if (ndy > eps_pinf) {
+          for (int i = 0; i < NC; ++i) dyv[i] = GLD(a.ws, WS_DY + i);
+          T ndy = T(0), lhs = T(0);
 #pragma unroll
-          for (int i = 0; i < NC; ++i) {
-            const T ui = i < NEQ ? lo[i] : up3[i - NEQ];
-            lhs += ui * umpc_max(dyv[i], T(0)) + lo[i] * umpc_min(dyv[i], T(0));
-          }
-          if (lhs < -eps_pinf * ndy) {
-            T Atdy[NX];
-#define IN_DY(i) dyv[i]
-#define OUT_ATDY(j) Atdy[j]
-            UMPC_GEN_AT_MUL(IN_DY, OUT_ATDY);
-            T nrm = T(0);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) nrm = umpc_max(nrm, umpc_abs(Atdy[j] * Dinv[j]));
-            pinf = nrm < eps_pinf * ndy;
-          }
-        }
-      }
-      if (!dual_ok) {
-        // is_dual_infeasible, auxil.c:426-512
-        T ndx = T(0), qdx = T(0);
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-          const T dx = x[j] - xprev[j];
-          ndx = umpc_max(ndx, umpc_abs(Ds[j] * dx));
-          qdx += q[j] * dx;
-        }
-        if (ndx > eps_dinf && qdx < -cscale * eps_dinf * ndx) {
-          T nP = T(0);
-#pragma unroll
-          for (int j = 0; j < NX; ++j) nP = umpc_max(nP, umpc_abs((P[j] * (x[j] - xprev[j])) * Dinv[j]));
-          if (nP < cscale * eps_dinf * ndx) {
-            T dxv[NX], Adx[NC];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) dxv[j] = x[j] - xprev[j];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) Adx[i] = T(0);
-#define IN_DX(j) dxv[j]
-#define OUT_ADX(i) Adx[i]
-            UMPC_GEN_A_MUL(IN_DX, OUT_ADX);
-            bool ok = true;
+          for (int i = 0; i < NC; ++i) ndy = umpc_max(ndy, umpc_abs(dyv[i] * Es[i]));
+          if (ndy > eps_pinf) {
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-              const T v = Adx[i] * Einv[i];
-              if (v > eps_dinf * ndx || v < -eps_dinf * ndx) ok = false;  // all bounds finite
+              const T li = i < NEQ ? z[i < NEQ ? i : 0] : lo3[i < NEQ ? 0 : i - NEQ];
+              const T ui = i < NEQ ? li : up3[i < NEQ ? 0 : i - NEQ];
+              lhs += ui * umpc_max(dyv[i], T(0)) + li * umpc_min(dyv[i], T(0));
             }
-            dinf = ok;
+            if (lhs < -eps_pinf * ndy) {
+              T Atdy[NX];
+#define IN_DY(i) dyv[i]
+#define OUT_ATDY(j) Atdy[j]
+              UMPC_GEN_AT_MUL(IN_DY, OUT_ATDY);
+              T nrm = T(0);
+#pragma unroll
+              for (int j = 0; j < NX; ++j) nrm = umpc_max(nrm, umpc_abs(Atdy[j] * umpc_rcp_fast(Ds[j])));
+              pinf = nrm < eps_pinf * ndy;
+            }
           }
         }
+        if (!dual_ok) {
+          // is_dual_infeasible, auxil.c:426-512
+          T dxv[NX];
+#pragma unroll
+          for (int j = 0; j < NX; ++j) dxv[j] = x[j] - GLD(a.ws, WS_XPREV + j);
+          T ndx = T(0), qdx = T(0);
+#pragma unroll
+          for (int j = 0; j < NX; ++j) {
+            ndx = umpc_max(ndx, umpc_abs(Ds[j] * dxv[j]));
+            qdx += Q_(j) * dxv[j];
+          }
+          if (ndx > eps_dinf && qdx < -cscale * eps_dinf * ndx) {
+            T nP = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) nP = umpc_max(nP, umpc_abs((P[j] * dxv[j]) * umpc_rcp_fast(Ds[j])));
+            if (nP < cscale * eps_dinf * ndx) {
+              T Adx[NC];
+#pragma unroll
+              for (int i = 0; i < NC; ++i) Adx[i] = T(0);
+#define IN_DX(j) dxv[j]
+#define OUT_ADX(i) Adx[i]
+              UMPC_GEN_A_MUL(IN_DX, OUT_ADX);
+              bool ok = true;
+#pragma unroll
+              for (int i = 0; i < NC; ++i) {
+                const T v = Adx[i] * umpc_rcp_fast(Es[i]);
+                if (v > eps_dinf * ndx || v < -eps_dinf * ndx) ok = false;  // all bounds finite
+              }
+              dinf = ok;
+            }
+          }
+        }
+        if (prim_ok && dual_ok) status = approx ? ST_SOLVED_INACC : ST_SOLVED;
+        else if (pinf) status = approx ? ST_PINF_INACC : ST_PINF;
+        else if (dinf) status = approx ? ST_DINF_INACC : ST_DINF;
       }
-      if (prim_ok && dual_ok) status = approx ? ST_SOLVED_INACC : ST_SOLVED;
-      else if (pinf) status = approx ? ST_PINF_INACC : ST_PINF;
-      else if (dinf) status = approx ? ST_DINF_INACC : ST_DINF;
+      if (status == ST_UNSOLVED) status = ST_MAX_ITER;
     }
-    if (status == ST_UNSOLVED) status = ST_MAX_ITER;
+#undef A_
   }
 
-  // ---- store_solution (auxil.c:527-565) + extraction (uprightmpc2.c:253-269) ------
+  // ---- store_solution (auxil.c:527-565) + extraction (uprightmpc2.c:253-269) ----
   const bool has_sol = status != ST_PINF && status != ST_PINF_INACC && status != ST_DINF &&
                        status != ST_DINF_INACC && status != ST_NON_CVX;
   T u0, u1, u2, dy1[NY];
@@ -519,27 +680,71 @@ __device__ __forceinline__ int mpc_step(const DevParams<T> &prm, const T (&Ibi)[
     for (int i = 0; i < NC; ++i) { y[i] = T(0); z[i] = T(0); }
   }
   T0 += u0;
-  uquad[0] = T0; uquad[1] = u1; uquad[2] = u2;
-  // dq1des = (dy1des[0:3], e3h R0' dy1des[3:6]); e3h R0' v = (-(R0' v)_y, (R0' v)_x, 0)
-  const T rx = (R0[0] * dy1[3] + R0[1] * dy1[4]) + R0[2] * dy1[5];
-  const T ry = (R0[3] * dy1[3] + R0[4] * dy1[4]) + R0[5] * dy1[5];
-  const T dq1[NY] = {dy1[0], dy1[1], dy1[2], -ry, rx, T(0)};
+  T uq[3] = {T0, u1, u2}, acc[NY];
+  {
+    // dq1des = (dy1des[0:3], e3h R0' dy1des[3:6]); e3h R0' v = (-(R0' v)_y, (R0' v)_x, 0)
+    const T rx = (R0[0] * dy1[3] + R0[1] * dy1[4]) + R0[2] * dy1[5];
+    const T ry = (R0[3] * dy1[3] + R0[4] * dy1[4]) + R0[5] * dy1[5];
+    const T dq1[NY] = {dy1[0], dy1[1], dy1[2], -ry, rx, T(0)};
 #pragma unroll
-  for (int i = 0; i < NY; ++i) accdes[i] = (dq1[i] - dq0[i]) / prm.dt;
-  return status;
-#undef A_
-#undef P_
-#undef LX_
+    for (int i = 0; i < NY; ++i) acc[i] = (dq1[i] - dq0[i]) / prm.dt;
+  }
+  // controller record + outputs back to HBM
+#pragma unroll
+  for (int j = 0; j < NX; ++j) GLD(a.ctrl, j) = x[j];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) GLD(a.ctrl, NX + i) = y[i];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) GLD(a.ctrl, NX + NC + i) = z[i];
+  GLD(a.ctrl, NX + 2 * NC) = T0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) GLD(a.ctrl, NX + 2 * NC + 1 + k) = Eprev3[k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) GLD(a.out, i) = uq[i];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) GLD(a.out, 3 + i) = acc[i];
+  if (a.status) a.status[bb] = status;
+  if (a.info) { GLD(a.info, 0) = pri_res; GLD(a.info, 1) = dua_res; }
+
+  // ---- plant: template/uprightmpc2.py:148-151 ----
+  if (prm.nsub > 0) {
+    T Ib[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ib[i] = a.Ib ? GLD(a.Ib, i) : prm.Ib[i];
+    const T gain = a.gain ? a.gain[bb] : T(1);
+    // the harness clips what the PLANT sees; the controller's return value stays unclipped
+    const T uc[3] = {uq[0], umpc_min(umpc_max(uq[1], -prm.taulim), prm.taulim),
+                     umpc_min(umpc_max(uq[2], -prm.taulim), prm.taulim)};
+    T s_err = a.stats ? GLD(a.stats, 0) : T(0), s_eff = a.stats ? GLD(a.stats, 1) : T(0);
+#pragma nounroll
+    for (int s = 0; s < prm.nsub; ++s) {
+      plant_step(p0, R0, dq0, uc, prm.dtsim, Ib, gain, prm.plant_mode);
+      s_err += p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2];
+      s_eff += uc[1] * uc[1] + uc[2] * uc[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) GLD(a.state, i) = p0[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) GLD(a.state, 3 + i) = R0[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) GLD(a.state, 12 + i) = dq0[i];
+    if (a.stats) { GLD(a.stats, 0) = s_err; GLD(a.stats, 1) = s_eff; }
+  }
+#undef GLD
+#undef UMPC_PHASE_FENCE
+#undef UMPC_SCHED_FENCE
+#undef Q_
 #undef DI_
+#undef LX_
 #undef RINV3_
 #undef RHO3_
+#undef LO3_
+#undef UP3_
 #undef W_
 #undef X_
 #undef Y_
 #undef Z_
-#undef Q_
-#undef LO_
-#undef UP3_
+#undef UMPC_CAPTURE_X
 }
 
 }  // namespace umpc
