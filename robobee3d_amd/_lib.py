@@ -48,9 +48,10 @@ class UprightMPC_t(C.Structure):
 
 def build(force=False, verbose=False):
     """Generate umpc_gen.h and compile the HIP library for gfx950 (works without a GPU)."""
-    from . import codegen
+    from . import asmgen, codegen
     gen, _ = codegen.write()
-    deps = [SRC, gen, os.path.join(HERE, "csrc", "umpc_step.h"),
+    gasm, _ = asmgen.write()
+    deps = [SRC, gen, gasm, os.path.join(HERE, "csrc", "umpc_step.h"),
             os.path.join(ROOT, "include", "umpc_mi355x.h")]
     if (not force and os.path.exists(SO_PATH)
             and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps)):

@@ -28,19 +28,20 @@ int fail(hipError_t e, const char *what) {
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-// K closed-loop steps per robot; lane b of the grid owns robot b. One wavefront per
-// workgroup (no barriers, no cross-lane traffic); fp32 keeps q and 1/D of the factor in LDS
-// (33 float4 per lane = 33,792 B per workgroup -> 4 workgroups = 4 waves per CU, one per SIMD).
+// K closed-loop steps per robot; lane b of the grid owns robot b. One wavefront per workgroup
+// (no barriers, no cross-lane traffic). fp32: the ADMM phase is the generated assembly with
+// L[0..160) in LDS (40 float4 per lane = 40,960 B per workgroup -> 4 workgroups = 4 waves per CU,
+// one per SIMD, which is also what 512 registers per lane allow).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a, int K, const T *actualT0) {
-  constexpr bool kLds = sizeof(T) == 4;
-  __shared__ float4 lds[kLds ? (umpc::HOT_WORDS / 4) * kBlock : 1];
+  constexpr bool kAsm = sizeof(T) == 4;
+  __shared__ float4 lds[kAsm ? (umpcasm::LDS_BYTES_PER_LANE / 16) * kBlock : 1];
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= a.B) return;
-  umpc::Hot<T, kLds> hot;
-  if constexpr (kLds) hot.base = reinterpret_cast<T *>(lds) + 4 * threadIdx.x;
+  // low 32 bits of a flat LDS pointer = the LDS byte address
+  const unsigned ldsaddr = kAsm ? (unsigned)(size_t)(&lds[threadIdx.x]) : 0u;
 #pragma nounroll
-  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kLds>(a, b, hot, k == 0, actualT0);
+  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, k == 0, actualT0);
 }
 
 template <typename T>

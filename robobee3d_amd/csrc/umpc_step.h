@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "umpc_gen.h"
+#include "umpc_admm_asm.h"
 
 namespace umpc {
 
@@ -269,39 +270,25 @@ __device__ __forceinline__ void assemble(const DevParams<T> &prm, const T (&Ibi)
 }
 
 // ---------------------------------------------------------------------------
-// Where the per-robot working set lives (one lane = one robot, one wave per SIMD):
+// Where the per-robot working set lives (one lane = one robot, one wave per SIMD).
 //
-//   ADMM-loop residents            words   home
-//   L (strict lower factor)         213    registers (VGPR/AGPR, compiler-allocated)
-//   W (KKT rhs / solution)           84    registers
-//   x, y, z                         123    registers
-//   thrust-row bounds / rho          12    registers
-//   q (scaled linear cost)           45    LDS  (fp32)   float4-interleaved per lane
-//   1/D of the factor                84    LDS  (fp32)
-//   -------------------------------------
-//   Ruiz D, E, c; x_prev, delta_y   169    parked in the HBM workspace across the loop
-//   P, A (scaled)                   156    dead after the factorisation; re-derived from
-//                                          the raw entries and D, E, c for the residuals
+// The ADMM loop needs, per robot: L 213 + 1/D 84 + q 45 + W 84 + x,y,z 123 + 12 thrust-row
+// words = 561 words. A CU can give one lane 256 VGPRs + 256 AGPRs + 160 LDS words at one wave
+// per SIMD, so the loop only fits when every word has a fixed home in one of the three. hipcc
+// cannot do that (it allocates from 256 VGPRs and spills the factor to scratch: measured 2-3 GB
+// of spill traffic per launch), so for fp32 the loop is the generated assembly of
+// umpc_admm_asm.h (asmgen.py): W, x, y, z in VGPRs, L[160..], 1/D and q in AGPRs, L[0..160)
+// in LDS. The C++ phases around it (assembly, Ruiz, LDL' before; residuals, status, extraction,
+// plant after) talk to it through the HBM workspace rows below; that traffic stays in L2 /
+// Infinity Cache. fp64 has no such budget (2x words): it runs the C++ loop (UMPC_GEN_ADMM_ITER)
+// and lets the compiler spill.
 //
-// 512 registers + 160 LDS words per lane is everything a CU can give a lane at
-// one wave per SIMD; the loop needs ~560 words, so q and 1/D (read-only inside
-// the loop, one ds_read_b128 per four words) go to LDS and everything that is
-// not touched by the loop leaves the chip. fp64 has no such budget (2x words):
-// it keeps the same code and lets the compiler spill.
+// workspace rows [WS_ROWS][B]:
+//   FAC_L 213 | FAC_DI 84 | FAC_Q 45 | FAC_LOEQ 36 | FAC_M 12 (lo3 up3 rho3 rinv3)   phase A -> loop
+//   WS_DS 45 | WS_ES 39 | WS_C 1                                                       phase A -> phase C
+//   WS_XPREV 45 | WS_DY 39   x_prev / delta_y of the last iteration                    loop -> phase C
 // ---------------------------------------------------------------------------
-constexpr int HOT_Q = 0, HOT_DI = 48, HOT_WORDS = 132;  // 33 float4 per lane
-constexpr int WS_DS = 0, WS_ES = WS_DS + NX, WS_C = WS_ES + NC, WS_XPREV = WS_C + 1, WS_DY = WS_XPREV + NX,
-              WS_ROWS = WS_DY + NC;  // 169
-
-template <typename T, bool LDS> struct Hot;
-template <typename T> struct Hot<T, false> {
-  T v[HOT_WORDS];
-  __device__ __forceinline__ T &at(int w) { return v[w]; }
-};
-template <typename T> struct Hot<T, true> {
-  T *base;  // = lds + 4 * lane
-  __device__ __forceinline__ T &at(int w) { return base[(w >> 2) * 256 + (w & 3)]; }
-};
+using namespace umpcasm;
 
 template <typename T>
 struct StepIO {
@@ -322,9 +309,10 @@ struct StepIO {
 // One closed-loop step of robot b: controller step (= umpcUpdate) + nsub plant substeps.
 // Everything persistent round-trips through the SoA arrays, so K steps in one launch and K
 // launches of one step are the same computation.
-template <typename T, bool LDS>
-__device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, Hot<T, LDS> &hot, const bool first_step,
-                                                 const T *actualT0) {
+template <typename T, bool ASM>
+__device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, const unsigned ldsaddr,
+                                                 const bool first_step, const T *actualT0) {
+  static_assert(!ASM || sizeof(T) == 4, "the assembly loop is fp32");
   const size_t B = (size_t)a.B;
   const DevParams<T> &prm = a.prm;
   const T sigma = T(1e-6), alpha = T(1.6), oma = T(1.0) - T(1.6);
@@ -337,8 +325,8 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #define UMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define UMPC_PHASE_FENCE() asm volatile("" : "+v"(bb)::"memory")
 #define GLD(arr, row) ((arr) + (size_t)(row) * B)[bb]
-#define Q_(j) hot.at(HOT_Q + (j))
-#define DI_(k) hot.at(HOT_DI + (k))
+#define Q_(j) qv[j]
+#define DI_(k) Di[k]
 #define LX_(e) Lx[e]
 #define RINV3_(k) rinv3[k]
 #define RHO3_(k) rho3[k]
@@ -349,7 +337,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #define Y_(i) y[i]
 #define Z_(i) z[i]
 
-  T Lx[NNZL];
+  T Lx[NNZL], Di[NK], qv[NX];
   T lo[NEQ];  // scaled bounds of the dynamics rows; consumed by the first ADMM iteration
   T lo3[N], up3[N], rho3[N], rinv3[N], Eprev3[N];
   T T0 = GLD(a.ctrl, NX + 2 * NC);
@@ -442,9 +430,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     }
 #undef DT_
 #undef ET_
-    // park what the loop does not touch; hand q to its loop home
+    // hand-off rows: what phase C needs again, and what the loop consumes
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { GLD(a.ws, WS_DS + j) = Ds[j]; Q_(j) = q[j]; }
+    for (int j = 0; j < NX; ++j) { GLD(a.ws, WS_DS + j) = Ds[j]; GLD(a.ws, FAC_Q + j) = q[j]; Q_(j) = q[j]; }
 #pragma unroll
     for (int i = 0; i < NC; ++i) GLD(a.ws, WS_ES + i) = Es[i];
     GLD(a.ws, WS_C) = cscale;
@@ -455,6 +443,10 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
       lo3[k] = lraw[NEQ + k] * Es[NEQ + k];
       up3[k] = up3[k] * Es[NEQ + k];
       Eprev3[k] = Es[NEQ + k];
+      GLD(a.ws, FAC_M + k) = lo3[k];
+      GLD(a.ws, FAC_M + N + k) = up3[k];
+      GLD(a.ws, FAC_M + 2 * N + k) = rho3[k];
+      GLD(a.ws, FAC_M + 3 * N + k) = rinv3[k];
     }
     // ---- KKT fill + LDL', kkt.c:184-222 + qdldl.c:86-247 ----
     int npos = 0;
@@ -462,18 +454,32 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     (void)npos;
 #undef A_
 #undef P_
+    if constexpr (ASM) {
+#pragma unroll
+      for (int e = 0; e < NNZL; ++e) GLD(a.ws, FAC_L + e) = Lx[e];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) GLD(a.ws, FAC_DI + k) = Di[k];
+#pragma unroll
+      for (int i = 0; i < NEQ; ++i) GLD(a.ws, FAC_LOEQ + i) = lo[i];
+    }
   }
 
   // =========================== phase B: ADMM, osqp.c:354-370 ===========================
   UMPC_PHASE_FENCE();
-  T x[NX], y[NC], z[NC];
+  if constexpr (ASM) {
+    // generated gfx950 assembly (umpc_admm_asm.h): reads FAC_* and x,y,z, runs maxIter iterations with
+    // a static VGPR/AGPR/LDS placement, writes x,y,z back and x_prev / delta_y of the last iteration
+    const unsigned voff = bb * 4u, stride = (unsigned)a.B * 4u;
+    const int iters = prm.maxIter;
+    UMPC_ADMM_ASM(voff, ldsaddr, a.ws, a.ctrl, stride, iters);
+  } else {
+    T x[NX], y[NC], z[NC];
 #pragma unroll
-  for (int j = 0; j < NX; ++j) x[j] = GLD(a.ctrl, j);
+    for (int j = 0; j < NX; ++j) x[j] = GLD(a.ctrl, j);
 #pragma unroll
-  for (int i = 0; i < NC; ++i) y[i] = GLD(a.ctrl, NX + i);
+    for (int i = 0; i < NC; ++i) y[i] = GLD(a.ctrl, NX + i);
 #pragma unroll
-  for (int i = 0; i < NC; ++i) z[i] = GLD(a.ctrl, NX + NC + i);
-  {
+    for (int i = 0; i < NC; ++i) z[i] = GLD(a.ctrl, NX + NC + i);
     T W[NK];
     // x_prev / delta_y of the LAST iteration feed the infeasibility tests (auxil.c:362-512)
 #define UMPC_CAPTURE_X() _Pragma("unroll") for (int j = 0; j < NX; ++j) GLD(a.ws, WS_XPREV + j) = x[j]
@@ -494,24 +500,41 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #define UMPC_ADMM_DY(i, v)
 #pragma nounroll
     for (int it = 2; it < prm.maxIter; ++it) {
-      // keep the LDS-resident q and 1/D in LDS: without this the (loop-invariant) ds_reads are
-      // hoisted into 129 registers and the factor spills to scratch instead
-      asm volatile("" ::: "memory");
       UMPC_GEN_ADMM_ITER();
     }
 #undef UMPC_ADMM_DY
 #define UMPC_ADMM_DY(i, v) GLD(a.ws, WS_DY + (i)) = (v)
     if (prm.maxIter >= 2) {
-      UMPC_PHASE_FENCE();
       UMPC_CAPTURE_X();
       UMPC_GEN_ADMM_ITER();
     }
 #undef UMPC_ADMM_DY
 #undef LOEQ_
+#pragma unroll
+    for (int j = 0; j < NX; ++j) GLD(a.ctrl, j) = x[j];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) GLD(a.ctrl, NX + i) = y[i];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) GLD(a.ctrl, NX + NC + i) = z[i];
   }
 
   // =========================== phase C: residuals, status, extraction, plant ===========================
   UMPC_PHASE_FENCE();
+  T x[NX], y[NC], z[NC];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) { x[j] = GLD(a.ctrl, j); qv[j] = GLD(a.ws, FAC_Q + j); }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) y[i] = GLD(a.ctrl, NX + i);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) z[i] = GLD(a.ctrl, NX + NC + i);
+#pragma unroll
+  for (int k = 0; k < N; ++k) { lo3[k] = GLD(a.ws, FAC_M + k); up3[k] = GLD(a.ws, FAC_M + N + k); }
+  if (prm.maxIter < 1) {  // no iteration ran: nothing was captured
+#pragma unroll
+    for (int j = 0; j < NX; ++j) GLD(a.ws, WS_XPREV + j) = x[j];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) GLD(a.ws, WS_DY + i) = T(0);
+  }
   T p0[3], R0[9], dq0[6];
 #pragma unroll
   for (int i = 0; i < 3; ++i) p0[i] = GLD(a.state, i);
