@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--plant", default="euler", choices=["euler", "rk4"],
                     help="euler = the reference's Euler+expm step (parity mode); rk4 = build-defined RK4")
+    ap.add_argument("--max-iter", type=int, default=50, help="ADMM iterations (50 = the reference; other values are diagnostics)")
+    ap.add_argument("--nsub", type=int, default=25, help="plant substeps per MPC step (25 = the metric; 0 = QP only)")
+    ap.add_argument("--steps-per-launch", type=int, default=1, help="closed-loop steps fused into one kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-robots", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=100)
@@ -97,7 +100,7 @@ def main():
 
     # synthetic inputs, resident in HBM before the timed region
     st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=rank * B)
-    mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode)
+    mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode, maxIter=args.max_iter, nsub=args.nsub)
     mpc.set_state(st, ref)
 
     def barrier():
@@ -108,11 +111,14 @@ def main():
     for _ in range(args.warmup):
         mpc.rollout(1)
     barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    spl = max(1, min(args.steps_per_launch, args.steps))
+    assert args.steps % spl == 0, "--steps must be a multiple of --steps-per-launch"
+    nlaunch = args.steps // spl
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(nlaunch):
         evs[k][0].record()
-        mpc.rollout(1)          # ONE launch = one closed-loop step of all B robots
+        mpc.rollout(spl)        # ONE launch = spl closed-loop steps of all B robots
         evs[k][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -135,7 +141,7 @@ def main():
         total_steps = world * B * args.steps
         value = total_steps / elapsed
         bps = ALG_BYTES_PER_STEP_FP32 * (2 if args.dtype == "f64" else 1)
-        achieved = bps * B / (kern_ms * 1e-3) / 1e9
+        achieved = bps * B * spl / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
@@ -158,9 +164,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": _lib.lib().umpcKernelName(0 if args.dtype == "f32" else 1, plant_mode).decode(),
-                         "kernel_ms": kern_ms, "alg_bytes_per_launch": bps * B,
+                         "kernel_ms": kern_ms, "steps_per_launch": spl, "alg_bytes_per_launch": bps * B * spl,
                          "note": "path is VALU-issue/latency bound, not HBM bound (DESIGN.md): ~1.1e5 flop per "
-                                 "1208 B; achieved fp32 rate %.1f TFLOP/s" % (1.1e5 * B / (kern_ms * 1e-3) / 1e12)},
+                                 "1208 B; achieved fp32 rate %.1f TFLOP/s" % (1.1e5 * B * spl / (kern_ms * 1e-3) / 1e12)},
             "check": {"nonfinite_state_values": nbad,
                       "mean_pos_err_mm2": float(metric[0].mean().item()),
                       "status_solved_frac": float((status > 0).float().mean().item())},

@@ -17,7 +17,7 @@ placement is static (one lane = one robot, one wave per SIMD):
     v238..v243    AGPR read temporaries
     v244..v251    arithmetic temporaries
     v221, v252..v255   not touched (left to the compiler for values that live across the block)
-    a0..a52       L[160..212]    a53..a136  1/D    a137..a181  q
+    a0..a52       L[160..212]    a53..a136  1/D    a137..a181  q    a182..a217  l(=u) of the dynamics rows
     LDS           L[0..159] as 40 float4 per lane (ds_read_b128, conflict-free)
 
 Per middle iteration: 84 rhs FMAs, 426 solve FMAs + 84 multiplies, 90 x-update
@@ -50,7 +50,7 @@ WS_ROWS = 559
 V_W, V_X, V_Y, V_Z, V_M = 2, 86, 131, 170, 209
 V_RING, V_AT, V_TT = 222, 238, 244   # v221 and v252..v255 are left to the compiler (SGPR spill lanes)
 N_AT = 6
-A_L, A_D, A_Q = 0, 53, 137
+A_L, A_D, A_Q, A_LO = 0, 53, 137, 182
 S_WS, S_CTRL, S_STRIDE, S_ITERS = 4, 6, 10, 11
 S_P, S_CNT, S_P2 = 12, 14, 16
 S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO = 20, 21, 22, 23, 24
@@ -88,38 +88,33 @@ def prologue(e, s):
     e("s_mov_b32", "s%d" % S_SIGMA, f32bits(1e-6))
     e("s_mov_b32", "s%d" % S_RINV, f32bits(0.01))
     e("s_mov_b32", "s%d" % S_RHO, f32bits(100.0))
-    # thrust-row words
-    _row_ptr(e, S_P, S_WS, FAC_M)
+    # Two memory round trips in all (every wave of the grid is in this phase at the same time, so each
+    # exposed round trip costs microseconds): (1) L[0..NLDS) staged through v2..v161 (W/x/y are not live
+    # yet) into LDS; (2) everything else, back to back, one wait.
+    assert NLDS <= V_Z - V_W
+    e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_WS, S_WS + 1))
+    for r in range(NLDS):
+        e("global_load_dword", "v%d" % (V_W + r), "v0", "s[%d:%d]" % (S_P, S_P + 1))
+        _adv(e, S_P)
+    e("s_waitcnt", "vmcnt(0)")
+    for g in range(NLDS // 4):
+        e("ds_write_b128", "v1", "v[%d:%d]" % (V_W + 4 * g, V_W + 4 * g + 3), g * 1024)
+    # the rest of L, 1/D, q and the dynamics-row bounds -> AGPRs (rows are consecutive in the workspace)
+    nrest = len(s.L_i) - NLDS + s.nk + s.nx + 2 * s.N * symbolic.NY
+    assert A_LO == nrest - 2 * s.N * symbolic.NY and nrest <= 256
+    for r in range(nrest):
+        e("global_load_dword", "a%d" % r, "v0", "s[%d:%d]" % (S_P, S_P + 1))
+        _adv(e, S_P)
+    # thrust-row words (rows follow FAC_LOEQ)
     for k in range(12):
         e("global_load_dword", "v%d" % (V_M + k), "v0", "s[%d:%d]" % (S_P, S_P + 1))
         _adv(e, S_P)
+    e("s_waitcnt", "lgkmcnt(0)")  # ds_writes have read v2..v161
     # x, y, z
     e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_CTRL, S_CTRL + 1))
     for r in range(s.nx + 2 * s.nc):
         e("global_load_dword", "v%d" % (V_X + r), "v0", "s[%d:%d]" % (S_P, S_P + 1))
         _adv(e, S_P)
-        if r % 40 == 39:
-            e("s_waitcnt", "vmcnt(0)")
-    e("s_waitcnt", "vmcnt(0)")
-    # L[0..NLDS) -> LDS through the ring registers, 16 rows per batch
-    e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_WS, S_WS + 1))
-    for g0 in range(0, NLDS // 4, 4):
-        for q in range(4):
-            for w in range(4):
-                e("global_load_dword", "v%d" % (V_RING + 4 * q + w), "v0", "s[%d:%d]" % (S_P, S_P + 1))
-                _adv(e, S_P)
-        e("s_waitcnt", "vmcnt(0)")
-        for q in range(4):
-            e("ds_write_b128", "v1", "v[%d:%d]" % (V_RING + 4 * q, V_RING + 4 * q + 3), (g0 + q) * 1024)
-        e("s_waitcnt", "lgkmcnt(0)")
-    # the rest of L, 1/D and q -> AGPRs (rows are consecutive in the workspace)
-    n = 0
-    for r in range(NLDS, len(s.L_i) + s.nk + s.nx):
-        e("global_load_dword", "a%d" % (r - NLDS), "v0", "s[%d:%d]" % (S_P, S_P + 1))
-        _adv(e, S_P)
-        n += 1
-        if n % 48 == 0:
-            e("s_waitcnt", "vmcnt(0)")
     e("s_waitcnt", "vmcnt(0)")
 
 
@@ -249,16 +244,12 @@ def body(e, s, first, capture):
     # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
     if capture:
         _row_ptr(e, S_P2, S_WS, WS_DY)
-    if first:  # l == u of the dynamics rows, 16 at a time into the (idle) ring registers
-        _row_ptr(e, S_P, S_WS, FAC_LOEQ)
     for i in range(nc):
         eq = i < neq
         if first and eq and i % 16 == 0:
-            cnt = min(16, neq - i)
-            for w in range(cnt):
-                e("global_load_dword", "v%d" % (V_RING + w), "v0", "s[%d:%d]" % (S_P, S_P + 1))
-                _adv(e, S_P)
-            e("s_waitcnt", "vmcnt(0)")
+            # l == u of the dynamics rows sit in spare AGPRs; 16 at a time into the (idle) ring registers
+            for w in range(min(16, neq - i)):
+                e("v_accvgpr_read_b32", "v%d" % (V_RING + w), "a%d" % (A_LO + i + w))
         b = V_TT + 4 * (i % 2)
         t1, t2, t3 = "v%d" % b, "v%d" % (b + 1), "v%d" % (b + 2)
         rinv = sRi if eq else M(9 + i - neq)
@@ -284,8 +275,6 @@ def body(e, s, first, capture):
         if capture:
             e("global_store_dword", "v0", t2, ptr)
             _adv(e, S_P2)
-    if capture:
-        e("s_waitcnt", "vmcnt(0)")
 
 
 def program(N=3, perm=None):

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -33,13 +34,22 @@ int fail(hipError_t e, const char *what) {
 // L[0..160) in LDS (40 float4 per lane = 40,960 B per workgroup -> 4 workgroups = 4 waves per CU,
 // one per SIMD, which is also what 512 registers per lane allow).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a, int K, const T *actualT0) {
+__global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a, int K, const T *actualT0, int skew_ticks) {
   constexpr bool kAsm = sizeof(T) == 4;
   __shared__ float4 lds[kAsm ? (umpcasm::LDS_BYTES_PER_LANE / 16) * kBlock : 1];
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= a.B) return;
   // low 32 bits of a flat LDS pointer = the LDS byte address
   const unsigned ldsaddr = kAsm ? (unsigned)(size_t)(&lds[threadIdx.x]) : 0u;
+  // Every wave runs the same phases (memory-heavy hand-offs, then the ALU-only ADMM loop). Started
+  // together, all 1024 resident waves hit HBM at the same instants and idle the ALUs meanwhile. For
+  // multi-step launches the waves are started in `skew_groups` staggered groups so that the memory
+  // phase of one group overlaps the ADMM loop of the others (costs one partial step per launch).
+  if (skew_ticks > 0) {
+    const unsigned g = (blockIdx.x / 8u) % 4u;  // blocks b and b+8 share an XCD: spread groups inside each
+    const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (long long)g * skew_ticks) __builtin_amdgcn_s_sleep(64);
+  }
 #pragma nounroll
   for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, k == 0, actualT0);
 }
@@ -156,8 +166,11 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   a.Ib = (const T *)Ib; a.gain = (const T *)gain; a.ws = (T *)h->ws; a.out = (T *)out; a.stats = (T *)stats;
   a.status = status; a.info = (T *)info;
   const int grid = (h->B + kBlock - 1) / kBlock;
+  // stagger wave groups by ~1/4 step (measured step ~0.33 ms fp32) when a launch carries many steps
+  const char *env = getenv("UMPC_SKEW_US");
+  const int skew_us = env ? atoi(env) : (K >= 8 && sizeof(T) == 4 && h->B >= 32768 ? 80 : 0);
   hipLaunchKernelGGL(umpc_rollout_kernel<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
-                     (const T *)actualT0);
+                     (const T *)actualT0, skew_us * 100);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
 }

@@ -55,7 +55,9 @@ struct DevParams {
 enum { ST_SOLVED = 1, ST_SOLVED_INACC = 2, ST_PINF_INACC = 3, ST_DINF_INACC = 4,
        ST_MAX_ITER = -2, ST_PINF = -3, ST_DINF = -4, ST_NON_CVX = -7, ST_UNSOLVED = -10 };
 
-template <typename T> __device__ __forceinline__ T umpc_abs(T v) { return v < T(0) ? -v : v; }
+// |v| as a source modifier (c_absval of glob_opts.h:91; identical for every non-NaN value)
+__device__ __forceinline__ float umpc_abs(float v) { return __builtin_fabsf(v); }
+__device__ __forceinline__ double umpc_abs(double v) { return __builtin_fabs(v); }
 // max/min of non-NaN values (c_max / c_min of glob_opts.h:95-99): one v_max / v_min
 __device__ __forceinline__ float umpc_max(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float umpc_min(float a, float b) { return __builtin_fminf(a, b); }
