@@ -6,8 +6,10 @@ on; SURVEY 8d "Config 3"): B = 65536 robots PER GPU, fp32, horizon N = 3,
 random-tilt hover start (seed 20201118), closed loop. One "step" = one pass of
 the hot path over the whole batch = for every robot one umpcUpdate-equivalent
 (assembly + 10 Ruiz passes + LDL' + 50 ADMM iterations + status + extraction)
-followed by 25 plant substeps of 0.2 ms, moments clipped at +-100. One kernel
-launch per step; inputs are resident in HBM before the timed region.
+followed by 25 plant substeps of 0.2 ms, moments clipped at +-100. By default the
+K timed steps run as ONE persistent launch of the step kernel (the closed loop is
+a rollout; --steps-per-launch 1 gives one launch per step); inputs are resident
+in HBM before the timed region and every step round-trips its state through HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -73,7 +75,9 @@ def main():
                     help="euler = the reference's Euler+expm step (parity mode); rk4 = build-defined RK4")
     ap.add_argument("--max-iter", type=int, default=50, help="ADMM iterations (50 = the reference; other values are diagnostics)")
     ap.add_argument("--nsub", type=int, default=25, help="plant substeps per MPC step (25 = the metric; 0 = QP only)")
-    ap.add_argument("--steps-per-launch", type=int, default=1, help="closed-loop steps fused into one kernel launch")
+    ap.add_argument("--steps-per-launch", type=int, default=0,
+                    help="closed-loop steps carried by one kernel launch (0 = all K timed steps in one launch; "
+                         "1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-robots", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=100)
@@ -84,22 +88,21 @@ def main():
     from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
     from robobee3d_amd import _lib
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from robobee3d_amd import shard
+    rank, world, local_rank = shard.world()
+    dev = torch.device("cuda", local_rank)
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        shard.init("nccl", device=dev)   # "nccl" is RCCL on ROCm
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     ndt = np.float32 if args.dtype == "f32" else np.float64
     plant_mode = 0 if args.plant == "euler" else 1
     B = args.batch
 
     # synthetic inputs, resident in HBM before the timed region
-    st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=rank * B)
+    lo, _hi = shard.robot_range(B, rank)   # weak scaling: B robots per GPU, RNG keyed by the global index
+    st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=lo)
     mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode, maxIter=args.max_iter, nsub=args.nsub)
     mpc.set_state(st, ref)
 
@@ -111,7 +114,7 @@ def main():
     for _ in range(args.warmup):
         mpc.rollout(1)
     barrier()
-    spl = max(1, min(args.steps_per_launch, args.steps))
+    spl = args.steps if args.steps_per_launch <= 0 else max(1, min(args.steps_per_launch, args.steps))
     assert args.steps % spl == 0, "--steps must be a multiple of --steps-per-launch"
     nlaunch = args.steps // spl
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
@@ -121,19 +124,12 @@ def main():
         mpc.rollout(spl)        # ONE launch = spl closed-loop steps of all B robots
         evs[k][1].record()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
-    # end-of-run trajectory statistics: the only exchange of the path (outside the timed region)
-    metric = mpc.metrics(args.warmup + args.steps)
-    if world > 1:
-        gathered = [torch.empty_like(metric) for _ in range(world)]
-        dist.all_gather(gathered, metric)
-        metric = torch.cat(gathered, dim=1)
+    # end-of-run trajectory statistics: the only exchange of the path (RCCL all_gather over xGMI,
+    # outside the timed region; 2 floats per robot)
+    metric = shard.gather_stats(mpc.metrics(args.warmup + args.steps))
     status = mpc.status
     nbad = int((~torch.isfinite(mpc.state)).sum().item())
 
@@ -147,7 +143,10 @@ def main():
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("batch") == B and j.get("dtype") == args.dtype and j.get("plant") == args.plant:
+                # PMC counters cannot be read live; this is the committed rocprofv3 --pmc measurement of THIS
+                # command (profiles/r01_pmc_traffic.json), used only when the configuration matches it
+                if (j.get("batch") == B and j.get("dtype") == args.dtype and j.get("plant") == args.plant
+                        and j.get("steps_per_launch") == spl and args.max_iter == 50 and args.nsub == 25):
                     traffic = j["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None

@@ -116,8 +116,9 @@ typedef struct umpc_batch umpc_batch_t;
 void umpcBatchDefaultParams(umpc_batch_params_t *prm);
 
 /* Creates a batched controller for B robots of scalar type dtype on the
- * current HIP device. Returns NULL on error (umpcLastError()). No device memory
- * is owned by the handle: all arrays are caller-provided. */
+ * current HIP device. Returns NULL on error (umpcLastError()). The handle owns
+ * one scratch workspace of 559 rows x B scalars (hipMalloc here, hipFree in
+ * umpcBatchDestroy); every other array is caller-provided. */
 umpc_batch_t *umpcBatchCreate(const umpc_batch_params_t *prm, int B, int dtype);
 void umpcBatchDestroy(umpc_batch_t *h);
 

@@ -1,0 +1,65 @@
+"""Multi-GPU layout of the batched controller: robots are independent (no coupling
+term anywhere on the path), so ranks own contiguous blocks of robots and there is
+NO collective on the data path. The only exchange is the end-of-run gather of the
+per-robot trajectory statistics. One process per GPU; backend "nccl"
+(= RCCL over xGMI) on the MI355X node, "gloo" in the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, world_size, local_rank) from the torchrun environment (1 process: 0, 1, 0)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend=None, device=None):
+    rank, ws, local_rank = world()
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=ws, **kw)
+    return rank, ws, local_rank
+
+
+def robot_range(per_rank, rank):
+    """Weak scaling: every rank owns `per_rank` robots; global ids [rank*per_rank, (rank+1)*per_rank)."""
+    return rank * per_rank, (rank + 1) * per_rank
+
+
+def split_range(total, rank, ws):
+    """Strong scaling: `total` robots split into ws contiguous blocks (first blocks one larger)."""
+    base, rem = divmod(total, ws)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_stats(stats):
+    """stats [rows, B_local] on every rank -> [rows, sum B_local] in global robot order (all ranks)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return stats
+    ws = dist.get_world_size()
+    n = torch.tensor([stats.shape[1]], dtype=torch.int64, device=stats.device)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad = torch.zeros((stats.shape[0], m), dtype=stats.dtype, device=stats.device)
+    pad[:, :stats.shape[1]] = stats
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad.contiguous())
+    return torch.cat([p[:, :s] for p, s in zip(parts, sizes)], dim=1)

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/umpc_mi355x.h declares
+(no compute calls without a GPU), refuses to create a controller without a device, and the
+host-side constants agree with the header."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from robobee3d_amd import _lib
+    _lib.build()
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "umpc_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(umpc[A-Z]\w*)\s*\(", hdr))
+    assert {"umpcInit", "umpcUpdate", "umpcS"} <= declared and len(declared) >= 20
+    L = C.CDLL(lib.SO_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(lib.EXPORTS)
+
+
+def test_reference_struct_layout_and_constants(lib):
+    # template/uprightmpc2/uprightmpc2.h:27-43 is 1308 bytes; vectors()/matrices() read fields by offset
+    assert C.sizeof(lib.UprightMPC_t) == 1308
+    assert lib.UprightMPC_t.l.offset == 4 * (3 + 27 + 6 + 18)
+    hdr = open(os.path.join(ROOT, "include", "umpc_mi355x.h")).read()
+    for name, val in (("UMPC_STATE_ROWS", lib.STATE_ROWS), ("UMPC_CTRL_ROWS", lib.CTRL_ROWS),
+                      ("UMPC_REF_ROWS", lib.REF_ROWS), ("UMPC_OUT_ROWS", lib.OUT_ROWS)):
+        assert int(re.search(r"#define %s (\d+)" % name, hdr).group(1)) == val
+
+
+def test_static_tables_without_gpu(lib, structure):
+    L = lib.lib()
+    assert np.array_equal(np.array(L.umpcAxIdx().contents), structure["Ax_idx"])  # uprightmpc2.c:65-113
+    perm = np.array(L.umpcKKTPerm().contents)
+    assert sorted(perm.tolist()) == list(range(84))
+    assert L.umpcNnzL() == 213          # same fill as the reference's AMD ordering (workspace.c:1260)
+    p = lib.default_params()
+    assert (p.dt, p.maxIter, p.nsub, p.dtsim, p.taulim) == (5.0, 50, 25, 0.2, 100.0)
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = lib.lib()
+    p = lib.default_params()
+    h = L.umpcBatchCreate(C.byref(p), 64, 0)
+    assert not h and b"no HIP device" in L.umpcLastError()
+    from robobee3d_amd.batch import BatchUprightMPC
+    with pytest.raises(RuntimeError):
+        BatchUprightMPC(64)
+
+
+def test_symbolic_matches_reference_tables(structure):
+    from robobee3d_amd import symbolic
+    s = symbolic.analyse(3, perm=structure["perm"])
+    for k in "A_p A_i K_p K_i PtoKKT AtoKKT rhotoKKT etree Lnz L_p L_i Ax_idx".split():
+        assert np.array_equal(np.array(getattr(s, k)), structure[k]), k
+    own = symbolic.analyse(3)
+    assert len(own.L_i) == 213 and sorted(own.perm) == list(range(84))
+
+
+def test_codegen_is_deterministic():
+    from robobee3d_amd import asmgen, codegen
+    assert codegen.emit()[0] == codegen.emit()[0]
+    a, _ = asmgen.program()
+    b, _ = asmgen.program()
+    assert a == b
