@@ -168,6 +168,44 @@ const char *umpcLastError(void);
 /* name and duration of the kernels, for bench.py */
 const char *umpcKernelName(int dtype, int plant_mode);
 
+/* ------------------------------------------------------------------ */
+/* Part 3: wrench-linearisation step (the consumer of accdes)          */
+/* template/uprightmpc2/funapprox.h:18-54, funapprox.c:102-176          */
+/* ------------------------------------------------------------------ */
+#define NDELU 4
+typedef struct {
+  int k;
+  float a0;
+  float a1[NDELU];
+  float A2[NDELU * NDELU];
+} FunApprox_t; /* funapprox.h:18-23 */
+
+typedef struct {
+  float u0[NDELU], umin[NDELU], umax[NDELU], dumax[NDELU];
+  float Qw[6 * 6];
+  FunApprox_t fa[6];
+} WLCon_t; /* funapprox.h:37-41; caller-allocated, holds ALL state (u0) like the reference */
+
+/* funapprox.h:43 / funapprox.c:102-116. popts: 6 x (a0, a1[4], upper-triangular A2 row-major [10]). */
+void wlConInit(WLCon_t *wl, const float u0[/* 4 */], const float umin[/* 4 */], const float umax[/* 4 */],
+               const float dumax[/* 4 */], const float Qw[/* 6 */], float controlRate,
+               const float popts[/* 90 */]);
+/* funapprox.h:45 / funapprox.c:118-165: w0 = w(u0); one projected-gradient step of
+ * |w(u) - h0 - pdotdes|^2_Qw with step 1e3, clipped to the rate limit and frozen at the box. */
+void wlConUpdate(WLCon_t *wl, float u1[/* 4 */], float w0[/* 6 */], const float h0[/* 6 */],
+                 const float pdotdes[/* 6 */]);
+/* funapprox.h:48 / funapprox.c:171-176 */
+void wlconS(float u1_y1[/* 4 */], float w0_y2[/* 6 */], const float u0init_u1[/* 4 */],
+            const float umin_u2[/* 4 */], const float umax_u3[/* 4 */], const float dumax_u4[/* 4 */],
+            const float Qw_u5[/* 6 */], float controlRate_u6, const float popts_u7[/* 90 */],
+            const float h0_u8[/* 6 */], const float pdotdes_u9[/* 6 */]);
+
+/* Batched: `wl` supplies limits, weights and wrench-map coefficients for every robot (its u0 is
+ * ignored); u [4][B] is the per-robot input state (in: u0, out: u1), h0 / pdotdes [6][B] in,
+ * w0 [6][B] out. fp32 (UMPC_F32) or fp64 device arrays. Asynchronous on `stream`. */
+int umpcBatchWLUpdate(const WLCon_t *wl, int B, int dtype, void *u, const void *h0, const void *pdotdes,
+                      void *w0, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

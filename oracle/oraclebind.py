@@ -170,3 +170,31 @@ def batch_rollout(state, ctrl, ref, K, dtype=np.float32, perm=None, Ib=None, gai
                                 P(out), P(stats), status.ctypes.data_as(C.POINTER(C.c_int)),
                                 C.c_int(nthreads))
     return out, stats, status
+
+
+class WLOracle:
+    """wlConInit / wlConUpdate twin (oracle/umpc_oracle.c, funapprox.c restated)."""
+
+    def __init__(self, u0, umin, umax, dumax, Qw, controlRate, popts, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        self.ct = C.c_float if self.dtype == np.float32 else C.c_double
+        self.L = lib(self.dtype)
+        self.L.umpc_oracle_wl_sizeof.restype = C.c_size_t
+        self.buf = C.create_string_buffer(self.L.umpc_oracle_wl_sizeof())
+        a = lambda v, n: np.ascontiguousarray(np.asarray(v, self.dtype).reshape(n))
+        P = lambda v: v.ctypes.data_as(C.POINTER(self.ct))
+        self._keep = [a(u0, 4), a(umin, 4), a(umax, 4), a(dumax, 4), a(Qw, 6), a(popts, 90)]
+        k = self._keep
+        self.L.umpc_oracle_wl_init(self.buf, P(k[0]), P(k[1]), P(k[2]), P(k[3]), P(k[4]), self.ct(controlRate), P(k[5]))
+
+    def set_u0(self, u0):
+        u0 = np.ascontiguousarray(u0, self.dtype)
+        self.L.umpc_oracle_wl_set_u0(self.buf, u0.ctypes.data_as(C.POINTER(self.ct)))
+
+    def update(self, h0, pdotdes):
+        P = lambda v: v.ctypes.data_as(C.POINTER(self.ct))
+        h0 = np.ascontiguousarray(h0, self.dtype)
+        pd = np.ascontiguousarray(pdotdes, self.dtype)
+        u1, w0 = np.zeros(4, self.dtype), np.zeros(6, self.dtype)
+        self.L.umpc_oracle_wl_update(self.buf, P(u1), P(w0), P(h0), P(pd))
+        return u1, w0

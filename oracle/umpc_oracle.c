@@ -982,3 +982,70 @@ void umpc_oracle_batch_rollout(const umpc_oracle_params_t *prm, const int *perm,
   }
   free(proto);
 }
+
+/* ====================================================================== */
+/* Wrench-linearisation step: funapprox.c                    */
+/* ====================================================================== */
+#define NDELU 4
+#define NW 6
+struct umpc_oracle_wl {
+  real u0[NDELU], umin[NDELU], umax[NDELU], dumax[NDELU];
+  real Qw[NW * NW];
+  struct { real a0, a1[NDELU], A2[NDELU * NDELU]; } fa[NW];
+};
+size_t umpc_oracle_wl_sizeof(void) { return sizeof(struct umpc_oracle_wl); }
+
+/* wlConInit + funApproxInit, funapprox.c:35-51, 102-116 */
+void umpc_oracle_wl_init(umpc_oracle_wl_t *wl, const real u0[4], const real umin[4], const real umax[4],
+                         const real dumax[4], const real Qw[6], real controlRate, const real popts[90]) {
+  memset(wl, 0, sizeof(*wl));
+  for (int i = 0; i < NDELU; ++i) {
+    wl->u0[i] = u0[i]; wl->umin[i] = umin[i]; wl->umax[i] = umax[i];
+    wl->dumax[i] = dumax[i] / controlRate;
+  }
+  for (int i = 0; i < NW; ++i) {
+    const real *p = &popts[15 * i];
+    wl->fa[i].a0 = p[0];
+    memcpy(wl->fa[i].a1, &p[1], NDELU * sizeof(real));
+    int kk = 0;
+    for (int r = 0; r < NDELU; ++r)
+      for (int c = r; c < NDELU; ++c) {
+        wl->fa[i].A2[r + NDELU * c] = wl->fa[i].A2[c + NDELU * r] = p[NDELU + 1 + kk];
+        kk++;
+      }
+    wl->Qw[i + NW * i] = Qw[i];
+  }
+}
+
+/* wlConUpdate, funapprox.c:118-165 (funApproxF :53-65, funApproxDf :67-76) */
+void umpc_oracle_wl_update(umpc_oracle_wl_t *wl, real u1[4], real w0[6], const real h0[6], const real pdotdes[6]) {
+  real A1[NW * NDELU], a0[NW], delu[NDELU], dum[NW * NDELU], L[NDELU], U[NDELU], vout[NDELU], fout;
+  for (int i = 0; i < NW; ++i) { /* wrenchMap */
+    real res = wl->fa[i].a0;
+    mm(vout, wl->u0, wl->fa[i].a1, 1, 1, NDELU, (real)1.0, 0, 0);
+    res += vout[0];
+    mm(vout, wl->fa[i].A2, wl->u0, NDELU, 1, NDELU, (real)1.0, 0, 0);
+    mm(&fout, wl->u0, vout, 1, 1, NDELU, (real)0.5, 0, 0);
+    w0[i] = res + fout;
+  }
+  for (int i = 0; i < NW; ++i) { /* wrenchJacMap */
+    real Df[NDELU];
+    memcpy(Df, wl->fa[i].a1, NDELU * sizeof(real));
+    mm(vout, wl->fa[i].A2, wl->u0, NDELU, 1, NDELU, (real)1.0, 0, 0);
+    for (int j = 0; j < NDELU; ++j) { Df[j] += vout[j]; A1[i + NW * j] = Df[j]; }
+  }
+  for (int i = 0; i < NW; ++i) a0[i] = w0[i] - h0[i] - pdotdes[i];
+  for (int i = 0; i < NDELU; ++i) { L[i] = -wl->dumax[i]; U[i] = wl->dumax[i]; }
+  for (int i = 0; i < NDELU; ++i) {
+    if (wl->u0[i] < wl->umin[i]) L[i] = 0;
+    else if (wl->u0[i] > wl->umax[i]) U[i] = 0;
+  }
+  mm(dum, wl->Qw, a0, NW, 1, NW, (real)1.0, 0, 0);
+  mm(delu, A1, dum, NDELU, 1, NW, (real)-1e3, 1, 0);
+  for (int i = 0; i < NDELU; ++i) {
+    if (delu[i] < L[i]) delu[i] = L[i];
+    else if (delu[i] > U[i]) delu[i] = U[i];
+  }
+  for (int i = 0; i < NDELU; ++i) { wl->u0[i] += delu[i]; u1[i] = wl->u0[i]; }
+}
+void umpc_oracle_wl_set_u0(umpc_oracle_wl_t *wl, const real u0[4]) { memcpy(wl->u0, u0, sizeof(wl->u0)); }

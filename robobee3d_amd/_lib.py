@@ -22,7 +22,18 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
-           "umpcLastError", "umpcKernelName"]
+           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate"]
+
+
+class FunApprox_t(C.Structure):
+    # funapprox.h:18-23
+    _fields_ = [("k", C.c_int), ("a0", C.c_float), ("a1", C.c_float * 4), ("A2", C.c_float * 16)]
+
+
+class WLCon_t(C.Structure):
+    # funapprox.h:37-41
+    _fields_ = [("u0", C.c_float * 4), ("umin", C.c_float * 4), ("umax", C.c_float * 4), ("dumax", C.c_float * 4),
+                ("Qw", C.c_float * 36), ("fa", FunApprox_t * 6)]
 
 
 class BatchParams(C.Structure):
@@ -86,6 +97,7 @@ def lib():
         L.umpcKernelName.restype = C.c_char_p
         L.umpcAxIdx.restype = C.POINTER(C.c_int * NADATA)
         L.umpcKKTPerm.restype = C.POINTER(C.c_int * (NX + NC))
+        L.umpcBatchWLUpdate.argtypes = [C.POINTER(WLCon_t), C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcUpdate.restype = C.c_int
         L.umpcLastStatus.restype = C.c_int
         _lib = L

@@ -139,3 +139,32 @@ class BatchUprightMPC:
         over the nsteps*nsub plant substeps accumulated so far."""
         n = max(1, int(nsteps) * int(self.prm.nsub))
         return self.stats / n
+
+
+class BatchWLCon:
+    """B wrench-linearisation controllers (the step that consumes accdes, SURVEY 8f-1;
+    template/uprightmpc2/funapprox.c:118-165), one lane each. `u` [4,B] is the input state."""
+
+    def __init__(self, B, u0, umin, umax, dumax, Qw, controlRate, popts, dtype=torch.float32, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchWLCon needs a HIP device; there is no CPU path")
+        self.L = _lib.lib()
+        self.B, self.dtype, self.device = int(B), dtype, torch.device(device)
+        self.wl = _lib.WLCon_t()
+        f = lambda a, n: np.ascontiguousarray(np.asarray(a, np.float32).reshape(n))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        self.L.wlConInit(C.byref(self.wl), fp(f(u0, 4)), fp(f(umin, 4)), fp(f(umax, 4)), fp(f(dumax, 4)),
+                         fp(f(Qw, 6)), C.c_float(controlRate), fp(f(popts, 90)))
+        self.u = torch.as_tensor(np.asarray(u0, np.float64)).to(dtype).to(self.device)[:, None].repeat(1, self.B).contiguous()
+        self.w0 = torch.zeros((6, self.B), dtype=dtype, device=self.device)
+
+    def update(self, h0, pdotdes):
+        h0 = torch.as_tensor(h0, dtype=self.dtype, device=self.device).contiguous()
+        pd = torch.as_tensor(pdotdes, dtype=self.dtype, device=self.device).contiguous()
+        assert h0.shape == (6, self.B) and pd.shape == (6, self.B)
+        with torch.cuda.device(self.device):
+            rc = self.L.umpcBatchWLUpdate(C.byref(self.wl), self.B, _DT[self.dtype], _ptr(self.u), _ptr(h0), _ptr(pd),
+                                          _ptr(self.w0), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        return self.u, self.w0

@@ -386,4 +386,138 @@ void umpcRelease(UprightMPC_t *up) {
   g_single.erase(it);
 }
 
+// ---------------------------------------------------------------------------
+// Part 3: wrench-linearisation step, funapprox.c
+// ---------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct WLDev {  // everything wlConUpdate reads, passed by value (wave-uniform, lives in SGPRs / kernarg)
+  float umin[4], umax[4], dumax[4], Qw[6];
+  float a0[6], a1[6][4], A2[6][16];
+};
+
+// one lane = one robot: w0 = w(u0), A1 = dw/du(u0), one clipped gradient step (funapprox.c:118-165)
+template <typename T>
+__global__ __launch_bounds__(256) void umpc_wl_kernel(WLDev p, int B_, T *u, const T *h0, const T *pd, T *w0out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B_) return;
+  const size_t B = (size_t)B_;
+  T u0[4], A1[6][4], a0v[6];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u0[j] = u[(size_t)j * B + b];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    // funApproxF: a0 + u.a1 + 0.5 u'(A2 u), accumulated like the reference's matMult (funapprox.c:53-65)
+    T dot = T(0), vout[4], quad = T(0);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) dot += u0[l] * T(p.a1[i][l]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T acc = T(0);
+#pragma unroll
+      for (int l = 0; l < 4; ++l) acc += T(p.A2[i][r + 4 * l]) * u0[l];
+      vout[r] = acc;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) quad += u0[l] * vout[l];
+    const T w = (T(p.a0[i]) + dot) + T(0.5) * quad;
+    w0out[(size_t)i * B + b] = w;
+    a0v[i] = w - h0[(size_t)i * B + b] - pd[(size_t)i * B + b];
+    // funApproxDf: a1 + A2 u  (funapprox.c:67-76)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A1[i][j] = T(p.a1[i][j]) + vout[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    T Lb = -T(p.dumax[j]), Ub = T(p.dumax[j]);
+    if (u0[j] < T(p.umin[j])) Lb = T(0);
+    else if (u0[j] > T(p.umax[j])) Ub = T(0);
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc += A1[i][j] * (T(p.Qw[i]) * a0v[i]);
+    T d = T(-1e3) * acc;
+    if (d < Lb) d = Lb;
+    else if (d > Ub) d = Ub;
+    u[(size_t)j * B + b] = u0[j] + d;
+  }
+}
+
+WLDev make_wl(const WLCon_t *wl) {
+  WLDev d;
+  for (int j = 0; j < 4; ++j) { d.umin[j] = wl->umin[j]; d.umax[j] = wl->umax[j]; d.dumax[j] = wl->dumax[j]; }
+  for (int i = 0; i < 6; ++i) {
+    d.Qw[i] = wl->Qw[i + 6 * i];
+    d.a0[i] = wl->fa[i].a0;
+    for (int j = 0; j < 4; ++j) d.a1[i][j] = wl->fa[i].a1[j];
+    for (int j = 0; j < 16; ++j) d.A2[i][j] = wl->fa[i].A2[j];
+  }
+  return d;
+}
+float *g_wl_dev = nullptr;  // 4 + 6 + 6 + 6 floats for the B = 1 entry point
+}  // namespace
+
+extern "C" {
+
+int umpcBatchWLUpdate(const WLCon_t *wl, int B, int dtype, void *u, const void *h0, const void *pdotdes, void *w0,
+                      void *stream) {
+  if (!wl || B <= 0 || !u || !h0 || !pdotdes || !w0) { g_err = "umpcBatchWLUpdate: bad argument"; return -1; }
+  const WLDev d = make_wl(wl);
+  const int grid = (B + 255) / 256;
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL(umpc_wl_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, B, (float *)u,
+                       (const float *)h0, (const float *)pdotdes, (float *)w0);
+  else
+    hipLaunchKernelGGL(umpc_wl_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, B, (double *)u,
+                       (const double *)h0, (const double *)pdotdes, (double *)w0);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchWLUpdate");
+}
+
+void wlConInit(WLCon_t *wl, const float u0[4], const float umin[4], const float umax[4], const float dumax[4],
+               const float Qw[6], float controlRate, const float popts[90]) {
+  // funapprox.c:102-116 + funApproxInit :35-51 (host-side unpacking; the struct carries all state)
+  memset(wl, 0, sizeof(*wl));
+  for (int i = 0; i < 4; ++i) {
+    wl->u0[i] = u0[i]; wl->umin[i] = umin[i]; wl->umax[i] = umax[i];
+    wl->dumax[i] = dumax[i] / controlRate;
+  }
+  for (int i = 0; i < 6; ++i) {
+    const float *p = &popts[15 * i];
+    wl->fa[i].k = NDELU;
+    wl->fa[i].a0 = p[0];
+    memcpy(wl->fa[i].a1, &p[1], 4 * sizeof(float));
+    int kk = 0;
+    for (int r = 0; r < 4; ++r)
+      for (int c = r; c < 4; ++c) wl->fa[i].A2[r + 4 * c] = wl->fa[i].A2[c + 4 * r] = p[5 + kk++];
+    wl->Qw[i + 6 * i] = Qw[i];
+  }
+}
+
+void wlConUpdate(WLCon_t *wl, float u1[4], float w0[6], const float h0[6], const float pdotdes[6]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_wl_dev && hipMalloc((void **)&g_wl_dev, 22 * sizeof(float)) != hipSuccess) {
+    fprintf(stderr, "wlConUpdate: no GPU (no CPU path exists)\n");
+    return;
+  }
+  float hin[16];
+  memcpy(hin, wl->u0, 16); memcpy(hin + 4, h0, 24); memcpy(hin + 10, pdotdes, 24);
+  (void)hipMemcpy(g_wl_dev, hin, sizeof(hin), hipMemcpyHostToDevice);
+  if (umpcBatchWLUpdate(wl, 1, UMPC_F32, g_wl_dev, g_wl_dev + 4, g_wl_dev + 10, g_wl_dev + 16, nullptr)) return;
+  float hout[22];
+  if (hipMemcpy(hout, g_wl_dev, sizeof(hout), hipMemcpyDeviceToHost) != hipSuccess) return;
+  memcpy(wl->u0, hout, 16); memcpy(u1, hout, 16); memcpy(w0, hout + 16, 24);
+}
+
+namespace { WLCon_t g_wl; int g_wl_inited = 0; }
+void wlconS(float u1[4], float w0[6], const float u0init[4], const float umin[4], const float umax[4],
+            const float dumax[4], const float Qw[6], float controlRate, const float popts[90], const float h0[6],
+            const float pdotdes[6]) {
+  if (!g_wl_inited) {  // funapprox.c:172-175
+    wlConInit(&g_wl, u0init, umin, umax, dumax, Qw, controlRate, popts);
+    g_wl_inited = 1;
+  }
+  wlConUpdate(&g_wl, u1, w0, h0, pdotdes);
+}
+
 }  // extern "C"

@@ -63,6 +63,25 @@ class UprightMPC2C:
         return int(self._L.umpcLastStatus(C.byref(self.umpc)))
 
 
+class WLCon:
+    """Mirror of the pybind `WLCon` class (template/uprightmpc2/py/uprightmpc2py.cpp:54-68):
+    WLCon(u0, umin, umax, dumax, Qw, controlRate, popts).update(h0, pdotdes) -> (u1[4], w0[6]),
+    over the reference's own C symbols wlConInit / wlConUpdate (funapprox.h:43-45) in libumpc_mi355x.so."""
+
+    def __init__(self, u0, umin, umax, dumax, Qw, controlRate, popts):
+        self._L = _lib.lib()
+        self.wl = _lib.WLCon_t()
+        f = lambda a, n: np.ascontiguousarray(np.asarray(a, np.float32).reshape(n))
+        self._L.wlConInit(C.byref(self.wl), _fp(f(u0, 4)), _fp(f(umin, 4)), _fp(f(umax, 4)), _fp(f(dumax, 4)),
+                          _fp(f(Qw, 6)), C.c_float(controlRate), _fp(f(popts, 90)))
+
+    def update(self, h0, pdotdes):
+        f = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).reshape(6))
+        u1, w0 = np.zeros(4, np.float32), np.zeros(6, np.float32)
+        self._L.wlConUpdate(C.byref(self.wl), _fp(u1), _fp(w0), _fp(f(h0)), _fp(f(pdotdes)))
+        return u1, w0
+
+
 def createMPC(N=3, ws=1e1, wds=1e3, wpr=1, wvr=1e3, wpf=5, wvf=2e3, wthrust=1e-1, wmom=1e-2, TtoWmax=2, **kwargs):
     """C-version half of template/template_controllers.py:260-280 (same defaults)."""
     assert N == 3, "the compiled horizon is N = 3 (template/uprightmpc2/uprightmpc2.h:20)"

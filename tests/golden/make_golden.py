@@ -209,8 +209,48 @@ def tasks(mods):
     print("flight_tasks.npz")
 
 
+def wl_step():
+    """§8f-1: wlConInit / wlConUpdate of the reference (template/uprightmpc2/funapprox.c:118-165)
+    with the constructor arguments and the fitted wrench-map coefficients of WaypointHover
+    (template/robobee_test_controllers.py:71-76), read from the reference's source text as DATA."""
+    import ctypes as C
+    import re
+    src = open(os.path.join(REF_T, "robobee_test_controllers.py")).read()
+    m = re.search(r"\n\s+popts = \[(.*?)\]", src, re.S)
+    popts = np.array([float(v) for v in m.group(1).replace("\n", " ").split(",")], np.float32)
+    assert popts.shape == (90,)
+    r = refbind.RefUMPC(do_init=False)
+    wl = (C.c_float * 184)()  # WLCon_t: u0,umin,umax,dumax (16) + Qw (36) + 6 x {k,a0,a1[4],A2[16]} (132)
+    f = lambda a: np.ascontiguousarray(a, np.float32).ctypes.data_as(C.POINTER(C.c_float))
+    u0 = np.array([140.0, 0, 0, 0], np.float32)
+    umin, umax = np.array([90, -0.5, -0.2, -0.1], np.float32), np.array([240, 0.5, 0.2, 0.1], np.float32)
+    dumax, Qw = np.array([5e3, 10, 10, 10], np.float32), np.array([1, 1, 1, 0.1, 0.1, 0.1], np.float32)
+    r.lib.wlConInit(wl, f(u0), f(umin), f(umax), f(dumax), f(Qw), C.c_float(1000.0), f(popts))
+    rng = np.random.default_rng(77)
+    rec = {k: [] for k in "pre_u0 h0 pdotdes u1 w0".split()}
+    M0 = np.array([100, 100, 100, 3333, 3333, 1000.0])
+    for k in range(96):
+        Rb = rand_rot(rng, 0.3)
+        h0 = np.hstack((Rb.T @ np.array([0, 0, 100 * 9.81e-3]), np.zeros(3))).astype(np.float32)
+        acc = np.hstack((rng.normal(size=3) * 5e-3, rng.normal(size=3) * 2e-4))
+        pd = (M0 * acc).astype(np.float32)
+        if k % 17 == 16:
+            pd = pd * 50  # drive the rate / box limits
+        rec["pre_u0"].append(np.array(wl[0:4], np.float32))
+        u1, w0 = np.zeros(4, np.float32), np.zeros(6, np.float32)
+        r.lib.wlConUpdate(wl, f(u1), f(w0), f(h0), f(pd))
+        for key, v in zip(("h0", "pdotdes", "u1", "w0"), (h0, pd, u1, w0)):
+            rec[key].append(np.array(v))
+    np.savez_compressed(os.path.join(HERE, "wl_step.npz"), popts=popts, u0=u0, umin=umin, umax=umax, dumax=dumax,
+                        Qw=Qw, controlRate=np.float32(1000.0), **{k: np.stack(v) for k, v in rec.items()})
+    print("wl_step.npz: 96 updates, final u =", np.array(wl[0:4]))
+
+
 if __name__ == "__main__":
     assert refbind.available(), "build oracle/_ref first: make -C oracle ref"
+    if len(sys.argv) > 1 and sys.argv[1] == "wl":
+        wl_step()
+        sys.exit(0)
     structure()
     sequence(20201117, 256, 50, "seq_iter50.npz")
     for k in (1, 2, 10):
@@ -220,3 +260,4 @@ if __name__ == "__main__":
     assembly_fp64(mods)
     plant(mods)
     tasks(mods)
+    wl_step()

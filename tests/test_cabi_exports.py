@@ -21,7 +21,7 @@ def lib():
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "umpc_mi355x.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(umpc[A-Z]\w*)\s*\(", hdr))
+    declared = set(re.findall(r"\b(umpc[A-Z]\w*|wlCon[A-Z]\w*|wlconS)\s*\(", hdr))
     assert {"umpcInit", "umpcUpdate", "umpcS"} <= declared and len(declared) >= 20
     L = C.CDLL(lib.SO_PATH)
     for name in sorted(declared):
