@@ -158,6 +158,26 @@ int umpcBatchPlant(umpc_batch_t *h, int nsub, void *state, const void *u, const 
 int umpcBatchAssemble(umpc_batch_t *h, const void *state, const void *ctrl, const void *ref,
                       const void *Ib, void *l, void *u, void *q, void *Px, void *Ax, void *stream);
 
+/* Reference generators evaluated on device at every MPC fire (template/flight_tasks.py:6-49,
+ * called at template/uprightmpc2.py:124-131). task 0 (default): `ref` rows are (pdes, dpdes, sdes).
+ * task != 0: `ref` rows 0..2 hold initialPos and the reference is generated at time
+ *   t = t_ms + step * nsub * dtsim   (umpcBatchTime() advances with every rollout):
+ *   1 helix       params (trajAmp, trajFreq [Hz], dz, useY)
+ *   2 straightAcc params (tduration, vdes)
+ *   3 flip        params (tstart, tend)
+ *   4 perch       params (tend, trotstart, trotend, vdes) */
+#define UMPC_TASK_REF 0
+#define UMPC_TASK_HELIX 1
+#define UMPC_TASK_STRAIGHTACC 2
+#define UMPC_TASK_FLIP 3
+#define UMPC_TASK_PERCH 4
+int umpcBatchSetTask(umpc_batch_t *h, int task, const double params[/* 4 */], double t_ms);
+double umpcBatchTime(const umpc_batch_t *h);
+/* Per-robot objective weights for gain sweeps (template/uprightmpc2.py:272-303): device table
+ * [8][B] = (ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom) in the handle's dtype, or NULL for the
+ * batch-constant createMPC weights. The pointer is kept, not copied. */
+int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
+
 /* Static facts */
 int umpcBatchSize(const umpc_batch_t *h);
 int umpcBatchDtype(const umpc_batch_t *h);

@@ -137,7 +137,7 @@ def plant_step_d(L32, p, R, dq, u, dt, Ib=IB, gain=1.0, mode=0):
 
 def batch_rollout(state, ctrl, ref, K, dtype=np.float32, perm=None, Ib=None, gain=None,
                   Ib_nom=IB, maxIter=50, dtsim=0.2, taulim=100.0, nsub=25, plant_mode=0,
-                  nthreads=0, **kw):
+                  nthreads=0, weights=None, task=0, task_p=None, t0=0.0, **kw):
     """SoA arrays state[18,B], ctrl[127,B], ref[9,B] (modified in place).
     Returns (out[9,B], stats[2,B], status[B])."""
     dtype = np.dtype(dtype)
@@ -165,11 +165,31 @@ def batch_rollout(state, ctrl, ref, K, dtype=np.float32, perm=None, Ib=None, gai
         assert Ib.shape == (3, B)
     if gain is not None:
         gain = np.ascontiguousarray(gain, dtype)
-    L.umpc_oracle_batch_rollout(C.byref(ps), None if pp is None else pp.ctypes.data_as(C.POINTER(C.c_int)),
-                                C.c_int(B), C.c_int(K), P(state), P(ctrl), P(ref), P(Ib), P(gain),
-                                P(out), P(stats), status.ctypes.data_as(C.POINTER(C.c_int)),
-                                C.c_int(nthreads))
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype)
+        assert weights.shape == (8, B)
+    tp = np.zeros(4, dtype)
+    if task_p is not None:
+        tp[:len(task_p)] = task_p
+    L.umpc_oracle_batch_rollout2(C.byref(ps), None if pp is None else pp.ctypes.data_as(C.POINTER(C.c_int)),
+                                 C.c_int(B), C.c_int(K), P(state), P(ctrl), P(ref), P(Ib), P(gain), P(weights),
+                                 C.c_int(task), P(tp), ct(t0), P(out), P(stats),
+                                 status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(nthreads))
     return out, stats, status
+
+
+def task_reference(task, task_p, t, initial_pos, dtype=np.float64):
+    """(pdes, dpdes, sdes) of template/flight_tasks.py as restated in the oracle."""
+    dtype = np.dtype(dtype)
+    L = lib(dtype)
+    ct = C.c_float if dtype == np.float32 else C.c_double
+    tp = np.zeros(4, dtype)
+    tp[:len(task_p)] = task_p
+    r = np.zeros(9, dtype)
+    r[:3] = initial_pos
+    L.umpc_oracle_task_reference(C.c_int(task), tp.ctypes.data_as(C.POINTER(ct)), ct(t),
+                                 r.ctypes.data_as(C.POINTER(ct)))
+    return r
 
 
 class WLOracle:

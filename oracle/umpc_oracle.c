@@ -913,11 +913,54 @@ void umpc_oracle_plant_step_d(double p[3], double R[9], double dq[6],
   plant_step_d(p, R, dq, u, dt, Ib, thrust_gain, mode);
 }
 
+/* Reference generators, template/flight_tasks.py:6-49 (same task ids / parameter order as
+ * include/umpc_mi355x.h). r: (initialPos, -, -) in, (pdes, dpdes, sdes) out. */
+void umpc_oracle_task_reference(int task, const real tp[4], real t, real r[9]) {
+  if (task == 0) return;
+  const real ip[3] = {r[0], r[1], r[2]};
+  const double PI = 3.14159265358979323846;
+  for (int i = 0; i < 3; ++i) { r[3 + i] = 0; r[6 + i] = i == 2 ? 1 : 0; }
+  if (task == 1) {
+    const real amp = tp[0], omg = (real)(2 * PI) * tp[1] * (real)1e-3;
+    r[0] = ip[0] + amp * (real)sin((double)(omg * t));
+    r[3] = amp * omg * (real)cos((double)(omg * t));
+    if (tp[3] != 0) {
+      r[1] = ip[1] + amp * ((real)1 - (real)cos((double)(omg * t)));
+      r[4] = amp * omg * (real)sin((double)(omg * t));
+    }
+    if (amp > (real)1e-3) { r[2] = ip[2] + tp[2] * t; r[5] = tp[2]; }
+  } else if (task == 2) {
+    r[3] = t < tp[0] ? tp[1] : 0;
+    r[0] = ip[0] + tp[1] * c_min(c_max(t, 0), tp[0]);
+  } else if (task == 3) {
+    const real ph = c_min(c_max((t - tp[0]) / tp[1], 0), 1);
+    r[6] = -(real)sin((double)ph * 2 * PI); r[7] = 0; r[8] = (real)cos((double)ph * 2 * PI);
+  } else if (task == 4) {
+    r[0] = ip[0] + tp[3] * c_min(c_max(t, 0), tp[0]);
+    r[3] = t < tp[0] ? tp[3] : 0;
+    if (t < tp[0]) {
+      const real ph = c_min(c_max((t - tp[2]) / tp[1], 0), 1);
+      r[6] = -(real)sin((double)ph * PI); r[7] = 0; r[8] = (real)cos((double)ph * PI);
+    } else { r[6] = -1; r[7] = 0; r[8] = 0; }
+  }
+}
+
 void umpc_oracle_batch_rollout(const umpc_oracle_params_t *prm, const int *perm,
                                int B, int K, real *state, real *ctrl,
                                const real *ref, const real *Ib,
                                const real *thrust_gain, real *out, real *stats,
                                int *status, int nthreads) {
+  umpc_oracle_batch_rollout2(prm, perm, B, K, state, ctrl, ref, Ib, thrust_gain, NULL, 0, NULL, 0, out, stats,
+                             status, nthreads);
+}
+
+/* + per-robot weights [8][B] (ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom) and an on-line task */
+void umpc_oracle_batch_rollout2(const umpc_oracle_params_t *prm, const int *perm,
+                                int B, int K, real *state, real *ctrl,
+                                const real *ref, const real *Ib,
+                                const real *thrust_gain, const real *weights, int task,
+                                const real *task_p, real t0, real *out, real *stats,
+                                int *status, int nthreads) {
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -951,9 +994,20 @@ void umpc_oracle_batch_rollout(const umpc_oracle_params_t *prm, const int *perm,
       for (int i = 0; i < NC; ++i) o->z[i] = ctrl[(size_t)(NX + NC + i) * B + b];
       o->T0 = ctrl[(size_t)(NX + 2 * NC) * B + b];
       for (int k = 0; k < NN; ++k) o->Eprev3[k] = ctrl[(size_t)(NX + 2 * NC + 1 + k) * B + b];
-      for (int i = 0; i < 9; ++i) rf[i] = ref[(size_t)i * B + b];
+      if (weights) { /* umpcInit weight vectors, uprightmpc2.c:27-36 */
+        const real ws = weights[b], wds = weights[(size_t)B + b], wpr = weights[(size_t)2 * B + b],
+                   wpf = weights[(size_t)3 * B + b], wvr = weights[(size_t)4 * B + b],
+                   wvf = weights[(size_t)5 * B + b];
+        for (int i = 0; i < 3; ++i) {
+          o->Qyr[i] = wpr; o->Qyf[i] = wpf; o->Qyr[3 + i] = o->Qyf[3 + i] = ws;
+          o->Qdyr[i] = wvr; o->Qdyf[i] = wvf; o->Qdyr[3 + i] = o->Qdyf[3 + i] = wds;
+        }
+        o->Rw[0] = weights[(size_t)6 * B + b]; o->Rw[1] = o->Rw[2] = weights[(size_t)7 * B + b];
+      }
       real s_err = stats ? stats[b] : 0, s_eff = stats ? stats[(size_t)B + b] : 0;
       for (int k = 0; k < K; ++k) {
+        for (int i = 0; i < 9; ++i) rf[i] = ref[(size_t)i * B + b];
+        if (task) umpc_oracle_task_reference(task, task_p, t0 + (real)k * ((real)prm->nsub * prm->dtsim), rf);
         umpc_oracle_update(o, uq, acc, p, R, dq, &rf[0], &rf[3], &rf[6], (real)-1);
         real uc[3] = {uq[0], c_min(c_max(uq[1], -prm->taulim), prm->taulim),
                       c_min(c_max(uq[2], -prm->taulim), prm->taulim)};

@@ -22,6 +22,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
+           "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights",
            "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate"]
 
 
@@ -97,7 +98,11 @@ def lib():
         L.umpcKernelName.restype = C.c_char_p
         L.umpcAxIdx.restype = C.POINTER(C.c_int * NADATA)
         L.umpcKKTPerm.restype = C.POINTER(C.c_int * (NX + NC))
-        L.umpcBatchWLUpdate.argtypes = [C.POINTER(WLCon_t), C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.umpcBatchSetTask.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double]
+        L.umpcBatchSetWeights.argtypes = [C.c_void_p, C.c_void_p]
+        L.umpcBatchTime.argtypes = [C.c_void_p]
+        L.umpcBatchTime.restype = C.c_double
+        L.umpcBatchWLUpdate.argtypes =[C.POINTER(WLCon_t), C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcUpdate.restype = C.c_int
         L.umpcLastStatus.restype = C.c_int
         _lib = L

@@ -104,6 +104,40 @@ class BatchUprightMPC:
         if ref is not None:
             self.ref.copy_(torch.as_tensor(ref, dtype=self.dtype))
 
+    TASKS = {"ref": (0, ()), "helix": (1, ("trajAmp", "trajFreq", "dz", "useY")),
+             "straightAcc": (2, ("tduration", "vdes")), "flip": (3, ("tstart", "tend")),
+             "perch": (4, ("tend", "trotstart", "trotend", "vdes"))}
+    TASK_DEFAULTS = {"trajAmp": 80, "trajFreq": 1, "dz": 0.15, "useY": True, "tduration": 500, "vdes": None,
+                     "tstart": 100, "tend": None, "trotstart": 100, "trotend": 450}
+
+    def set_task(self, name, t_ms=0.0, **kw):
+        """On-device reference generator (template/flight_tasks.py, same keyword names and defaults).
+        With a task other than "ref", rows 0..2 of `self.ref` are the robots' initialPos."""
+        tid, names = self.TASKS[name]
+        dflt = dict(self.TASK_DEFAULTS)
+        dflt["vdes"] = {"straightAcc": 2, "perch": 0.2}.get(name, 0)
+        dflt["tend"] = {"flip": 200, "perch": 500}.get(name, 0)
+        vals = [float(kw.pop(n, dflt[n])) for n in names] + [0.0] * (4 - len(names))
+        if kw:
+            raise TypeError("unknown task parameter(s) %r" % sorted(kw))
+        arr = (C.c_double * 4)(*vals)
+        self._check(self.L.umpcBatchSetTask(self.h, tid, arr, float(t_ms)))
+
+    def set_weights(self, weights):
+        """Per-robot objective weights [8, B] = (ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom), or None."""
+        if weights is None:
+            self._weights = None
+            self._check(self.L.umpcBatchSetWeights(self.h, None))
+            return
+        w = torch.as_tensor(weights, dtype=self.dtype).to(self.device).contiguous()
+        assert w.shape == (8, self.B)
+        self._weights = w  # keep alive: the library stores the pointer
+        self._check(self.L.umpcBatchSetWeights(self.h, _ptr(w)))
+
+    @property
+    def time_ms(self):
+        return float(self.L.umpcBatchTime(self.h))
+
     def rollout(self, K=1):
         """K closed-loop MPC steps (QP + nsub plant substeps each) in one launch."""
         with torch.cuda.device(self.device):

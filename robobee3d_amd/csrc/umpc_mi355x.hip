@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a,
     while (__builtin_amdgcn_s_memrealtime() - t0 < (long long)g * skew_ticks) __builtin_amdgcn_s_sleep(64);
   }
 #pragma nounroll
-  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, k == 0, actualT0);
+  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, k, actualT0);
 }
 
 template <typename T>
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kBlock) void umpc_assemble_kernel(DevParams<T> prm,
   for (int i = 0; i < 3; ++i) Ibi[i] = T(1) / (IbA ? IbA[(size_t)i * B + b] : prm.Ib[i]);
   const T T0 = ctrl[(size_t)(NX + 2 * NC) * B + b];
   umpc::RawQP<T> qp;
-  umpc::assemble(prm, Ibi, T0, p, R, dq, ref, qp);
+  const umpc::Weights<T> wt = {prm.ws, prm.wds, prm.wpr, prm.wpf, prm.wvr, prm.wvf, prm.wthrust, prm.wmom};
+  umpc::assemble(prm, wt, Ibi, T0, p, R, dq, ref, qp);
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     l[(size_t)i * B + b] = qp.l[i];
@@ -142,6 +143,8 @@ DevParams<T> make_dev(const umpc_batch_params_t &p) {
   for (int i = 0; i < 3; ++i) d.Ib[i] = (T)p.Ib[i];
   d.dtsim = (T)p.dtsim; d.taulim = (T)p.taulim;
   d.maxIter = p.maxIter; d.nsub = p.nsub; d.plant_mode = p.plant_mode;
+  d.task = 0;
+  for (int i = 0; i < 4; ++i) d.task_p[i] = T(0);
   return d;
 }
 
@@ -150,6 +153,10 @@ DevParams<T> make_dev(const umpc_batch_params_t &p) {
 struct umpc_batch {
   umpc_batch_params_t prm;
   int B, dtype;
+  int task = 0;
+  double task_p[4] = {0, 0, 0, 0};
+  double t_ms = 0;               // time of the next MPC step (advanced by every rollout)
+  const void *weights = nullptr;  // [8][B] device table or null
   void *ws;  // [WS_ROWS][B] scratch the step parks Ruiz scalings / x_prev / delta_y in
 };
 
@@ -163,6 +170,10 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   a.prm.nsub = nsub;
   a.B = h->B;
   a.state = (T *)state; a.ctrl = (T *)ctrl; a.ref = (const T *)ref;
+  a.prm.task = h->task;
+  for (int i = 0; i < 4; ++i) a.prm.task_p[i] = (T)h->task_p[i];
+  a.weights = (const T *)h->weights; a.t0 = (T)h->t_ms;
+  if (nsub > 0) h->t_ms += (double)K * nsub * h->prm.dtsim;
   a.Ib = (const T *)Ib; a.gain = (const T *)gain; a.ws = (T *)h->ws; a.out = (T *)out; a.stats = (T *)stats;
   a.status = status; a.info = (T *)info;
   const int grid = (h->B + kBlock - 1) / kBlock;
@@ -215,6 +226,19 @@ void umpcBatchDestroy(umpc_batch_t *h) {
   if (h->ws) (void)hipFree(h->ws);
   delete h;
 }
+int umpcBatchSetTask(umpc_batch_t *h, int task, const double params[4], double t_ms) {
+  if (!h || task < 0 || task > 4) { g_err = "umpcBatchSetTask: bad argument"; return -1; }
+  h->task = task;
+  for (int i = 0; i < 4; ++i) h->task_p[i] = params ? params[i] : 0.0;
+  h->t_ms = t_ms;
+  return 0;
+}
+int umpcBatchSetWeights(umpc_batch_t *h, const void *weights) {
+  if (!h) return -1;
+  h->weights = weights;
+  return 0;
+}
+double umpcBatchTime(const umpc_batch_t *h) { return h->t_ms; }
 int umpcBatchSize(const umpc_batch_t *h) { return h->B; }
 int umpcBatchDtype(const umpc_batch_t *h) { return h->dtype; }
 

@@ -39,7 +39,66 @@ struct DevParams {
   T Ib[3];
   T dtsim, taulim;
   int maxIter, nsub, plant_mode;
+  int task;       // 0: ref rows are (pdes, dpdes, sdes); 1 helix, 2 straightAcc, 3 flip, 4 perch (flight_tasks.py)
+  T task_p[4];    // task parameters, see task_reference()
 };
+
+// objective weights of one robot (createMPC arguments, template_controllers.py:260); batch-constant unless
+// the caller supplies a per-robot table (gain-tuning sweeps, uprightmpc2.py:272-303)
+template <typename T>
+struct Weights {
+  T ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom;
+};
+
+__device__ __forceinline__ float umpc_sin(float v);
+__device__ __forceinline__ double umpc_sin(double v);
+__device__ __forceinline__ float umpc_cos(float v);
+__device__ __forceinline__ double umpc_cos(double v);
+__device__ __forceinline__ float umpc_max(float a, float b);
+__device__ __forceinline__ float umpc_min(float a, float b);
+__device__ __forceinline__ double umpc_max(double a, double b);
+__device__ __forceinline__ double umpc_min(double a, double b);
+
+// Reference generators of template/flight_tasks.py:6-49, evaluated on device at the MPC fire time t (ms).
+// `r` holds (initialPos, -, -) on entry for task != 0 and (pdes, dpdes, sdes) on exit.
+//   1 helix(trajAmp, trajFreq[Hz], dz, useY)   :6-20     2 straightAcc(tduration, vdes)            :22-29
+//   3 flip(tstart, tend)                       :31-36    4 perch(tend, trotstart, trotend, vdes)   :38-49
+template <typename T>
+__device__ __forceinline__ void task_reference(int task, const T (&tp)[4], T t, T (&r)[9]) {
+  if (task == 0) return;
+  const T ip[3] = {r[0], r[1], r[2]};
+  const T twopi = T(6.283185307179586476925286766559);
+  const T pi = T(3.1415926535897932384626433832795);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { r[3 + i] = T(0); r[6 + i] = i == 2 ? T(1) : T(0); }
+  if (task == 1) {
+    const T amp = tp[0], omg = twopi * tp[1] * T(1e-3);
+    r[0] = ip[0] + amp * umpc_sin(omg * t);
+    r[3] = amp * omg * umpc_cos(omg * t);
+    if (tp[3] != T(0)) {
+      r[1] = ip[1] + amp * (T(1) - umpc_cos(omg * t));
+      r[4] = amp * omg * umpc_sin(omg * t);
+    }
+    if (amp > T(1e-3)) { r[2] = ip[2] + tp[2] * t; r[5] = tp[2]; }
+  } else if (task == 2) {
+    const T tdur = tp[0], vdes = tp[1];
+    r[3] = t < tdur ? vdes : T(0);
+    r[0] = ip[0] + vdes * umpc_min(umpc_max(t, T(0)), tdur);
+  } else if (task == 3) {
+    const T ph = umpc_min(umpc_max((t - tp[0]) / tp[1], T(0)), T(1));
+    r[6] = -umpc_sin(ph * twopi); r[7] = T(0); r[8] = umpc_cos(ph * twopi);
+  } else if (task == 4) {
+    const T tend = tp[0], trotstart = tp[1], trotend = tp[2], vdes = tp[3];
+    r[0] = ip[0] + vdes * umpc_min(umpc_max(t, T(0)), tend);
+    r[3] = t < tend ? vdes : T(0);
+    if (t < tend) {
+      const T ph = umpc_min(umpc_max((t - trotend) / trotstart, T(0)), T(1));
+      r[6] = -umpc_sin(ph * pi); r[7] = T(0); r[8] = umpc_cos(ph * pi);
+    } else {
+      r[6] = T(-1); r[7] = T(0); r[8] = T(0);
+    }
+  }
+}
 
 // OSQP constants (template/uprightmpc2/constants.h:59-110, workspace.c:561)
 #define RHO_EQ 100.0   /* RHO_EQ_OVER_RHO_INEQ * rho, rounded to T */
@@ -206,8 +265,9 @@ struct RawQP {
 };
 
 template <typename T>
-__device__ __forceinline__ void assemble(const DevParams<T> &prm, const T (&Ibi)[3], T T0, const T (&p0)[3],
-                                         const T (&R0)[9], const T (&dq0)[6], const T (&ref)[9], RawQP<T> &qp) {
+__device__ __forceinline__ void assemble(const DevParams<T> &prm, const Weights<T> &wt, const T (&Ibi)[3], T T0,
+                                         const T (&p0)[3], const T (&R0)[9], const T (&dq0)[6], const T (&ref)[9],
+                                         RawQP<T> &qp) {
   const T dt = prm.dt;
   T s0[3], ds0[3], Btau[6], yv0[NY], dy0[NY], yv1[NY], ydes[NY], dydes[NY];
 #pragma unroll
@@ -256,8 +316,8 @@ __device__ __forceinline__ void assemble(const DevParams<T> &prm, const T (&Ibi)
   for (int k = 0; k < N; ++k) {
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-      const T wy = i < 3 ? (k == N - 1 ? prm.wpf : prm.wpr) : prm.ws;
-      const T wd = i < 3 ? (k == N - 1 ? prm.wvf : prm.wvr) : prm.wds;
+      const T wy = i < 3 ? (k == N - 1 ? wt.wpf : wt.wpr) : wt.ws;
+      const T wd = i < 3 ? (k == N - 1 ? wt.wvf : wt.wvr) : wt.wds;
       qp.Px[k * NY + i] = wy;
       qp.q[k * NY + i] = -wy * ydes[i];
       qp.Px[N * NY + k * NY + i] = wd;
@@ -265,7 +325,7 @@ __device__ __forceinline__ void assemble(const DevParams<T> &prm, const T (&Ibi)
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      qp.Px[2 * N * NY + k * NU + i] = i == 0 ? prm.wthrust : prm.wmom;
+      qp.Px[2 * N * NY + k * NU + i] = i == 0 ? wt.wthrust : wt.wmom;
       qp.q[2 * N * NY + k * NU + i] = T(0);
     }
   }
@@ -301,6 +361,8 @@ struct StepIO {
   const T *ref;    // [9][B]
   const T *Ib;     // [3][B] or null
   const T *gain;   // [B] or null
+  const T *weights;  // [8][B] per-robot (ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom) or null
+  T t0;            // time (ms) of the first step of this launch, for the task generators
   T *ws;           // [WS_ROWS][B] workspace
   T *out;          // [9][B]
   T *stats;        // [2][B] or null
@@ -313,7 +375,8 @@ struct StepIO {
 // launches of one step are the same computation.
 template <typename T, bool ASM>
 __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, const unsigned ldsaddr,
-                                                 const bool first_step, const T *actualT0) {
+                                                 const int step, const T *actualT0) {
+  const bool first_step = step == 0;
   static_assert(!ASM || sizeof(T) == 4, "the assembly loop is fp32");
   const size_t B = (size_t)a.B;
   const DevParams<T> &prm = a.prm;
@@ -350,6 +413,13 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   T Ibi[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) Ibi[i] = T(1) / (a.Ib ? GLD(a.Ib, i) : prm.Ib[i]);  // uprightmpc2.c:50-52
+  // MPC fire time of this step (the harness evaluates the task at the fire substep, uprightmpc2.py:124-139)
+  const T tnow = a.t0 + T(step) * (T(prm.nsub) * prm.dtsim);
+  Weights<T> wt = {prm.ws, prm.wds, prm.wpr, prm.wpf, prm.wvr, prm.wvf, prm.wthrust, prm.wmom};
+  if (a.weights) {
+    wt.ws = GLD(a.weights, 0); wt.wds = GLD(a.weights, 1); wt.wpr = GLD(a.weights, 2); wt.wpf = GLD(a.weights, 3);
+    wt.wvr = GLD(a.weights, 4); wt.wvf = GLD(a.weights, 5); wt.wthrust = GLD(a.weights, 6); wt.wmom = GLD(a.weights, 7);
+  }
 
   // =========================== phase A: assemble, equilibrate, factor ===========================
   UMPC_PHASE_FENCE();
@@ -363,13 +433,14 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     for (int i = 0; i < 6; ++i) dq0[i] = GLD(a.state, 12 + i);
 #pragma unroll
     for (int i = 0; i < 9; ++i) ref[i] = GLD(a.ref, i);
+    task_reference(prm.task, prm.task_p, tnow, ref);
 #pragma unroll
     for (int k = 0; k < N; ++k) Eprev3[k] = GLD(a.ctrl, NX + 2 * NC + 1 + k);
 
     T P[NX], A[NNZA], q[NX], Ds[NX], Es[NC], lraw[NC];
     {
       RawQP<T> qp;
-      assemble(prm, Ibi, T0, p0, R0, dq0, ref, qp);
+      assemble(prm, wt, Ibi, T0, p0, R0, dq0, ref, qp);
 #define A_(p) A[p]
       UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
 #pragma unroll
@@ -560,8 +631,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
       T ref[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) ref[i] = GLD(a.ref, i);
+      task_reference(prm.task, prm.task_p, tnow, ref);
       RawQP<T> qp;
-      assemble(prm, Ibi, T0, p0, R0, dq0, ref, qp);
+      assemble(prm, wt, Ibi, T0, p0, R0, dq0, ref, qp);
 #define A_(p) A[p]
 #define DT_(j) Ds[j]
 #define ET_(i) Es[i]
