@@ -61,8 +61,16 @@ def test_closed_loop_with_task_matches_oracle(oracle_built, case):
     s32 = m32.state.cpu().numpy().astype(np.float64)
     # straightAcc commands a 2 m/s velocity step: moments saturate at the clip and positions reach 40 mm,
     # so the fp32 band is relative there
-    np.testing.assert_allclose(s32[0:3], s_o[0:3], rtol=1e-3, atol=5e-3)
-    np.testing.assert_allclose(s32[3:], s_o[3:], rtol=1e-3, atol=2e-3)
+    # (saturated, fast transients amplify fp32 round-off). Self-calibrating band: the kernel may be at most
+    # 4x as far from the fp64 trajectory as the fp32 CPU oracle (the reference's arithmetic) itself is.
+    s_o32 = st.astype(np.float32)
+    c32 = np.zeros((127, B), np.float32); c32[124:] = 1
+    oracle_built.batch_rollout(s_o32, c32, ref.astype(np.float32), K, dtype=np.float32, perm=perm, task=task,
+                               task_p=tp, t0=t0)
+    band_p = max(2e-3, 4 * np.abs(s_o32[0:3].astype(np.float64) - s_o[0:3]).max())
+    band_r = max(3e-4, 4 * np.abs(s_o32[3:].astype(np.float64) - s_o[3:]).max())
+    assert np.abs(s32[0:3] - s_o[0:3]).max() <= band_p, (np.abs(s32[0:3] - s_o[0:3]).max(), band_p)
+    assert np.abs(s32[3:] - s_o[3:]).max() <= band_r, (np.abs(s32[3:] - s_o[3:]).max(), band_r)
 
 
 @pytest.mark.gpu
