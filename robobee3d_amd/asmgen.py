@@ -91,14 +91,9 @@ def prologue(e, s):
     # Two memory round trips in all (every wave of the grid is in this phase at the same time, so each
     # exposed round trip costs microseconds): (1) L[0..NLDS) staged through v2..v161 (W/x/y are not live
     # yet) into LDS; (2) everything else, back to back, one wait.
-    assert NLDS <= V_Z - V_W
-    e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_WS, S_WS + 1))
-    for r in range(NLDS):
-        e("global_load_dword", "v%d" % (V_W + r), "v0", "s[%d:%d]" % (S_P, S_P + 1))
-        _adv(e, S_P)
-    e("s_waitcnt", "vmcnt(0)")
-    for g in range(NLDS // 4):
-        e("ds_write_b128", "v1", "v[%d:%d]" % (V_W + 4 * g, V_W + 4 * g + 3), g * 1024)
+    # L[0..NLDS) was written into LDS by phase A (same lane, same layout); everything else arrives through
+    # the workspace rows, issued back to back with ONE wait.
+    _row_ptr(e, S_P, S_WS, FAC_L + NLDS)
     # the rest of L, 1/D, q and the dynamics-row bounds -> AGPRs (rows are consecutive in the workspace)
     nrest = len(s.L_i) - NLDS + s.nk + s.nx + 2 * s.N * symbolic.NY
     assert A_LO == nrest - 2 * s.N * symbolic.NY and nrest <= 256
@@ -109,7 +104,6 @@ def prologue(e, s):
     for k in range(12):
         e("global_load_dword", "v%d" % (V_M + k), "v0", "s[%d:%d]" % (S_P, S_P + 1))
         _adv(e, S_P)
-    e("s_waitcnt", "lgkmcnt(0)")  # ds_writes have read v2..v161
     # x, y, z
     e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_CTRL, S_CTRL + 1))
     for r in range(s.nx + 2 * s.nc):
@@ -119,11 +113,12 @@ def prologue(e, s):
 
 
 def epilogue(e, s):
-    e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_CTRL, S_CTRL + 1))
-    for r in range(s.nx + 2 * s.nc):
-        e("global_store_dword", "v0", "v%d" % (V_X + r), "s[%d:%d]" % (S_P, S_P + 1))
-        _adv(e, S_P)
-    e("s_waitcnt", "vmcnt(0)")
+    # x, y, z stay on chip: the factor in LDS is dead now, phase C reads the iterates from LDS words 0..122
+    # (v86..v208 are consecutive; the last quad also carries v209, which nobody reads)
+    n = s.nx + 2 * s.nc
+    for g in range((n + 3) // 4):
+        e("ds_write_b128", "v1", "v[%d:%d]" % (V_X + 4 * g, V_X + 4 * g + 3), g * 1024)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
 
 class Fetcher:
@@ -351,15 +346,17 @@ def write(path=None, N=3, perm=None):
 # ---------------------------------------------------------------------------
 # CPU interpreter of the emitted instruction list (one lane), for the tests
 # ---------------------------------------------------------------------------
-def simulate(ins, mem_ws, mem_ctrl, iters):
-    """mem_ws: float32[WS_ROWS], mem_ctrl: float32[127] (one robot). Runs the program; returns nothing
-    (memories are updated in place). Branch targets are the numeric local labels used above."""
+def simulate(ins, mem_ws, mem_ctrl, iters, lds=None):
+    """mem_ws: float32[WS_ROWS], mem_ctrl: float32[127], lds: float32[160] (one robot / one lane).
+    Runs the program; memories are updated in place (lds holds L[0..160) on entry, x,y,z on exit).
+    Branch targets are the numeric local labels used above. Returns the executed instruction count."""
     import numpy as np
     f32 = np.float32
     V = np.zeros(256, f32)
     A = np.zeros(256, f32)
     S = {}
-    lds = np.zeros(40 * 4, f32)
+    if lds is None:
+        lds = np.zeros(40 * 4, f32)
     scc = 0
     labels = {}
     for k, t in enumerate(ins):

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a,
     const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
     while (__builtin_amdgcn_s_memrealtime() - t0 < (long long)g * skew_ticks) __builtin_amdgcn_s_sleep(64);
   }
+  T *ldsw = kAsm ? reinterpret_cast<T *>(lds) + 4 * threadIdx.x : nullptr;
 #pragma nounroll
-  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, k, actualT0);
+  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, ldsw, k, actualT0);
 }
 
 template <typename T>

@@ -374,8 +374,10 @@ struct StepIO {
 // Everything persistent round-trips through the SoA arrays, so K steps in one launch and K
 // launches of one step are the same computation.
 template <typename T, bool ASM>
-__device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, const unsigned ldsaddr,
+__device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, const unsigned ldsaddr, T *ldsw,
                                                  const int step, const T *actualT0) {
+// word w of this lane's LDS slot: float4-interleaved, ldsw = (T *)lds + 4 * lane
+#define LDSW(w) ldsw[((w) >> 2) * 256 + ((w) & 3)]
   const bool first_step = step == 0;
   static_assert(!ASM || sizeof(T) == 4, "the assembly loop is fp32");
   const size_t B = (size_t)a.B;
@@ -528,8 +530,11 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #undef A_
 #undef P_
     if constexpr (ASM) {
+      // L[0..160) goes straight to its loop home in LDS (float4-interleaved per lane), the rest through rows
 #pragma unroll
-      for (int e = 0; e < NNZL; ++e) GLD(a.ws, FAC_L + e) = Lx[e];
+      for (int e = 0; e < LDS_BYTES_PER_LANE / 4; ++e) LDSW(e) = Lx[e];
+#pragma unroll
+      for (int e = LDS_BYTES_PER_LANE / 4; e < NNZL; ++e) GLD(a.ws, FAC_L + e) = Lx[e];
 #pragma unroll
       for (int k = 0; k < NK; ++k) GLD(a.ws, FAC_DI + k) = Di[k];
 #pragma unroll
@@ -594,12 +599,23 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   // =========================== phase C: residuals, status, extraction, plant ===========================
   UMPC_PHASE_FENCE();
   T x[NX], y[NC], z[NC];
+  if constexpr (ASM) {  // the assembly left x, y, z in LDS words 0..122
 #pragma unroll
-  for (int j = 0; j < NX; ++j) { x[j] = GLD(a.ctrl, j); qv[j] = GLD(a.ws, FAC_Q + j); }
+    for (int j = 0; j < NX; ++j) x[j] = LDSW(j);
 #pragma unroll
-  for (int i = 0; i < NC; ++i) y[i] = GLD(a.ctrl, NX + i);
+    for (int i = 0; i < NC; ++i) y[i] = LDSW(NX + i);
 #pragma unroll
-  for (int i = 0; i < NC; ++i) z[i] = GLD(a.ctrl, NX + NC + i);
+    for (int i = 0; i < NC; ++i) z[i] = LDSW(NX + NC + i);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) x[j] = GLD(a.ctrl, j);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) y[i] = GLD(a.ctrl, NX + i);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) z[i] = GLD(a.ctrl, NX + NC + i);
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) qv[j] = GLD(a.ws, FAC_Q + j);
 #pragma unroll
   for (int k = 0; k < N; ++k) { lo3[k] = GLD(a.ws, FAC_M + k); up3[k] = GLD(a.ws, FAC_M + N + k); }
   if (prm.maxIter < 1) {  // no iteration ran: nothing was captured
@@ -842,6 +858,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #undef Y_
 #undef Z_
 #undef UMPC_CAPTURE_X
+#undef LDSW
 }
 
 }  // namespace umpc

@@ -45,11 +45,14 @@ def _case(oracle_built, asmgen, ins, s, seq, k, iters):
     if iters >= 1:
         ob = fresh(iters - 1)
         x_before_last = ob.get("x") if iters > 1 else seq["pre_x"][k]
-    asmgen.simulate(ins, ws, ctrl, iters)
+    lds = np.zeros(160, np.float32)
+    lds[:asmgen.NLDS] = o.get("L_x")[:asmgen.NLDS]   # phase A leaves L[0..160) in LDS
+    ws[asmgen.FAC_L:asmgen.FAC_L + asmgen.NLDS] = np.nan  # ... and the program must not read those rows
+    asmgen.simulate(ins, ws, ctrl, iters, lds)
     o2 = fresh(iters)
     for name, sl in (("x", slice(0, 45)), ("y", slice(45, 84)), ("z", slice(84, 123))):
         ref = o2.get(name)
-        assert np.abs(ctrl[sl] - ref).max() <= 2e-5 * max(1e-6, np.abs(ref).max()), (name, k, iters)
+        assert np.abs(lds[sl] - ref).max() <= 2e-5 * max(1e-6, np.abs(ref).max()), (name, k, iters)
     if iters >= 1:  # captured x_prev of the last iteration
         xp = ws[asmgen.WS_XPREV:asmgen.WS_XPREV + 45]
         assert np.abs(xp - x_before_last).max() <= 2e-5 * np.abs(x_before_last).max()
