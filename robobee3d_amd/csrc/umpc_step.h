@@ -598,29 +598,17 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 
   // =========================== phase C: residuals, status, extraction, plant ===========================
   UMPC_PHASE_FENCE();
-  T x[NX], y[NC], z[NC];
-  if constexpr (ASM) {  // the assembly left x, y, z in LDS words 0..122
-#pragma unroll
-    for (int j = 0; j < NX; ++j) x[j] = LDSW(j);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) y[i] = LDSW(NX + i);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) z[i] = LDSW(NX + NC + i);
-  } else {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) x[j] = GLD(a.ctrl, j);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) y[i] = GLD(a.ctrl, NX + i);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) z[i] = GLD(a.ctrl, NX + NC + i);
-  }
-#pragma unroll
-  for (int j = 0; j < NX; ++j) qv[j] = GLD(a.ws, FAC_Q + j);
+  // x, y, z are consumed where they lie: LDS words 0..122 after the assembly loop (fp32), the ctrl rows after
+  // the C++ loop (fp64). No arrays: this phase must stay under 256 live VGPRs (the assembly block clobbers
+  // every AGPR, so the compiler has nowhere cheap to spill).
+#define XV(j) (ASM ? LDSW(j) : GLD(a.ctrl, j))
+#define YV(i) (ASM ? LDSW(NX + (i)) : GLD(a.ctrl, NX + (i)))
+#define ZV(i) (ASM ? LDSW(NX + NC + (i)) : GLD(a.ctrl, NX + NC + (i)))
 #pragma unroll
   for (int k = 0; k < N; ++k) { lo3[k] = GLD(a.ws, FAC_M + k); up3[k] = GLD(a.ws, FAC_M + N + k); }
   if (prm.maxIter < 1) {  // no iteration ran: nothing was captured
 #pragma unroll
-    for (int j = 0; j < NX; ++j) GLD(a.ws, WS_XPREV + j) = x[j];
+    for (int j = 0; j < NX; ++j) GLD(a.ws, WS_XPREV + j) = XV(j);
 #pragma unroll
     for (int i = 0; i < NC; ++i) GLD(a.ws, WS_DY + i) = T(0);
   }
@@ -633,164 +621,159 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   for (int i = 0; i < 6; ++i) dq0[i] = GLD(a.state, 12 + i);
   int status = ST_UNSOLVED;
   T pri_res = T(0), dua_res = T(0);
-  T Ds[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) Ds[j] = GLD(a.ws, WS_DS + j);
+  T u0 = T(0), u1 = T(0), u2 = T(0), dy1[NY];
   {
-    T Es[NC], A[NNZA], P[NX];
+    T Ds[NX], Es[NC];
     const T cscale = GLD(a.ws, WS_C);
     const T cinv = T(1) / cscale;
 #pragma unroll
-    for (int i = 0; i < NC; ++i) Es[i] = GLD(a.ws, WS_ES + i);
-    {
-      // scaled P, A again: raw entries times the final D, E, c (the factorisation consumed the originals)
-      T ref[9];
+    for (int j = 0; j < NX; ++j) Ds[j] = GLD(a.ws, WS_DS + j);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) ref[i] = GLD(a.ref, i);
-      task_reference(prm.task, prm.task_p, tnow, ref);
-      RawQP<T> qp;
-      assemble(prm, wt, Ibi, T0, p0, R0, dq0, ref, qp);
-#define A_(p) A[p]
+    for (int i = 0; i < NC; ++i) Es[i] = GLD(a.ws, WS_ES + i);
+    // raw entries of A: the scaled matrix is re-derived entry by entry as (raw * E_i) * D_j wherever it is
+    // needed (the factorisation consumed the equilibrated copy); nothing of size 111 is ever live here
+    T dtT0, s0dt[3], Btaudt[6];
+    {
+      const T dt = prm.dt;
+      dtT0 = dt * T0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        s0dt[r] = dt * R0[6 + r];
+        Btaudt[r] = dt * (-(R0[r + 3] * Ibi[0]));
+        Btaudt[3 + r] = dt * (-(R0[r] * (-Ibi[1])));
+      }
+    }
 #define DT_(j) Ds[j]
 #define ET_(i) Es[i]
-      UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
-      UMPC_GEN_RUIZ_APPLY_A();
-#undef DT_
-#undef ET_
-#pragma unroll
-      for (int j = 0; j < NX; ++j) P[j] = ((qp.Px[j] * Ds[j]) * Ds[j]) * cscale;
-    }
+#define PXRAW(j) ((j) < 2 * N * NY ? ((j) % NY < 3 ? ((j) < N * NY ? ((j) / NY == N - 1 ? wt.wpf : wt.wpr)                    \
+                                                                     : (((j) - N * NY) / NY == N - 1 ? wt.wvf : wt.wvr))        \
+                                                       : ((j) < N * NY ? wt.ws : wt.wds))                                       \
+                                   : (((j) - 2 * N * NY) % NU == 0 ? wt.wthrust : wt.wmom))
     // ---- update_info: residuals (auxil.c:243-307) ----
-    T Ax[NC], Aty[NX];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) Ax[i] = T(0);
-#define IN_X(j) x[j]
-#define OUT_AX(i) Ax[i]
-    UMPC_GEN_A_MUL(IN_X, OUT_AX);
-#define IN_Y(i) y[i]
-#define OUT_ATY(j) Aty[j]
-    UMPC_GEN_AT_MUL(IN_Y, OUT_ATY);
     T nz = T(0), nAx = T(0), nq = T(0), nAty = T(0), nPx = T(0);
+    {
+      T Ax[NC];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const T einv = umpc_rcp_fast(Es[i]);
-      pri_res = umpc_max(pri_res, umpc_abs(einv * (Ax[i] - z[i])));
-      nz = umpc_max(nz, umpc_abs(einv * z[i]));
-      nAx = umpc_max(nAx, umpc_abs(einv * Ax[i]));
+      for (int i = 0; i < NC; ++i) Ax[i] = T(0);
+#define OUT_AX(i) Ax[i]
+      UMPC_GEN_A_MUL_SCALED(prm.dt, dtT0, s0dt, Btaudt, XV, OUT_AX);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const T einv = umpc_rcp_fast(Es[i]);
+        const T zi = ZV(i);
+        pri_res = umpc_max(pri_res, umpc_abs(einv * (Ax[i] - zi)));
+        nz = umpc_max(nz, umpc_abs(einv * zi));
+        nAx = umpc_max(nAx, umpc_abs(einv * Ax[i]));
+      }
     }
+    {
+      T Aty[NX];
+#define OUT_ATY(j) Aty[j]
+      UMPC_GEN_AT_MUL_SCALED(prm.dt, dtT0, s0dt, Btaudt, YV, OUT_ATY);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const T dinv = umpc_rcp_fast(Ds[j]);
-      const T Pxj = P[j] * x[j];
-      dua_res = umpc_max(dua_res, umpc_abs(dinv * ((Q_(j) + Pxj) + Aty[j])));
-      nq = umpc_max(nq, umpc_abs(dinv * Q_(j)));
-      nAty = umpc_max(nAty, umpc_abs(dinv * Aty[j]));
-      nPx = umpc_max(nPx, umpc_abs(dinv * Pxj));
+      for (int j = 0; j < NX; ++j) {
+        const T dinv = umpc_rcp_fast(Ds[j]);
+        const T qj = GLD(a.ws, FAC_Q + j);
+        const T Pxj = (((PXRAW(j) * Ds[j]) * Ds[j]) * cscale) * XV(j);
+        dua_res = umpc_max(dua_res, umpc_abs(dinv * ((qj + Pxj) + Aty[j])));
+        nq = umpc_max(nq, umpc_abs(dinv * qj));
+        nAty = umpc_max(nAty, umpc_abs(dinv * Aty[j]));
+        nPx = umpc_max(nPx, umpc_abs(dinv * Pxj));
+      }
     }
     dua_res = cinv * dua_res;
 
     // ---- check_termination (auxil.c:684-789), exact then approximate (osqp.c:524-573) ----
+    // The infeasibility certificates are seven scalars that do not depend on the tolerance (all bounds are
+    // finite, so is_primal_infeasible projects nothing): they are computed once, straight-line, and compared
+    // against the exact and then the 10x tolerances. (A two-trip loop here made the compiler hoist ~500
+    // loop-invariant words into scratch.)
     if ((pri_res > T(UMPC_INFTY)) || (dua_res > T(UMPC_INFTY))) {
       status = ST_NON_CVX;
     } else {
-#pragma nounroll
-      for (int approx = 0; approx < 2 && status == ST_UNSOLVED; ++approx) {
-        const T mul = approx ? T(10) : T(1);
-        const T eps_abs = eps_abs0 * mul, eps_rel = eps_rel0 * mul;
-        const T eps_pinf = eps_pinf0 * mul, eps_dinf = eps_dinf0 * mul;
-        const T eps_prim = eps_abs + eps_rel * umpc_max(nz, nAx);
-        const T eps_dual = eps_abs + eps_rel * (umpc_max(umpc_max(nq, nAty), nPx) * cinv);
-        const bool prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual;
-        bool pinf = false, dinf = false;
-        if (!prim_ok) {
-          // is_primal_infeasible, auxil.c:362-424 (all bounds finite here: no projection of delta_y)
-          T dyv[NC];
+      const T rel_p = umpc_max(nz, nAx), rel_d = umpc_max(umpc_max(nq, nAty), nPx) * cinv;
+      const bool prim_ok0 = pri_res < eps_abs0 + eps_rel0 * rel_p, dual_ok0 = dua_res < eps_abs0 + eps_rel0 * rel_d;
+      const bool prim_ok1 = pri_res < T(10) * eps_abs0 + (T(10) * eps_rel0) * rel_p;
+      const bool dual_ok1 = dua_res < T(10) * eps_abs0 + (T(10) * eps_rel0) * rel_d;
+      T ndy = T(0), lhs = T(0), nrm = T(UMPC_INFTY);                 // is_primal_infeasible, auxil.c:362-424
+      T ndx = T(0), qdx = T(0), nP = T(UMPC_INFTY), nAdx = T(UMPC_INFTY);  // is_dual_infeasible, auxil.c:426-512
+      if (!prim_ok0) {
 #pragma unroll
-          for (int i = 0; i < NC; ++i) dyv[i] = GLD(a.ws, WS_DY + i);
-          T ndy = T(0), lhs = T(0);
-#pragma unroll
-          for (int i = 0; i < NC; ++i) ndy = umpc_max(ndy, umpc_abs(dyv[i] * Es[i]));
-          if (ndy > eps_pinf) {
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-              const T li = i < NEQ ? z[i < NEQ ? i : 0] : lo3[i < NEQ ? 0 : i - NEQ];
-              const T ui = i < NEQ ? li : up3[i < NEQ ? 0 : i - NEQ];
-              lhs += ui * umpc_max(dyv[i], T(0)) + li * umpc_min(dyv[i], T(0));
-            }
-            if (lhs < -eps_pinf * ndy) {
-              T Atdy[NX];
-#define IN_DY(i) dyv[i]
-#define OUT_ATDY(j) Atdy[j]
-              UMPC_GEN_AT_MUL(IN_DY, OUT_ATDY);
-              T nrm = T(0);
-#pragma unroll
-              for (int j = 0; j < NX; ++j) nrm = umpc_max(nrm, umpc_abs(Atdy[j] * umpc_rcp_fast(Ds[j])));
-              pinf = nrm < eps_pinf * ndy;
-            }
-          }
+        for (int i = 0; i < NC; ++i) {
+          const T dyi = GLD(a.ws, WS_DY + i);
+          const T li = i < NEQ ? ZV(i) : lo3[i < NEQ ? 0 : i - NEQ];  // z == l == u on the dynamics rows
+          const T ui = i < NEQ ? li : up3[i < NEQ ? 0 : i - NEQ];
+          ndy = umpc_max(ndy, umpc_abs(dyi * Es[i]));
+          lhs += ui * umpc_max(dyi, T(0)) + li * umpc_min(dyi, T(0));
         }
-        if (!dual_ok) {
-          // is_dual_infeasible, auxil.c:426-512
-          T dxv[NX];
+        if (ndy > eps_pinf0 && lhs < -eps_pinf0 * ndy) {  // the 10x test implies this one
+          T Atdy[NX];
+#define IN_DY(i) GLD(a.ws, WS_DY + (i))
+#define OUT_ATDY(j) Atdy[j]
+          UMPC_GEN_AT_MUL_SCALED(prm.dt, dtT0, s0dt, Btaudt, IN_DY, OUT_ATDY);
+          nrm = T(0);
 #pragma unroll
-          for (int j = 0; j < NX; ++j) dxv[j] = x[j] - GLD(a.ws, WS_XPREV + j);
-          T ndx = T(0), qdx = T(0);
+          for (int j = 0; j < NX; ++j) nrm = umpc_max(nrm, umpc_abs(Atdy[j] * umpc_rcp_fast(Ds[j])));
+        }
+      }
+      if (!dual_ok0) {
+        T dxv[NX];
 #pragma unroll
-          for (int j = 0; j < NX; ++j) {
-            ndx = umpc_max(ndx, umpc_abs(Ds[j] * dxv[j]));
-            qdx += Q_(j) * dxv[j];
-          }
-          if (ndx > eps_dinf && qdx < -cscale * eps_dinf * ndx) {
-            T nP = T(0);
+        for (int j = 0; j < NX; ++j) {
+          dxv[j] = XV(j) - GLD(a.ws, WS_XPREV + j);
+          ndx = umpc_max(ndx, umpc_abs(Ds[j] * dxv[j]));
+          qdx += GLD(a.ws, FAC_Q + j) * dxv[j];
+        }
+        if (ndx > eps_dinf0 && qdx < -cscale * eps_dinf0 * ndx) {
+          nP = T(0);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) nP = umpc_max(nP, umpc_abs((P[j] * dxv[j]) * umpc_rcp_fast(Ds[j])));
-            if (nP < cscale * eps_dinf * ndx) {
-              T Adx[NC];
+          for (int j = 0; j < NX; ++j)
+            nP = umpc_max(nP, umpc_abs(((((PXRAW(j) * Ds[j]) * Ds[j]) * cscale) * dxv[j]) * umpc_rcp_fast(Ds[j])));
+          if (nP < cscale * (T(10) * eps_dinf0) * ndx) {
+            T Adx[NC];
 #pragma unroll
-              for (int i = 0; i < NC; ++i) Adx[i] = T(0);
+            for (int i = 0; i < NC; ++i) Adx[i] = T(0);
 #define IN_DX(j) dxv[j]
 #define OUT_ADX(i) Adx[i]
-              UMPC_GEN_A_MUL(IN_DX, OUT_ADX);
-              bool ok = true;
+            UMPC_GEN_A_MUL_SCALED(prm.dt, dtT0, s0dt, Btaudt, IN_DX, OUT_ADX);
+            nAdx = T(0);
 #pragma unroll
-              for (int i = 0; i < NC; ++i) {
-                const T v = Adx[i] * umpc_rcp_fast(Es[i]);
-                if (v > eps_dinf * ndx || v < -eps_dinf * ndx) ok = false;  // all bounds finite
-              }
-              dinf = ok;
-            }
+            for (int i = 0; i < NC; ++i) nAdx = umpc_max(nAdx, umpc_abs(Adx[i] * umpc_rcp_fast(Es[i])));
           }
         }
-        if (prim_ok && dual_ok) status = approx ? ST_SOLVED_INACC : ST_SOLVED;
-        else if (pinf) status = approx ? ST_PINF_INACC : ST_PINF;
-        else if (dinf) status = approx ? ST_DINF_INACC : ST_DINF;
       }
-      if (status == ST_UNSOLVED) status = ST_MAX_ITER;
+#define UMPC_PINF(e) (ndy > (e) && lhs < -(e) * ndy && nrm < (e) * ndy)
+#define UMPC_DINF(e) (ndx > (e) && qdx < -cscale * (e) * ndx && nP < cscale * (e) * ndx && !(nAdx > (e) * ndx))
+      if (prim_ok0 && dual_ok0) status = ST_SOLVED;
+      else if (!prim_ok0 && UMPC_PINF(eps_pinf0)) status = ST_PINF;
+      else if (!dual_ok0 && UMPC_DINF(eps_dinf0)) status = ST_DINF;
+      else if (prim_ok1 && dual_ok1) status = ST_SOLVED_INACC;
+      else if (!prim_ok1 && UMPC_PINF(T(10) * eps_pinf0)) status = ST_PINF_INACC;
+      else if (!dual_ok1 && UMPC_DINF(T(10) * eps_dinf0)) status = ST_DINF_INACC;
+      else status = ST_MAX_ITER;
+#undef UMPC_PINF
+#undef UMPC_DINF
     }
-#undef A_
+    // ---- store_solution (auxil.c:527-565): unscale what the extraction needs ----
+    u0 = XV(2 * NY * N + 0) * Ds[2 * NY * N + 0];
+    u1 = XV(2 * NY * N + 1) * Ds[2 * NY * N + 1];
+    u2 = XV(2 * NY * N + 2) * Ds[2 * NY * N + 2];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) dy1[i] = XV(NY * N + i) * Ds[NY * N + i];
+#undef DT_
+#undef ET_
   }
 
-  // ---- store_solution (auxil.c:527-565) + extraction (uprightmpc2.c:253-269) ----
+  // ---- extraction (uprightmpc2.c:253-269) ----
   const bool has_sol = status != ST_PINF && status != ST_PINF_INACC && status != ST_DINF &&
                        status != ST_DINF_INACC && status != ST_NON_CVX;
-  T u0, u1, u2, dy1[NY];
-  if (has_sol) {
-    u0 = x[2 * NY * N + 0] * Ds[2 * NY * N + 0];
-    u1 = x[2 * NY * N + 1] * Ds[2 * NY * N + 1];
-    u2 = x[2 * NY * N + 2] * Ds[2 * NY * N + 2];
-#pragma unroll
-    for (int i = 0; i < NY; ++i) dy1[i] = x[NY * N + i] * Ds[NY * N + i];
-  } else {
+  if (!has_sol) {
     // the reference's OSQP_NAN is the NUMBER (c_float)0x7fc00000 = 2143289344 (constants.h:96),
     // and the iterates are cold-started (auxil.c:563)
     const T nanv = T(2143289344.0);
     u0 = u1 = u2 = nanv;
 #pragma unroll
     for (int i = 0; i < NY; ++i) dy1[i] = nanv;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) x[j] = T(0);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) { y[i] = T(0); z[i] = T(0); }
   }
   T0 += u0;
   T uq[3] = {T0, u1, u2}, acc[NY];
@@ -802,13 +785,15 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #pragma unroll
     for (int i = 0; i < NY; ++i) acc[i] = (dq1[i] - dq0[i]) / prm.dt;
   }
-  // controller record + outputs back to HBM
+  // controller record + outputs back to HBM (fp64: x, y, z are already in their rows unless cold-started)
+  if (ASM || !has_sol) {
 #pragma unroll
-  for (int j = 0; j < NX; ++j) GLD(a.ctrl, j) = x[j];
+    for (int j = 0; j < NX; ++j) { const T v = has_sol ? XV(j) : T(0); GLD(a.ctrl, j) = v; }
 #pragma unroll
-  for (int i = 0; i < NC; ++i) GLD(a.ctrl, NX + i) = y[i];
+    for (int i = 0; i < NC; ++i) { const T v = has_sol ? YV(i) : T(0); GLD(a.ctrl, NX + i) = v; }
 #pragma unroll
-  for (int i = 0; i < NC; ++i) GLD(a.ctrl, NX + NC + i) = z[i];
+    for (int i = 0; i < NC; ++i) { const T v = has_sol ? ZV(i) : T(0); GLD(a.ctrl, NX + NC + i) = v; }
+  }
   GLD(a.ctrl, NX + 2 * NC) = T0;
 #pragma unroll
   for (int k = 0; k < N; ++k) GLD(a.ctrl, NX + 2 * NC + 1 + k) = Eprev3[k];
@@ -859,6 +844,10 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #undef Z_
 #undef UMPC_CAPTURE_X
 #undef LDSW
+#undef XV
+#undef YV
+#undef ZV
+#undef PXRAW
 }
 
 }  // namespace umpc
