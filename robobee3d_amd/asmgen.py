@@ -132,21 +132,31 @@ class Fetcher:
         """ops: list of dicts {emit: fn(src_reg_name), src: ('A', areg) | ('L', ldsword) | None}"""
         e = self.e
         n = len(ops)
-        # LDS instances: maximal runs of consecutive ops (among LDS-sourced ops) using the same quad
+        # LDS instances: a quad stays resident in one of the 4 ring slots until it is the least recently used
+        # one when another quad needs a slot (the backward solve revisits quads that straddle two rows)
         inst_of = [None] * n
-        insts = []  # dict(quad, first, last, slot, issued_no)
-        last_inst = None
+        insts = []  # dict(quad, first, last, slot, prev, issued)
+        slots = [None] * 4  # instance index resident in each slot
         for i, op in enumerate(ops):
             if op["src"] and op["src"][0] == "L":
                 qd = op["src"][1] // 4
-                if last_inst is not None and insts[last_inst]["quad"] == qd:
-                    insts[last_inst]["last"] = i
-                else:
-                    insts.append(dict(quad=qd, first=i, last=i, issued=None))
-                    last_inst = len(insts) - 1
-                inst_of[i] = last_inst
-        for k, it in enumerate(insts):
-            it["slot"] = k % 4
+                hit = [k for k in slots if k is not None and insts[k]["quad"] == qd]
+                if hit:
+                    insts[hit[0]]["last"] = i
+                    inst_of[i] = hit[0]
+                    continue
+                free = [sl for sl in range(4) if slots[sl] is None]
+                sl = free[0] if free else min(range(4), key=lambda q: insts[slots[q]]["last"])
+                insts.append(dict(quad=qd, first=i, last=i, slot=sl, prev=slots[sl], issued=None))
+                slots[sl] = len(insts) - 1
+                inst_of[i] = slots[sl]
+
+        def issue(it):
+            e("ds_read_b128", "v[%d:%d]" % (V_RING + 4 * it["slot"], V_RING + 4 * it["slot"] + 3), "v1",
+              it["quad"] * 1024)
+            it["issued"] = self.nds
+            self.nds += 1
+
         next_inst = 0
         atemp = {}
         next_acc = 0  # next op index whose AGPR fetch has not been issued
@@ -164,12 +174,9 @@ class Fetcher:
             # LDS instance reads whose first consumer is within the window and whose slot is free
             while next_inst < len(insts):
                 it = insts[next_inst]
-                prev = insts[next_inst - 4] if next_inst >= 4 else None
+                prev = insts[it["prev"]] if it["prev"] is not None else None
                 if it["first"] <= i + 3 * self.la and (prev is None or prev["last"] < i):
-                    e("ds_read_b128", "v[%d:%d]" % (V_RING + 4 * it["slot"], V_RING + 4 * it["slot"] + 3), "v1",
-                      it["quad"] * 1024)
-                    it["issued"] = self.nds
-                    self.nds += 1
+                    issue(it)
                     next_inst += 1
                 else:
                     break
@@ -180,7 +187,10 @@ class Fetcher:
                 op["emit"]("v%d" % atemp.pop(i))
             else:
                 it = insts[inst_of[i]]
-                assert it["issued"] is not None, "LDS fetch not issued in time"
+                if it["issued"] is None:  # slot was busy until now: fetch on demand (instances issue in order)
+                    assert inst_of[i] == next_inst and (it["prev"] is None or insts[it["prev"]]["last"] < i)
+                    issue(it)
+                    next_inst += 1
                 if it["first"] == i:
                     e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nds - 1 - it["issued"]))
                 op["emit"]("v%d" % (V_RING + 4 * it["slot"] + op["src"][1] % 4))
@@ -250,6 +260,17 @@ def body(e, s, first, capture):
         rinv = sRi if eq else M(9 + i - neq)
         rho = sRh if eq else M(6 + i - neq)
         nu = W(s.pinv[nx + i])
+        if eq and not first:
+            # Dynamics rows after the first iteration: z == l == u, so z stays and
+            #   delta_y = rho (alpha z~ + (1-alpha) z - z) = rho alpha (z~ - z) = rho alpha rinv (nu - y) = alpha (nu - y)
+            # (rho rinv = 1). Two instructions instead of seven; same value up to the rounding of the longer chain.
+            e("v_sub_f32", t1, nu, Y(i))
+            if capture:
+                e("v_mul_f32", t2, sA, t1)
+                e("global_store_dword", "v0", t2, ptr)
+                _adv(e, S_P2)
+            e("v_fma_f32", Y(i), sA, t1, Y(i))
+            continue
         e("v_fma_f32", t1, "-" + rinv, Y(i), Z(i))        # z - y/rho (the rhs again)
         e("v_fma_f32", t1, rinv, nu, t1)                  # z~
         e("v_mul_f32", t2, sO, Z(i))
