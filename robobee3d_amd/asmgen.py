@@ -10,28 +10,31 @@ placement is static (one lane = one robot, one wave per SIMD):
 
     v0            robot byte offset (4*b)              input
     v1            lane LDS address (base + 16*lane)    input
-    v2..v85       W      KKT rhs / solution (permuted order)
-    v86..v130     x      v131..v169  y      v170..v208  z
-    v209..v220    lo3 up3 rho3 rinv3 (thrust rows)
-    v222..v237    LDS read ring (4 x float4)
-    v238..v243    AGPR read temporaries
-    v244..v251    arithmetic temporaries
-    v221, v252..v255   not touched (left to the compiler for values that live across the block)
-    a0..a52       L[160..212]    a53..a136  1/D    a137..a181  q    a182..a217  l(=u) of the dynamics rows
-    LDS           L[0..159] as 40 float4 per lane (ds_read_b128, conflict-free)
+    v2..v86       W      KKT rhs / solution, stored by ORIGINAL index (x part v2..v46, z part v48..v86)
+    v88..v132     x      v134..v172  y      v174..v212  z        (even bases: v_pk_* register pairs)
+    v214..v229    LDS read ring (4 x float4)
+    v230..v237    AGPR read temporaries (4 pairs)
+    v238..v245    arithmetic temporaries
+    v246..v255    not touched (left to the compiler for values that live across the block)
+    a0..a52       L[160..212]   a53..a136  1/D   a137..a181  q   a182..a217  l(=u) dynamics rows
+    a218..a229    lo3 up3 rho3 rinv3 (thrust rows)
+    LDS           L[0..159] as 40 float4 per lane (ds_read_b128, conflict-free); x, y, z on exit
 
-Per middle iteration: 84 rhs FMAs, 426 solve FMAs + 84 multiplies, 90 x-update
-and ~260 z/y-update ops, 235 v_accvgpr_read and 80 ds_read_b128 -- no scratch,
-no HBM traffic. The arithmetic (operation order, where an FMA replaces a
-multiply-add) is identical to UMPC_GEN_ADMM_ITER in umpc_gen.h, which stays the
-fp64 / reference implementation of the same iteration.
+A lone wave issues one VALU instruction per ~5 cycles whether it is v_fma_f32 or v_pk_fma_f32
+(tools/microbench.hip), so everything elementwise runs packed, two rows per instruction: the rhs,
+the 1/D scaling, the x update and the y update of the dynamics rows. The triangular solves stay
+scalar (426 FMAs). Per middle iteration: ~1000 instructions, no scratch, no HBM.
+
+Arithmetic vs UMPC_GEN_ADMM_ITER (the C++ / fp64 statement of the same iteration): same operation
+order and the same FMA placement, except that after the first iteration the dynamics rows (z == l == u)
+use delta_y = alpha (nu - y) instead of the seven-operation chain it is algebraically equal to.
 
 Reference mapping: auxil.c:164-228 (compute_rhs, update_x, update_z, update_y),
 qdldl_interface.c:322-369, qdldl.c:250-293, proj.c:4-14.
 
 `simulate()` interprets the emitted instruction list on numpy float32 so that
-the CPU test-suite can check the schedule (register reuse, fetch distances)
-against the oracle without a GPU.
+the CPU test-suite can check the schedule (register reuse, fetch distances,
+packed-operand selects) against the oracle without a GPU.
 """
 import os
 import struct
@@ -47,13 +50,13 @@ FAC_ROWS = 390
 WS_DS, WS_ES, WS_C, WS_XPREV, WS_DY = 390, 435, 474, 475, 520
 WS_ROWS = 559
 
-V_W, V_X, V_Y, V_Z, V_M = 2, 86, 131, 170, 209
-V_RING, V_AT, V_TT = 222, 238, 244   # v221 and v252..v255 are left to the compiler (SGPR spill lanes)
-N_AT = 6
-A_L, A_D, A_Q, A_LO = 0, 53, 137, 182
+V_W, V_WZ, V_X, V_Y, V_Z = 2, 48, 88, 134, 174
+V_RING, V_AT, V_TT, V_END = 214, 230, 238, 246
+N_ATP = 4  # AGPR-read temporaries, in pairs
+A_L, A_D, A_Q, A_LO, A_M = 0, 53, 137, 182, 218
 S_WS, S_CTRL, S_STRIDE, S_ITERS = 4, 6, 10, 11
 S_P, S_CNT, S_P2 = 12, 14, 16
-S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO = 20, 21, 22, 23, 24
+S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO = 20, 22, 24, 26, 28  # even: low half of an SGPR pair (packed broadcast)
 
 
 def f32bits(v):
@@ -62,7 +65,7 @@ def f32bits(v):
 
 class Emit:
     def __init__(self):
-        self.ins = []  # tuples (mnemonic, operands...)
+        self.ins = []  # tuples (mnemonic, operands..., [dict of VOP3P modifiers])
 
     def __call__(self, *t):
         self.ins.append(t)
@@ -82,54 +85,51 @@ def _adv(e, sreg):
 
 
 def prologue(e, s):
-    e("s_mov_b32", "s%d" % S_ALPHA, f32bits(1.6))
     import numpy as np
-    e("s_mov_b32", "s%d" % S_OMA, f32bits(float(np.float32(1.0) - np.float32(1.6))))
-    e("s_mov_b32", "s%d" % S_SIGMA, f32bits(1e-6))
-    e("s_mov_b32", "s%d" % S_RINV, f32bits(0.01))
-    e("s_mov_b32", "s%d" % S_RHO, f32bits(100.0))
-    # Two memory round trips in all (every wave of the grid is in this phase at the same time, so each
-    # exposed round trip costs microseconds): (1) L[0..NLDS) staged through v2..v161 (W/x/y are not live
-    # yet) into LDS; (2) everything else, back to back, one wait.
+    for reg, val in ((S_ALPHA, 1.6), (S_OMA, float(np.float32(1.0) - np.float32(1.6))), (S_SIGMA, 1e-6),
+                     (S_RINV, 0.01), (S_RHO, 100.0)):
+        e("s_mov_b32", "s%d" % reg, f32bits(val))
+        e("s_mov_b32", "s%d" % (reg + 1), f32bits(val))
     # L[0..NLDS) was written into LDS by phase A (same lane, same layout); everything else arrives through
-    # the workspace rows, issued back to back with ONE wait.
+    # the workspace rows, issued back to back with ONE wait (every wave of the grid is in this phase at the
+    # same time, so each exposed round trip costs microseconds).
     _row_ptr(e, S_P, S_WS, FAC_L + NLDS)
-    # the rest of L, 1/D, q and the dynamics-row bounds -> AGPRs (rows are consecutive in the workspace)
-    nrest = len(s.L_i) - NLDS + s.nk + s.nx + 2 * s.N * symbolic.NY
-    assert A_LO == nrest - 2 * s.N * symbolic.NY and nrest <= 256
+    # the rest of L, 1/D, q, the dynamics-row bounds and the thrust-row words -> AGPRs (consecutive rows)
+    nrest = len(s.L_i) - NLDS + s.nk + s.nx + 2 * s.N * symbolic.NY + 12
+    assert A_LO == nrest - 12 - 2 * s.N * symbolic.NY and A_M == nrest - 12 and nrest <= 256
     for r in range(nrest):
         e("global_load_dword", "a%d" % r, "v0", "s[%d:%d]" % (S_P, S_P + 1))
         _adv(e, S_P)
-    # thrust-row words (rows follow FAC_LOEQ)
-    for k in range(12):
-        e("global_load_dword", "v%d" % (V_M + k), "v0", "s[%d:%d]" % (S_P, S_P + 1))
-        _adv(e, S_P)
     # x, y, z
     e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_CTRL, S_CTRL + 1))
-    for r in range(s.nx + 2 * s.nc):
-        e("global_load_dword", "v%d" % (V_X + r), "v0", "s[%d:%d]" % (S_P, S_P + 1))
-        _adv(e, S_P)
+    for base, n in ((V_X, s.nx), (V_Y, s.nc), (V_Z, s.nc)):
+        for r in range(n):
+            e("global_load_dword", "v%d" % (base + r), "v0", "s[%d:%d]" % (S_P, S_P + 1))
+            _adv(e, S_P)
     e("s_waitcnt", "vmcnt(0)")
 
 
 def epilogue(e, s):
-    # x, y, z stay on chip: the factor in LDS is dead now, phase C reads the iterates from LDS words 0..122
-    # (v86..v208 are consecutive; the last quad also carries v209, which nobody reads)
-    n = s.nx + 2 * s.nc
-    for g in range((n + 3) // 4):
-        e("ds_write_b128", "v1", "v[%d:%d]" % (V_X + 4 * g, V_X + 4 * g + 3), g * 1024)
+    # x, y, z stay on chip: the factor in LDS is dead now, phase C reads the iterates from LDS words 0..122.
+    # Registers are [x 45 | pad | y 39 | pad | z 39]; LDS words are contiguous, so y and z are written one
+    # word at a time where they straddle a pad.
+    w = 0
+    for base, n in ((V_X, s.nx), (V_Y, s.nc), (V_Z, s.nc)):
+        for r in range(n):
+            e("ds_write_b32", "v1", "v%d" % (base + r), (w // 4) * 1024 + (w % 4) * 4)
+            w += 1
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
 
 class Fetcher:
-    """Issues the L / 1-over-D / q operand fetches a fixed distance ahead of their consumers."""
+    """Issues the L / 1-over-D / q operand fetches a fixed distance ahead of their consumers.
+    src: None | ('A', a) -> one VGPR | ('A2', a_lo, a_hi) -> an aligned VGPR pair | ('L', lds_word)."""
 
-    def __init__(self, e, la=4):
+    def __init__(self, e, la=3):
         self.e, self.la = e, la
         self.nds = 0          # ds_reads issued so far in this body
 
     def run(self, ops):
-        """ops: list of dicts {emit: fn(src_reg_name), src: ('A', areg) | ('L', ldsword) | None}"""
         e = self.e
         n = len(ops)
         # LDS instances: a quad stays resident in one of the 4 ring slots until it is the least recently used
@@ -162,20 +162,22 @@ class Fetcher:
         next_acc = 0  # next op index whose AGPR fetch has not been issued
         acc_rr = 0
         for i in range(n):
-            # AGPR fetches for ops i .. i+la-1
+            # AGPR fetches for ops i .. i+la-1 (one temporary PAIR per fetch, la < N_ATP pairs in flight)
             while next_acc < n and next_acc < i + self.la:
                 op = ops[next_acc]
-                if op["src"] and op["src"][0] == "A":
-                    t = V_AT + (acc_rr % N_AT)
+                if op["src"] and op["src"][0] in ("A", "A2"):
+                    t = V_AT + 2 * (acc_rr % N_ATP)
                     acc_rr += 1
                     e("v_accvgpr_read_b32", "v%d" % t, "a%d" % op["src"][1])
+                    if op["src"][0] == "A2":
+                        e("v_accvgpr_read_b32", "v%d" % (t + 1), "a%d" % op["src"][2])
                     atemp[next_acc] = t
                 next_acc += 1
             # LDS instance reads whose first consumer is within the window and whose slot is free
             while next_inst < len(insts):
                 it = insts[next_inst]
                 prev = insts[it["prev"]] if it["prev"] is not None else None
-                if it["first"] <= i + 3 * self.la and (prev is None or prev["last"] < i):
+                if it["first"] <= i + 4 * self.la and (prev is None or prev["last"] < i):
                     issue(it)
                     next_inst += 1
                 else:
@@ -183,8 +185,8 @@ class Fetcher:
             op = ops[i]
             if op["src"] is None:
                 op["emit"](None)
-            elif op["src"][0] == "A":
-                op["emit"]("v%d" % atemp.pop(i))
+            elif op["src"][0] in ("A", "A2"):
+                op["emit"](atemp.pop(i))
             else:
                 it = insts[inst_of[i]]
                 if it["issued"] is None:  # slot was busy until now: fetch on demand (instances issue in order)
@@ -193,21 +195,51 @@ class Fetcher:
                     next_inst += 1
                 if it["first"] == i:
                     e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nds - 1 - it["issued"]))
-                op["emit"]("v%d" % (V_RING + 4 * it["slot"] + op["src"][1] % 4))
+                op["emit"](V_RING + 4 * it["slot"] + op["src"][1] % 4)
 
 
 def l_src(eidx):
     return ("L", eidx) if eidx < NLDS else ("A", A_L + eidx - NLDS)
 
 
+# ---- packed (VOP3P) operand helpers: every operand is a 64-bit register pair plus a half select ----
+def _vp(n):   # both halves of the aligned VGPR pair starting at even n
+    assert n % 2 == 0
+    return ("v[%d:%d]" % (n, n + 1), 0, 1)
+
+
+def _vb(n):   # one VGPR broadcast to both halves
+    lo = n - (n % 2)
+    return ("v[%d:%d]" % (lo, lo + 1), n % 2, n % 2)
+
+
+def _sb(n):   # SGPR constant (low half of an even pair) broadcast
+    assert n % 2 == 0
+    return ("s[%d:%d]" % (n, n + 1), 0, 0)
+
+
+def pk(e, mnem, dst, srcs, neg=None):
+    """srcs: list of (reg, sel_lo, sel_hi); neg: list of 0/1 per source (applied to both halves)."""
+    assert dst % 2 == 0
+    neg = neg or [0] * len(srcs)
+    mods = dict(op_sel=[s_[1] for s_ in srcs], op_sel_hi=[s_[2] for s_ in srcs], neg_lo=list(neg), neg_hi=list(neg))
+    e(mnem, "v[%d:%d]" % (dst, dst + 1), *[s_[0] for s_ in srcs], mods)
+
+
 def body(e, s, first, capture):
     nx, nc, nk = s.nx, s.nc, s.nk
     neq = 2 * s.N * symbolic.NY
-    W = lambda k: "v%d" % (V_W + k)
+
+    def wreg(k):  # W is stored by ORIGINAL KKT index so that rows j, j+1 of x / y / z pair up with it
+        o = s.perm[k]
+        return V_W + o if o < nx else V_WZ + (o - nx)
+    W = lambda k: "v%d" % wreg(k)
+    WX = lambda j: V_W + j            # register of the KKT unknown paired with x_j
+    WZ = lambda i: V_WZ + i           # ... with constraint row i
     X = lambda j: "v%d" % (V_X + j)
     Y = lambda i: "v%d" % (V_Y + i)
     Z = lambda i: "v%d" % (V_Z + i)
-    M = lambda k: "v%d" % (V_M + k)  # lo3[0:3] up3[3:6] rho3[6:9] rinv3[9:12]
+    v = lambda n: "v%d" % n
     sA, sO, sS, sRi, sRh = ("s%d" % r for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO))
     ptr = "s[%d:%d]" % (S_P2, S_P2 + 1)
     f = Fetcher(e)
@@ -221,70 +253,91 @@ def body(e, s, first, capture):
         for j in range(nx):
             e("global_store_dword", "v0", X(j), ptr)
             _adv(e, S_P2)
-    # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178), written in permuted order
-    for j in range(nx):
-        op(("A", A_Q + j), lambda r, j=j: e("v_fma_f32", W(s.pinv[j]), sS, X(j), "-" + r))
-    for i in range(nc):
-        rinv = sRi if i < neq else M(9 + i - neq)
-        op(None, lambda r, i=i, rinv=rinv: e("v_fma_f32", W(s.pinv[nx + i]), "-" + rinv, Y(i), Z(i)))
+    # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178)
+    for j in range(0, nx - 1, 2):
+        op(("A2", A_Q + j, A_Q + j + 1),
+           lambda t, j=j: pk(e, "v_pk_fma_f32", WX(j), [_sb(S_SIGMA), _vp(V_X + j), _vp(t)], [0, 0, 1]))
+    op(("A", A_Q + nx - 1), lambda t: e("v_fma_f32", v(WX(nx - 1)), sS, X(nx - 1), "-" + v(t)))
+    for i in range(0, neq, 2):
+        op(None, lambda t, i=i: pk(e, "v_pk_fma_f32", WZ(i), [_sb(S_RINV), _vp(V_Y + i), _vp(V_Z + i)], [1, 0, 0]))
+    for i in range(neq, nc):
+        op(("A", A_M + 9 + i - neq), lambda t, i=i: e("v_fma_f32", v(WZ(i)), "-" + v(t), Y(i), Z(i)))
     # ---- forward substitution (qdldl.c:250-262)
     for c in range(nk):
         for j in range(s.L_p[c], s.L_p[c + 1]):
             r_ = s.L_i[j]
-            op(l_src(j), lambda r, r_=r_, c=c: e("v_fma_f32", W(r_), "-" + r, W(c), W(r_)))
-    # ---- diagonal (qdldl.c:289)
-    for k in range(nk):
-        op(("A", A_D + k), lambda r, k=k: e("v_mul_f32", W(k), r, W(k)))
+            op(l_src(j), lambda t, r_=r_, c=c: e("v_fma_f32", W(r_), "-" + v(t), W(c), W(r_)))
+    # ---- diagonal (qdldl.c:289): two unknowns per instruction, paired by register
+    kof = {wreg(k): k for k in range(nk)}
+    for r0 in range(V_W, V_Z, 2):
+        k0, k1 = kof.get(r0), kof.get(r0 + 1)
+        if k0 is not None and k1 is not None:
+            op(("A2", A_D + k0, A_D + k1), lambda t, r0=r0: pk(e, "v_pk_mul_f32", r0, [_vp(r0), _vp(t)]))
+        elif k0 is not None or k1 is not None:
+            k, r = (k0, r0) if k0 is not None else (k1, r0 + 1)
+            op(("A", A_D + k), lambda t, r=r: e("v_mul_f32", v(r), v(t), v(r)))
     # ---- backward substitution (qdldl.c:265-277)
     for c in range(nk - 1, -1, -1):
         for j in range(s.L_p[c], s.L_p[c + 1]):
             r_ = s.L_i[j]
-            op(l_src(j), lambda r, r_=r_, c=c: e("v_fma_f32", W(c), "-" + r, W(r_), W(c)))
+            op(l_src(j), lambda t, r_=r_, c=c: e("v_fma_f32", W(c), "-" + v(t), W(r_), W(c)))
     f.run(ops)
     # ---- x <- alpha x~ + (1 - alpha) x   (auxil.c:188-201)
-    for j in range(nx):
-        t = "v%d" % (V_TT + j % 8)
-        e("v_mul_f32", t, sO, X(j))
-        e("v_fma_f32", X(j), sA, W(s.pinv[j]), t)
+    for j in range(0, nx - 1, 2):
+        t = V_TT + 2 * ((j // 2) % 4)
+        pk(e, "v_pk_mul_f32", t, [_sb(S_OMA), _vp(V_X + j)])
+        pk(e, "v_pk_fma_f32", V_X + j, [_sb(S_ALPHA), _vp(WX(j)), _vp(t)])
+    e("v_mul_f32", v(V_TT), sO, X(nx - 1))
+    e("v_fma_f32", X(nx - 1), sA, v(WX(nx - 1)), v(V_TT))
     # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
     if capture:
         _row_ptr(e, S_P2, S_WS, WS_DY)
+    if not first:
+        # Dynamics rows after the first iteration: z == l == u, so z stays and
+        #   delta_y = rho (alpha z~ + (1-alpha) z - z) = rho alpha (z~ - z) = rho alpha rinv (nu - y) = alpha (nu - y)
+        # (rho rinv = 1). Two packed instructions per two rows instead of seven per row; same value up to the
+        # rounding of the longer chain.
+        for i in range(0, neq, 2):
+            t = V_TT + 2 * ((i // 2) % 2)
+            pk(e, "v_pk_add_f32", t, [_vp(WZ(i)), _vp(V_Y + i)], [0, 1])
+            if capture:
+                pk(e, "v_pk_mul_f32", t + 4, [_sb(S_ALPHA), _vp(t)])
+                for h in range(2):
+                    e("global_store_dword", "v0", v(t + 4 + h), ptr)
+                    _adv(e, S_P2)
+            pk(e, "v_pk_fma_f32", V_Y + i, [_sb(S_ALPHA), _vp(t), _vp(V_Y + i)])
     for i in range(nc):
         eq = i < neq
+        if eq and not first:
+            continue
         if first and eq and i % 16 == 0:
             # l == u of the dynamics rows sit in spare AGPRs; 16 at a time into the (idle) ring registers
             for w in range(min(16, neq - i)):
-                e("v_accvgpr_read_b32", "v%d" % (V_RING + w), "a%d" % (A_LO + i + w))
+                e("v_accvgpr_read_b32", v(V_RING + w), "a%d" % (A_LO + i + w))
         b = V_TT + 4 * (i % 2)
-        t1, t2, t3 = "v%d" % b, "v%d" % (b + 1), "v%d" % (b + 2)
-        rinv = sRi if eq else M(9 + i - neq)
-        rho = sRh if eq else M(6 + i - neq)
-        nu = W(s.pinv[nx + i])
-        if eq and not first:
-            # Dynamics rows after the first iteration: z == l == u, so z stays and
-            #   delta_y = rho (alpha z~ + (1-alpha) z - z) = rho alpha (z~ - z) = rho alpha rinv (nu - y) = alpha (nu - y)
-            # (rho rinv = 1). Two instructions instead of seven; same value up to the rounding of the longer chain.
-            e("v_sub_f32", t1, nu, Y(i))
-            if capture:
-                e("v_mul_f32", t2, sA, t1)
-                e("global_store_dword", "v0", t2, ptr)
-                _adv(e, S_P2)
-            e("v_fma_f32", Y(i), sA, t1, Y(i))
-            continue
+        t1, t2, t3, t4 = v(b), v(b + 1), v(b + 2), v(b + 3)
+        if eq:
+            rinv, rho = sRi, sRh
+        else:  # thrust rows: their own rho / bounds, kept in AGPRs (a: lo3 up3 rho3 rinv3)
+            k = i - neq
+            rinv, rho = v(V_AT), v(V_AT + 1)
+            e("v_accvgpr_read_b32", rinv, "a%d" % (A_M + 9 + k))
+            e("v_accvgpr_read_b32", rho, "a%d" % (A_M + 6 + k))
+            e("v_accvgpr_read_b32", v(V_AT + 2), "a%d" % (A_M + k))
+            e("v_accvgpr_read_b32", v(V_AT + 3), "a%d" % (A_M + 3 + k))
+        nu = v(WZ(i))
         e("v_fma_f32", t1, "-" + rinv, Y(i), Z(i))        # z - y/rho (the rhs again)
         e("v_fma_f32", t1, rinv, nu, t1)                  # z~
         e("v_mul_f32", t2, sO, Z(i))
         e("v_fma_f32", t1, sA, t1, t2)                    # t = alpha z~ + (1-alpha) z
         if eq:
-            zn = ("v%d" % (V_RING + i % 16)) if first else Z(i)
+            zn = v(V_RING + i % 16)
             e("v_sub_f32", t2, t1, zn)
-            if first:
-                e("v_mov_b32", Z(i), zn)
+            e("v_mov_b32", Z(i), zn)
         else:
-            k = i - neq
             e("v_fma_f32", t3, rinv, Y(i), t1)
-            e("v_max_f32", t3, t3, M(k))
-            e("v_min_f32", Z(i), t3, M(3 + k))
+            e("v_max_f32", t3, t3, v(V_AT + 2))
+            e("v_min_f32", Z(i), t3, v(V_AT + 3))
             e("v_sub_f32", t2, t1, Z(i))
         e("v_mul_f32", t2, rho, t2)                       # delta_y
         e("v_add_f32", Y(i), Y(i), t2)
@@ -321,27 +374,31 @@ def fmt(t):
     m = t[0]
     if m == "label":
         return "%s:" % t[1]
+    mods = ""
+    if isinstance(t[-1], dict):
+        d = t[-1]
+        t = t[:-1]
+        mods = " " + " ".join("%s:[%s]" % (k, ",".join(map(str, d[k]))) for k in ("op_sel", "op_sel_hi", "neg_lo", "neg_hi"))
     a = [("0x%x" % x if (m == "s_mov_b32" and isinstance(x, int)) else str(x)) for x in t[1:]]
-    if m in ("ds_read_b128", "ds_write_b128"):
+    if m in ("ds_read_b128", "ds_write_b128", "ds_write_b32"):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
-    if m == "global_load_dword":
-        return "%s %s, %s, %s" % (m, a[0], a[1], a[2])
-    if m == "global_store_dword":
+    if m in ("global_load_dword", "global_store_dword"):
         return "%s %s, %s, %s" % (m, a[0], a[1], a[2])
     if m == "s_waitcnt":
         return "s_waitcnt " + " ".join(a)
-    return "%s %s" % (m, ", ".join(a))
+    return "%s %s%s" % (m, ", ".join(a), mods)
 
 
 def write(path=None, N=3, perm=None):
     path = path or os.path.join(HERE, "csrc", "umpc_admm_asm.h")
     ins, s = program(N, perm)
-    used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1, S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO]
-    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, 252) if i != 221] + ['"a%d"' % i for i in range(256)] + \
-           ['"s%d"' % i for i in used_s]
+    used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1] + list(range(S_ALPHA, S_RHO + 2))
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
+           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
+    lab7 = [k for k, t in enumerate(ins) if t == ("label", "7")][0]
+    lab8 = [k for k, t in enumerate(ins) if t == ("label", "8")][0]
     out = ["// GENERATED by robobee3d_amd/asmgen.py -- do not edit.",
-           "// ADMM phase of the fp32 step kernel: %d instructions, middle-iteration body %d." %
-           (len(ins), sum(1 for _ in ins) // 3),
+           "// ADMM phase of the fp32 step kernel: %d instructions, middle-iteration body %d." % (len(ins), lab8 - lab7),
            "#pragma once",
            "namespace umpcasm {",
            "constexpr int FAC_L = %d, FAC_DI = %d, FAC_Q = %d, FAC_LOEQ = %d, FAC_M = %d, FAC_ROWS = %d;" %
@@ -392,20 +449,24 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds=None):
             return S.get(lo, 0) | (S.get(lo + 1, 0) << 32)
         return S.get(int(x[1:]), 0)
 
+    def sf(n):
+        return np.frombuffer(struct.pack("<I", S[n] & 0xFFFFFFFF), f32)[0]
+
     def fval(x):
         neg = x.startswith("-")
         if neg:
             x = x[1:]
         if x[0] == "v":
-            v = V[int(x[1:])]
+            val = V[int(x[1:])]
         elif x[0] == "s":
-            v = np.frombuffer(struct.pack("<I", S[int(x[1:])] & 0xFFFFFFFF), f32)[0]
+            val = sf(int(x[1:]))
         else:
             raise ValueError(x)
-        return -v if neg else v
+        return -val if neg else val
 
-    def ptr_row(x):  # 's[a:b]' -> (which memory, row): pointers are simulated as base_id * 2^40 + row * stride
-        return sval(x)
+    def half(x, sel):  # one half of a 64-bit packed operand
+        lo = int(x[2:x.index(":")])
+        return V[lo + sel] if x[0] == "v" else sf(lo + sel)
 
     STRIDE = 4096
     S[S_WS], S[S_WS + 1] = 1 << 20, 0          # workspace "address"
@@ -430,8 +491,8 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds=None):
             S[int(t[1][1:])] = t[2] if isinstance(t[2], int) else sval(t[2])
         elif m == "s_mov_b64":
             lo = int(t[1][2:t[1].index(":")])
-            v = sval(t[2])
-            S[lo], S[lo + 1] = v & 0xFFFFFFFF, v >> 32
+            val = sval(t[2])
+            S[lo], S[lo + 1] = val & 0xFFFFFFFF, val >> 32
         elif m == "s_mul_i32":
             S[int(t[1][1:])] = (sval(t[2]) * sval(t[3])) & 0xFFFFFFFF
         elif m == "s_mul_hi_u32":
@@ -456,17 +517,19 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds=None):
                 cands = labels[lab]
                 pc = min(c for c in cands if c > pc) if d == "f" else max(c for c in cands if c < pc)
         elif m == "global_load_dword":
-            arr, row = mem(ptr_row(t[3]))
+            arr, row = mem(sval(t[3]))
             if t[1][0] == "a":
                 A[int(t[1][1:])] = arr[row]
             else:
                 V[int(t[1][1:])] = arr[row]
         elif m == "global_store_dword":
-            arr, row = mem(ptr_row(t[3]))
+            arr, row = mem(sval(t[3]))
             arr[row] = V[int(t[2][1:])]
         elif m == "ds_write_b128":
             lo = int(t[2][2:t[2].index(":")])
             lds[t[3] // 1024 * 4:t[3] // 1024 * 4 + 4] = V[lo:lo + 4]
+        elif m == "ds_write_b32":
+            lds[t[3] // 1024 * 4 + (t[3] % 1024) // 4] = V[int(t[2][1:])]
         elif m == "ds_read_b128":
             lo = int(t[1][2:t[1].index(":")])
             V[lo:lo + 4] = lds[t[3] // 1024 * 4:t[3] // 1024 * 4 + 4]
@@ -486,6 +549,22 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds=None):
             V[int(t[1][1:])] = max(fval(t[2]), fval(t[3]))
         elif m == "v_min_f32":
             V[int(t[1][1:])] = min(fval(t[2]), fval(t[3]))
+        elif m in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
+            d = t[-1]
+            srcs = t[2:-1]
+            dlo = int(t[1][2:t[1].index(":")])
+            res = []
+            for hi in (0, 1):
+                sel = d["op_sel_hi"] if hi else d["op_sel"]
+                ng = d["neg_hi"] if hi else d["neg_lo"]
+                vals = [np.float64(half(x, sel[q])) * (-1 if ng[q] else 1) for q, x in enumerate(srcs)]
+                if m == "v_pk_fma_f32":
+                    res.append(f32(vals[0] * vals[1] + vals[2]))
+                elif m == "v_pk_mul_f32":
+                    res.append(f32(f32(vals[0]) * f32(vals[1])))
+                else:
+                    res.append(f32(f32(vals[0]) + f32(vals[1])))
+            V[dlo], V[dlo + 1] = res  # both halves are computed from the OLD register contents
         else:
             raise ValueError("unknown instruction %r" % (t,))
         pc += 1

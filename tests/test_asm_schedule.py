@@ -70,10 +70,19 @@ def test_generated_admm_program_matches_oracle(oracle_built, prog, iters):
 
 def test_register_map_is_disjoint():
     from robobee3d_amd import asmgen as g
-    regs = [(g.V_W, 84), (g.V_X, 45), (g.V_Y, 39), (g.V_Z, 39), (g.V_M, 12), (g.V_RING, 16), (g.V_AT, g.N_AT), (g.V_TT, 8)]
+    regs = [(g.V_W, 45), (g.V_WZ, 39), (g.V_X, 45), (g.V_Y, 39), (g.V_Z, 39), (g.V_RING, 16),
+            (g.V_AT, 2 * g.N_ATP), (g.V_TT, 8)]
     used = set()
     for lo, n in regs:
         r = set(range(lo, lo + n))
-        assert not (used & r) and min(r) >= 2 and max(r) <= 251 and 221 not in r
+        assert lo % 2 == 0, "packed operands need even-aligned bases"
+        assert not (used & r) and min(r) >= 2 and max(r) < g.V_END
         used |= r
-    assert g.V_RING % 2 == 0 and g.A_Q + 45 <= 256 and g.NLDS * 4 * 64 <= 40960
+    assert g.A_M + 12 <= 256 and g.NLDS * 4 * 64 <= 40960
+    # every register the program writes is inside the declared clobber range
+    ins, _ = g.program()
+    import re
+    for t in ins:
+        if t[0].startswith(("v_", "ds_read", "global_load")) and isinstance(t[1], str) and t[1].startswith("v"):
+            hi = max(int(n) for n in re.findall(r"\d+", t[1]))
+            assert 2 <= hi < g.V_END, t
