@@ -226,6 +226,21 @@ void wlconS(float u1_y1[/* 4 */], float w0_y2[/* 6 */], const float u0init_u1[/*
 int umpcBatchWLUpdate(const WLCon_t *wl, int B, int dtype, void *u, const void *h0, const void *pdotdes,
                       void *w0, void *stream);
 
+/* ------------------------------------------------------------------ */
+/* Part 4: the reference's other rigid-body vector fields */
+/* ------------------------------------------------------------------ */
+/* UMPC_MODEL_CA6: template/ca6dynamics.py:35-50. y [18][B] = (p, R column-major, dq = (v_world, omega_body)),
+ *   u [6][B] = (u1L,u2L,u3L,u1R,u2R,u3R); wrenchMap + M ddq = w - h (h = (R'(0,0,mb g), 0), body frame).
+ * UMPC_MODEL_TSD: ThrustStrokeDev.dynamics, template/FlappingModels3D.py:19-38. y [12][B] = (p, rotvec, v, omega),
+ *   u [4][B] = (FzL, dxL, FzR, dxR), restated as written.
+ * nsub == 0: aux receives ydot ([18] or [12] rows; CA6 appends wrench [6] and h [6] -> 30 rows), y unchanged.
+ * nsub  > 0: y advances by nsub classical RK4 steps of dt with u held (build-defined integrator: the
+ *            reference has none for these models); aux unused. */
+#define UMPC_MODEL_CA6 0
+#define UMPC_MODEL_TSD 1
+int umpcBatchModel(int model, int B, int dtype, int nsub, double dt, void *y, const void *u, void *aux,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1103,3 +1103,84 @@ void umpc_oracle_wl_update(umpc_oracle_wl_t *wl, real u1[4], real w0[6], const r
   for (int i = 0; i < NDELU; ++i) { wl->u0[i] += delu[i]; u1[i] = wl->u0[i]; }
 }
 void umpc_oracle_wl_set_u0(umpc_oracle_wl_t *wl, const real u0[4]) { memcpy(wl->u0, u0, sizeof(wl->u0)); }
+
+/* ====================================================================== */
+/* a19 / a20: the reference's other vector fields + build-defined RK4      */
+/* ====================================================================== */
+static real r_sin(real v) { return (real)sin((double)v); }
+static real r_cos(real v) { return (real)cos((double)v); }
+
+/* template/ca6dynamics.py:35-50; y = (p, R col-major, dq=(v_world, omega_body)); aux = ydot[18] w[6] h[6] */
+static void ca6_vf(const real *y, const real *u, real *yd, real *w, real *h) {
+  const real ycp = 10, mb = 100, g = (real)9.81e-3, I[3] = {3333, 3333, 1000};
+  const real *R = &y[3];
+  w[0] = u[2] + u[5]; w[1] = 0; w[2] = u[0] + u[3];
+  w[3] = (u[0] - u[3]) * ycp; w[4] = -u[0] * u[1] - u[3] * u[4]; w[5] = (-u[2] + u[5]) * ycp;
+  for (int c = 0; c < 3; ++c) { h[c] = R[2 + 3 * c] * (mb * g); h[3 + c] = 0; }
+  real ab[3];
+  for (int c = 0; c < 3; ++c) ab[c] = (w[c] - h[c]) / mb;
+  for (int i = 0; i < 3; ++i) yd[i] = y[12 + i];
+  const real wx = y[15], wy = y[16], wz = y[17];
+  for (int r = 0; r < 3; ++r) {
+    yd[3 + r + 0] = R[r + 3] * wz - R[r + 6] * wy;
+    yd[3 + r + 3] = -R[r + 0] * wz + R[r + 6] * wx;
+    yd[3 + r + 6] = R[r + 0] * wy - R[r + 3] * wx;
+    yd[12 + r] = (R[r] * ab[0] + R[r + 3] * ab[1]) + R[r + 6] * ab[2];
+    yd[15 + r] = w[3 + r] / I[r];
+  }
+}
+
+/* ThrustStrokeDev.dynamics, template/FlappingModels3D.py:19-38 (as written) */
+static void tsd_vf(const real *y, const real *u, real *yd) {
+  const real m = (real)0.5, g = (real)9.81, ycp = (real)0.5, Ib[3] = {(real)5e-4, (real)5e-4, (real)1e-3};
+  const real ax = y[3], ay = y[4], az = y[5], t = ax * ax + ay * ay + az * az;
+  real a, b, e[3][3];
+  if (t < (real)1e-2) {
+    a = (real)1 - t * ((real)1 / 6 - t * ((real)1 / 120 - t * ((real)1 / 5040 - t * ((real)1 / 362880))));
+    b = (real)0.5 - t * ((real)1 / 24 - t * ((real)1 / 720 - t * ((real)1 / 40320 - t * ((real)1 / 3628800))));
+  } else {
+    const real th = r_sqrt(t);
+    a = r_sin(th) / th; b = ((real)1 - r_cos(th)) / t;
+  }
+  e[0][0] = (real)1 - b * (ay * ay + az * az); e[1][1] = (real)1 - b * (ax * ax + az * az);
+  e[2][2] = (real)1 - b * (ax * ax + ay * ay);
+  e[0][1] = -a * az + b * ax * ay; e[1][0] = a * az + b * ax * ay;
+  e[0][2] = a * ay + b * ax * az;  e[2][0] = -a * ay + b * ax * az;
+  e[1][2] = -a * ax + b * ay * az; e[2][1] = a * ax + b * ay * az;
+  const real om[3] = {y[9], y[10], y[11]}, Fz = u[0] + u[2];
+  const real tq[3] = {ycp * u[0] + (-ycp) * u[2], -(u[1] * u[0]) - (u[3] * u[2]), 0};
+  const real Iw[3] = {Ib[0] * om[0], Ib[1] * om[1], Ib[2] * om[2]};
+  const real cr[3] = {om[1] * Iw[2] - om[2] * Iw[1], om[2] * Iw[0] - om[0] * Iw[2], om[0] * Iw[1] - om[1] * Iw[0]};
+  real ob[3];
+  for (int i = 0; i < 3; ++i) ob[i] = (tq[i] - cr[i]) / Ib[i];
+  for (int i = 0; i < 6; ++i) yd[i] = y[6 + i];
+  for (int i = 0; i < 3; ++i) {
+    yd[6 + i] = ((i == 2 ? -m * g : (real)0) + e[i][2] * Fz) / m;
+    yd[9 + i] = (e[0][i] * ob[0] + e[1][i] * ob[1]) + e[2][i] * ob[2];
+  }
+}
+
+static void model_vf(int model, const real *y, const real *u, real *yd) {
+  real w[6], h[6];
+  if (model == 0) ca6_vf(y, u, yd, w, h); else tsd_vf(y, u, yd);
+}
+
+/* one robot: nsub == 0 -> aux = ydot (ca6: + w, h), else y advanced by nsub RK4 steps */
+void umpc_oracle_model(int model, int nsub, real dt, real *y, const real *u, real *aux) {
+  const int ny = model == 0 ? 18 : 12;
+  if (nsub == 0) {
+    if (model == 0) ca6_vf(y, u, aux, aux + 18, aux + 24); else tsd_vf(y, u, aux);
+    return;
+  }
+  for (int s = 0; s < nsub; ++s) {
+    real y0[18], ys[18], acc[18], k[18];
+    const real cs[4] = {0, (real)0.5, (real)0.5, 1}, wt[4] = {1, 2, 2, 1};
+    for (int i = 0; i < ny; ++i) y0[i] = y[i];
+    for (int st = 0; st < 4; ++st) {
+      for (int i = 0; i < ny; ++i) ys[i] = st ? y0[i] + cs[st] * dt * k[i] : y0[i];
+      model_vf(model, ys, u, k);
+      for (int i = 0; i < ny; ++i) acc[i] = st ? acc[i] + wt[st] * k[i] : k[i];
+    }
+    for (int i = 0; i < ny; ++i) y[i] = y0[i] + dt * acc[i] / (real)6;
+  }
+}

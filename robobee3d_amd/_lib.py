@@ -23,7 +23,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights",
-           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate"]
+           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel"]
 
 
 class FunApprox_t(C.Structure):
@@ -102,6 +102,7 @@ def lib():
         L.umpcBatchSetWeights.argtypes = [C.c_void_p, C.c_void_p]
         L.umpcBatchTime.argtypes = [C.c_void_p]
         L.umpcBatchTime.restype = C.c_double
+        L.umpcBatchModel.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4
         L.umpcBatchWLUpdate.argtypes =[C.POINTER(WLCon_t), C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcUpdate.restype = C.c_int
         L.umpcLastStatus.restype = C.c_int

@@ -175,6 +175,42 @@ class BatchUprightMPC:
         return self.stats / n
 
 
+MODELS = {"ca6": (0, 18, 6, 30), "ThrustStrokeDev": (1, 12, 4, 12)}  # id, state rows, input rows, vf output rows
+
+
+def model_vector_field(model, y, u):
+    """ydot of the reference's ca6 / ThrustStrokeDev models (template/ca6dynamics.py:35-50,
+    template/FlappingModels3D.py:19-38) for a batch: y [ny,B], u [nu,B] CUDA tensors. ca6 also returns the
+    wrench and the bias h: rows [ydot 18 | w 6 | h 6]."""
+    mid, ny, nu, nout = MODELS[model]
+    L = _lib.lib()
+    B = y.shape[1]
+    assert y.shape == (ny, B) and u.shape == (nu, B) and y.is_cuda and y.dtype == u.dtype
+    y, u = y.contiguous(), u.contiguous()
+    aux = torch.empty((nout, B), dtype=y.dtype, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = L.umpcBatchModel(mid, B, _DT[y.dtype], 0, 0.0, _ptr(y), _ptr(u), _ptr(aux),
+                              C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    if rc:
+        raise RuntimeError(L.umpcLastError().decode())
+    return aux
+
+
+def model_rk4(model, y, u, dt, nsub=1):
+    """Advance y in place by nsub RK4 steps of dt under constant u (build-defined integrator)."""
+    mid, ny, nu, _ = MODELS[model]
+    L = _lib.lib()
+    B = y.shape[1]
+    assert y.shape == (ny, B) and u.shape == (nu, B) and y.is_cuda and y.is_contiguous() and nsub >= 1
+    u = u.contiguous()
+    with torch.cuda.device(y.device):
+        rc = L.umpcBatchModel(mid, B, _DT[y.dtype], int(nsub), float(dt), _ptr(y), _ptr(u), None,
+                              C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    if rc:
+        raise RuntimeError(L.umpcLastError().decode())
+    return y
+
+
 class BatchWLCon:
     """B wrench-linearisation controllers (the step that consumes accdes, SURVEY 8f-1;
     template/uprightmpc2/funapprox.c:118-165), one lane each. `u` [4,B] is the input state."""

@@ -12,6 +12,7 @@
 
 #include "../../include/umpc_mi355x.h"
 #include "umpc_step.h"
+#include "umpc_models.h"
 
 namespace {
 
@@ -468,6 +469,46 @@ __global__ __launch_bounds__(256) void umpc_wl_kernel(WLDev p, int B_, T *u, con
   }
 }
 
+// a19 / a20 vector fields: nsub == 0 evaluates ydot (ca6 also appends wrench and bias h), nsub > 0
+// advances y by nsub RK4 steps of dt with u held
+template <typename T, int MODEL>
+__global__ __launch_bounds__(256) void umpc_model_kernel(int B_, int nsub, T dt, T *y, const T *u, T *aux) {
+  constexpr int NYV = MODEL == 0 ? 18 : 12, NUV = MODEL == 0 ? 6 : 4;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B_) return;
+  const size_t B = (size_t)B_;
+  T yv[NYV], uv[NUV];
+#pragma unroll
+  for (int i = 0; i < NYV; ++i) yv[i] = y[(size_t)i * B + b];
+#pragma unroll
+  for (int i = 0; i < NUV; ++i) uv[i] = u[(size_t)i * B + b];
+  auto vf = [&](const T (&ys)[NYV], T (&k)[NYV]) {
+    if constexpr (MODEL == 0) {
+      T w[6], h[6];
+      umpc::ca6_vf(ys, uv, k, w, h);
+    } else {
+      umpc::tsd_vf(ys, uv, k);
+    }
+  };
+  if (nsub == 0) {
+    T k[NYV];
+    vf(yv, k);
+#pragma unroll
+    for (int i = 0; i < NYV; ++i) aux[(size_t)i * B + b] = k[i];
+    if constexpr (MODEL == 0) {
+      T w[6], h[6], kk[NYV];
+      umpc::ca6_vf(yv, uv, kk, w, h);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { aux[(size_t)(18 + i) * B + b] = w[i]; aux[(size_t)(24 + i) * B + b] = h[i]; }
+    }
+    return;
+  }
+#pragma nounroll
+  for (int s = 0; s < nsub; ++s) umpc::rk4_step<T, NYV>(yv, dt, vf);
+#pragma unroll
+  for (int i = 0; i < NYV; ++i) y[(size_t)i * B + b] = yv[i];
+}
+
 WLDev make_wl(const WLCon_t *wl) {
   WLDev d;
   for (int j = 0; j < 4; ++j) { d.umin[j] = wl->umin[j]; d.umax[j] = wl->umax[j]; d.dumax[j] = wl->dumax[j]; }
@@ -497,6 +538,28 @@ int umpcBatchWLUpdate(const WLCon_t *wl, int B, int dtype, void *u, const void *
                        (const double *)h0, (const double *)pdotdes, (double *)w0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchWLUpdate");
+}
+
+int umpcBatchModel(int model, int B, int dtype, int nsub, double dt, void *y, const void *u, void *aux, void *stream) {
+  if ((model != UMPC_MODEL_CA6 && model != UMPC_MODEL_TSD) || B <= 0 || nsub < 0 || !y || !u || (nsub == 0 && !aux)) {
+    g_err = "umpcBatchModel: bad argument";
+    return -1;
+  }
+  const dim3 grid((B + 255) / 256), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UMPC_F32) {
+    if (model == UMPC_MODEL_CA6)
+      hipLaunchKernelGGL((umpc_model_kernel<float, 0>), grid, blk, 0, s, B, nsub, (float)dt, (float *)y, (const float *)u, (float *)aux);
+    else
+      hipLaunchKernelGGL((umpc_model_kernel<float, 1>), grid, blk, 0, s, B, nsub, (float)dt, (float *)y, (const float *)u, (float *)aux);
+  } else {
+    if (model == UMPC_MODEL_CA6)
+      hipLaunchKernelGGL((umpc_model_kernel<double, 0>), grid, blk, 0, s, B, nsub, dt, (double *)y, (const double *)u, (double *)aux);
+    else
+      hipLaunchKernelGGL((umpc_model_kernel<double, 1>), grid, blk, 0, s, B, nsub, dt, (double *)y, (const double *)u, (double *)aux);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchModel");
 }
 
 void wlConInit(WLCon_t *wl, const float u0[4], const float umin[4], const float umax[4], const float dumax[4],
