@@ -67,17 +67,20 @@ def cpu_baseline(args, plant_mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--plant", default="euler", choices=["euler", "rk4"],
-                    help="euler = the reference's Euler+expm step (parity mode); rk4 = build-defined RK4")
+    ap.add_argument("--plant", default="rk4", choices=["euler", "rk4"],
+                    help="rk4 = RK4 substeps of the reference's vector field (what BASELINE configs[2] names; "
+                         "build-defined, SURVEY finding 2); euler = the reference's own Euler+expm step (parity mode)")
     ap.add_argument("--max-iter", type=int, default=50, help="ADMM iterations (50 = the reference; other values are diagnostics)")
     ap.add_argument("--nsub", type=int, default=25, help="plant substeps per MPC step (25 = the metric; 0 = QP only)")
     ap.add_argument("--steps-per-launch", type=int, default=0,
                     help="closed-loop steps carried by one kernel launch (0 = all K timed steps in one launch; "
                          "1 = one launch per step)")
+    ap.add_argument("--monte-carlo", action="store_true",
+                    help="BASELINE configs[4]: per-robot inertia (controller + plant) and plant thrust gain, +-20 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-robots", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=100)
@@ -105,17 +108,25 @@ def main():
     st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=lo)
     mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode, maxIter=args.max_iter, nsub=args.nsub)
     mpc.set_state(st, ref)
+    if args.monte_carlo:  # Ib = Ib0 (1 + d), d ~ U(-0.2, 0.2)^3, thrust gain 1 + U(-0.2, 0.2)
+        rng = np.random.default_rng(20201120 + rank)
+        mpc.Ib = torch.as_tensor((np.array([3333.0, 3333.0, 1000.0])[:, None] *
+                                  (1 + rng.uniform(-0.2, 0.2, (3, B)))).astype(ndt)).to(dev)
+        mpc.gain = torch.as_tensor((1 + rng.uniform(-0.2, 0.2, B)).astype(ndt)).to(dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        mpc.rollout(1)
-    barrier()
     spl = args.steps if args.steps_per_launch <= 0 else max(1, min(args.steps_per_launch, args.steps))
     assert args.steps % spl == 0, "--steps must be a multiple of --steps-per-launch"
+    # warm-up steps use the timed launch shape when they divide into it (so a rocprofv3 --stats average over
+    # all dispatches of the step kernel is the timed launch's duration), one-step launches otherwise
+    wspl = spl if args.warmup % spl == 0 else 1
+    for _ in range(args.warmup // wspl):
+        mpc.rollout(wspl)
+    barrier()
     nlaunch = args.steps // spl
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
     t0 = time.perf_counter()
