@@ -1,0 +1,318 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the general-structure batch QP solver.
+
+A numpy restatement, vectorised over the robot axis only, of the OSQP 0.6.0 EMBEDDED=2 call sequence the
+reference runs per MPC step (template/uprightmpc2/ C sources), for an arbitrary sparse A and a diagonal P:
+
+    scale_data            scaling.c:44-156   (10 Ruiz passes, limit_scaling scaling.c:7-14)
+    update_rho_vec        auxil.c:103-145
+    form_KKT / symperm    kkt.c:6-177 ; QDLDL_etree / QDLDL_factor qdldl.c:34-247
+    osqp_solve loop       osqp.c:354-370 ; auxil.c:164-228 ; qdldl_interface.c:322-369 ; qdldl.c:250-293
+    update_info / check_termination / store_solution   auxil.c:243-362, 517-565, 684-789
+
+Every scalar operation is carried out in the requested dtype in the reference's order (numpy never contracts
+a*b+c), so with dtype float32 and the reference's KKT permutation this file reproduces the compiled reference
+bit-for-bit on the uprightmpc2 N = 3 fixtures (tests/test_bqp.py pins it that way: parity status PINNED through
+tests/golden/seq_iter*.npz). It performs its own symbolic analysis from (A pattern, perm) and shares no code
+with robobee3d_amd/. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+"""
+import numpy as np
+
+INFTY, MIN_SCALING, MAX_SCALING = 1e30, 1e-4, 1e4
+RHO_MIN, RHO_TOL, RHO_EQ_OVER_RHO_INEQ = 1e-6, 1e-4, 1e3
+SOLVED, SOLVED_INACC, MAX_ITER, PINF, PINF_INACC, DINF, DINF_INACC, UNSOLVED, NON_CVX = 1, 2, -2, -3, 3, -4, 4, -10, -7
+
+
+class Settings:
+    def __init__(self, rho=0.1, sigma=1e-6, alpha=1.6, max_iter=50, scaling=10, eps_abs=1e-4, eps_rel=1e-4,
+                 eps_prim_inf=1e-4, eps_dual_inf=1e-4):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+class KKTSymbolic:
+    """kkt.c:6-177 (triplets P+sigma | A' | -1/rho, bucketed by column, cs_symperm upper part) + QDLDL_etree."""
+
+    def __init__(self, n, m, A_p, A_i, perm):
+        nk = n + m
+        self.n, self.m, self.nk, self.perm = n, m, nk, [int(v) for v in perm]
+        pinv = [0] * nk
+        for k, v in enumerate(self.perm):
+            pinv[v] = k
+        self.pinv = pinv
+        cols = [[] for _ in range(nk)]
+        for j in range(n):
+            cols[j].append((j, ('P', j)))
+        for j in range(n):
+            for p in range(A_p[j], A_p[j + 1]):
+                cols[n + A_i[p]].append((j, ('A', p)))
+        for i in range(m):
+            cols[n + i].append((n + i, ('R', i)))
+        pc = [[] for _ in range(nk)]
+        for j in range(nk):
+            for (i, src) in cols[j]:
+                i2, j2 = pinv[i], pinv[j]
+                pc[max(i2, j2)].append((min(i2, j2), src))
+        self.K_p, self.K_i, self.K_src = [0], [], []
+        for j in range(nk):
+            for (i, src) in pc[j]:
+                self.K_i.append(i)
+                self.K_src.append(src)
+            self.K_p.append(len(self.K_i))
+        work, Lnz, etree = [0] * nk, [0] * nk, [-1] * nk
+        for j in range(nk):
+            work[j] = j
+            for p in range(self.K_p[j], self.K_p[j + 1]):
+                i = self.K_i[p]
+                while work[i] != j:
+                    if etree[i] == -1:
+                        etree[i] = j
+                    Lnz[i] += 1
+                    work[i] = j
+                    i = etree[i]
+        self.etree = etree
+        self.L_p = [0]
+        for i in range(nk):
+            self.L_p.append(self.L_p[-1] + Lnz[i])
+
+
+def _limit_scaling(D):
+    """scaling.c:7-14: the comparisons are carried out in double."""
+    d64 = D.astype(np.float64)
+    D = np.where(d64 < MIN_SCALING, D.dtype.type(1.0), D)
+    return np.where(D.astype(np.float64) > MAX_SCALING, D.dtype.type(MAX_SCALING), D)
+
+
+def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, settings=None, dtype=np.float64,
+          trace=None):
+    """One canonical-restart QP step for a batch: raw (Pv [nnzP][B], Av [nnzA][B], q [n][B], l, u [m][B]), warm
+    start (x, y, z: scaled iterates as OSQP keeps them) and the previous call's E (row classification,
+    osqp.c:812-820). Returns dict(x, y, z, E, sol_x, sol_y, status, pri_res, dua_res, D, c, L, Dinv)."""
+    st = settings or Settings()
+    T = np.dtype(dtype).type
+    f = lambda a: np.array(a, dtype=dtype, copy=True)
+    Ps, As, qs, l, u, x, y, z, Eprev = map(f, (Pv, Av, q, l, u, x, y, z, Eprev))
+    B = qs.shape[1]
+    nk = n + m
+    sym = KKTSymbolic(n, m, A_p, A_i, perm)
+    pidx = [-1] * n
+    for k, j in enumerate(P_cols):
+        pidx[j] = k
+    zero = np.zeros(B, dtype)
+    sigma, alpha, rho0 = T(st.sigma), T(st.alpha), T(st.rho)
+
+    # ---- update_rho_vec with the previous E (auxil.c:103-145); comparisons in double
+    ls, us = (l * Eprev).astype(np.float64), (u * Eprev).astype(np.float64)
+    loose = (ls < -INFTY * MIN_SCALING) & (us > INFTY * MIN_SCALING)
+    eq = ~loose & ((u * Eprev - l * Eprev).astype(np.float64) < RHO_TOL)
+    rho_eq = T(RHO_EQ_OVER_RHO_INEQ * float(rho0))
+    rho = np.where(loose, T(RHO_MIN), np.where(eq, rho_eq, rho0)).astype(dtype)
+    rinv = np.where(loose, T(1. / RHO_MIN), np.where(eq, T(1. / float(rho_eq)), T(1. / float(rho0)))).astype(dtype)
+
+    # ---- scale_data (scaling.c:44-156)
+    c = np.ones(B, dtype)
+    D = np.ones((n, B), dtype)
+    E = np.ones((m, B), dtype)
+    for _ in range(st.scaling):
+        Dt = np.zeros((n, B), dtype)
+        for j in range(n):
+            if pidx[j] >= 0:
+                Dt[j] = np.maximum(np.abs(Ps[pidx[j]]), Dt[j])
+        DtA = np.zeros((n, B), dtype)
+        for j in range(n):
+            for p in range(A_p[j], A_p[j + 1]):
+                DtA[j] = np.maximum(np.abs(As[p]), DtA[j])
+        Dt = np.maximum(Dt, DtA)
+        Et = np.zeros((m, B), dtype)
+        for j in range(n):
+            for p in range(A_p[j], A_p[j + 1]):
+                Et[A_i[p]] = np.maximum(np.abs(As[p]), Et[A_i[p]])
+        Dt, Et = _limit_scaling(Dt), _limit_scaling(Et)
+        Dt, Et = T(1.0) / np.sqrt(Dt), T(1.0) / np.sqrt(Et)
+        for j in range(n):
+            if pidx[j] >= 0:
+                Ps[pidx[j]] = (Ps[pidx[j]] * Dt[j]) * Dt[j]
+        for j in range(n):
+            for p in range(A_p[j], A_p[j + 1]):
+                As[p] = (As[p] * Et[A_i[p]]) * Dt[j]
+        qs = qs * Dt
+        D = Dt * D
+        E = Et * E
+        ct = np.zeros(B, dtype)
+        for j in range(n):      # vec_mean of the column norms of P (0 where P has no entry)
+            ct = ct + (np.abs(Ps[pidx[j]]) if pidx[j] >= 0 else zero)
+        ct = ct / T(n)
+        qn = np.zeros(B, dtype)
+        for j in range(n):
+            qn = np.maximum(qn, np.abs(qs[j]))   # vec_norm_inf: running max from 0
+        qn = _limit_scaling(qn)
+        ct = np.maximum(ct, qn)
+        ct = _limit_scaling(ct)
+        ct = T(1.0) / ct
+        Ps = Ps * ct
+        qs = qs * ct
+        c = c * ct
+    cinv = T(1.0) / c
+    Dinv, Einv = T(1.0) / D, T(1.0) / E
+    lsc, usc = l * E, u * E
+
+    # ---- KKT values + QDLDL_factor (qdldl.c:86-247), dynamic reach exactly as the reference
+    def kval(src):
+        if src[0] == 'P':
+            return (Ps[pidx[src[1]]] + sigma) if pidx[src[1]] >= 0 else np.full(B, sigma, dtype)
+        if src[0] == 'A':
+            return As[src[1]]
+        return -rinv[src[1]]
+    K_p, K_i, K_src, etree, L_p = sym.K_p, sym.K_i, sym.K_src, sym.etree, sym.L_p
+    nnzL = L_p[-1]
+    L_i = [0] * nnzL
+    Lx = np.zeros((nnzL, B), dtype)
+    Dd = np.zeros((nk, B), dtype)
+    Ddinv = np.zeros((nk, B), dtype)
+    yVals = np.zeros((nk, B), dtype)
+    yMark = [0] * nk
+    LNext = list(L_p[:-1])
+    for k in range(nk):
+        yIdx = []
+        for p in range(K_p[k], K_p[k + 1]):
+            bidx = K_i[p]
+            if bidx == k:
+                Dd[k] = kval(K_src[p])
+                continue
+            yVals[bidx] = kval(K_src[p])
+            nxt = bidx
+            if yMark[nxt] == 0:
+                yMark[nxt] = 1
+                buf = [nxt]
+                nxt = etree[bidx]
+                while nxt != -1 and nxt < k:
+                    if yMark[nxt] == 1:
+                        break
+                    yMark[nxt] = 1
+                    buf.append(nxt)
+                    nxt = etree[nxt]
+                while buf:
+                    yIdx.append(buf.pop())
+        for cidx in reversed(yIdx):
+            tmp = LNext[cidx]
+            yv = yVals[cidx].copy()
+            for j in range(L_p[cidx], tmp):
+                yVals[L_i[j]] = yVals[L_i[j]] - Lx[j] * yv
+            L_i[tmp] = k
+            Lx[tmp] = yv * Ddinv[cidx]
+            Dd[k] = Dd[k] - yv * Lx[tmp]
+            LNext[cidx] += 1
+            yVals[cidx] = 0
+            yMark[cidx] = 0
+        Ddinv[k] = T(1.0) / Dd[k]
+
+    # ---- ADMM iterations (osqp.c:354-370)
+    perm = sym.perm
+    oma = T(1.0) - alpha
+    dx = np.zeros((n, B), dtype)
+    dy = np.zeros((m, B), dtype)
+    for it in range(st.max_iter):
+        xp, zp = x, z
+        rhs = np.concatenate((sigma * xp - qs, zp - rinv * y), 0)
+        bp = rhs[perm].copy()
+        for i in range(nk):
+            for j in range(L_p[i], L_p[i + 1]):
+                bp[L_i[j]] = bp[L_i[j]] - Lx[j] * bp[i]
+        bp = bp * Ddinv
+        for i in range(nk - 1, -1, -1):
+            for j in range(L_p[i], L_p[i + 1]):
+                bp[i] = bp[i] - Lx[j] * bp[L_i[j]]
+        sol = np.empty_like(bp)
+        sol[perm] = bp
+        xt = sol[:n]
+        zt = rhs[n:] + rinv * sol[n:]
+        x = alpha * xt + oma * xp
+        dx = x - xp
+        zz = alpha * zt + oma * zp + rinv * y
+        z = np.minimum(np.maximum(zz, lsc), usc)
+        dy = rho * (alpha * zt + oma * zp - z)
+        y = y + dy
+        if trace is not None:
+            trace.append((x.copy(), y.copy(), z.copy()))
+
+    # ---- update_info + check_termination + store_solution
+    def A_mul(v):
+        out = np.zeros((m, B), dtype)
+        for j in range(n):
+            for p in range(A_p[j], A_p[j + 1]):
+                out[A_i[p]] = out[A_i[p]] + As[p] * v[j]
+        return out
+
+    def At_mul(v):
+        out = np.zeros((n, B), dtype)
+        for j in range(n):
+            for p in range(A_p[j], A_p[j + 1]):
+                out[j] = out[j] + As[p] * v[A_i[p]]
+        return out
+
+    def P_mul(v):
+        out = np.zeros((n, B), dtype)
+        for j in range(n):
+            if pidx[j] >= 0:
+                out[j] = out[j] + Ps[pidx[j]] * v[j]
+        return out
+
+    def ninf(v):
+        r = np.zeros(B, dtype)
+        for i in range(v.shape[0]):
+            r = np.maximum(r, np.abs(v[i]))
+        return r
+    Ax = A_mul(x)
+    pri_res = ninf(Einv * (Ax - z))
+    Px = P_mul(x)
+    Aty = At_mul(y)
+    dua_res = cinv * ninf(Dinv * ((qs + Px) + Aty))
+
+    def term(approx):
+        k = T(10) if approx else T(1)
+        eps_abs, eps_rel = T(st.eps_abs) * k, T(st.eps_rel) * k
+        eps_pinf, eps_dinf = T(st.eps_prim_inf) * k, T(st.eps_dual_inf) * k
+        eps_prim = eps_abs + eps_rel * np.maximum(ninf(Einv * z), ninf(Einv * Ax))
+        mr = np.maximum(np.maximum(ninf(Dinv * qs), ninf(Dinv * Aty)), ninf(Dinv * Px)) * cinv
+        eps_dual = eps_abs + eps_rel * mr
+        prim_ok = pri_res < eps_prim
+        dual_ok = dua_res < eps_dual
+        # is_primal_infeasible, auxil.c:362-424
+        upinf = usc.astype(np.float64) > INFTY * MIN_SCALING
+        lninf = lsc.astype(np.float64) < -INFTY * MIN_SCALING
+        dyp = np.where(upinf & lninf, T(0), np.where(upinf, np.minimum(dy, T(0)), np.where(lninf, np.maximum(dy, T(0)), dy)))
+        norm_dy = ninf(dyp * E)
+        lhs = np.zeros(B, dtype)
+        with np.errstate(invalid="ignore", over="ignore"):
+            for i in range(m):
+                lhs = lhs + (usc[i] * np.maximum(dyp[i], T(0)) + lsc[i] * np.minimum(dyp[i], T(0)))
+            pinf = (norm_dy > eps_pinf) & (lhs < -eps_pinf * norm_dy) & (ninf(At_mul(dyp) * Dinv) < eps_pinf * norm_dy)
+        # is_dual_infeasible, auxil.c:426-512
+        norm_dx = ninf(D * dx)
+        qdx = np.zeros(B, dtype)
+        for j in range(n):
+            qdx = qdx + qs[j] * dx[j]
+        Adx = A_mul(dx) * Einv
+        thr = eps_dinf * norm_dx
+        viol = ((usc.astype(np.float64) < INFTY * MIN_SCALING) & (Adx > thr)) | \
+               ((lsc.astype(np.float64) > -INFTY * MIN_SCALING) & (Adx < -thr))
+        dinf = (norm_dx > eps_dinf) & (qdx < -c * eps_dinf * norm_dx) & \
+               (ninf(P_mul(dx) * Dinv) < c * eps_dinf * norm_dx) & ~viol.any(0)
+        pinf = pinf & ~prim_ok
+        dinf = dinf & ~dual_ok
+        code = np.where(prim_ok & dual_ok, SOLVED_INACC if approx else SOLVED,
+                        np.where(pinf, PINF_INACC if approx else PINF,
+                                 np.where(dinf, DINF_INACC if approx else DINF, 0)))
+        return code
+    with np.errstate(invalid="ignore"):
+        ncvx = (pri_res.astype(np.float64) > INFTY) | (dua_res.astype(np.float64) > INFTY)
+    s1 = term(False)
+    s2 = term(True)
+    status = np.where(ncvx, NON_CVX, np.where(s1 != 0, s1, np.where(s2 != 0, s2, MAX_ITER))).astype(np.int32)
+    bad = (status == PINF) | (status == PINF_INACC) | (status == DINF) | (status == DINF_INACC) | (status == NON_CVX)
+    sol_x = np.where(bad, T(np.nan), x * D)
+    sol_y = np.where(bad, T(np.nan), (y * E) * cinv)
+    x = np.where(bad, T(0), x)
+    y = np.where(bad, T(0), y)
+    z = np.where(bad, T(0), z)
+    return dict(x=x, y=y, z=z, E=E, D=D, c=c, sol_x=sol_x, sol_y=sol_y, status=status, pri_res=pri_res,
+                dua_res=dua_res, L=Lx, Dinv=Ddinv, L_i=L_i, L_p=L_p, As=As, Ps=Ps, qs=qs, rho=rho)

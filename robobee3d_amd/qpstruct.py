@@ -1,0 +1,206 @@
+"""Build-time symbolic analysis of an ARBITRARY sparse QP structure for the table-driven batch solver
+(csrc/umpc_bqp.hip; SURVEY 8 rows a21 / a22 / f-4: planar p5f MPC, the v1 template QP, general-N
+uprightmpc2). Same mathematics as symbolic.py (which bakes the N = 3 structure into straight-line code);
+here the result is a flat int32 table blob that the generic kernel walks with scalar loads.
+
+  min 1/2 x'Px + q'x  s.t.  l <= Ax <= u,   P diagonal on a subset of the columns, A in CSC.
+
+What is restated (reference file:line):
+  * KKT [[P + sigma I, A'], [A, -diag(1/rho)]] in upper-triangular CSC form and its symmetric
+    permutation: template/uprightmpc2/kkt.c:6-177 (form_KKT), workspace.c:2004-2165;
+  * elimination tree / column counts / up-looking LDL' schedule: template/uprightmpc2/qdldl.c:34-247.
+The fill-reducing ordering is symbolic.min_fill_ordering (our own); an explicit `perm` can be passed so
+the tests can replay the reference's tables.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from . import symbolic
+
+QPStructure = namedtuple(
+    "QPStructure", "n m nk nnzP nnzA nnzL P_cols A_p A_i perm pinv K_p K_i K_src etree L_p L_i factor_ops "
+                   "tables blob rows nrows")
+
+# workspace rows, in order; sizes in terms of (n, m, nk, nnzP, nnzA, nnzL)
+_ROWS = [("PS", "nnzP"), ("AS", "nnzA"), ("QS", "n"), ("LS", "m"), ("US", "m"), ("D", "n"), ("E", "m"),
+         ("DT", "n"), ("ET", "m"), ("RHO", "m"), ("RINV", "m"), ("KD", "nk"), ("LX", "nnzL"), ("DI", "nk"),
+         ("YV", "nk"), ("WV", "nk"), ("XP", "n"), ("DY", "m"), ("T1", "n"), ("T2", "n"), ("T3", "m"), ("SC", 4)]
+_TABLES = ["pinv", "pidx", "A_p", "A_i", "Ar_p", "Ar_j", "Ar_k", "fi_p", "fi_b", "fi_src", "fe_p", "fe_c",
+           "fe_new", "L_p", "L_i", "Lr_p", "Lr_j", "Lr_k"]
+HEADER_WORDS = 64
+
+
+def analyse_pattern(nx, nc, A_p, A_i, perm=None):
+    """The structure-only part shared with symbolic.analyse: permuted upper-triangular KKT, etree, L pattern
+    and the recorded up-looking factorisation schedule. Every column has a diagonal entry ('P', j) (= P_jj +
+    sigma, or sigma alone) / ('R', i)."""
+    nk = nx + nc
+    if perm is None:
+        adj = [set() for _ in range(nk)]
+        for j in range(nx):
+            for p in range(A_p[j], A_p[j + 1]):
+                r = nx + A_i[p]
+                adj[j].add(r)
+                adj[r].add(j)
+        perm = symbolic.min_fill_ordering(adj)
+    perm = [int(v) for v in perm]
+    pinv = [0] * nk
+    for k, v in enumerate(perm):
+        pinv[v] = k
+    trip = [(j, j, ('P', j)) for j in range(nx)]
+    for j in range(nx):
+        for p in range(A_p[j], A_p[j + 1]):
+            trip.append((j, nx + A_i[p], ('A', p)))
+    for i in range(nc):
+        trip.append((nx + i, nx + i, ('R', i)))
+    cols = [[] for _ in range(nk)]
+    for (i, j, src) in trip:
+        cols[j].append((i, src))
+    pcols = [[] for _ in range(nk)]
+    for j in range(nk):
+        j2 = pinv[j]
+        for (i, src) in cols[j]:
+            i2 = pinv[i]
+            pcols[max(i2, j2)].append((min(i2, j2), src))
+    K_p, K_i, K_src = [0], [], []
+    for j in range(nk):
+        for (i, src) in pcols[j]:
+            K_i.append(i)
+            K_src.append(src)
+        K_p.append(len(K_i))
+    work, Lnz, etree = [0] * nk, [0] * nk, [-1] * nk
+    for j in range(nk):
+        work[j] = j
+        for p in range(K_p[j], K_p[j + 1]):
+            i = K_i[p]
+            while work[i] != j:
+                if etree[i] == -1:
+                    etree[i] = j
+                Lnz[i] += 1
+                work[i] = j
+                i = etree[i]
+    L_p = [0]
+    for i in range(nk):
+        L_p.append(L_p[-1] + Lnz[i])
+    L_i = [-1] * L_p[-1]
+    Lnext = list(L_p[:-1])
+    ops = []
+    for k in range(nk):
+        marked = [False] * nk
+        yIdx, init, diag = [], [], None
+        for p in range(K_p[k], K_p[k + 1]):
+            b = K_i[p]
+            if b == k:
+                diag = p
+                continue
+            init.append((b, p))
+            nxt = b
+            if not marked[nxt]:
+                marked[nxt] = True
+                buf = [nxt]
+                nxt = etree[b]
+                while nxt != -1 and nxt < k:
+                    if marked[nxt]:
+                        break
+                    marked[nxt] = True
+                    buf.append(nxt)
+                    nxt = etree[nxt]
+                while buf:
+                    yIdx.append(buf.pop())
+        elim = []
+        for c in reversed(yIdx):
+            upd = [(j, L_i[j]) for j in range(L_p[c], Lnext[c])]
+            new = Lnext[c]
+            L_i[new] = k
+            Lnext[c] += 1
+            elim.append((c, upd, new))
+        assert diag is not None
+        ops.append(dict(k=k, diag=diag, init=init, elim=elim))
+    assert all(v >= 0 for v in L_i)
+    return perm, pinv, K_p, K_i, K_src, etree, L_p, L_i, ops
+
+
+def analyse_qp(n, m, A_p, A_i, P_cols, perm=None):
+    """n, m: sizes; (A_p, A_i): CSC pattern of A (row indices ascending within a column); P_cols: sorted list of
+    the columns j that carry a diagonal P entry (value index k = position in this list)."""
+    A_p = [int(v) for v in A_p]
+    A_i = [int(v) for v in A_i]
+    P_cols = [int(v) for v in P_cols]
+    nk, nnzA, nnzP = n + m, len(A_i), len(P_cols)
+    perm, pinv, K_p, K_i, K_src, etree, L_p, L_i, ops = analyse_pattern(n, m, A_p, A_i, perm)
+    nnzL = len(L_i)
+    sizes = dict(n=n, m=m, nk=nk, nnzP=nnzP, nnzA=nnzA, nnzL=nnzL)
+    rows, off = {}, 0
+    for name, sz in _ROWS:
+        rows[name] = off
+        off += sizes[sz] if isinstance(sz, str) else sz
+    nrows = off
+    pidx = [-1] * n
+    for k, j in enumerate(P_cols):
+        pidx[j] = k
+    # CSR view of A: entries of row i in ascending column order (= the order in which CSC traversal meets them)
+    rlist = [[] for _ in range(m)]
+    for j in range(n):
+        for p in range(A_p[j], A_p[j + 1]):
+            rlist[A_i[p]].append((j, p))
+    Ar_p, Ar_j, Ar_k = [0], [], []
+    for i in range(m):
+        for (j, p) in rlist[i]:
+            Ar_j.append(j)
+            Ar_k.append(p)
+        Ar_p.append(len(Ar_j))
+    # factor schedule; init sources are workspace rows (off-diagonal KKT entries are A values; P is diagonal)
+    fi_p, fi_b, fi_src, fe_p, fe_c, fe_new = [0], [], [], [0], [], []
+    for op in ops:
+        for (b, p) in op["init"]:
+            src = K_src[p]
+            assert src[0] == 'A', "off-diagonal KKT entries come from A (P is diagonal)"
+            fi_b.append(b)
+            fi_src.append(rows["AS"] + src[1])
+        fi_p.append(len(fi_b))
+        for (c, upd, new) in op["elim"]:
+            assert [j for j, _ in upd] == list(range(L_p[c], new))
+            fe_c.append(c)
+            fe_new.append(new)
+        fe_p.append(len(fe_c))
+    # CSR view of L (row r: entries L[r, c] in ascending c = the order the column-oriented forward solve applies them)
+    lrows = [[] for _ in range(nk)]
+    for c in range(nk):
+        for j in range(L_p[c], L_p[c + 1]):
+            lrows[L_i[j]].append((c, j))
+    Lr_p, Lr_j, Lr_k = [0], [], []
+    for r in range(nk):
+        for (c, j) in lrows[r]:
+            Lr_j.append(c)
+            Lr_k.append(j)
+        Lr_p.append(len(Lr_j))
+    tables = dict(pinv=pinv, pidx=pidx, A_p=A_p, A_i=A_i, Ar_p=Ar_p, Ar_j=Ar_j, Ar_k=Ar_k, fi_p=fi_p, fi_b=fi_b,
+                  fi_src=fi_src, fe_p=fe_p, fe_c=fe_c, fe_new=fe_new, L_p=L_p, L_i=L_i, Lr_p=Lr_p, Lr_j=Lr_j,
+                  Lr_k=Lr_k)
+    # blob: [HEADER_WORDS header | tables]; header = sizes, nrows, then (table offset) x len(_TABLES), then row offsets
+    hdr = [n, m, nk, nnzP, nnzA, nnzL, nrows, 0]
+    body, offs = [], []
+    pos = HEADER_WORDS
+    for name in _TABLES:
+        offs.append(pos)
+        t = tables[name]
+        body += t
+        pos += len(t)
+    hdr += offs
+    hdr += [rows[name] for name, _ in _ROWS]
+    assert len(hdr) <= HEADER_WORDS
+    hdr += [0] * (HEADER_WORDS - len(hdr))
+    blob = np.asarray(hdr + body, dtype=np.int32)
+    return QPStructure(n, m, nk, nnzP, nnzA, nnzL, P_cols, A_p, A_i, perm, pinv, K_p, K_i, K_src, etree, L_p, L_i,
+                       ops, tables, blob, rows, nrows)
+
+
+def csc_pattern(dense_mask):
+    """CSC (A_p, A_i) of a boolean [m][n] mask."""
+    dense_mask = np.asarray(dense_mask, bool)
+    A_p, A_i = [0], []
+    for j in range(dense_mask.shape[1]):
+        A_i += [int(i) for i in np.nonzero(dense_mask[:, j])[0]]
+        A_p.append(len(A_i))
+    return A_p, A_i
