@@ -241,6 +241,47 @@ int umpcBatchWLUpdate(const WLCon_t *wl, int B, int dtype, void *u, const void *
 int umpcBatchModel(int model, int B, int dtype, int nsub, double dt, void *y, const void *u, void *aux,
                    void *stream);
 
+/* ------------------------------------------------------------------ */
+/* Part 5: general-structure batch QP            */
+/* ------------------------------------------------------------------ */
+/* The embedded-OSQP step of Part 1/2 for an ARBITRARY structure: min 1/2 x'Px + q'x s.t. l <= Ax <= u with
+ * P diagonal on a subset of the columns and A sparse. This is what the reference's other MPC formulations hand
+ * to `osqp.OSQP().setup / update / solve`: planar/mpc_osqp_p5f.py:87-147,172 (n = 87, m = 164 at N = 10),
+ * template/genqp.py:43-168 (v1 UprightMPC, n = m = 9N), template/template_controllers.py:170-258 (UprightMPC2 at
+ * any horizon N). The sparsity is analysed on the host (robobee3d_amd/qpstruct.py: KKT ordering, elimination
+ * tree, LDL' schedule = what OSQP's code generator bakes into workspace.c:743-2467) and handed over as one int32
+ * table blob. Per call and per robot: 10 Ruiz passes, row classification, numeric LDL', max_iter ADMM
+ * iterations (no early exit), residuals / status / solution -- the call sequence of
+ * template/uprightmpc2/osqp.c:288-641,752-833,1158-1266 in canonical-restart form. */
+typedef struct {
+  double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  int max_iter, scaling;
+} umpcQPSettings;
+/* the reference's generated settings (workspace.c) with umpcInit's max_iter = 50 (uprightmpc2.c:116-117) */
+void umpcQPDefaultSettings(umpcQPSettings *s);
+/* blob: robobee3d_amd/qpstruct.py layout (64-word header, 18 index tables); validated here. NULL on error. */
+void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpcQPSettings *settings);
+void umpcQPDestroy(void *h);
+int umpcQPSetMaxIter(void *h, int max_iter);
+/* All arrays are DEVICE pointers, SoA [rows][B] of the handle's dtype:
+ *   Pv [nnzP], Av [nnzA] (CSC order), q [n], l, u [m]   raw problem data                     in
+ *   x [n], y [m], z [m]   OSQP's (scaled) iterates, warm start                                in/out
+ *   Eprev [m]             E of the previous call (1 before the first), osqp.c:812-820          in/out
+ *   sol_x [n], sol_y [m]  unscaled solution (NaN on an infeasibility status) or NULL           out
+ *   status [B] int32 (OSQP codes) or NULL; info [4][B] = pri_res, dua_res, c, zero-pivot flag or NULL
+ * Asynchronous on `stream`. */
+int umpcQPSolve(void *h, const void *Pv, const void *Av, const void *q, const void *l, const void *u, void *x,
+                void *y, void *z, void *Eprev, void *sol_x, void *sol_y, int32_t *status, void *info, void *stream);
+/* out[k][b] = src[k] < 0 ? cst[k] : cst[k] * par[src[k]][b]  (k < nnz): fills a value array whose entries are
+ * constants or scaled per-robot parameters, e.g. A <- kron(I,-I) + kron(eye(k=-1), Ad) | kron(.., Bd) of
+ * planar/mpc_osqp_p5f.py:168-170. cst, src are device arrays of length nnz. */
+int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src, const void *par, void *out,
+                 void *stream);
+/* planar/mpc_osqp_p5f.py: getLin (:45-85) at (u[b], sigma = y[0][b], phi = y[3][b]) -> lin [5][B] =
+ * (Ad[4][3], Ad[5][3], Bd[4], Bd[5], Bd[6]); mode 1 additionally applies the reference's plant tick
+ * y <- y + (Ad y + Bd u) dt (:176). y [7][B], u [B]; lin may be NULL in mode 1. */
+int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, void *lin, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO_PATH = os.path.join(HERE, "libumpc_mi355x.so")
 SRC = os.path.join(HERE, "csrc", "umpc_mi355x.hip")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+SRC_BQP = os.path.join(HERE, "csrc", "umpc_bqp.hip")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17"]
 
 UMPC_F32, UMPC_F64 = 0, 1
 STATE_ROWS, CTRL_ROWS, REF_ROWS, OUT_ROWS, STAT_ROWS = 18, 127, 9, 9, 2
@@ -23,7 +25,14 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights",
-           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel"]
+           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel",
+           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSolve", "umpcQPGather",
+           "umpcP5fStep"]
+
+
+class QPSettings(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf",
+                                          "eps_dual_inf")] + [("max_iter", C.c_int), ("scaling", C.c_int)]
 
 
 class FunApprox_t(C.Structure):
@@ -59,20 +68,37 @@ class UprightMPC_t(C.Structure):
 
 
 def build(force=False, verbose=False):
-    """Generate umpc_gen.h and compile the HIP library for gfx950 (works without a GPU)."""
+    """Generate umpc_gen.h / umpc_admm_asm.h and compile the HIP library for gfx950 (works without a GPU).
+    One object per translation unit (recompiled only when it or its headers changed), then one link."""
     from . import asmgen, codegen
     gen, _ = codegen.write()
     gasm, _ = asmgen.write()
-    deps = [SRC, gen, gasm, os.path.join(HERE, "csrc", "umpc_step.h"),
-            os.path.join(ROOT, "include", "umpc_mi355x.h")]
-    if (not force and os.path.exists(SO_PATH)
-            and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps)):
-        return SO_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", SO_PATH, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=os.path.join(HERE, "csrc"),
-                   stderr=None if verbose else subprocess.DEVNULL)
+    hdr = os.path.join(ROOT, "include", "umpc_mi355x.h")
+    csrc = os.path.join(HERE, "csrc")
+    units = [(SRC, [gen, gasm, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
+             (SRC_BQP, [hdr, os.path.join(csrc, "umpc_err.h")])]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs, relink = [], force or not os.path.exists(SO_PATH)
+    procs = []
+    for src, deps in units:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if (force or not os.path.exists(obj)
+                or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + deps)):
+            cmd = ["hipcc"] + HIPCC_FLAGS + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, cwd=csrc, stderr=None if verbose else subprocess.PIPE)))
+            relink = True
+    for cmd, p in procs:
+        _, err = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), (err or b"").decode()[-4000:]))
+    if relink or any(os.path.getmtime(SO_PATH) < os.path.getmtime(o) for o in objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=csrc, stderr=None if verbose else subprocess.DEVNULL)
     return SO_PATH
 
 
@@ -105,6 +131,14 @@ def lib():
         L.umpcBatchModel.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4
         L.umpcBatchWLUpdate.argtypes =[C.POINTER(WLCon_t), C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcUpdate.restype = C.c_int
+        L.umpcQPDefaultSettings.argtypes = [C.POINTER(QPSettings)]
+        L.umpcQPCreate.restype = C.c_void_p
+        L.umpcQPCreate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(QPSettings)]
+        L.umpcQPDestroy.argtypes = [C.c_void_p]
+        L.umpcQPSetMaxIter.argtypes = [C.c_void_p, C.c_int]
+        L.umpcQPSolve.argtypes = [C.c_void_p] * 15
+        L.umpcQPGather.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.umpcP5fStep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4
         L.umpcLastStatus.restype = C.c_int
         _lib = L
     return _lib

@@ -1,0 +1,299 @@
+"""Host side of the general-structure batch QP solver (csrc/umpc_bqp.hip, include/umpc_mi355x.h Part 5) and the
+reference MPC formulations built on it:
+
+  BatchQP          B independent QPs of one sparsity structure; mirrors the osqp.OSQP() setup / update / solve
+                   usage of the reference's Python MPCs (template/genqp.py:206-209,157-158;
+                   planar/mpc_osqp_p5f.py:131-147,172) with the embedded-C step of template/uprightmpc2/.
+  PlanarP5fMPC     planar/mpc_osqp_p5f.py: stroke-plane MPC, nx = 7, nu = 1, N = 10 (config 4).
+  UprightMPCv1     template/genqp.py:43-168: the v1 template QP (nq = 6, nu = 3).
+
+torch is device memory / streams only; every computation is a kernel of libumpc_mi355x.so. Arrays are SoA
+[rows, B], robot index fastest. There is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, qpstruct
+
+_DT = {torch.float32: _lib.UMPC_F32, torch.float64: _lib.UMPC_F64}
+OSQP_INFTY = 1e30   # the osqp Python wrapper clips +-inf bounds to this before setup
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchQP:
+    def __init__(self, n, m, A_p, A_i, P_cols, B, dtype=torch.float32, device="cuda", perm=None, **settings):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchQP needs a HIP device; there is no CPU path")
+        self.L = _lib.lib()
+        self.s = qpstruct.analyse_qp(n, m, A_p, A_i, P_cols, perm=perm)
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.n, self.m, self.B, self.dtype, self.device = n, m, int(B), dtype, dev
+        st = _lib.QPSettings()
+        self.L.umpcQPDefaultSettings(C.byref(st))
+        for k, v in settings.items():
+            if not hasattr(st, k):
+                raise TypeError("unknown setting %r" % k)
+            setattr(st, k, v)
+        self.settings = st
+        blob = np.ascontiguousarray(self.s.blob, np.int32)
+        with torch.cuda.device(self.device):
+            self.h = self.L.umpcQPCreate(blob.ctypes.data_as(C.c_void_p), int(blob.size), self.B, _DT[dtype],
+                                         C.byref(st))
+        if not self.h:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        z = lambda r, dt=dtype: torch.zeros((max(r, 1), self.B), dtype=dt, device=self.device)
+        self.x, self.y, self.z = z(n), z(m), z(m)
+        self.Eprev = torch.ones((m, self.B), dtype=dtype, device=self.device)
+        self.sol_x, self.sol_y, self.info = z(n), z(m), z(4)
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.L.umpcQPDestroy(h)
+
+    def reset(self):
+        """Cold start (x = y = z = 0) and E = 1, the state of a freshly set-up solver."""
+        for t in (self.x, self.y, self.z):
+            t.zero_()
+        self.Eprev.fill_(1)
+
+    def _chk(self, t, rows, name):
+        if t is None:
+            if rows == 0:
+                return None
+            raise ValueError("%s is required" % name)
+        if t.dtype != self.dtype or t.device != self.device or tuple(t.shape) != (rows, self.B) or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous [%d, %d] %s tensor on %s" % (name, rows, self.B, self.dtype, self.device))
+        return t
+
+    def solve(self, Pv, Av, q, l, u, max_iter=None):
+        """One canonical-restart step on raw data; returns (sol_x, sol_y, status) (views of this object's buffers)."""
+        s = self.s
+        Pv = self._chk(Pv, s.nnzP, "Pv"); Av = self._chk(Av, s.nnzA, "Av")
+        q = self._chk(q, s.n, "q"); l = self._chk(l, s.m, "l"); u = self._chk(u, s.m, "u")
+        if max_iter is not None:
+            self.L.umpcQPSetMaxIter(self.h, int(max_iter))
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.L.umpcQPSolve(self.h, _ptr(Pv), _ptr(Av), _ptr(q), _ptr(l), _ptr(u), _ptr(self.x), _ptr(self.y),
+                                _ptr(self.z), _ptr(self.Eprev), _ptr(self.sol_x), _ptr(self.sol_y),
+                                _ptr(self.status), _ptr(self.info), stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        return self.sol_x, self.sol_y, self.status
+
+    def gather(self, cst, src, par, out):
+        """out[k] = cst[k] if src[k] < 0 else cst[k] * par[src[k]] (umpcQPGather)."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.L.umpcQPGather(self.B, _DT[self.dtype], int(cst.numel()), _ptr(cst), _ptr(src), _ptr(par), _ptr(out),
+                                 stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# planar/mpc_osqp_p5f.py
+# ---------------------------------------------------------------------------------------------------------
+def p5f_structure(N=10):
+    """The QP of planar/mpc_osqp_p5f.py:87-147: x = (y(0..N) [7 each], u(0..N-1)); rows = (N+1)*7 dynamics
+    equalities + identity box rows. Returns dict(n, m, A_p, A_i, P_cols, cst, src, Pv, q, l, u) where
+    A[k] = cst[k] (src < 0) or cst[k] * lin[src[k]] with lin = (Ad43, Ad53, Bd4, Bd5, Bd6) (getLin :45-85).
+    Structural pattern of (Ad, Bd): the entries the symbolic expressions of getLin can make non-zero."""
+    nx, nu = 7, 1
+    n = (N + 1) * nx + N * nu
+    neq = (N + 1) * nx
+    m = neq + n
+    ent = {}
+    for k in range(N + 1):
+        for i in range(nx):
+            ent[(k * nx + i, k * nx + i)] = (-1.0, -1)                 # kron(eye(N+1), -eye(nx))
+        if k > 0:
+            c0 = (k - 1) * nx
+            for (r, c, v, sidx) in ((1, 4, 1.0, -1), (2, 5, 1.0, -1), (3, 6, 1.0, -1), (4, 3, 1.0, 0), (5, 3, 1.0, 1)):
+                ent[(k * nx + r, c0 + c)] = (v, sidx)                  # kron(eye(N+1, k=-1), Ad)
+            cu = (N + 1) * nx + (k - 1)
+            for (r, v, sidx) in ((0, 1.0, -1), (4, 1.0, 2), (5, 1.0, 3), (6, 1.0, 4)):
+                ent[(k * nx + r, cu)] = (v, sidx)                      # kron(vstack(0, eye(N)), Bd)
+    for j in range(n):
+        ent[(neq + j, j)] = (1.0, -1)                                  # Aineq = eye
+    A_p, A_i, cst, src = [0], [], [], []
+    for j in range(n):
+        for i in sorted(r for (r, c) in ent if c == j):
+            A_i.append(i)
+            cst.append(ent[(i, j)][0])
+            src.append(ent[(i, j)][1])
+        A_p.append(len(A_i))
+    Qd = np.array([0., 10., 10., 10., 0., 0., 0.])
+    Pfull = np.hstack([np.tile(Qd, N + 1), np.full(N * nu, 0.1)])
+    P_cols = [j for j in range(n) if Pfull[j] != 0.0]                  # scipy/osqp keep the non-zeros of P
+    yr = np.array([0., 0., 1., 0., 0., 0., 0.])
+    q = np.hstack([np.tile(-Qd * yr, N + 1), np.zeros(N * nu)])
+    l = np.hstack([np.zeros(neq), np.full(n, -OSQP_INFTY)])
+    u = np.hstack([np.zeros(neq), np.full(n, OSQP_INFTY)])
+    return dict(N=N, n=n, m=m, A_p=A_p, A_i=A_i, P_cols=P_cols, cst=np.array(cst), src=np.array(src, np.int32),
+                Pv=Pfull[P_cols], q=q, l=l, u=u)
+
+
+class PlanarP5fMPC:
+    """B copies of the planar stroke-plane MPC loop of planar/mpc_osqp_p5f.py:151-176. Per tick and robot:
+    getLin about (unom(t), sigma, phi) of the previous state, rebuild A, one fixed-iteration QP step (the
+    reference calls prob.update(Ax=A) and never solve(); the step is the build's), then the
+    reference's plant tick y += (Ad y + Bd unom) dt."""
+
+    def __init__(self, B, dtype=torch.float32, device="cuda", N=10, dt=0.002, **settings):
+        st = p5f_structure(N)
+        self.st, self.B, self.dt, self.dtype = st, int(B), float(dt), dtype
+        self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, **settings)
+        dev = self.qp.device
+        col = lambda v: torch.as_tensor(np.repeat(np.asarray(v, np.float64)[:, None], B, 1)).to(dev, dtype).contiguous()
+        self.Pv, self.q, self.l, self.u = col(st["Pv"]), col(st["q"]), col(st["l"]), col(st["u"])
+        self.cst = torch.as_tensor(st["cst"]).to(dev, dtype)
+        self.src = torch.as_tensor(st["src"]).to(dev)
+        self.Av = torch.zeros((len(st["A_i"]), B), dtype=dtype, device=dev)
+        self.lin = torch.zeros((5, B), dtype=dtype, device=dev)
+        self.y = torch.zeros((7, B), dtype=dtype, device=dev)
+        self.u_nom = torch.zeros(B, dtype=dtype, device=dev)
+        self.L = self.qp.L
+
+    def linearise(self, u):
+        """getLin at (u, sigma = y[0], phi = y[3]) -> lin [5, B] and the assembled A values."""
+        self.u_nom.copy_(u) if torch.is_tensor(u) else self.u_nom.fill_(float(u))
+        stream = C.c_void_p(torch.cuda.current_stream(self.qp.device).cuda_stream)
+        rc = self.L.umpcP5fStep(self.B, _DT[self.dtype], 0, self.dt, _ptr(self.u_nom), _ptr(self.y), _ptr(self.lin), stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        self.qp.gather(self.cst, self.src, self.lin, self.Av)
+        return self.lin
+
+    def tick(self, t, solve=True):
+        """One loop body of mpc_osqp_p5f.py:157-176 at time t (unom = 15 sin(2 pi 170 t), :157)."""
+        unom = 15.0 * np.sin(2 * np.pi * 170 * t)
+        self.linearise(unom)
+        if solve:
+            self.qp.solve(self.Pv, self.Av, self.q, self.l, self.u)
+        stream = C.c_void_p(torch.cuda.current_stream(self.qp.device).cuda_stream)
+        rc = self.L.umpcP5fStep(self.B, _DT[self.dtype], 1, self.dt, _ptr(self.u_nom), _ptr(self.y), None, stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        return self.y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# template/genqp.py UprightMPC (v1)
+# ---------------------------------------------------------------------------------------------------------
+def v1_structure(N=3):
+    """Pattern of genqp.UprightMPC.__init__ (template/genqp.py:49-112) and the positions `Axidx` of its
+    state-dependent A entries (saveAxidx :120-135). x = (q_1..q_N [6 each], u_0..u_{N-1} [3 each]); rows =
+    6N dynamics + 3N s-limits. Returns dict(n, m, A_p, A_i, P_cols, A0, Axidx)."""
+    nq, nu = 6, 3
+    nx = N * (nq + nu)
+    ncon = N * (nq + 3)
+    A = np.zeros((ncon, nx))
+    Bs = lambda s: np.block([[np.reshape(s, (3, 1)), np.zeros((3, 2))], [np.zeros((2, 1)), np.eye(2)],
+                             [np.zeros((1, 1)), -s[None, :2] / s[2]]]) * 2.0
+    A0 = np.eye(nq) + np.diag(np.ones(3), k=3)
+    for k in range(N):
+        A[k * nq:(k + 1) * nq, k * nq:(k + 1) * nq] = -np.eye(nq)
+        if k > 0:
+            A[k * nq:(k + 1) * nq, (k - 1) * nq:k * nq] = A0
+        A[k * nq:(k + 1) * nq, N * nq + k * nu:N * nq + (k + 1) * nu] = Bs(np.ones(3))
+        A[N * nq + 3 * k:N * nq + 3 * (k + 1), k * nq + 3:k * nq + 6] = np.eye(3)
+    A_p, A_i = qpstruct.csc_pattern(A != 0)
+    Adata = np.array([A[i, j] for j in range(nx) for i in A_i[A_p[j]:A_p[j + 1]]])
+    A1nnz = 18 * N - 9
+    Axidx = [18 * k + i for k in range(N - 1) for i in (7, 11, 15)] + list(range(A1nnz, A1nnz + 7 * N))
+    P_cols = list(range((N - 1) * nq, N * nq)) + list(range(N * nq, nx))
+    return dict(N=N, n=nx, m=ncon, A_p=A_p, A_i=A_i, P_cols=P_cols, Adata=Adata, Axidx=Axidx)
+
+
+class UprightMPCv1:
+    """B copies of genqp.UprightMPC (template/genqp.py:43-168). update() takes per-robot [rows, B] tensors (or
+    broadcastable numpy) of the reference's arguments and returns (x [n, B], uu [3, B]); the nominal-trajectory
+    bookkeeping (snom, vT0; :163-166) is kept per robot on the device."""
+
+    def __init__(self, B, N=3, dtype=torch.float64, device="cuda", **settings):
+        st = v1_structure(N)
+        self.st, self.N, self.B, self.dtype = st, N, int(B), dtype
+        self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, **settings)
+        dev = self.qp.device
+        self.dev = dev
+        nnzA = len(st["A_i"])
+        # A = constants except at Axidx: parameter rows par = [dt*vT0 | dt*(sx,sy,sz,1,-sx/sz,1,-sy/sz) per stage]
+        cst = np.array(st["Adata"], np.float64)
+        src = np.full(nnzA, -1, np.int32)
+        for r, k in enumerate(st["Axidx"]):
+            cst[k] = 1.0
+            src[k] = 0 if r < 3 * (N - 1) else 1 + (r - 3 * (N - 1))
+        self.cst = torch.as_tensor(cst).to(dev, dtype)
+        self.src = torch.as_tensor(src).to(dev)
+        self.par = torch.zeros((1 + 7 * N, B), dtype=dtype, device=dev)
+        self.Av = torch.zeros((nnzA, B), dtype=dtype, device=dev)
+        self.Pv = torch.zeros((len(st["P_cols"]), B), dtype=dtype, device=dev)
+        self.q = torch.zeros((st["n"], B), dtype=dtype, device=dev)
+        self.l = torch.zeros((st["m"], B), dtype=dtype, device=dev)
+        self.u = torch.zeros((st["m"], B), dtype=dtype, device=dev)
+        self.resetNominal()
+
+    def resetNominal(self):
+        self.snom = torch.zeros((3 * self.N, self.B), dtype=self.dtype, device=self.dev)
+        self.snom[2::3] = 1.0
+        self.vT0 = torch.zeros(self.B, dtype=self.dtype, device=self.dev)
+
+    def _t(self, v, rows):
+        t = torch.as_tensor(np.asarray(v, np.float64)) if not torch.is_tensor(v) else v
+        t = t.to(self.dev, self.dtype)
+        if t.dim() == 1:
+            t = t[:, None].expand(rows, self.B)
+        return t
+
+    def assemble(self, q0, qdes, Qfdiag, Rdiag, smin, smax, dt, snom=None, vT0=None):
+        """The data updates of genqp.py:132-155 (device tensor arithmetic is row copies / scalings only; the
+        A values go through umpcQPGather)."""
+        N, nq = self.N, 6
+        q0, qdes, Qf, Rd = self._t(q0, 6), self._t(qdes, 6), self._t(Qfdiag, 6), self._t(Rdiag, 3)
+        smin, smax = self._t(smin, 3), self._t(smax, 3)
+        snom = self.snom if snom is None else self._t(snom, 3 * N)
+        if vT0 is None:
+            vT0 = self.vT0
+        elif torch.is_tensor(vT0):
+            vT0 = vT0.to(self.dev, self.dtype).expand(self.B)
+        else:
+            vT0 = torch.as_tensor(np.broadcast_to(np.asarray(vT0, np.float64), (self.B,)).copy()).to(self.dev, self.dtype)
+        self.vT0 = vT0.clone()
+        dtv = dt * vT0
+        a0q0 = q0.clone()
+        a0q0[:3] += dtv * q0[3:]                                      # A0 @ q0, A0 = I + dt vT0 diag(1,1,1; k=3)
+        self.l.zero_(); self.u.zero_()
+        self.l[:nq] = -a0q0; self.u[:nq] = -a0q0
+        self.l[N * nq:] = smin.repeat(N, 1); self.u[N * nq:] = smax.repeat(N, 1)
+        self.q.zero_()
+        self.q[(N - 1) * nq:N * nq] = -(Qf * qdes)
+        self.Pv[:nq] = Qf
+        self.Pv[nq:] = Rd.repeat(N, 1)
+        self.par[0] = dtv
+        for k in range(N):
+            s = snom[3 * k:3 * k + 3]
+            blk = self.par[1 + 7 * k:8 + 7 * k]
+            blk[0], blk[1], blk[2] = dt * s[0], dt * s[1], dt * s[2]
+            blk[3] = dt
+            blk[4] = dt * (-s[0] / s[2])
+            blk[5] = dt
+            blk[6] = dt * (-s[1] / s[2])
+        self.qp.gather(self.cst, self.src, self.par, self.Av)
+
+    def update(self, q0, qdes, Qfdiag, Rdiag, smin, smax, dt, snom=None, vT0=None, max_iter=None):
+        self.assemble(q0, qdes, Qfdiag, Rdiag, smin, smax, dt, snom, vT0)
+        x, _, _ = self.qp.solve(self.Pv, self.Av, self.q, self.l, self.u, max_iter=max_iter)
+        N, nq = self.N, 6
+        uu = x[N * nq:N * nq + 3].clone()
+        self.snom = torch.cat([x[i * nq + 3:i * nq + 6] for i in range(N)], 0).clone()   # genqp.py:164
+        self.vT0 = self.vT0 + uu[0]                                                       # genqp.py:165
+        return x, uu

@@ -1,0 +1,555 @@
+// General-structure batch QP solver for MI355X (gfx950): SURVEY 8 rows a21 / a22 / f-4.
+//
+//   min 1/2 x'Px + q'x   s.t.  l <= Ax <= u      P diagonal (on a subset of columns), A sparse (CSC)
+//
+// One GPU lane per robot, exactly the per-step call sequence of the reference's embedded OSQP 0.6.0
+// (template/uprightmpc2/: scaling.c:44-156, auxil.c:103-145, kkt.c:184-222, qdldl.c:86-293,
+// osqp.c:354-370, auxil.c:164-228, 243-362, 517-565, 684-789), in canonical-restart form (every call
+// starts from the raw data; persistent state = x, y, z and the previous E used for row classification).
+//
+// Where umpc_step.h bakes the N = 3 uprightmpc2 structure into straight-line code + assembly, this kernel is
+// TABLE-DRIVEN: the sparsity (A in CSC and CSR order, the permuted KKT's up-looking LDL' schedule, L in
+// CSC and CSR order) is an int32 blob built on the host by robobee3d_amd/qpstruct.py, read with wave-uniform
+// scalar loads, so one kernel serves any MPC structure (planar p5f N = 10: n = 87, m = 164; v1 template QP;
+// uprightmpc2 at any horizon). Every per-robot vector and matrix value lives in a SoA workspace W[row][B]
+// (row index wave-uniform -> SGPR base + 4*lane: every access is a coalesced 256 B wave transaction).
+// The path is HBM/L2-stream bound by construction: per ADMM iteration a robot reads L twice and the solve
+// vector ~2 nnz(L) times; DESIGN.md 10 has the byte count.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <limits>
+#include <string>
+
+#include "../../include/umpc_mi355x.h"
+#include "umpc_err.h"
+
+namespace {
+
+constexpr double QP_INFTY = 1e30, QP_MIN_SCALING = 1e-4, QP_MAX_SCALING = 1e4;
+constexpr double QP_RHO_MIN = 1e-6, QP_RHO_TOL = 1e-4, QP_RHO_EQ_OVER_RHO_INEQ = 1e3;
+constexpr int HEADER_WORDS = 64;
+// header word indices (qpstruct.py)
+enum { H_N, H_M, H_NK, H_NNZP, H_NNZA, H_NNZL, H_NROWS, H_PAD, H_TAB0 };
+enum { T_PINV, T_PIDX, T_AP, T_AI, T_ARP, T_ARJ, T_ARK, T_FIP, T_FIB, T_FIS, T_FEP, T_FEC, T_FEN, T_LP, T_LI, T_LRP,
+       T_LRJ, T_LRK, T_COUNT };
+enum { R_PS, R_AS, R_QS, R_LS, R_US, R_D, R_E, R_DT, R_ET, R_RHO, R_RINV, R_KD, R_LX, R_DI, R_YV, R_WV, R_XP, R_DY,
+       R_T1, R_T2, R_T3, R_SC, R_COUNT };
+
+template <typename T>
+struct QPArgs {
+  const int32_t *tab;
+  int B;
+  T *W;
+  const T *Pv, *Av, *q, *l, *u;
+  T *x, *y, *z, *Eprev, *sol_x, *sol_y;
+  int32_t *status;
+  T *info;
+  T sigma, alpha, rho, eps_abs, eps_rel, eps_pinf, eps_dinf;
+  int max_iter, scaling;
+};
+
+template <typename T> __device__ __forceinline__ T qabs(T v) { return v < T(0) ? -v : v; }
+template <> __device__ __forceinline__ float qabs<float>(float v) { return __builtin_fabsf(v); }
+template <> __device__ __forceinline__ double qabs<double>(double v) { return __builtin_fabs(v); }
+// c_max / c_min of the reference: (a > b) ? a : b
+template <typename T> __device__ __forceinline__ T qmax(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T qmin(T a, T b) { return a < b ? a : b; }
+__device__ __forceinline__ float qsqrt(float v) { return __fsqrt_rn(v); }
+__device__ __forceinline__ double qsqrt(double v) { return __dsqrt_rn(v); }
+// limit_scaling, scaling.c:7-14 (comparisons in double)
+template <typename T> __device__ __forceinline__ T limit_scaling(T v) {
+  v = (double)v < QP_MIN_SCALING ? T(1.0) : v;
+  v = (double)v > QP_MAX_SCALING ? T(QP_MAX_SCALING) : v;
+  return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  const int32_t *__restrict__ tab = a.tab;
+  const size_t B = (size_t)a.B;
+  const int n = tab[H_N], m = tab[H_M], nk = tab[H_NK], nnzP = tab[H_NNZP], nnzA = tab[H_NNZA];
+  const int32_t *pinv = tab + tab[H_TAB0 + T_PINV], *pidx = tab + tab[H_TAB0 + T_PIDX];
+  const int32_t *A_p = tab + tab[H_TAB0 + T_AP], *A_i = tab + tab[H_TAB0 + T_AI];
+  const int32_t *Ar_p = tab + tab[H_TAB0 + T_ARP], *Ar_j = tab + tab[H_TAB0 + T_ARJ], *Ar_k = tab + tab[H_TAB0 + T_ARK];
+  const int32_t *fi_p = tab + tab[H_TAB0 + T_FIP], *fi_b = tab + tab[H_TAB0 + T_FIB], *fi_s = tab + tab[H_TAB0 + T_FIS];
+  const int32_t *fe_p = tab + tab[H_TAB0 + T_FEP], *fe_c = tab + tab[H_TAB0 + T_FEC], *fe_n = tab + tab[H_TAB0 + T_FEN];
+  const int32_t *L_p = tab + tab[H_TAB0 + T_LP], *L_i = tab + tab[H_TAB0 + T_LI];
+  const int32_t *Lr_p = tab + tab[H_TAB0 + T_LRP], *Lr_j = tab + tab[H_TAB0 + T_LRJ], *Lr_k = tab + tab[H_TAB0 + T_LRK];
+  const int32_t *rows = tab + H_TAB0 + T_COUNT;
+  T *__restrict__ W = a.W;
+#define WR(base, i) W[(size_t)(rows[base] + (i)) * B + b]
+#define WROW(r) W[(size_t)(r) * B + b]
+#define IN(arr, i) (arr)[(size_t)(i) * B + b]
+  const T sigma = a.sigma, alpha = a.alpha, oma = T(1.0) - a.alpha;
+
+  // ---- raw data -> working copies; row classification with the previous E (auxil.c:103-145) ----
+  for (int k = 0; k < nnzP; ++k) WR(R_PS, k) = IN(a.Pv, k);
+  for (int k = 0; k < nnzA; ++k) WR(R_AS, k) = IN(a.Av, k);
+  for (int j = 0; j < n; ++j) { WR(R_QS, j) = IN(a.q, j); WR(R_D, j) = T(1.0); }
+  const T rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);
+  for (int i = 0; i < m; ++i) {
+    const T e = IN(a.Eprev, i), ls = IN(a.l, i) * e, us = IN(a.u, i) * e;
+    T r, ri;
+    if (((double)ls < -QP_INFTY * QP_MIN_SCALING) && ((double)us > QP_INFTY * QP_MIN_SCALING)) {
+      r = T(QP_RHO_MIN); ri = T(1. / QP_RHO_MIN);
+    } else if ((double)(us - ls) < QP_RHO_TOL) {
+      r = rho_eq; ri = T(1. / (double)rho_eq);
+    } else {
+      r = a.rho; ri = T(1. / (double)a.rho);
+    }
+    WR(R_RHO, i) = r; WR(R_RINV, i) = ri; WR(R_E, i) = T(1.0);
+  }
+
+  // ---- scale_data: Ruiz equilibration, scaling.c:44-156 ----
+  T c = T(1.0);
+  for (int pass = 0; pass < a.scaling; ++pass) {
+    // column norms of [P; A] (compute_inf_norm_cols_KKT), clamp, 1/sqrt
+    for (int j = 0; j < n; ++j) {
+      const int kp = pidx[j];
+      T dP = T(0.0);
+      if (kp >= 0) dP = qmax(qabs(WR(R_PS, kp)), dP);
+      T dA = T(0.0);
+      for (int p = A_p[j]; p < A_p[j + 1]; ++p) dA = qmax(qabs(WR(R_AS, p)), dA);
+      T d = limit_scaling(qmax(dP, dA));
+      WR(R_DT, j) = T(1.0) / qsqrt(d);
+    }
+    for (int i = 0; i < m; ++i) {
+      T e = T(0.0);
+      for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) e = qmax(qabs(WR(R_AS, Ar_k[p])), e);
+      WR(R_ET, i) = T(1.0) / qsqrt(limit_scaling(e));
+    }
+    // P <- D P D, A <- E A D, q <- D q, accumulate D, E
+    T qn = T(0.0), csum = T(0.0);
+    for (int j = 0; j < n; ++j) {
+      const T d = WR(R_DT, j);
+      const int kp = pidx[j];
+      if (kp >= 0) {
+        T pv = WR(R_PS, kp);
+        pv *= d; pv *= d;
+        WR(R_PS, kp) = pv;
+        csum += qabs(pv);
+      } else {
+        csum += T(0.0);
+      }
+      for (int p = A_p[j]; p < A_p[j + 1]; ++p) {
+        T v = WR(R_AS, p);
+        v *= WR(R_ET, A_i[p]);
+        v *= d;
+        WR(R_AS, p) = v;
+      }
+      const T qv = WR(R_QS, j) * d;
+      WR(R_QS, j) = qv;
+      qn = qmax(qabs(qv), qn);   // vec_norm_inf: if (a > mx) mx = a
+      WR(R_D, j) = d * WR(R_D, j);
+    }
+    for (int i = 0; i < m; ++i) WR(R_E, i) = WR(R_ET, i) * WR(R_E, i);
+    // cost normalisation
+    T ct = csum / T(n);
+    qn = limit_scaling(qn);
+    ct = qmax(ct, qn);
+    ct = limit_scaling(ct);
+    ct = T(1.0) / ct;
+    for (int k = 0; k < nnzP; ++k) WR(R_PS, k) *= ct;
+    for (int j = 0; j < n; ++j) WR(R_QS, j) *= ct;
+    c *= ct;
+  }
+  const T cinv = T(1.0) / c;
+  for (int i = 0; i < m; ++i) {
+    const T e = WR(R_E, i);
+    WR(R_LS, i) = IN(a.l, i) * e;
+    WR(R_US, i) = IN(a.u, i) * e;
+    IN(a.Eprev, i) = e;
+  }
+
+  // ---- KKT diagonal (kkt.c:184-222) and the up-looking LDL' (qdldl.c:86-247) ----
+  for (int j = 0; j < n; ++j) {
+    const int kp = pidx[j];
+    WR(R_KD, pinv[j]) = kp >= 0 ? WR(R_PS, kp) + sigma : sigma;
+  }
+  for (int i = 0; i < m; ++i) WR(R_KD, pinv[n + i]) = -WR(R_RINV, i);
+  for (int k = 0; k < nk; ++k) WR(R_YV, k) = T(0.0);
+  int fail = 0;
+  for (int k = 0; k < nk; ++k) {
+    for (int p = fi_p[k]; p < fi_p[k + 1]; ++p) WR(R_YV, fi_b[p]) = WROW(fi_s[p]);
+    T dk = WR(R_KD, k);
+    for (int e = fe_p[k]; e < fe_p[k + 1]; ++e) {
+      const int cidx = fe_c[e], lnew = fe_n[e];
+      const T yv = WR(R_YV, cidx);
+      for (int j = L_p[cidx]; j < lnew; ++j) WR(R_YV, L_i[j]) -= WR(R_LX, j) * yv;
+      const T lv = yv * WR(R_DI, cidx);
+      WR(R_LX, lnew) = lv;
+      dk -= yv * lv;
+      WR(R_YV, cidx) = T(0.0);
+    }
+    if (dk == T(0.0)) fail = 1;
+    WR(R_DI, k) = T(1.0) / dk;
+  }
+
+  // ---- ADMM iterations, osqp.c:354-370 ----
+  if (a.max_iter == 0) {
+    for (int j = 0; j < n; ++j) WR(R_XP, j) = IN(a.x, j);
+    for (int i = 0; i < m; ++i) WR(R_DY, i) = T(0.0);
+  }
+  for (int it = 0; it < a.max_iter; ++it) {
+    // compute_rhs (auxil.c:164-178), permuted on the fly
+    for (int j = 0; j < n; ++j) {
+      const T xp = IN(a.x, j);
+      WR(R_XP, j) = xp;
+      WR(R_WV, pinv[j]) = sigma * xp - WR(R_QS, j);
+    }
+    for (int i = 0; i < m; ++i) {
+      const T r = IN(a.z, i) - WR(R_RINV, i) * IN(a.y, i);
+      WR(R_T3, i) = r;
+      WR(R_WV, pinv[n + i]) = r;
+    }
+    // QDLDL_solve (qdldl.c:250-293): forward in row order (same per-element subtraction order as the reference's
+    // column sweep), diagonal, backward
+    for (int r = 0; r < nk; ++r) {
+      T acc = WR(R_WV, r);
+      for (int p = Lr_p[r]; p < Lr_p[r + 1]; ++p) acc -= WR(R_LX, Lr_k[p]) * WR(R_WV, Lr_j[p]);
+      WR(R_WV, r) = acc;
+    }
+    for (int r = 0; r < nk; ++r) WR(R_WV, r) *= WR(R_DI, r);
+    for (int r = nk - 1; r >= 0; --r) {
+      T acc = WR(R_WV, r);
+      for (int j = L_p[r]; j < L_p[r + 1]; ++j) acc -= WR(R_LX, j) * WR(R_WV, L_i[j]);
+      WR(R_WV, r) = acc;
+    }
+    // update_x, update_z (+ projection), update_y (auxil.c:188-228)
+    for (int j = 0; j < n; ++j) {
+      const T xt = WR(R_WV, pinv[j]);
+      IN(a.x, j) = alpha * xt + oma * WR(R_XP, j);
+    }
+    for (int i = 0; i < m; ++i) {
+      const T ri = WR(R_RINV, i), yi = IN(a.y, i), zp = IN(a.z, i);
+      const T zt = WR(R_T3, i) + ri * WR(R_WV, pinv[n + i]);
+      T zn = alpha * zt + oma * zp + ri * yi;
+      zn = qmin(qmax(zn, WR(R_LS, i)), WR(R_US, i));
+      IN(a.z, i) = zn;
+      const T dy = WR(R_RHO, i) * (alpha * zt + oma * zp - zn);
+      WR(R_DY, i) = dy;
+      IN(a.y, i) = yi + dy;
+    }
+  }
+
+  // ---- update_info / check_termination (auxil.c:243-362, 684-789) ----
+  // T3 <- Ax (scaled), then primal residual and tolerance
+  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);
+  for (int i = 0; i < m; ++i) {
+    T acc = T(0.0);
+    for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) acc += WR(R_AS, Ar_k[p]) * IN(a.x, Ar_j[p]);
+    WR(R_T3, i) = acc;
+    const T einv = T(1.0) / WR(R_E, i), zi = IN(a.z, i);
+    pri_res = qmax(pri_res, qabs(einv * (acc - zi)));
+    nz = qmax(nz, qabs(einv * zi));
+    nAx = qmax(nAx, qabs(einv * acc));
+  }
+  // T1 <- Px, T2 <- A'y, dual residual and tolerance
+  T dua_res = T(0.0), nq = T(0.0), nAty = T(0.0), nPx = T(0.0);
+  for (int j = 0; j < n; ++j) {
+    const int kp = pidx[j];
+    T px = T(0.0);
+    if (kp >= 0) px += WR(R_PS, kp) * IN(a.x, j);
+    T aty = T(0.0);
+    for (int p = A_p[j]; p < A_p[j + 1]; ++p) aty += WR(R_AS, p) * IN(a.y, A_i[p]);
+    WR(R_T1, j) = px; WR(R_T2, j) = aty;
+    const T dinv = T(1.0) / WR(R_D, j), qj = WR(R_QS, j);
+    dua_res = qmax(dua_res, qabs(dinv * ((qj + px) + aty)));
+    nq = qmax(nq, qabs(dinv * qj)); nAty = qmax(nAty, qabs(dinv * aty)); nPx = qmax(nPx, qabs(dinv * px));
+  }
+  dua_res = cinv * dua_res;
+  const T dual_rel = qmax(qmax(nq, nAty), nPx) * cinv, prim_rel = qmax(nz, nAx);
+
+  // infeasibility certificates: quantities shared by the exact and the 10x-relaxed check
+  // is_primal_infeasible (auxil.c:362-424): project delta_y on the polar of the recession cone
+  T norm_dy = T(0.0), ineq_lhs = T(0.0);
+  for (int i = 0; i < m; ++i) {
+    const T us = WR(R_US, i), ls = WR(R_LS, i);
+    T dy = WR(R_DY, i);
+    const bool up = (double)us > QP_INFTY * QP_MIN_SCALING, lo = (double)ls < -QP_INFTY * QP_MIN_SCALING;
+    if (up) dy = lo ? T(0.0) : qmin(dy, T(0.0));
+    else if (lo) dy = qmax(dy, T(0.0));
+    WR(R_DY, i) = dy;
+    norm_dy = qmax(norm_dy, qabs(dy * WR(R_E, i)));
+    ineq_lhs += us * qmax(dy, T(0.0)) + ls * qmin(dy, T(0.0));
+  }
+  T nAtdy = T(0.0);
+  for (int j = 0; j < n; ++j) {
+    T acc = T(0.0);
+    for (int p = A_p[j]; p < A_p[j + 1]; ++p) acc += WR(R_AS, p) * WR(R_DY, A_i[p]);
+    nAtdy = qmax(nAtdy, qabs(acc * (T(1.0) / WR(R_D, j))));
+  }
+  // is_dual_infeasible (auxil.c:426-512)
+  T norm_dx = T(0.0), qdx = T(0.0), nPdx = T(0.0);
+  for (int j = 0; j < n; ++j) {
+    const T dx = IN(a.x, j) - WR(R_XP, j);
+    WR(R_T1, j) = dx;
+    norm_dx = qmax(norm_dx, qabs(WR(R_D, j) * dx));
+    qdx += WR(R_QS, j) * dx;
+    const int kp = pidx[j];
+    T pdx = T(0.0);
+    if (kp >= 0) pdx += WR(R_PS, kp) * dx;
+    nPdx = qmax(nPdx, qabs(pdx * (T(1.0) / WR(R_D, j))));
+  }
+  int status = -10;  // OSQP_UNSOLVED
+  if (((double)pri_res > QP_INFTY) || ((double)dua_res > QP_INFTY)) status = -7;  // OSQP_NON_CVX
+  for (int approx = 0; approx < 2 && status == -10; ++approx) {
+    const T k = approx ? T(10) : T(1);
+    const T eps_abs = a.eps_abs * k, eps_rel = a.eps_rel * k, eps_pinf = a.eps_pinf * k, eps_dinf = a.eps_dinf * k;
+    const bool prim_ok = pri_res < eps_abs + eps_rel * prim_rel;
+    const bool dual_ok = dua_res < eps_abs + eps_rel * dual_rel;
+    bool pinf = false, dinf = false;
+    if (!prim_ok && norm_dy > eps_pinf && ineq_lhs < -eps_pinf * norm_dy) pinf = nAtdy < eps_pinf * norm_dy;
+    if (!dual_ok && norm_dx > eps_dinf && qdx < -c * eps_dinf * norm_dx && nPdx < c * eps_dinf * norm_dx) {
+      dinf = true;
+      const T thr = eps_dinf * norm_dx;
+      for (int i = 0; i < m; ++i) {
+        T acc = T(0.0);
+        for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) acc += WR(R_AS, Ar_k[p]) * WR(R_T1, Ar_j[p]);
+        acc = acc * (T(1.0) / WR(R_E, i));
+        if ((((double)WR(R_US, i) < QP_INFTY * QP_MIN_SCALING) && (acc > thr)) ||
+            (((double)WR(R_LS, i) > -QP_INFTY * QP_MIN_SCALING) && (acc < -thr)))
+          dinf = false;
+      }
+    }
+    if (prim_ok && dual_ok) status = approx ? 2 : 1;
+    else if (pinf) status = approx ? 3 : -3;
+    else if (dinf) status = approx ? 4 : -4;
+  }
+  if (status == -10) status = -2;  // OSQP_MAX_ITER_REACHED
+  (void)fail;
+  // ---- store_solution (auxil.c:517-565) ----
+  const bool bad = status == -3 || status == 3 || status == -4 || status == 4 || status == -7;
+  const T qnan = std::numeric_limits<T>::quiet_NaN();
+  for (int j = 0; j < n; ++j) {
+    if (a.sol_x) IN(a.sol_x, j) = bad ? qnan : IN(a.x, j) * WR(R_D, j);
+    if (bad) IN(a.x, j) = T(0.0);
+  }
+  for (int i = 0; i < m; ++i) {
+    if (a.sol_y) IN(a.sol_y, i) = bad ? qnan : (IN(a.y, i) * WR(R_E, i)) * cinv;
+    if (bad) { IN(a.y, i) = T(0.0); IN(a.z, i) = T(0.0); }
+  }
+  if (a.status) a.status[b] = status;
+  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); }
+#undef WR
+#undef WROW
+#undef IN
+}
+
+// Av[k] = cst[k] if src[k] < 0 else par[src[k]][b] * cst[k]: assembles any per-robot value vector (A, P, q, l, u)
+// whose entries are constants or scaled copies of a few per-robot parameters.
+template <typename T>
+__global__ void bqp_gather_kernel(int B, int nnz, const T *__restrict__ cst, const int32_t *__restrict__ src,
+                                  const T *__restrict__ par, T *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int k = 0; k < nnz; ++k) {
+    const int s = src[k];
+    const T cv = cst[k];
+    out[(size_t)k * B + b] = s < 0 ? cv : par[(size_t)s * B + b] * cv;
+  }
+}
+
+// getLin, planar/mpc_osqp_p5f.py:45-85: (u, sigma, phi) -> the state-dependent entries of (Ad, Bd):
+// out rows = Ad[4][3], Ad[5][3], Bd[4], Bd[5], Bd[6]. Constants of the module (:33-43).
+template <typename T>
+__device__ __forceinline__ void p5f_getlin(T u, T sigma, T phi, T o[5]) {
+  const T CDmax = T(3.4), CLmax = T(1.8), CD0 = T(0.4), khinge0 = T(0.1), mb = T(100), kaero = T(1), d = T(5);
+  const T ib = T(1.) / T(12.) * mb * T(144);
+  const T kh = u < T(0) ? -khinge0 : khinge0;
+  const T uu = u * u;
+  const T ang = T(2) * kh * uu;
+  const T s2 = std::sin(ang), c2 = std::cos(ang), sp = std::sin(phi), cp = std::cos(phi);
+  const T CDs = CD0 + CDmax, CDd = CD0 - CDmax;
+  o[0] = -(kaero * u * (T(2) * CLmax * cp * s2 + (CDs + CDd * c2) * sp)) / (T(2.) * mb);
+  o[1] = (kaero * u * ((CDs + CDd * c2) * cp - T(2) * CLmax * s2 * sp)) / (T(2.) * mb);
+  o[2] = (kaero * (cp * (CDs + CDd * c2 - T(4) * CDd * kh * uu * s2) -
+                   T(2) * CLmax * (T(4) * kh * uu * c2 + s2) * sp)) / (T(2.) * mb);
+  o[3] = (kaero * (T(2) * CLmax * cp * s2 + (CDs - T(4) * CDd * kh * uu * s2) * sp +
+                   c2 * (T(8) * CLmax * kh * uu * cp + CDd * sp))) / (T(2.) * mb);
+  o[4] = (kaero * (-(d * (CDs + CDd * c2 - T(4) * CDd * kh * uu * s2)) +
+                   T(2) * CLmax * (T(4) * kh * uu * c2 + s2) * sigma)) / (T(2.) * ib);
+}
+
+// mode 0: lin[5][B] <- getLin(u[b], y[0][b], y[3][b]) (the reference linearises about the PREVIOUS state, :165-167)
+// mode 1: the same, then the reference's plant tick y += (Ad y + Bd u) dt (:176)
+template <typename T>
+__global__ void p5f_kernel(int B, int mode, T dt, const T *__restrict__ u, T *__restrict__ y, T *__restrict__ lin) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const size_t Bz = (size_t)B;
+  T yy[7], o[5];
+  for (int i = 0; i < 7; ++i) yy[i] = y[i * Bz + b];
+  const T ub = u[b];
+  p5f_getlin(ub, yy[0], yy[3], o);
+  if (lin) for (int i = 0; i < 5; ++i) lin[i * Bz + b] = o[i];
+  if (mode == 1) {
+    // Ad rows: 1: y4, 2: y5, 3: y6, 4: Ad43 y3, 5: Ad53 y3; Bd = (1, 0, 0, 0, Bd4, Bd5, Bd6)
+    const T dy[7] = {ub, yy[4], yy[5], yy[6], o[0] * yy[3] + o[2] * ub, o[1] * yy[3] + o[3] * ub, o[4] * ub};
+    for (int i = 0; i < 7; ++i) y[i * Bz + b] = yy[i] + dy[i] * dt;
+  }
+}
+
+struct qp_batch {
+  int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows;
+  umpcQPSettings st;
+  int32_t *tab;
+  void *W;
+};
+
+template <typename T>
+int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, const void *l, const void *u, void *x,
+                 void *y, void *z, void *Eprev, void *sol_x, void *sol_y, int32_t *status, void *info,
+                 hipStream_t s) {
+  QPArgs<T> a;
+  a.tab = h->tab; a.B = h->B; a.W = (T *)h->W;
+  a.Pv = (const T *)Pv; a.Av = (const T *)Av; a.q = (const T *)q; a.l = (const T *)l; a.u = (const T *)u;
+  a.x = (T *)x; a.y = (T *)y; a.z = (T *)z; a.Eprev = (T *)Eprev; a.sol_x = (T *)sol_x; a.sol_y = (T *)sol_y;
+  a.status = status; a.info = (T *)info;
+  a.sigma = T(h->st.sigma); a.alpha = T(h->st.alpha); a.rho = T(h->st.rho);
+  a.eps_abs = T(h->st.eps_abs); a.eps_rel = T(h->st.eps_rel);
+  a.eps_pinf = T(h->st.eps_prim_inf); a.eps_dinf = T(h->st.eps_dual_inf);
+  a.max_iter = h->st.max_iter; a.scaling = h->st.scaling;
+  hipLaunchKernelGGL(bqp_solve_kernel<T>, dim3((h->B + 63) / 64), dim3(64), 0, s, a);
+  return 0;
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    umpc_set_error((std::string(what) + ": " + hipGetErrorString(e)).c_str());
+    return -1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void umpcQPDefaultSettings(umpcQPSettings *s) {
+  // the generated workspace of the reference (template/uprightmpc2/workspace.c settings block) + umpcInit's
+  // max_iter / check_termination = 0 override (uprightmpc2.c:116-117)
+  s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6;
+  s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
+  s->max_iter = 50; s->scaling = 10;
+}
+
+void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpcQPSettings *st) {
+  if (!blob || nwords < HEADER_WORDS || B <= 0 || (dtype != UMPC_F32 && dtype != UMPC_F64)) {
+    umpc_set_error("umpcQPCreate: bad argument");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    umpc_set_error("umpcQPCreate: no HIP device (this library has no CPU path)");
+    return nullptr;
+  }
+  // every table offset / row offset must lie inside the blob / workspace: the kernel trusts them
+  const int n = blob[H_N], m = blob[H_M], nk = blob[H_NK], nrows = blob[H_NROWS];
+  if (n <= 0 || m <= 0 || nk != n + m || nrows <= 0) { umpc_set_error("umpcQPCreate: bad header"); return nullptr; }
+  for (int t = 0; t < T_COUNT; ++t)
+    if (blob[H_TAB0 + t] < HEADER_WORDS || blob[H_TAB0 + t] > nwords) { umpc_set_error("umpcQPCreate: bad table offset"); return nullptr; }
+  for (int r = 0; r < R_COUNT; ++r)
+    if (blob[H_TAB0 + T_COUNT + r] < 0 || blob[H_TAB0 + T_COUNT + r] >= nrows) { umpc_set_error("umpcQPCreate: bad row offset"); return nullptr; }
+  // index tables: every entry of a table that addresses rows / vectors must be in range
+  {
+    const int nnzA = blob[H_NNZA], nnzL = blob[H_NNZL], nnzP = blob[H_NNZP];
+    auto tabp = [&](int t) { return blob + blob[H_TAB0 + t]; };
+    auto in_range = [&](int t, int cnt, int lo, int hi) {
+      if (blob[H_TAB0 + t] + cnt > nwords) return false;
+      for (int k = 0; k < cnt; ++k) if (tabp(t)[k] < lo || tabp(t)[k] >= hi) return false;
+      return true;
+    };
+    const int nfi = tabp(T_FIP)[nk], nfe = tabp(T_FEP)[nk];
+    bool ok = in_range(T_PINV, nk, 0, nk) && in_range(T_PIDX, n, -1, nnzP) && in_range(T_AP, n + 1, 0, nnzA + 1) &&
+              in_range(T_AI, nnzA, 0, m) && in_range(T_ARP, m + 1, 0, nnzA + 1) && in_range(T_ARJ, nnzA, 0, n) &&
+              in_range(T_ARK, nnzA, 0, nnzA) && in_range(T_FIP, nk + 1, 0, nnzA + 1) && nfi >= 0 && nfi <= nnzA &&
+              in_range(T_FIB, nfi, 0, nk) && in_range(T_FIS, nfi, 0, nrows) && in_range(T_FEP, nk + 1, 0, nnzL + 1) &&
+              nfe == nnzL && in_range(T_FEC, nfe, 0, nk) && in_range(T_FEN, nfe, 0, nnzL) &&
+              in_range(T_LP, nk + 1, 0, nnzL + 1) && in_range(T_LI, nnzL, 0, nk) && in_range(T_LRP, nk + 1, 0, nnzL + 1) &&
+              in_range(T_LRJ, nnzL, 0, nk) && in_range(T_LRK, nnzL, 0, nnzL);
+    if (!ok) { umpc_set_error("umpcQPCreate: table entry out of range"); return nullptr; }
+  }
+  qp_batch *h = new qp_batch();
+  h->B = B; h->dtype = dtype; h->n = n; h->m = m; h->nk = nk;
+  h->nnzP = blob[H_NNZP]; h->nnzA = blob[H_NNZA]; h->nnzL = blob[H_NNZL]; h->nrows = nrows;
+  if (st) h->st = *st; else umpcQPDefaultSettings(&h->st);
+  const size_t esz = dtype == UMPC_F32 ? 4 : 8;
+  if (hipMalloc((void **)&h->tab, (size_t)nwords * 4) != hipSuccess ||
+      hipMalloc(&h->W, (size_t)nrows * (size_t)B * esz) != hipSuccess) {
+    umpc_set_error("umpcQPCreate: hipMalloc failed");
+    delete h;
+    return nullptr;
+  }
+  if (hipMemcpy(h->tab, blob, (size_t)nwords * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(h->W, 0, (size_t)nrows * (size_t)B * esz) != hipSuccess) {
+    umpc_set_error("umpcQPCreate: table upload failed");
+    (void)hipFree(h->tab); (void)hipFree(h->W);
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+void umpcQPDestroy(void *hv) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h) return;
+  (void)hipFree(h->tab);
+  (void)hipFree(h->W);
+  delete h;
+}
+
+int umpcQPSetMaxIter(void *hv, int max_iter) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h || max_iter < 0) { umpc_set_error("umpcQPSetMaxIter: bad argument"); return -1; }
+  h->st.max_iter = max_iter;
+  return 0;
+}
+
+int umpcQPSolve(void *hv, const void *Pv, const void *Av, const void *q, const void *l, const void *u, void *x,
+                void *y, void *z, void *Eprev, void *sol_x, void *sol_y, int32_t *status, void *info, void *stream) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h || !Av || !q || !l || !u || !x || !y || !z || !Eprev || (h->nnzP > 0 && !Pv)) {
+    umpc_set_error("umpcQPSolve: null array");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (h->dtype == UMPC_F32) launch_solve<float>(h, Pv, Av, q, l, u, x, y, z, Eprev, sol_x, sol_y, status, info, s);
+  else launch_solve<double>(h, Pv, Av, q, l, u, x, y, z, Eprev, sol_x, sol_y, status, info, s);
+  return check_launch("umpcQPSolve");
+}
+
+int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src, const void *par, void *out,
+                 void *stream) {
+  if (B <= 0 || nnz <= 0 || !cst || !src || !out) { umpc_set_error("umpcQPGather: bad argument"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL(bqp_gather_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, s, B, nnz, (const float *)cst, src,
+                       (const float *)par, (float *)out);
+  else
+    hipLaunchKernelGGL(bqp_gather_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, nnz, (const double *)cst,
+                       src, (const double *)par, (double *)out);
+  return check_launch("umpcQPGather");
+}
+
+int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, void *lin, void *stream) {
+  if (B <= 0 || !u || !y || (mode != 0 && mode != 1) || (mode == 0 && !lin)) {
+    umpc_set_error("umpcP5fStep: bad argument");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL(p5f_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, (float)dt, (const float *)u,
+                       (float *)y, (float *)lin);
+  else
+    hipLaunchKernelGGL(p5f_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, dt, (const double *)u,
+                       (double *)y, (double *)lin);
+  return check_launch("umpcP5fStep");
+}
+
+}  // extern "C"

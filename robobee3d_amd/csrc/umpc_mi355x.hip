@@ -13,6 +13,7 @@
 #include "../../include/umpc_mi355x.h"
 #include "umpc_step.h"
 #include "umpc_models.h"
+#include "umpc_err.h"
 
 namespace {
 
@@ -187,6 +188,8 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
 }
+
+void umpc_set_error(const char *msg) { g_err = msg; }
 
 extern "C" {
 

@@ -246,10 +246,100 @@ def wl_step():
     print("wl_step.npz: 96 updates, final u =", np.array(wl[0:4]))
 
 
+
+class _RecordingOSQP:
+    """Placeholder for the absent pip `osqp` on the two assembly-only paths below: records what the reference
+    hands to setup()/update() and computes NOTHING; solve() aborts the caller."""
+
+    class Stop(Exception):
+        pass
+
+    def __init__(self):
+        self.setup_args, self.updates = None, []
+
+    def setup(self, *a, **kw):
+        self.setup_args = (a, kw)
+
+    def update(self, **kw):
+        self.updates.append({k: np.array(v) for k, v in kw.items()})
+
+    def solve(self):
+        raise _RecordingOSQP.Stop()
+
+
+def v1_qp(mods):
+    """the data genqp.UprightMPC.update (template/genqp.py:132-158) assembles, for random
+    arguments, N = 3; plus its dynamics / dynamicsNLVF one-liners (:170-187)."""
+    genqp = mods[0]
+    sys.modules["osqp"].OSQP = _RecordingOSQP
+    rng = np.random.default_rng(22)
+    N = 3
+    up = genqp.UprightMPC(N)
+    rec = {k: [] for k in "q0 qdes Qf Rd smin smax dt snom vT0 Pdata Adata q l u dyn_u dyn_out nlvf_out".split()}
+    for _ in range(32):
+        q0 = np.hstack((rng.normal(size=3), rng.normal(size=3) * 0.2 + np.array([0, 0, 1.0])))
+        qdes = np.hstack((rng.normal(size=3), [0, 0, 1.0]))
+        Qf = rng.uniform(0.5, 50, 6)
+        Rd = rng.uniform(0.1, 5, 3)
+        smin = -rng.uniform(1.2, 2, 3)
+        smax = rng.uniform(1.2, 2, 3)
+        dt = float(rng.uniform(1, 5))
+        snom = [rng.normal(size=3) * 0.2 + np.array([0, 0, 1.0]) for _ in range(N)]
+        vT0 = float(rng.normal() * 0.05)
+        try:
+            up.update(q0, qdes, Qf, Rd, smin, smax, dt, snom, vT0)
+        except _RecordingOSQP.Stop:
+            pass
+        uu = rng.normal(size=3)
+        for k, v in dict(q0=q0, qdes=qdes, Qf=Qf, Rd=Rd, smin=smin, smax=smax, dt=dt, snom=np.hstack(snom), vT0=vT0,
+                         Pdata=up.P.data, Adata=up.A.data, q=up.q, l=up.l, u=up.u, dyn_u=uu,
+                         dyn_out=up.dynamics(q0, uu, dt, snom[0], vT0), nlvf_out=up.dynamicsNLVF(q0, uu)).items():
+            rec[k].append(np.array(v, dtype=np.float64))
+    np.savez_compressed(os.path.join(HERE, "v1_qp.npz"), N=N, A_indices=up.A.indices, A_indptr=up.A.indptr,
+                        P_indices=up.P.indices, P_indptr=up.P.indptr, Axidx=np.array(up.Axidx),
+                        **{k: np.stack(v) for k, v in rec.items()})
+    print("v1_qp.npz: nnzA=%d nnzP=%d" % (up.A.nnz, up.P.nnz))
+
+
+def planar_p5f():
+    """planar/mpc_osqp_p5f.py is a script whose module body stops with a ValueError under this
+    scipy (block_diag is handed a list, :116), so it cannot be imported whole. Its model constants (:33-43) and
+    getLin (:45-85) are self-contained: those statements alone are compiled from the file where it lies and
+    evaluated. Fixture = getLin samples + the constants."""
+    import ast
+    path = "/root/reference/planar/mpc_osqp_p5f.py"
+    tree = ast.parse(open(path).read(), path)
+    keep = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "getLin":
+            keep.append(node)
+            break
+        if isinstance(node, ast.Assign) and all(isinstance(t, ast.Name) for t in node.targets):
+            keep.append(node)
+    ns = {"np": np}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    rng = np.random.default_rng(21)
+    us, sg, ph = rng.normal(size=64) * 10, rng.normal(size=64) * 0.3, rng.normal(size=64) * 0.5
+    us[:4] = [0.0, -0.0, 1e-3, -1e-3]
+    Ads, Bds = [], []
+    for a, b, c in zip(us, sg, ph):
+        Ad, Bd = ns["getLin"](a, b, c)
+        Ads.append(np.asarray(Ad))
+        Bds.append(np.asarray(Bd).ravel())
+    np.savez_compressed(os.path.join(HERE, "planar_p5f.npz"), dt=ns["dt"], tf=ns["tf"], mb=ns["mb"], ib=ns["ib"],
+                        lin_u=us, lin_sigma=sg, lin_phi=ph, lin_Ad=np.stack(Ads), lin_Bd=np.stack(Bds))
+    print("planar_p5f.npz: %d getLin samples; Ad non-zeros at" % len(us),
+          sorted(set(zip(*[a.tolist() for a in np.nonzero(np.abs(np.stack(Ads)).sum(0))]))))
+
+
 if __name__ == "__main__":
     assert refbind.available(), "build oracle/_ref first: make -C oracle ref"
     if len(sys.argv) > 1 and sys.argv[1] == "wl":
         wl_step()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "qp":
+        v1_qp(import_reference_python())
+        planar_p5f()
         sys.exit(0)
     structure()
     sequence(20201117, 256, 50, "seq_iter50.npz")
@@ -261,3 +351,5 @@ if __name__ == "__main__":
     plant(mods)
     tasks(mods)
     wl_step()
+    v1_qp(mods)
+    planar_p5f()

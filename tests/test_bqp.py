@@ -72,3 +72,222 @@ def test_table_oracle_is_bitwise_the_c_oracle(oracle_built, structure, fixture):
         assert o.get("c")[0] == r["c"][k] and o.get("pri_res")[0] == r["pri_res"][k]
         assert o.get("dua_res")[0] == r["dua_res"][k]
         assert int(o.get("status_val")[0]) == int(r["status"][k])
+
+
+# ------------------------------------------------------------------------------------------------------
+# structures of the reference's other MPC formulations (CPU)
+# ------------------------------------------------------------------------------------------------------
+def test_v1_structure_is_the_reference_pattern():
+    """genqp.UprightMPC(3): CSC pattern of A, the diagonal pattern of P and Axidx (tests/golden/v1_qp.npz)."""
+    from robobee3d_amd.batchqp import v1_structure
+    g = golden("v1_qp.npz")
+    st = v1_structure(int(g["N"]))
+    assert st["A_p"] == g["A_indptr"].tolist() and st["A_i"] == g["A_indices"].tolist()
+    assert st["P_cols"] == g["P_indices"].tolist() and st["Axidx"] == g["Axidx"].tolist()
+    assert (st["n"], st["m"]) == (27, 27)
+
+
+def p5f_dense_A(N, Ad, Bd):
+    """planar/mpc_osqp_p5f.py:168-171 restated with numpy's kron (test-side)."""
+    nx = 7
+    Ax = np.kron(np.eye(N + 1), -np.eye(nx)) + np.kron(np.eye(N + 1, k=-1), Ad)
+    Bu = np.kron(np.vstack([np.zeros((1, N)), np.eye(N)]), Bd.reshape(7, 1))
+    Aeq = np.hstack([Ax, Bu])
+    return np.vstack([Aeq, np.eye((N + 1) * nx + N)])
+
+
+def test_p5f_structure_reproduces_the_kron_construction():
+    from robobee3d_amd.batchqp import p5f_structure
+    g = golden("planar_p5f.npz")
+    st = p5f_structure(10)
+    assert (st["n"], st["m"]) == (87, 164)
+    for k in (5, 17, 40):
+        Ad, Bd = g["lin_Ad"][k], g["lin_Bd"][k]
+        lin = np.array([Ad[4, 3], Ad[5, 3], Bd[4], Bd[5], Bd[6]])
+        vals = np.where(st["src"] < 0, st["cst"], st["cst"] * lin[np.maximum(st["src"], 0)])
+        A = np.zeros((st["m"], st["n"]))
+        for j in range(st["n"]):
+            for p in range(st["A_p"][j], st["A_p"][j + 1]):
+                A[st["A_i"][p], j] = vals[p]
+        assert np.array_equal(A, p5f_dense_A(10, Ad, Bd))
+    assert st["P_cols"] == [j for j in range(87) if (j < 77 and j % 7 in (1, 2, 3)) or j >= 77]
+
+
+def test_table_oracle_converges_on_v1_and_p5f():
+    """Self-consistency of the oracle on the two unpinned problems: run long, KKT residuals vanish."""
+    import osqp_table
+    from robobee3d_amd.batchqp import p5f_structure, v1_structure
+    from robobee3d_amd import qpstruct
+    g = golden("v1_qp.npz")
+    st = v1_structure(3)
+    s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    k = [0, 1, 2, 3]
+    z = lambda r: np.zeros((r, len(k)))
+    r = osqp_table.solve(27, 27, st["A_p"], st["A_i"], st["P_cols"], s.perm, g["Pdata"][k].T, g["Adata"][k].T,
+                         g["q"][k].T, g["l"][k].T, g["u"][k].T, z(27), z(27), z(27), np.ones((27, len(k))),
+                         osqp_table.Settings(max_iter=1500))
+    assert np.all(r["status"] == 1) and r["pri_res"].max() < 1e-6 and r["dua_res"].max() < 1e-6
+    x = r["sol_x"]
+    for c, kk in enumerate(k):
+        A = np.zeros((27, 27))
+        for j in range(27):
+            for p in range(st["A_p"][j], st["A_p"][j + 1]):
+                A[st["A_i"][p], j] = g["Adata"][kk][p]
+        Ax = A @ x[:, c]
+        assert np.all(Ax >= g["l"][kk] - 1e-5) and np.all(Ax <= g["u"][kk] + 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# GPU: the table-driven kernel against the oracle
+# ------------------------------------------------------------------------------------------------------
+def _run_gpu_qp(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, dtype, max_iter):
+    import torch
+    from robobee3d_amd.batchqp import BatchQP
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    B = q.shape[1]
+    qp = BatchQP(n, m, A_p, A_i, P_cols, B, tdt, perm=perm, max_iter=max_iter)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype)).cuda()
+    qp.x.copy_(dev(x)); qp.y.copy_(dev(y)); qp.z.copy_(dev(z)); qp.Eprev.copy_(dev(Eprev))
+    qp.solve(dev(Pv), dev(Av), dev(q), dev(l), dev(u))
+    torch.cuda.synchronize()
+    f = lambda t: t.cpu().numpy()
+    return dict(x=f(qp.x), y=f(qp.y), z=f(qp.z), E=f(qp.Eprev), sol_x=f(qp.sol_x), sol_y=f(qp.sol_y),
+                status=f(qp.status), info=f(qp.info)), qp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gpu_qp_on_uprightmpc2_fixture(structure, dtype):
+    """The generic kernel on the N = 3 uprightmpc2 QP with the reference's KKT permutation: the fp64 run agrees
+    with the fp64 oracle to 1e-9, the fp32 run with the fp32 oracle (= the reference C, bit-pinned) to round-off."""
+    import osqp_table
+    g = golden("seq_iter50.npz")
+    idx = np.arange(100)
+    perm = structure["perm"]
+    A_p, A_i, Pv, Av, q, l, u = raw_uprightmpc2_qp(g, idx, np.float64)
+    Eprev = np.ones((39, len(idx)))
+    Eprev[36:] = g["pre_E3"][idx].T
+    args = (Pv, Av, q, l, u, g["pre_x"][idx].T, g["pre_y"][idx].T, g["pre_z"][idx].T, Eprev)
+    ref = osqp_table.solve(45, 39, A_p, A_i, list(range(45)), perm, *args, osqp_table.Settings(max_iter=50), dtype=dtype)
+    got, _ = _run_gpu_qp(45, 39, A_p, A_i, list(range(45)), perm, *args, dtype, 50)
+    if dtype == np.float64:
+        for k in ("x", "y", "z", "E", "sol_x", "sol_y"):
+            assert np.allclose(got[k], ref[k], rtol=1e-9, atol=1e-11, equal_nan=True), k
+        assert np.array_equal(got["status"], ref["status"])
+    else:
+        nbit = sum(int(np.array_equal(got[k], ref[k], equal_nan=True)) for k in ("x", "y", "z", "E", "sol_x"))
+        print("fp32 arrays bit-identical to the oracle: %d of 5;" % nbit, "max |dE| rel", np.max(np.abs(got["E"] / ref["E"] - 1)),
+              "max |dx|", np.max(np.abs(got["x"] - ref["x"])))
+        sx = np.maximum(1.0, np.abs(ref["sol_x"]))
+        assert np.nanmax(np.abs(got["sol_x"] - ref["sol_x"]) / sx) < 2e-3
+        assert np.allclose(got["E"], ref["E"], rtol=1e-5)
+        assert np.count_nonzero(got["status"] != ref["status"]) <= len(idx) // 8
+    if dtype == np.float64:
+        assert np.allclose(got["info"][0], ref["pri_res"], rtol=1e-6, atol=1e-12)
+    else:   # fp32 residuals of a converged iterate are round-off
+        assert np.allclose(got["info"][0], ref["pri_res"], rtol=1e-2, atol=3e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_getlin_and_plant_match_reference_fixture():
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    g = golden("planar_p5f.npz")
+    B = len(g["lin_u"])
+    for tdt, tol in ((torch.float64, 1e-13), (torch.float32, 2e-6)):
+        mpc = PlanarP5fMPC(B, tdt)
+        mpc.y[0] = torch.as_tensor(g["lin_sigma"]).to(mpc.y)
+        mpc.y[3] = torch.as_tensor(g["lin_phi"]).to(mpc.y)
+        y0 = np.random.default_rng(3).normal(size=(7, B))
+        y0[0], y0[3] = g["lin_sigma"], g["lin_phi"]
+        mpc.y.copy_(torch.as_tensor(y0).to(mpc.y))
+        u = torch.as_tensor(g["lin_u"]).to(mpc.y)
+        lin = mpc.linearise(u).cpu().numpy().astype(np.float64)
+        want = np.stack([g["lin_Ad"][:, 4, 3], g["lin_Ad"][:, 5, 3], g["lin_Bd"][:, 4], g["lin_Bd"][:, 5], g["lin_Bd"][:, 6]])
+        sc = np.maximum(np.abs(want), 1e-3)
+        assert np.max(np.abs(lin - want) / sc) < tol * 50, tdt
+        # assembled A values = the kron construction
+        st = mpc.st
+        Av = mpc.Av.cpu().numpy().astype(np.float64)
+        for k in (4, 9, 33):
+            A = np.zeros((st["m"], st["n"]))
+            for j in range(st["n"]):
+                for p in range(st["A_p"][j], st["A_p"][j + 1]):
+                    A[st["A_i"][p], j] = Av[p, k]
+            assert np.allclose(A, p5f_dense_A(10, g["lin_Ad"][k], g["lin_Bd"][k]), rtol=tol * 50, atol=tol)
+        # plant tick y += (Ad y + Bd u) dt, planar/mpc_osqp_p5f.py:176
+        mpc.L.umpcP5fStep(B, 0 if tdt == torch.float32 else 1, 1, 0.002, u.data_ptr(), mpc.y.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        y1 = mpc.y.cpu().numpy().astype(np.float64)
+        for k in range(B):
+            yk = y0[:, k] + (g["lin_Ad"][k] @ y0[:, k] + g["lin_Bd"][k] * g["lin_u"][k]) * 0.002
+            assert np.allclose(y1[:, k], yk, rtol=tol * 100, atol=tol * 10), (tdt, k)
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_loop_matches_oracle():
+    """Config 4 path: per tick getLin -> A -> one 50-iteration QP step -> plant; fp64 GPU vs the table oracle fed with
+    the GPU's own A values (so the comparison isolates the solver), warm-started tick to tick."""
+    import torch
+    import osqp_table
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    B = 24
+    mpc = PlanarP5fMPC(B, torch.float64)
+    rng = np.random.default_rng(20201119)
+    y0 = np.zeros((7, B))
+    y0[0] = rng.uniform(-0.1, 0.1, B)
+    y0[3] = rng.uniform(-0.1, 0.1, B)
+    mpc.y.copy_(torch.as_tensor(y0).cuda())
+    st = mpc.st
+    perm = mpc.qp.s.perm
+    x, y, z, E = np.zeros((87, B)), np.zeros((164, B)), np.zeros((164, B)), np.ones((164, B))
+    f = lambda t: t.cpu().numpy()
+    for ti in range(2, 6):
+        t = 0.002 * ti
+        mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * t))
+        Av = f(mpc.Av)
+        r = osqp_table.solve(87, 164, st["A_p"], st["A_i"], st["P_cols"], perm, f(mpc.Pv), Av, f(mpc.q), f(mpc.l),
+                             f(mpc.u), x, y, z, E, osqp_table.Settings(max_iter=50))
+        x, y, z, E = r["x"], r["y"], r["z"], r["E"]
+        mpc.tick(t)
+        torch.cuda.synchronize()
+        for name, mine, want in (("x", f(mpc.qp.x), x), ("y", f(mpc.qp.y), y), ("z", f(mpc.qp.z), z),
+                                 ("sol_x", f(mpc.qp.sol_x), r["sol_x"])):
+            assert np.allclose(mine, want, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(want).max())), (ti, name)
+        assert np.array_equal(f(mpc.qp.status), r["status"])
+    assert np.isfinite(f(mpc.y)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_v1_assembly_matches_reference_and_solves():
+    import torch
+    import osqp_table
+    from robobee3d_amd.batchqp import UprightMPCv1
+    g = golden("v1_qp.npz")
+    B = len(g["dt"])
+    # dt is a scalar argument of the reference: group fixture rows by their own dt -> run one robot batch per row
+    mpc = UprightMPCv1(B, 3, torch.float64, max_iter=400)
+    st = mpc.st
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a.T)).cuda()
+    for k in range(0, B, 7):
+        dt = float(g["dt"][k])
+        rows = np.full(B, k)
+        mpc.assemble(T(g["q0"][rows]), T(g["qdes"][rows]), T(g["Qf"][rows]), T(g["Rd"][rows]), T(g["smin"][rows]),
+                     T(g["smax"][rows]), dt, T(g["snom"][rows]), torch.as_tensor(g["vT0"][rows]).cuda())
+        torch.cuda.synchronize()
+        for name, mine in (("Pdata", mpc.Pv), ("Adata", mpc.Av), ("q", mpc.q), ("l", mpc.l), ("u", mpc.u)):
+            assert np.allclose(mine.cpu().numpy()[:, 0], g[name][k], rtol=1e-14, atol=1e-15), (k, name)
+    # solve: all robots take fixture row b with dt of row 0 (the solver does not care that dt is shared)
+    rows = np.arange(B)
+    dt = float(g["dt"][0])
+    x, uu = mpc.update(T(g["q0"]), T(g["qdes"]), T(g["Qf"]), T(g["Rd"]), T(g["smin"]), T(g["smax"]), dt,
+                       T(g["snom"]), torch.as_tensor(g["vT0"]).cuda())
+    torch.cuda.synchronize()
+    f = lambda t: t.cpu().numpy()
+    z = lambda r: np.zeros((r, B))
+    ref = osqp_table.solve(27, 27, st["A_p"], st["A_i"], st["P_cols"], mpc.qp.s.perm, f(mpc.Pv), f(mpc.Av), f(mpc.q),
+                           f(mpc.l), f(mpc.u), z(27), z(27), z(27), np.ones((27, B)), osqp_table.Settings(max_iter=400))
+    assert np.allclose(f(x), ref["sol_x"], rtol=1e-8, atol=1e-9, equal_nan=True)
+    assert np.array_equal(f(mpc.qp.status), ref["status"])
+    assert np.allclose(f(uu), ref["sol_x"][18:21], rtol=1e-8, atol=1e-9, equal_nan=True)
+    assert np.allclose(f(mpc.vT0), g["vT0"] + ref["sol_x"][18], rtol=1e-8, atol=1e-9, equal_nan=True)
