@@ -64,6 +64,70 @@ def cpu_baseline(args, plant_mode):
             "single_thread_value": n1 * Ks / dt1}
 
 
+def main_p5f(args):
+    """BASELINE configs[3]: one step = one tick of planar/mpc_osqp_p5f.py:157-176 for every
+    robot = getLin + A rebuild + one 50-iteration QP step (10 Ruiz passes, LDL' refactor) + the reference's plant
+    tick. Results are parity-unpinned in the reference (it never solves); tests/test_bqp.py checks the kernel
+    against the table oracle."""
+    import torch
+    import torch.distributed as dist
+    from robobee3d_amd import shard
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    rank, world, local_rank = shard.world()
+    dev = torch.device("cuda", local_rank)
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus
+        torch.cuda.set_device(local_rank)
+        shard.init("nccl", device=dev)
+    B = args.batch if args.batch != 65536 else 16384
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    mpc = PlanarP5fMPC(B, tdt, device=dev, max_iter=args.max_iter)
+    lo, _ = shard.robot_range(B, rank)
+    rng = np.random.default_rng(20201119)
+    pert = rng.uniform(-0.1, 0.1, (2, world * B))[:, lo:lo + B]       # sigma, phi per robot (SURVEY 8d config 4)
+    mpc.y[0] = torch.as_tensor(pert[0]).to(mpc.y)
+    mpc.y[3] = torch.as_tensor(pert[1]).to(mpc.y)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    ti = 2
+    for _ in range(args.warmup):
+        mpc.tick(0.002 * ti); ti += 1
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        mpc.tick(0.002 * ti); ti += 1
+    e1.record()
+    barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    s = mpc.qp.s
+    esz = 4 if args.dtype == "f32" else 8
+    # algorithmic bytes per robot-tick: iterates x, y, z read + written, state 7 + 7, nominal input 1
+    alg = (2 * (s.n + 2 * s.m) + 15) * esz
+    if rank == 0:
+        kern_ms = e0.elapsed_time(e1) / args.steps
+        print(json.dumps({
+            "metric": "closed-loop MPC steps/sec (QP+dyn)", "value": world * B * args.steps / elapsed, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: planar/mpc_osqp_p5f stroke-plane MPC, N=10 (n=87, m=164, "
+                                   "nnz(L)=%d), %d ADMM it, 10 Ruiz, LDL' refactor per tick + Euler plant tick" % (s.nnzL, args.max_iter),
+                       "robots_per_gpu": B, "global_batch": world * B, "horizon": 10,
+                       "parallelism": "robots sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": alg * B / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "bqp_solve_kernel", "kernel_ms": kern_ms, "alg_bytes_per_launch": alg * B},
+            "check": {"nonfinite_state_values": int((~torch.isfinite(mpc.y)).sum().item()),
+                      "status_solved_frac": float((mpc.qp.status > 0).float().mean().item())}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +143,9 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=0,
                     help="closed-loop steps carried by one kernel launch (0 = all K timed steps in one launch; "
                          "1 = one launch per step)")
+    ap.add_argument("--workload", default="uprightmpc2", choices=["uprightmpc2", "p5f"],
+                    help="uprightmpc2 = the headline metric (BASELINE configs[2]); p5f = BASELINE configs[3], the planar "
+                         "stroke-plane MPC (N = 10, n = 87, m = 164) on the general-structure solver, default batch 16384")
     ap.add_argument("--monte-carlo", action="store_true",
                     help="BASELINE configs[4]: per-robot inertia (controller + plant) and plant thrust gain, +-20 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,6 +153,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
 
+    if args.workload == "p5f":
+        return main_p5f(args)
     import torch
     import torch.distributed as dist
     from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions

@@ -281,6 +281,19 @@ int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src,
  * (Ad[4][3], Ad[5][3], Bd[4], Bd[5], Bd[6]); mode 1 additionally applies the reference's plant tick
  * y <- y + (Ad y + Bd u) dt (:176). y [7][B], u [B]; lin may be NULL in mode 1. */
 int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, void *lin, void *stream);
+/* UprightMPC2 at any horizon N (template/template_controllers.py:170-258; N = 3 is Parts 1-2's specialised path):
+ * assembly (updateConstraint :65-125, updateObjective :127-143 = uprightmpc2.c:121-207) and extraction (update2 /
+ * getAccDes :232-250 = uprightmpc2.c:253-269) around umpcQPSolve on the structure of initConstraint (:28-63).
+ *   state [18][B] (p, R column-major, dq), ref [9][B] (pdes, dpdes, sdes), T0 [B] in/out, actualT0 [B] or NULL
+ *   Pv [nx], q [nx], l, u [nc]  (nx = 15 N, nc = 13 N);  par [10][B] = (dt T0, dt s0[3], dt Btau[6]) for umpcQPGather
+ *   out [9][B] = (uquad[3], accdes[6]); T0 <- T0 + x[12 N]. */
+typedef struct {
+  double dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib[3];
+} umpcNParams;
+int umpcNAssemble(int B, int dtype, int N, const umpcNParams *p, const void *state, const void *ref, void *T0,
+                  const void *actualT0, void *Pv, void *q, void *l, void *u, void *par, void *stream);
+int umpcNExtract(int B, int dtype, int N, double dt, const void *state, const void *sol_x, void *T0, void *out,
+                 void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,12 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights",
            "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSolve", "umpcQPGather",
-           "umpcP5fStep"]
+           "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
+
+
+class NParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("dt", "g", "TtoWmax", "ws", "wds", "wpr", "wpf", "wvr", "wvf", "wthrust",
+                                          "wmom")] + [("Ib", C.c_double * 3)]
 
 
 class QPSettings(C.Structure):
@@ -139,6 +144,8 @@ def lib():
         L.umpcQPSolve.argtypes = [C.c_void_p] * 15
         L.umpcQPGather.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcP5fStep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4
+        L.umpcNAssemble.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(NParams)] + [C.c_void_p] * 10
+        L.umpcNExtract.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 5
         L.umpcLastStatus.restype = C.c_int
         _lib = L
     return _lib

@@ -297,3 +297,69 @@ class UprightMPCv1:
         self.snom = torch.cat([x[i * nq + 3:i * nq + 6] for i in range(N)], 0).clone()   # genqp.py:164
         self.vT0 = self.vT0 + uu[0]                                                       # genqp.py:165
         return x, uu
+
+
+# ---------------------------------------------------------------------------------------------------------
+# template/template_controllers.py UprightMPC2 at any horizon N
+# ---------------------------------------------------------------------------------------------------------
+def uprightmpc2_structure(N):
+    """initConstraint(N, nx, nc) (template/template_controllers.py:28-63): CSC pattern of A and, per entry, its
+    constant or the umpcNAssemble parameter row that scales it."""
+    from . import symbolic
+    A_p, A_i, A_tag = symbolic.build_A(N)
+    nx, nc = symbolic.dims(N)
+    cst, src = [], []
+    for tag in A_tag:
+        if tag[0] == 'c':
+            cst.append(tag[1]); src.append(-1)
+        elif tag[0] == 'dt':
+            cst.append(None); src.append(-1)          # filled with dt by the caller
+        elif tag[0] == 'T0dt':
+            cst.append(1.0); src.append(0)
+        elif tag[0] == 's0':
+            cst.append(1.0); src.append(1 + tag[1])
+        else:
+            cst.append(1.0); src.append(4 + tag[1])
+    return dict(N=N, n=nx, m=nc, A_p=A_p, A_i=A_i, P_cols=list(range(nx)), cst=cst, src=np.array(src, np.int32))
+
+
+class UprightMPC2N:
+    """B copies of template_controllers.UprightMPC2(N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib)
+    (:170-258) for any horizon N >= 2, with the embedded-C step (fixed max_iter ADMM iterations) as the solve.
+    update(state, ref, actualT0=None) -> out [9, B] = (uquad, accdes); T0 is carried per robot."""
+
+    def __init__(self, B, N, dt=5.0, g=9.81e-3, TtoWmax=2.0, ws=1e1, wds=1e3, wpr=1.0, wpf=5.0, wvr=1e3, wvf=2e3,
+                 wthrust=1e-1, wmom=1e-2, Ib=(3333.0, 3333.0, 1000.0), dtype=torch.float32, device="cuda", **settings):
+        st = uprightmpc2_structure(N)
+        self.st, self.N, self.B, self.dtype = st, N, int(B), dtype
+        self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, **settings)
+        dev = self.qp.device
+        self.dev, self.L = dev, self.qp.L
+        self.prm = _lib.NParams(dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, (C.c_double * 3)(*Ib))
+        self.cst = torch.as_tensor(np.array([dt if c is None else c for c in st["cst"]], np.float64)).to(dev, dtype)
+        self.src = torch.as_tensor(st["src"]).to(dev)
+        z = lambda r: torch.zeros((r, self.B), dtype=dtype, device=dev)
+        self.Pv, self.q, self.l, self.u = z(st["n"]), z(st["n"]), z(st["m"]), z(st["m"])
+        self.Av, self.par, self.out = z(len(st["A_i"])), z(10), z(9)
+        self.T0 = torch.zeros(self.B, dtype=dtype, device=dev)
+
+    def assemble(self, state, ref, actualT0=None):
+        self.qp._chk(state, 18, "state")
+        self.qp._chk(ref, 9, "ref")
+        stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        rc = self.L.umpcNAssemble(self.B, _DT[self.dtype], self.N, C.byref(self.prm), _ptr(state), _ptr(ref), _ptr(self.T0),
+                                  _ptr(actualT0), _ptr(self.Pv), _ptr(self.q), _ptr(self.l), _ptr(self.u), _ptr(self.par),
+                                  stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        self.qp.gather(self.cst, self.src, self.par, self.Av)
+
+    def update(self, state, ref, actualT0=None):
+        self.assemble(state, ref, actualT0)
+        sol_x, _, _ = self.qp.solve(self.Pv, self.Av, self.q, self.l, self.u)
+        stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        rc = self.L.umpcNExtract(self.B, _DT[self.dtype], self.N, float(self.prm.dt), _ptr(state), _ptr(sol_x),
+                                 _ptr(self.T0), _ptr(self.out), stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
+        return self.out

@@ -394,6 +394,99 @@ __global__ void p5f_kernel(int B, int mode, T dt, const T *__restrict__ u, T *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// uprightmpc2 at any horizon N: the assembly (template/template_controllers.py:65-143 = uprightmpc2.c:121-207)
+// and the extraction (template_controllers.py:232-250 = uprightmpc2.c:253-269) around umpcQPSolve. Row layout
+// of x: [y_1..y_N (6 each) | dy_1..dy_N | u_0..u_{N-1} (3 each)]; rows of A: 6N + 6N dynamics, N thrust rows.
+// par rows (for umpcQPGather): 0 = dt*T0, 1..3 = dt*s0, 4..9 = dt*Btau (column-major 3x2).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct NArgs {
+  int B, N;
+  T dt, g, Tmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ibi[3];
+};
+
+template <typename T>
+__global__ void umpcn_assemble_kernel(NArgs<T> a, const T *__restrict__ state, const T *__restrict__ ref, T *T0io,
+                                      const T *actualT0, T *Pv, T *q, T *l, T *u, T *par) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const size_t B = (size_t)a.B;
+  const int N = a.N, NYc = 6, NUc = 3;
+#define ST(i) state[(size_t)(i) * B + b]
+#define O(arr, i) arr[(size_t)(i) * B + b]
+  T T0 = T0io[b];
+  if (actualT0) { const T t = actualT0[b]; if (t >= T(0)) T0 = t; }   // template_controllers.py:253-255
+  T0io[b] = T0;
+  T R0[9], dq0[6], p0[3];
+  for (int i = 0; i < 3; ++i) p0[i] = ST(i);
+  for (int i = 0; i < 9; ++i) R0[i] = ST(3 + i);
+  for (int i = 0; i < 6; ++i) dq0[i] = ST(12 + i);
+  const T dt = a.dt;
+  T s0[3], ds0[3], Btau[6], y0[6], dy0[6], y1[6], ydes[6], dydes[6];
+  for (int r = 0; r < 3; ++r) {
+    s0[r] = R0[6 + r];
+    ds0[r] = -(R0[r] * (-dq0[4]) + R0[r + 3] * dq0[3]);
+    Btau[r] = -(R0[r + 3] * a.Ibi[0]);
+    Btau[3 + r] = -(R0[r] * (-a.Ibi[1]));
+  }
+  for (int i = 0; i < 3; ++i) {
+    y0[i] = p0[i]; y0[3 + i] = s0[i];
+    dy0[i] = dq0[i]; dy0[3 + i] = ds0[i];
+    ydes[i] = O(ref, i); ydes[3 + i] = O(ref, 6 + i);
+    dydes[i] = O(ref, 3 + i); dydes[3 + i] = T(0);
+  }
+  const T c0[6] = {T(0), T(0), -a.g, T(0), T(0), T(0)};
+  for (int i = 0; i < NYc; ++i) y1[i] = y0[i] + dt * dy0[i];
+  const int neq = 2 * N * NYc;
+  for (int i = 0; i < N * NYc; ++i) { const T v = i < NYc ? -y1[i] : T(0); O(l, i) = v; O(u, i) = v; }
+  for (int k = 0; k < N; ++k)
+    for (int i = 0; i < NYc; ++i) {
+      T v;
+      if (k == 0) v = -dy0[i] - dt * (i < 3 ? T0 * y0[i + 3] : T(0)) - dt * c0[i];
+      else if (k == 1) v = -dt * (i < 3 ? T0 * y1[i + 3] : T(0)) - dt * c0[i];
+      else v = -dt * c0[i];
+      O(l, NYc * (N + k) + i) = v; O(u, NYc * (N + k) + i) = v;
+    }
+  for (int k = 0; k < N; ++k) { O(l, neq + k) = -T0; O(u, neq + k) = a.Tmax - T0; }
+  O(par, 0) = dt * T0;
+  for (int i = 0; i < 3; ++i) O(par, 1 + i) = dt * s0[i];
+  for (int i = 0; i < 6; ++i) O(par, 4 + i) = dt * Btau[i];
+  for (int k = 0; k < N; ++k) {
+    for (int i = 0; i < NYc; ++i) {
+      const T wy = i < 3 ? (k == N - 1 ? a.wpf : a.wpr) : a.ws;
+      const T wd = i < 3 ? (k == N - 1 ? a.wvf : a.wvr) : a.wds;
+      O(Pv, k * NYc + i) = wy; O(q, k * NYc + i) = -wy * ydes[i];
+      O(Pv, N * NYc + k * NYc + i) = wd; O(q, N * NYc + k * NYc + i) = -wd * dydes[i];
+    }
+    for (int i = 0; i < NUc; ++i) {
+      O(Pv, 2 * N * NYc + k * NUc + i) = i == 0 ? a.wthrust : a.wmom;
+      O(q, 2 * N * NYc + k * NUc + i) = T(0);
+    }
+  }
+}
+
+template <typename T>
+__global__ void umpcn_extract_kernel(int Bn, int N, T dt, const T *__restrict__ state, const T *__restrict__ sol_x,
+                                     T *T0io, T *out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bn) return;
+  const size_t B = (size_t)Bn;
+  T R0[9], dq0[6], dy1[6];
+  for (int i = 0; i < 9; ++i) R0[i] = ST(3 + i);
+  for (int i = 0; i < 6; ++i) dq0[i] = ST(12 + i);
+  for (int i = 0; i < 6; ++i) dy1[i] = O(sol_x, 6 * N + i);
+  const T T0 = T0io[b] + O(sol_x, 12 * N);
+  T0io[b] = T0;
+  O(out, 0) = T0; O(out, 1) = O(sol_x, 12 * N + 1); O(out, 2) = O(sol_x, 12 * N + 2);
+  const T rx = (R0[0] * dy1[3] + R0[1] * dy1[4]) + R0[2] * dy1[5];
+  const T ry = (R0[3] * dy1[3] + R0[4] * dy1[4]) + R0[5] * dy1[5];
+  const T dq1[6] = {dy1[0], dy1[1], dy1[2], -ry, rx, T(0)};
+  for (int i = 0; i < 6; ++i) O(out, 3 + i) = (dq1[i] - dq0[i]) / dt;
+#undef ST
+#undef O
+}
+
 struct qp_batch {
   int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows;
   umpcQPSettings st;
@@ -426,6 +519,18 @@ int check_launch(const char *what) {
   }
   return 0;
 }
+
+template <typename T>
+NArgs<T> make_nargs(int B, int N, const umpcNParams *p) {
+  NArgs<T> a;
+  a.B = B; a.N = N;
+  a.dt = T(p->dt); a.g = T(p->g); a.Tmax = T(p->TtoWmax * p->g);
+  a.ws = T(p->ws); a.wds = T(p->wds); a.wpr = T(p->wpr); a.wpf = T(p->wpf); a.wvr = T(p->wvr); a.wvf = T(p->wvf);
+  a.wthrust = T(p->wthrust); a.wmom = T(p->wmom);
+  for (int i = 0; i < 3; ++i) a.Ibi[i] = T(1) / T(p->Ib[i]);
+  return a;
+}
+
 
 }  // namespace
 
@@ -550,6 +655,39 @@ int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, v
     hipLaunchKernelGGL(p5f_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, dt, (const double *)u,
                        (double *)y, (double *)lin);
   return check_launch("umpcP5fStep");
+}
+
+int umpcNAssemble(int B, int dtype, int N, const umpcNParams *p, const void *state, const void *ref, void *T0,
+                  const void *actualT0, void *Pv, void *q, void *l, void *u, void *par, void *stream) {
+  if (B <= 0 || N < 2 || !p || !state || !ref || !T0 || !Pv || !q || !l || !u || !par) {
+    umpc_set_error("umpcNAssemble: bad argument");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((B + 255) / 256), block(256);
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL(umpcn_assemble_kernel<float>, grid, block, 0, s, make_nargs<float>(B, N, p), (const float *)state,
+                       (const float *)ref, (float *)T0, (const float *)actualT0, (float *)Pv, (float *)q, (float *)l,
+                       (float *)u, (float *)par);
+  else
+    hipLaunchKernelGGL(umpcn_assemble_kernel<double>, grid, block, 0, s, make_nargs<double>(B, N, p),
+                       (const double *)state, (const double *)ref, (double *)T0, (const double *)actualT0, (double *)Pv,
+                       (double *)q, (double *)l, (double *)u, (double *)par);
+  return check_launch("umpcNAssemble");
+}
+
+int umpcNExtract(int B, int dtype, int N, double dt, const void *state, const void *sol_x, void *T0, void *out,
+                 void *stream) {
+  if (B <= 0 || N < 2 || !state || !sol_x || !T0 || !out) { umpc_set_error("umpcNExtract: bad argument"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((B + 255) / 256), block(256);
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL(umpcn_extract_kernel<float>, grid, block, 0, s, B, N, (float)dt, (const float *)state,
+                       (const float *)sol_x, (float *)T0, (float *)out);
+  else
+    hipLaunchKernelGGL(umpcn_extract_kernel<double>, grid, block, 0, s, B, N, dt, (const double *)state,
+                       (const double *)sol_x, (double *)T0, (double *)out);
+  return check_launch("umpcNExtract");
 }
 
 }  // extern "C"

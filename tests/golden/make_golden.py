@@ -144,12 +144,12 @@ def closed_loop(mods):
           % (len(log["t"]), len(ctrl.calls), fire[0], np.round(y[-1, :3], 4), err, eff))
 
 
-def assembly_fp64(mods):
+def assembly_fp64(mods, N=3, fname="assembly_fp64.npz"):
     """F4: the pure-Python fp64 assembly for the inputs of sequence A (pins the
-    '#OK' identities of template_controllers.py:321-326)."""
+    '#OK' identities of template_controllers.py:321-326). N = 5 pins the general-horizon path."""
     genqp, tc, ft, um2 = mods
     seq = np.load(os.path.join(HERE, "seq_iter50.npz"))
-    N, ny, nu = 3, 6, 3
+    ny, nu = 6, 3
     nx, nc = N * (2 * ny + nu), 2 * N * ny + N
     A, P = tc.initConstraint(N, nx, nc)
     Ibi = np.diag(1 / genqp.Ib.diagonal())
@@ -174,9 +174,9 @@ def assembly_fp64(mods):
         Pdata, q = tc.updateObjective(N, *Wts, ydes, dydes)
         for key, v in zip(out, (l, u, q, Pdata, A.data.copy(), Axidx)):
             out[key].append(np.array(v))
-    np.savez_compressed(os.path.join(HERE, "assembly_fp64.npz"), n=np.int32(n),
+    np.savez_compressed(os.path.join(HERE, fname), n=np.int32(n),
                         A_indices=A.indices, A_indptr=A.indptr, **{k: np.stack(v) for k, v in out.items()})
-    print("assembly_fp64.npz:", n, "cases; A.nnz =", A.nnz)
+    print(fname, n, "cases; A.nnz =", A.nnz)
 
 
 def plant(mods):
@@ -338,6 +338,7 @@ if __name__ == "__main__":
         wl_step()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "qp":
+        assembly_fp64(import_reference_python(), 5, "assembly_fp64_N5.npz")
         v1_qp(import_reference_python())
         planar_p5f()
         sys.exit(0)
@@ -351,5 +352,6 @@ if __name__ == "__main__":
     plant(mods)
     tasks(mods)
     wl_step()
+    assembly_fp64(mods, 5, "assembly_fp64_N5.npz")
     v1_qp(mods)
     planar_p5f()

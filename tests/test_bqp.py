@@ -291,3 +291,86 @@ def test_gpu_v1_assembly_matches_reference_and_solves():
     assert np.array_equal(f(mpc.qp.status), ref["status"])
     assert np.allclose(f(uu), ref["sol_x"][18:21], rtol=1e-8, atol=1e-9, equal_nan=True)
     assert np.allclose(f(mpc.vT0), g["vT0"] + ref["sol_x"][18], rtol=1e-8, atol=1e-9, equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------------------
+# UprightMPC2 at a general horizon N (template/template_controllers.py:170-258)
+# ------------------------------------------------------------------------------------------------------
+def test_general_horizon_structure_is_initConstraint():
+    from robobee3d_amd import symbolic
+    from robobee3d_amd.batchqp import uprightmpc2_structure
+    g = golden("assembly_fp64_N5.npz")
+    st = uprightmpc2_structure(5)
+    assert st["A_p"] == g["A_indptr"].tolist() and st["A_i"] == g["A_indices"].tolist()
+    assert symbolic.ax_idx(5) == g["Axidx"][0].tolist()
+    assert (st["n"], st["m"]) == (75, 65)
+
+
+def _state_ref_from_seq(seq, idx, dtype):
+    st = np.zeros((18, len(idx)), dtype)
+    st[0:3] = seq["p0"][idx].T
+    st[3:12] = seq["R0"][idx].transpose(2, 1, 0).reshape(9, -1)     # column-major
+    st[12:18] = seq["dq0"][idx].T
+    # (vstack of transposed views comes back Fortran-ordered: force the [rows][B] layout)
+    ref = np.ascontiguousarray(np.vstack((seq["pdes"][idx].T, seq["dpdes"][idx].T, seq["sdes"][idx].T)), dtype)
+    T0 = np.where(seq["actualT0"][idx] >= 0, seq["actualT0"][idx], seq["pre_T0"][idx]).astype(dtype)
+    return st, ref, T0
+
+
+@pytest.mark.gpu
+def test_gpu_general_horizon_assembly_and_step():
+    import torch
+    import osqp_table
+    from robobee3d_amd.batchqp import UprightMPC2N
+    g = golden("assembly_fp64_N5.npz")
+    seq = golden("seq_iter50.npz")
+    idx = np.arange(int(g["n"]))
+    st, ref, T0 = _state_ref_from_seq(seq, idx, np.float64)
+    mpc = UprightMPC2N(len(idx), 5, dtype=torch.float64)
+    mpc.T0.copy_(torch.as_tensor(T0).cuda())
+    S, R = torch.as_tensor(st).cuda(), torch.as_tensor(ref).cuda()
+    mpc.assemble(S, R)
+    torch.cuda.synchronize()
+    f = lambda t: t.cpu().numpy()
+    for name, mine in (("l", mpc.l), ("u", mpc.u), ("q", mpc.q), ("Px", mpc.Pv), ("Adata", mpc.Av)):
+        assert np.allclose(f(mine).T, g[name], rtol=1e-13, atol=1e-15), name
+    out = f(mpc.update(S, R)).copy()
+    z = lambda r: np.zeros((r, len(idx)))
+    s = mpc.st
+    r = osqp_table.solve(75, 65, s["A_p"], s["A_i"], s["P_cols"], mpc.qp.s.perm, g["Px"].T, g["Adata"].T, g["q"].T,
+                         g["l"].T, g["u"].T, z(75), z(65), z(65), np.ones((65, len(idx))), osqp_table.Settings(max_iter=50))
+    assert np.allclose(f(mpc.qp.sol_x), r["sol_x"], rtol=1e-8, atol=1e-10, equal_nan=True)
+    ok = r["status"] > 0
+    assert np.allclose(out[0][ok], (T0 + r["sol_x"][60])[ok], rtol=1e-8, atol=1e-12)
+    assert np.allclose(out[1:3][:, ok], r["sol_x"][61:63][:, ok], rtol=1e-8, atol=1e-10)
+    # getAccDes (template_controllers.py:244-250) restated
+    e3h = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 0.0]])
+    for k in np.nonzero(ok)[0][:16]:
+        dy1 = r["sol_x"][30:36, k]
+        R0 = seq["R0"][k].astype(np.float64)
+        dq1 = np.hstack((dy1[:3], e3h @ R0.T @ dy1[3:6]))
+        assert np.allclose(out[3:, k], (dq1 - seq["dq0"][k]) / 5.0, rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.gpu
+def test_gpu_general_path_at_N3_agrees_with_the_specialised_kernel():
+    """The same controller step through both product paths (table-driven kernel vs the generated straight-line +
+    assembly kernel), fp32, own orderings: outputs agree within the fp32 parity band of test_gpu_parity.py."""
+    import torch
+    from robobee3d_amd.batch import BatchUprightMPC
+    from robobee3d_amd.batchqp import UprightMPC2N
+    seq = golden("seq_iter50.npz")
+    idx = np.arange(128)
+    st, ref, T0 = _state_ref_from_seq(seq, idx, np.float32)
+    S, R = torch.as_tensor(st).cuda(), torch.as_tensor(ref).cuda()
+    gen = UprightMPC2N(len(idx), 3, dtype=torch.float32)
+    gen.T0.copy_(torch.as_tensor(T0).cuda())
+    o1 = gen.update(S, R).cpu().numpy()
+    spec = BatchUprightMPC(len(idx), torch.float32)
+    spec.set_state(st, ref)
+    spec.ctrl[123] = torch.as_tensor(T0).cuda()
+    spec.update()
+    o2 = spec.out.cpu().numpy()
+    assert np.all(np.abs(o1[0] - o2[0]) <= 3e-5)
+    assert np.all(np.abs(o1[1:3] - o2[1:3]) <= np.maximum(2e-2, 1e-3 * np.abs(o2[1:3])))
+    assert np.all(np.abs(o1[3:] - o2[3:]) <= 3e-5)
