@@ -263,6 +263,11 @@ void umpcQPDefaultSettings(umpcQPSettings *s);
 void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpcQPSettings *settings);
 void umpcQPDestroy(void *h);
 int umpcQPSetMaxIter(void *h, int max_iter);
+/* For the structures known at build time (robobee3d_amd/codegen_qp.py: planar p5f N = 10, v1 N = 3, UprightMPC2
+ * N = 5) umpcQPCreate selects a generated straight-line kernel (same arithmetic, literal indices). UseTables(1)
+ * forces the table-driven kernel; returns the index of the specialisation or -1. KernelName: its name or "tables". */
+int umpcQPUseTables(void *h, int on);
+const char *umpcQPKernelName(void *h);
 /* All arrays are DEVICE pointers, SoA [rows][B] of the handle's dtype:
  *   Pv [nnzP], Av [nnzA] (CSC order), q [n], l, u [m]   raw problem data                     in
  *   x [n], y [m], z [m]   OSQP's (scaled) iterates, warm start                                in/out

@@ -26,7 +26,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights",
            "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel",
-           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSolve", "umpcQPGather",
+           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPUseTables", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
            "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
 
 
@@ -75,13 +75,14 @@ class UprightMPC_t(C.Structure):
 def build(force=False, verbose=False):
     """Generate umpc_gen.h / umpc_admm_asm.h and compile the HIP library for gfx950 (works without a GPU).
     One object per translation unit (recompiled only when it or its headers changed), then one link."""
-    from . import asmgen, codegen
+    from . import asmgen, codegen, codegen_qp
     gen, _ = codegen.write()
     gasm, _ = asmgen.write()
+    gqp, _ = codegen_qp.write()
     hdr = os.path.join(ROOT, "include", "umpc_mi355x.h")
     csrc = os.path.join(HERE, "csrc")
     units = [(SRC, [gen, gasm, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
-             (SRC_BQP, [hdr, os.path.join(csrc, "umpc_err.h")])]
+             (SRC_BQP, [hdr, gqp, os.path.join(csrc, "umpc_err.h")])]
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs, relink = [], force or not os.path.exists(SO_PATH)
     procs = []
@@ -141,6 +142,9 @@ def lib():
         L.umpcQPCreate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(QPSettings)]
         L.umpcQPDestroy.argtypes = [C.c_void_p]
         L.umpcQPSetMaxIter.argtypes = [C.c_void_p, C.c_int]
+        L.umpcQPUseTables.argtypes = [C.c_void_p, C.c_int]
+        L.umpcQPKernelName.argtypes = [C.c_void_p]
+        L.umpcQPKernelName.restype = C.c_char_p
         L.umpcQPSolve.argtypes = [C.c_void_p] * 15
         L.umpcQPGather.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcP5fStep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4

@@ -59,6 +59,14 @@ class BatchQP:
         if h:
             self.L.umpcQPDestroy(h)
 
+    def use_tables(self, on=True):
+        """Force the table-driven kernel (True) or allow the build-time specialisation (False); returns its index or -1."""
+        return self.L.umpcQPUseTables(self.h, int(bool(on)))
+
+    @property
+    def kernel_name(self):
+        return self.L.umpcQPKernelName(self.h).decode()
+
     def reset(self):
         """Cold start (x = y = z = 0) and E = 1, the state of a freshly set-up solver."""
         for t in (self.x, self.y, self.z):

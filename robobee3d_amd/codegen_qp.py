@@ -1,0 +1,264 @@
+"""Straight-line specialisations of the general batch QP kernel (csrc/umpc_bqp.hip) for structures known at build
+time: every index of the table-driven kernel becomes a literal, every per-robot word a scalar the compiler can
+keep in a register or a fixed scratch slot and schedule freely. Same arithmetic, same order as
+`bqp_solve_kernel` (so fp64 results are bit-identical to the table-driven path; tests/test_bqp.py checks it).
+
+Emits csrc/umpc_bqp_gen.h: one `bqp_fixed_<name>` device function + kernel per structure and a registry keyed by
+the FNV-1a hash of the structure's table blob; umpcQPCreate picks the specialisation when the blob it is handed
+matches (umpcQPUseTables switches back). Built-in structures: planar p5f N = 10, the v1
+template QP N = 3, UprightMPC2 N = 5.
+"""
+import os
+
+from . import batchqp, qpstruct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "csrc", "umpc_bqp_gen.h")
+
+
+def fnv1a(words):
+    h = 0xcbf29ce484222325
+    for w in words:
+        v = int(w) & 0xffffffff
+        for k in range(4):
+            h ^= (v >> (8 * k)) & 0xff
+            h = (h * 0x100000001b3) & 0xffffffffffffffff
+    return h
+
+
+def builtin_structures():
+    out = []
+    st = batchqp.p5f_structure(10)
+    out.append(("p5f10", qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])))
+    st = batchqp.v1_structure(3)
+    out.append(("v1n3", qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])))
+    st = batchqp.uprightmpc2_structure(5)
+    out.append(("umpc2n5", qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])))
+    return out
+
+
+def emit_structure(name, s):
+    n, m, nk = s.n, s.m, s.nk
+    t = s.tables
+    pinv, pidx, A_p, A_i = t["pinv"], t["pidx"], t["A_p"], t["A_i"]
+    Ar_p, Ar_j, Ar_k = t["Ar_p"], t["Ar_j"], t["Ar_k"]
+    L_p, L_i, Lr_p, Lr_j, Lr_k = t["L_p"], t["L_i"], t["Lr_p"], t["Lr_j"], t["Lr_k"]
+    o = []
+    E = o.append
+    E("template <typename T>")
+    E("__device__ __forceinline__ void bqp_fixed_%s(const QPArgs<T> &a, const int b) {" % name)
+    E("  const size_t B = (size_t)a.B;")
+    E("#define IN(arr, i) (arr)[(size_t)(i) * B + b]")
+    E("  const T sigma = a.sigma, alpha = a.alpha, oma = T(1.0) - a.alpha;")
+    if s.nnzP:
+        E("  T Ps[%d];" % s.nnzP)
+    E("  T As[%d], qs[%d], D[%d], Ev[%d], Dt[%d], Et[%d], rho[%d], rinv[%d], ls[%d], us[%d];" %
+      (s.nnzA, n, n, m, n, m, m, m, m, m))
+    E("  T Lx[%d], DI[%d], yv[%d], w[%d], x[%d], y[%d], z[%d], xp[%d], dy[%d], t3[%d], t1[%d];" %
+      (s.nnzL, nk, nk, nk, n, m, m, n, m, m, n))
+    for k in range(s.nnzP):
+        E("  Ps[%d] = IN(a.Pv, %d);" % (k, k))
+    for k in range(s.nnzA):
+        E("  As[%d] = IN(a.Av, %d);" % (k, k))
+    for j in range(n):
+        E("  qs[%d] = IN(a.q, %d); D[%d] = T(1.0); x[%d] = IN(a.x, %d);" % (j, j, j, j, j))
+    E("  const T rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);")
+    for i in range(m):
+        E("  { const T e = IN(a.Eprev, %d); qp_classify(IN(a.l, %d) * e, IN(a.u, %d) * e, a.rho, rho_eq, rho[%d], rinv[%d]); "
+          "Ev[%d] = T(1.0); y[%d] = IN(a.y, %d); z[%d] = IN(a.z, %d); }" % (i, i, i, i, i, i, i, i, i, i))
+    # ---- Ruiz
+    E("  T c = T(1.0);")
+    E("  for (int pass = 0; pass < a.scaling; ++pass) {")
+    for j in range(n):
+        terms = "T(0.0)"
+        dP = "qmax(qabs(Ps[%d]), T(0.0))" % pidx[j] if pidx[j] >= 0 else "T(0.0)"
+        for p in range(A_p[j], A_p[j + 1]):
+            terms = "qmax(qabs(As[%d]), %s)" % (p, terms)
+        E("    Dt[%d] = T(1.0) / qsqrt(limit_scaling(qmax(%s, %s)));" % (j, dP, terms))
+    for i in range(m):
+        terms = "T(0.0)"
+        for p in range(Ar_p[i], Ar_p[i + 1]):
+            terms = "qmax(qabs(As[%d]), %s)" % (Ar_k[p], terms)
+        E("    Et[%d] = T(1.0) / qsqrt(limit_scaling(%s));" % (i, terms))
+    E("    T qn = T(0.0), csum = T(0.0);")
+    for j in range(n):
+        if pidx[j] >= 0:
+            E("    { T pv = Ps[%d]; pv *= Dt[%d]; pv *= Dt[%d]; Ps[%d] = pv; csum += qabs(pv); }" % (pidx[j], j, j, pidx[j]))
+        else:
+            E("    csum += T(0.0);")
+        for p in range(A_p[j], A_p[j + 1]):
+            E("    { T v = As[%d]; v *= Et[%d]; v *= Dt[%d]; As[%d] = v; }" % (p, A_i[p], j, p))
+        E("    { const T qv = qs[%d] * Dt[%d]; qs[%d] = qv; qn = qmax(qabs(qv), qn); D[%d] = Dt[%d] * D[%d]; }" % (j, j, j, j, j, j))
+    for i in range(m):
+        E("    Ev[%d] = Et[%d] * Ev[%d];" % (i, i, i))
+    E("    T ct = csum / T(%d);" % n)
+    E("    qn = limit_scaling(qn); ct = qmax(ct, qn); ct = limit_scaling(ct); ct = T(1.0) / ct;")
+    for k in range(s.nnzP):
+        E("    Ps[%d] *= ct;" % k)
+    for j in range(n):
+        E("    qs[%d] *= ct;" % j)
+    E("    c *= ct;")
+    E("  }")
+    E("  const T cinv = T(1.0) / c;")
+    for i in range(m):
+        E("  ls[%d] = IN(a.l, %d) * Ev[%d]; us[%d] = IN(a.u, %d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, i, i, i, i))
+    # ---- factor
+    for k in range(nk):
+        E("  yv[%d] = T(0.0);" % k)
+    E("  int fail = 0;")
+    for op in s.factor_ops:
+        k = op["k"]
+        for (bb, p) in op["init"]:
+            E("  yv[%d] = As[%d];" % (bb, s.K_src[p][1]))
+        orig = s.perm[k]
+        if orig < n:
+            dk = "Ps[%d] + sigma" % pidx[orig] if pidx[orig] >= 0 else "sigma"
+        else:
+            dk = "-rinv[%d]" % (orig - n)
+        E("  { T dk = %s;" % dk)
+        for (cidx, upd, new) in op["elim"]:
+            E("    { const T yc = yv[%d];" % cidx)
+            for (j, row) in upd:
+                E("      yv[%d] -= Lx[%d] * yc;" % (row, j))
+            E("      const T lv = yc * DI[%d]; Lx[%d] = lv; dk -= yc * lv; yv[%d] = T(0.0); }" % (cidx, new, cidx))
+        E("    if (dk == T(0.0)) fail = 1;")
+        E("    DI[%d] = T(1.0) / dk; }" % k)
+    # ---- ADMM
+    for j in range(n):
+        E("  xp[%d] = x[%d];" % (j, j))
+    for i in range(m):
+        E("  dy[%d] = T(0.0);" % i)
+    E("#pragma nounroll")
+    E("  for (int it = 0; it < a.max_iter; ++it) {")
+    for j in range(n):
+        E("    xp[%d] = x[%d]; w[%d] = sigma * xp[%d] - qs[%d];" % (j, j, pinv[j], j, j))
+    for i in range(m):
+        E("    t3[%d] = z[%d] - rinv[%d] * y[%d]; w[%d] = t3[%d];" % (i, i, i, i, pinv[n + i], i))
+    for r in range(nk):
+        for p in range(Lr_p[r], Lr_p[r + 1]):
+            E("    w[%d] -= Lx[%d] * w[%d];" % (r, Lr_k[p], Lr_j[p]))
+    for r in range(nk):
+        E("    w[%d] *= DI[%d];" % (r, r))
+    for r in range(nk - 1, -1, -1):
+        for j in range(L_p[r], L_p[r + 1]):
+            E("    w[%d] -= Lx[%d] * w[%d];" % (r, j, L_i[j]))
+    for j in range(n):
+        E("    x[%d] = alpha * w[%d] + oma * xp[%d];" % (j, pinv[j], j))
+    for i in range(m):
+        E("    { const T zt = t3[%d] + rinv[%d] * w[%d]; T zn = alpha * zt + oma * z[%d] + rinv[%d] * y[%d]; "
+          "zn = qmin(qmax(zn, ls[%d]), us[%d]); const T d = rho[%d] * (alpha * zt + oma * z[%d] - zn); z[%d] = zn; "
+          "dy[%d] = d; y[%d] = y[%d] + d; }" % (i, i, pinv[n + i], i, i, i, i, i, i, i, i, i, i, i))
+    E("  }")
+    # ---- residuals
+    E("  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);")
+    for i in range(m):
+        E("  { T acc = T(0.0);")
+        for p in range(Ar_p[i], Ar_p[i + 1]):
+            E("    acc += As[%d] * x[%d];" % (Ar_k[p], Ar_j[p]))
+        E("    t3[%d] = acc; const T einv = T(1.0) / Ev[%d]; pri_res = qmax(pri_res, qabs(einv * (acc - z[%d]))); "
+          "nz = qmax(nz, qabs(einv * z[%d])); nAx = qmax(nAx, qabs(einv * acc)); }" % (i, i, i, i))
+    E("  T dua_res = T(0.0), nq = T(0.0), nAty = T(0.0), nPx = T(0.0);")
+    for j in range(n):
+        E("  { T px = T(0.0);%s T aty = T(0.0);" % (" px += Ps[%d] * x[%d];" % (pidx[j], j) if pidx[j] >= 0 else ""))
+        for p in range(A_p[j], A_p[j + 1]):
+            E("    aty += As[%d] * y[%d];" % (p, A_i[p]))
+        E("    const T dinv = T(1.0) / D[%d]; dua_res = qmax(dua_res, qabs(dinv * ((qs[%d] + px) + aty))); "
+          "nq = qmax(nq, qabs(dinv * qs[%d])); nAty = qmax(nAty, qabs(dinv * aty)); nPx = qmax(nPx, qabs(dinv * px)); }" % (j, j, j))
+    E("  dua_res = cinv * dua_res;")
+    E("  const T dual_rel = qmax(qmax(nq, nAty), nPx) * cinv, prim_rel = qmax(nz, nAx);")
+    E("  T norm_dy = T(0.0), ineq_lhs = T(0.0);")
+    for i in range(m):
+        E("  { T d = dy[%d]; const bool up = (double)us[%d] > QP_INFTY * QP_MIN_SCALING, lo = (double)ls[%d] < -QP_INFTY * QP_MIN_SCALING; "
+          "if (up) d = lo ? T(0.0) : qmin(d, T(0.0)); else if (lo) d = qmax(d, T(0.0)); dy[%d] = d; "
+          "norm_dy = qmax(norm_dy, qabs(d * Ev[%d])); ineq_lhs += us[%d] * qmax(d, T(0.0)) + ls[%d] * qmin(d, T(0.0)); }" %
+          (i, i, i, i, i, i, i))
+    E("  T nAtdy = T(0.0);")
+    for j in range(n):
+        E("  { T acc = T(0.0);")
+        for p in range(A_p[j], A_p[j + 1]):
+            E("    acc += As[%d] * dy[%d];" % (p, A_i[p]))
+        E("    nAtdy = qmax(nAtdy, qabs(acc * (T(1.0) / D[%d]))); }" % j)
+    E("  T norm_dx = T(0.0), qdx = T(0.0), nPdx = T(0.0);")
+    for j in range(n):
+        E("  { const T dx = x[%d] - xp[%d]; t1[%d] = dx; norm_dx = qmax(norm_dx, qabs(D[%d] * dx)); qdx += qs[%d] * dx; "
+          "T pdx = T(0.0);%s nPdx = qmax(nPdx, qabs(pdx * (T(1.0) / D[%d]))); }" %
+          (j, j, j, j, j, " pdx += Ps[%d] * dx;" % pidx[j] if pidx[j] >= 0 else "", j))
+    E("  int status = -10;")
+    E("  if (((double)pri_res > QP_INFTY) || ((double)dua_res > QP_INFTY)) status = -7;")
+    E("#pragma nounroll")
+    E("  for (int approx = 0; approx < 2 && status == -10; ++approx) {")
+    E("    const T k = approx ? T(10) : T(1);")
+    E("    const T eps_abs = a.eps_abs * k, eps_rel = a.eps_rel * k, eps_pinf = a.eps_pinf * k, eps_dinf = a.eps_dinf * k;")
+    E("    const bool prim_ok = pri_res < eps_abs + eps_rel * prim_rel;")
+    E("    const bool dual_ok = dua_res < eps_abs + eps_rel * dual_rel;")
+    E("    bool pinf = false, dinf = false;")
+    E("    if (!prim_ok && norm_dy > eps_pinf && ineq_lhs < -eps_pinf * norm_dy) pinf = nAtdy < eps_pinf * norm_dy;")
+    E("    if (!dual_ok && norm_dx > eps_dinf && qdx < -c * eps_dinf * norm_dx && nPdx < c * eps_dinf * norm_dx) {")
+    E("      dinf = true;")
+    E("      const T thr = eps_dinf * norm_dx;")
+    for i in range(m):
+        E("      { T acc = T(0.0);")
+        for p in range(Ar_p[i], Ar_p[i + 1]):
+            E("        acc += As[%d] * t1[%d];" % (Ar_k[p], Ar_j[p]))
+        E("        acc = acc * (T(1.0) / Ev[%d]);" % i)
+        E("        if ((((double)us[%d] < QP_INFTY * QP_MIN_SCALING) && (acc > thr)) || "
+          "(((double)ls[%d] > -QP_INFTY * QP_MIN_SCALING) && (acc < -thr))) dinf = false; }" % (i, i))
+    E("    }")
+    E("    if (prim_ok && dual_ok) status = approx ? 2 : 1;")
+    E("    else if (pinf) status = approx ? 3 : -3;")
+    E("    else if (dinf) status = approx ? 4 : -4;")
+    E("  }")
+    E("  if (status == -10) status = -2;")
+    E("  const bool bad = status == -3 || status == 3 || status == -4 || status == 4 || status == -7;")
+    E("  const T qnan = std::numeric_limits<T>::quiet_NaN();")
+    for j in range(n):
+        E("  if (a.sol_x) IN(a.sol_x, %d) = bad ? qnan : x[%d] * D[%d]; IN(a.x, %d) = bad ? T(0.0) : x[%d];" % (j, j, j, j, j))
+    for i in range(m):
+        E("  if (a.sol_y) IN(a.sol_y, %d) = bad ? qnan : (y[%d] * Ev[%d]) * cinv; IN(a.y, %d) = bad ? T(0.0) : y[%d]; "
+          "IN(a.z, %d) = bad ? T(0.0) : z[%d];" % (i, i, i, i, i, i, i))
+    E("  if (a.status) a.status[b] = status;")
+    E("  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); }")
+    E("#undef IN")
+    E("}")
+    E("template <typename T>")
+    E("__global__ void __launch_bounds__(64) bqp_fixed_%s_kernel(const QPArgs<T> a) {" % name)
+    E("  const int b = blockIdx.x * 64 + threadIdx.x;")
+    E("  if (b >= a.B) return;")
+    E("  bqp_fixed_%s<T>(a, b);" % name)
+    E("}")
+    E("void bqp_launch_%s_f32(const QPArgs<float> &a, hipStream_t s) { hipLaunchKernelGGL(bqp_fixed_%s_kernel<float>, "
+      "dim3((a.B + 63) / 64), dim3(64), 0, s, a); }" % (name, name))
+    E("void bqp_launch_%s_f64(const QPArgs<double> &a, hipStream_t s) { hipLaunchKernelGGL(bqp_fixed_%s_kernel<double>, "
+      "dim3((a.B + 63) / 64), dim3(64), 0, s, a); }" % (name, name))
+    return "\n".join(o) + "\n"
+
+
+def generate():
+    out = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
+           "// Straight-line specialisations of bqp_solve_kernel for the built-in structures.", ""]
+    reg = []
+    for name, s in builtin_structures():
+        out.append("// ---- %s: n = %d, m = %d, nnz(A) = %d, nnz(L) = %d ----" % (name, s.n, s.m, s.nnzA, s.nnzL))
+        out.append(emit_structure(name, s))
+        reg.append('  {0x%016xull, "%s", bqp_launch_%s_f32, bqp_launch_%s_f64},' % (fnv1a(s.blob), name, name, name))
+    out.append("struct FixedKernel { uint64_t hash; const char *name; void (*f32)(const QPArgs<float> &, hipStream_t); "
+               "void (*f64)(const QPArgs<double> &, hipStream_t); };")
+    out.append("const FixedKernel kFixedKernels[] = {")
+    out += reg
+    out.append("};")
+    out.append("constexpr int kNumFixedKernels = %d;" % len(reg))
+    return "\n".join(out) + "\n"
+
+
+def write(path=OUT):
+    src = generate()
+    old = open(path).read() if os.path.exists(path) else None
+    if old != src:
+        with open(path, "w") as f:
+            f.write(src)
+    return path, src
+
+
+if __name__ == "__main__":
+    p, src = write()
+    print(p, len(src.splitlines()), "lines")

@@ -65,6 +65,18 @@ template <typename T> __device__ __forceinline__ T limit_scaling(T v) {
   return v;
 }
 
+// update_rho_vec, auxil.c:103-145 (ls, us: bounds scaled by the previous E; comparisons in double)
+template <typename T>
+__device__ __forceinline__ void qp_classify(T ls, T us, T rho0, T rho_eq, T &r, T &ri) {
+  if (((double)ls < -QP_INFTY * QP_MIN_SCALING) && ((double)us > QP_INFTY * QP_MIN_SCALING)) {
+    r = T(QP_RHO_MIN); ri = T(1. / QP_RHO_MIN);
+  } else if ((double)(us - ls) < QP_RHO_TOL) {
+    r = rho_eq; ri = T(1. / (double)rho_eq);
+  } else {
+    r = rho0; ri = T(1. / (double)rho0);
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -92,15 +104,9 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
   for (int j = 0; j < n; ++j) { WR(R_QS, j) = IN(a.q, j); WR(R_D, j) = T(1.0); }
   const T rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);
   for (int i = 0; i < m; ++i) {
-    const T e = IN(a.Eprev, i), ls = IN(a.l, i) * e, us = IN(a.u, i) * e;
+    const T e = IN(a.Eprev, i);
     T r, ri;
-    if (((double)ls < -QP_INFTY * QP_MIN_SCALING) && ((double)us > QP_INFTY * QP_MIN_SCALING)) {
-      r = T(QP_RHO_MIN); ri = T(1. / QP_RHO_MIN);
-    } else if ((double)(us - ls) < QP_RHO_TOL) {
-      r = rho_eq; ri = T(1. / (double)rho_eq);
-    } else {
-      r = a.rho; ri = T(1. / (double)a.rho);
-    }
+    qp_classify(IN(a.l, i) * e, IN(a.u, i) * e, a.rho, rho_eq, r, ri);
     WR(R_RHO, i) = r; WR(R_RINV, i) = ri; WR(R_E, i) = T(1.0);
   }
 
@@ -487,8 +493,10 @@ __global__ void umpcn_extract_kernel(int Bn, int N, T dt, const T *__restrict__ 
 #undef O
 }
 
+#include "umpc_bqp_gen.h"
+
 struct qp_batch {
-  int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows;
+  int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows, fixed, use_tables;
   umpcQPSettings st;
   int32_t *tab;
   void *W;
@@ -507,7 +515,12 @@ int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, con
   a.eps_abs = T(h->st.eps_abs); a.eps_rel = T(h->st.eps_rel);
   a.eps_pinf = T(h->st.eps_prim_inf); a.eps_dinf = T(h->st.eps_dual_inf);
   a.max_iter = h->st.max_iter; a.scaling = h->st.scaling;
-  hipLaunchKernelGGL(bqp_solve_kernel<T>, dim3((h->B + 63) / 64), dim3(64), 0, s, a);
+  if (h->fixed >= 0 && !h->use_tables) {
+    if constexpr (sizeof(T) == 4) kFixedKernels[h->fixed].f32(a, s);
+    else kFixedKernels[h->fixed].f64(a, s);
+  } else {
+    hipLaunchKernelGGL(bqp_solve_kernel<T>, dim3((h->B + 63) / 64), dim3(64), 0, s, a);
+  }
   return 0;
 }
 
@@ -584,6 +597,16 @@ void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpc
   h->B = B; h->dtype = dtype; h->n = n; h->m = m; h->nk = nk;
   h->nnzP = blob[H_NNZP]; h->nnzA = blob[H_NNZA]; h->nnzL = blob[H_NNZL]; h->nrows = nrows;
   if (st) h->st = *st; else umpcQPDefaultSettings(&h->st);
+  // a straight-line specialisation generated at build time for exactly this structure?
+  h->fixed = -1; h->use_tables = 0;
+  {
+    uint64_t hash = 0xcbf29ce484222325ull;
+    for (int k = 0; k < nwords; ++k) {
+      const uint32_t v = (uint32_t)blob[k];
+      for (int q = 0; q < 4; ++q) { hash ^= (v >> (8 * q)) & 0xffu; hash *= 0x100000001b3ull; }
+    }
+    for (int k = 0; k < kNumFixedKernels; ++k) if (kFixedKernels[k].hash == hash) h->fixed = k;
+  }
   const size_t esz = dtype == UMPC_F32 ? 4 : 8;
   if (hipMalloc((void **)&h->tab, (size_t)nwords * 4) != hipSuccess ||
       hipMalloc(&h->W, (size_t)nrows * (size_t)B * esz) != hipSuccess) {
@@ -607,6 +630,19 @@ void umpcQPDestroy(void *hv) {
   (void)hipFree(h->tab);
   (void)hipFree(h->W);
   delete h;
+}
+
+int umpcQPUseTables(void *hv, int on) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h) { umpc_set_error("umpcQPUseTables: bad argument"); return -1; }
+  h->use_tables = on ? 1 : 0;
+  return h->fixed;
+}
+
+const char *umpcQPKernelName(void *hv) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h) return "";
+  return (h->fixed >= 0 && !h->use_tables) ? kFixedKernels[h->fixed].name : "tables";
 }
 
 int umpcQPSetMaxIter(void *hv, int max_iter) {

@@ -374,3 +374,54 @@ def test_gpu_general_path_at_N3_agrees_with_the_specialised_kernel():
     assert np.all(np.abs(o1[0] - o2[0]) <= 3e-5)
     assert np.all(np.abs(o1[1:3] - o2[1:3]) <= np.maximum(2e-2, 1e-3 * np.abs(o2[1:3])))
     assert np.all(np.abs(o1[3:] - o2[3:]) <= 3e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_specialised_kernels_equal_the_table_driven_kernel():
+    """codegen_qp.py's straight-line kernels carry out the table-driven kernel's operations in the same order:
+    fp64 results are bit-identical on all three built-in structures, fp32 ones too."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC, UprightMPC2N, UprightMPCv1
+    seq = golden("seq_iter50.npz")
+    for tdt, ndt in ((torch.float64, np.float64), (torch.float32, np.float32)):
+        B = 96
+        # p5f
+        mpc = PlanarP5fMPC(B, tdt)
+        assert mpc.qp.kernel_name == "p5f10"
+        mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
+        mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
+        mpc.linearise(7.0)
+        res = []
+        for tables in (False, True):
+            mpc.qp.reset()
+            mpc.qp.use_tables(tables)
+            assert mpc.qp.kernel_name == ("tables" if tables else "p5f10")
+            mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
+            torch.cuda.synchronize()
+            res.append([t.cpu().numpy().copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x, mpc.qp.status, mpc.qp.info)])
+        for a, b in zip(*res):
+            assert np.array_equal(a, b, equal_nan=True)
+        # UprightMPC2 N = 5
+        idx = np.arange(B)
+        st, ref, T0 = _state_ref_from_seq(seq, idx, ndt)
+        S, R = torch.as_tensor(st).cuda(), torch.as_tensor(ref).cuda()
+        res = []
+        for tables in (False, True):
+            m5 = UprightMPC2N(B, 5, dtype=tdt)
+            assert m5.qp.kernel_name == "umpc2n5"
+            m5.qp.use_tables(tables)
+            m5.T0.copy_(torch.as_tensor(T0).cuda())
+            res.append(m5.update(S, R).cpu().numpy().copy())
+        assert np.array_equal(res[0], res[1], equal_nan=True)
+        # v1
+        g = golden("v1_qp.npz")
+        T = lambda a: torch.as_tensor(np.ascontiguousarray(a.T, ndt)).cuda()
+        res = []
+        for tables in (False, True):
+            v1 = UprightMPCv1(len(g["dt"]), 3, tdt, max_iter=100)
+            assert v1.qp.kernel_name == "v1n3"
+            v1.qp.use_tables(tables)
+            x, uu = v1.update(T(g["q0"]), T(g["qdes"]), T(g["Qf"]), T(g["Rd"]), T(g["smin"]), T(g["smax"]), 2.5,
+                              T(g["snom"]), torch.as_tensor(g["vT0"].astype(ndt)).cuda())
+            res.append(x.cpu().numpy().copy())
+        assert np.array_equal(res[0], res[1], equal_nan=True)
