@@ -102,8 +102,10 @@ def main_p5f(args):
     for _ in range(args.steps):
         mpc.tick(0.002 * ti); ti += 1
     e1.record()
+    torch.cuda.synchronize(dev)
+    local = time.perf_counter() - t0
     barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = shard.max_over_ranks(local, device=dev)
     s = mpc.qp.s
     esz = 4 if args.dtype == "f32" else 8
     # algorithmic bytes per robot-tick: iterates x, y, z read + written, state 7 + 7, nominal input 1
@@ -131,8 +133,8 @@ def main_p5f(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--plant", default="rk4", choices=["euler", "rk4"],
@@ -203,8 +205,10 @@ def main():
         evs[k][0].record()
         mpc.rollout(spl)        # ONE launch = spl closed-loop steps of all B robots
         evs[k][1].record()
+    torch.cuda.synchronize(dev)
+    local = time.perf_counter() - t0          # this rank's K steps, start barrier -> local completion
     barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = shard.max_over_ranks(local, device=dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     # end-of-run trajectory statistics: the only exchange of the path (RCCL all_gather over xGMI,

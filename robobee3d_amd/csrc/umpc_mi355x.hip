@@ -73,8 +73,9 @@ __global__ __launch_bounds__(kBlock) void umpc_plant_kernel(DevParams<T> prm, in
 #pragma unroll
   for (int i = 0; i < 3; ++i) Ib[i] = IbA ? IbA[(size_t)i * B + b] : prm.Ib[i];
   const T gain = gainA ? gainA[b] : T(1);
+  const T Ibinv[3] = {T(1) / Ib[0], T(1) / Ib[1], T(1) / Ib[2]};
 #pragma nounroll
-  for (int s = 0; s < nsub; ++s) umpc::plant_step(p, R, dq, uq, prm.dtsim, Ib, gain, prm.plant_mode);
+  for (int s = 0; s < nsub; ++s) umpc::plant_step(p, R, dq, uq, prm.dtsim, Ib, Ibinv, gain, prm.plant_mode);
 #pragma unroll
   for (int i = 0; i < 3; ++i) state[(size_t)i * B + b] = p[i];
 #pragma unroll

@@ -148,7 +148,7 @@ template <typename T> __device__ __forceinline__ T limit_scaling(T v) {
 // ---------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void plant_vf(const T (&R)[9], const T (&dq)[6], const T (&u)[3],
-                                         const T (&Ib)[3], T gain, T (&ddq)[6]) {
+                                         const T (&Ib)[3], const T (&Ibinv)[3], T gain, T (&ddq)[6]) {
   const T wx = dq[3], wy = dq[4], wz = dq[5];
   const T Th = gain * u[0];
   ddq[0] = Th * R[6];
@@ -158,9 +158,10 @@ __device__ __forceinline__ void plant_vf(const T (&R)[9], const T (&dq)[6], cons
   const T cx = wy * hz - wz * hy;
   const T cy = wz * hx - wx * hz;
   const T cz = wx * hy - wy * hx;
-  ddq[3] = (-cx + u[1]) / Ib[0];
-  ddq[4] = (-cy + u[2]) / Ib[1];
-  ddq[5] = (-cz) / Ib[2];
+  // np.linalg.inv(Ib) @ (...), genqp.py:28: the reference multiplies by the inverse too
+  ddq[3] = (-cx + u[1]) * Ibinv[0];
+  ddq[4] = (-cy + u[2]) * Ibinv[1];
+  ddq[5] = (-cz) * Ibinv[2];
 }
 
 // R <- R expm(skew(w) h): Rodrigues form of scipy.linalg.expm(skew(w) dt), genqp.py:39
@@ -198,10 +199,10 @@ __device__ __forceinline__ void plant_rot(T (&R)[9], T w0, T w1, T w2, T h) {
 
 template <typename T>
 __device__ __forceinline__ void plant_step(T (&p)[3], T (&R)[9], T (&dq)[6], const T (&u)[3], T dt,
-                                           const T (&Ib)[3], T gain, int mode) {
+                                           const T (&Ib)[3], const T (&Ibinv)[3], T gain, int mode) {
   if (mode == 0) {
     T ddq[6];
-    plant_vf(R, dq, u, Ib, gain, ddq);
+    plant_vf(R, dq, u, Ib, Ibinv, gain, ddq);
 #pragma unroll
     for (int i = 0; i < 3; ++i) p[i] = p[i] + dt * dq[i];
     plant_rot(R, dq[3], dq[4], dq[5], dt);
@@ -236,15 +237,16 @@ __device__ __forceinline__ void plant_step(T (&p)[3], T (&R)[9], T (&dq)[6], con
         k[3 + r + 3] = -Rs[r + 0] * wz + Rs[r + 6] * wx;
         k[3 + r + 6] = Rs[r + 0] * wy - Rs[r + 3] * wx;
       }
-      plant_vf(Rs, dqs, u, Ib, gain, dd);
+      plant_vf(Rs, dqs, u, Ib, Ibinv, gain, dd);
 #pragma unroll
       for (int i = 0; i < 6; ++i) k[12 + i] = dd[i];
 #pragma unroll
       for (int i = 0; i < 18; ++i) acc[i] = s ? acc[i] + wt[s] * k[i] : k[i];
     }
-    // same association as the oracle: (k1 + 2 k2 + 2 k3 + k4)
+    // (k1 + 2 k2 + 2 k3 + k4) associated as in the oracle; the final dt/6 is one multiply (no per-word division)
+    const T dt6 = dt / T(6);
 #pragma unroll
-    for (int i = 0; i < 18; ++i) ys[i] = yv0[i] + dt * acc[i] / T(6);
+    for (int i = 0; i < 18; ++i) ys[i] = yv0[i] + dt6 * acc[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) p[i] = ys[i];
 #pragma unroll
@@ -814,9 +816,10 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     const T uc[3] = {uq[0], umpc_min(umpc_max(uq[1], -prm.taulim), prm.taulim),
                      umpc_min(umpc_max(uq[2], -prm.taulim), prm.taulim)};
     T s_err = a.stats ? GLD(a.stats, 0) : T(0), s_eff = a.stats ? GLD(a.stats, 1) : T(0);
+    const T Ibinv[3] = {T(1) / Ib[0], T(1) / Ib[1], T(1) / Ib[2]};
 #pragma nounroll
     for (int s = 0; s < prm.nsub; ++s) {
-      plant_step(p0, R0, dq0, uc, prm.dtsim, Ib, gain, prm.plant_mode);
+      plant_step(p0, R0, dq0, uc, prm.dtsim, Ib, Ibinv, gain, prm.plant_mode);
       s_err += p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2];
       s_eff += uc[1] * uc[1] + uc[2] * uc[2];
     }
