@@ -188,6 +188,17 @@ const char *umpcLastError(void);
 /* name and duration of the kernels, for bench.py */
 const char *umpcKernelName(int dtype, int plant_mode);
 
+/* The reactive baseline of the reference's gain sweeps: reactiveController (template/template_controllers.py:
+ * 282-296) inside controlTest(useMPC=False) (template/uprightmpc2.py:121-151): `nsteps` plant substeps of dtsim,
+ * the controller evaluated every `every` substeps (reference: 1), moments clipped at +-taulim, the handle's task
+ * generator / plant mode / time. gains [6][B] = (kpos0, kpos1, kz0, kz1, ks0, ks1) or NULL (the reference's
+ * defaults); out [3][B] last command or NULL; stats as in umpcBatchRollout. */
+int umpcBatchReactive(umpc_batch_t *h, int nsteps, int every, void *state, const void *ref, const void *gains,
+                      const void *Ib, const void *thrust_gain, void *out, void *stats, void *stream);
+/* out [9][B] = (pdes, dpdes, sdes) of the handle's task (template/flight_tasks.py:6-49) at time t_ms, what the
+ * step kernel evaluates at an MPC fire; ref as in umpcBatchRollout (rows 0..2 = initialPos for a task). */
+int umpcBatchTaskReference(umpc_batch_t *h, double t_ms, const void *ref, void *out, void *stream);
+
 /* ------------------------------------------------------------------ */
 /* Part 3: wrench-linearisation step (the consumer of accdes)          */
 /* template/uprightmpc2/funapprox.h:18-54, funapprox.c:102-176          */

@@ -178,6 +178,46 @@ def batch_rollout(state, ctrl, ref, K, dtype=np.float32, perm=None, Ib=None, gai
     return out, stats, status
 
 
+def reactive(p, R, dq, pdes, k=(5e-3, 5e-1, 1e-1, 1e0, 10e0, 1e2), dtype=np.float64):
+    """reactiveController (template/template_controllers.py:282-296) as restated in the oracle; R is a 3x3 matrix."""
+    dtype = np.dtype(dtype)
+    L = lib(dtype)
+    ct = C.c_float if dtype == np.float32 else C.c_double
+    f = lambda a: np.ascontiguousarray(np.asarray(a, dtype).ravel())
+    P = lambda a: a.ctypes.data_as(C.POINTER(ct))
+    u = np.zeros(3, dtype)
+    L.umpc_oracle_reactive(P(f(p)), P(f(np.asarray(R).T)), P(f(dq)), P(f(pdes)), P(f(k)), P(u))
+    return u
+
+
+def reactive_rollout(state, ref, nsteps, every=1, gains=None, dtype=np.float64, Ib=None, gain=None, Ib_nom=IB,
+                     dtsim=0.2, taulim=100.0, plant_mode=0, task=0, task_p=None, t0=0.0, log_robot=-1):
+    """controlTest(useMPC=False) twin: state [18,B] modified in place; returns (out[3,B], stats[2,B], log or None)."""
+    dtype = np.dtype(dtype)
+    L = lib(dtype)
+    ct = C.c_float if dtype == np.float32 else C.c_double
+    ps = _params_struct(ct)()
+    for k in DEFAULTS:
+        setattr(ps, k, DEFAULTS[k])
+    for i in range(3):
+        ps.Ib[i] = Ib_nom[i]
+    ps.maxIter, ps.dtsim, ps.taulim, ps.nsub, ps.plant_mode = 50, dtsim, taulim, 25, plant_mode
+    B = state.shape[1]
+    assert state.dtype == dtype and state.flags.c_contiguous and ref.dtype == dtype and ref.flags.c_contiguous
+    P = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(ct))
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype)
+    gains, Ib, gain = c(gains), c(Ib), c(gain)
+    out, stats = np.zeros((3, B), dtype), np.zeros((2, B), dtype)
+    log = np.zeros((nsteps, 15), dtype) if log_robot >= 0 else None
+    tp = np.zeros(4, dtype)
+    if task_p is not None:
+        tp[:len(task_p)] = task_p
+    L.umpc_oracle_reactive_rollout(C.byref(ps), C.c_int(B), C.c_int(nsteps), C.c_int(every), P(state), P(ref), P(gains),
+                                   P(Ib), P(gain), C.c_int(task), P(tp), ct(t0), P(out), P(stats), P(log),
+                                   C.c_int(log_robot))
+    return out, stats, log
+
+
 def task_reference(task, task_p, t, initial_pos, dtype=np.float64):
     """(pdes, dpdes, sdes) of template/flight_tasks.py as restated in the oracle."""
     dtype = np.dtype(dtype)

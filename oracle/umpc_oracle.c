@@ -1038,6 +1038,69 @@ void umpc_oracle_batch_rollout2(const umpc_oracle_params_t *prm, const int *perm
 }
 
 /* ====================================================================== */
+/* Reactive baseline                                         */
+/* ====================================================================== */
+/* reactiveController, template/template_controllers.py:282-296. k = (kpos0, kpos1, kz0, kz1, ks0, ks1). */
+void umpc_oracle_reactive(const real p[3], const real R[9], const real dq[6], const real pdes[3], const real k[6],
+                          real u[3]) {
+  real sdes[3], ds[3], fT[3];
+  for (int i = 0; i < 3; ++i) sdes[i] = c_min(c_max(k[0] * (pdes[i] - p[i]) - k[1] * dq[i], (real)-0.5), (real)0.5);
+  sdes[2] = 1;
+  for (int r = 0; r < 3; ++r) {
+    ds[r] = -(R[r] * (-dq[4]) + R[r + 3] * dq[3]);
+    fT[r] = k[4] * (R[6 + r] - sdes[r]) + k[5] * ds[r];
+  }
+  fT[2] = 0;
+  const real wx = (R[0] * fT[0] + R[1] * fT[1]) + R[2] * fT[2];
+  const real wy = (R[3] * fT[0] + R[4] * fT[1]) + R[5] * fT[2];
+  u[0] = k[2] * (pdes[2] - p[2]) - k[3] * dq[2];
+  u[1] = wy;
+  u[2] = -wx;
+}
+
+/* controlTest(useMPC=False), template/uprightmpc2.py:121-151, for B robots: nsteps substeps, controller every
+ * `every` substeps. log (or NULL) receives [nsteps][15] rows (p, s, dq, u) of robot `log_robot`. */
+void umpc_oracle_reactive_rollout(const umpc_oracle_params_t *prm, int B, int nsteps, int every, real *state,
+                                  const real *ref, const real *gains, const real *Ib, const real *thrust_gain,
+                                  int task, const real *task_p, real t0, real *out, real *stats, real *log,
+                                  int log_robot) {
+  for (int b = 0; b < B; ++b) {
+    real ib[3] = {prm->Ib[0], prm->Ib[1], prm->Ib[2]};
+    if (Ib) for (int i = 0; i < 3; ++i) ib[i] = Ib[i * (size_t)B + b];
+    const real gain = thrust_gain ? thrust_gain[b] : (real)1;
+    real k[6] = {(real)5e-3, (real)5e-1, (real)1e-1, (real)1e0, (real)10e0, (real)1e2};
+    if (gains) for (int i = 0; i < 6; ++i) k[i] = gains[(size_t)i * B + b];
+    real p[3], R[9], dq[6], rf[9], u[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) p[i] = state[(size_t)i * B + b];
+    for (int i = 0; i < 9; ++i) R[i] = state[(size_t)(3 + i) * B + b];
+    for (int i = 0; i < 6; ++i) dq[i] = state[(size_t)(12 + i) * B + b];
+    real s_err = stats ? stats[b] : 0, s_eff = stats ? stats[(size_t)B + b] : 0;
+    for (int ti = 0; ti < nsteps; ++ti) {
+      if (ti % every == 0) {
+        for (int i = 0; i < 9; ++i) rf[i] = ref[(size_t)i * B + b];
+        if (task) umpc_oracle_task_reference(task, task_p, t0 + (real)ti * prm->dtsim, rf);
+        umpc_oracle_reactive(p, R, dq, rf, k, u);
+        u[1] = c_min(c_max(u[1], -prm->taulim), prm->taulim);
+        u[2] = c_min(c_max(u[2], -prm->taulim), prm->taulim);
+      }
+      plant_step_r(p, R, dq, u, prm->dtsim, ib, gain, prm->plant_mode);
+      s_err += p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+      s_eff += u[1] * u[1] + u[2] * u[2];
+      if (log && b == log_robot) {
+        real *row = log + (size_t)ti * 15;
+        for (int i = 0; i < 3; ++i) { row[i] = p[i]; row[3 + i] = R[6 + i]; row[12 + i] = u[i]; }
+        for (int i = 0; i < 6; ++i) row[6 + i] = dq[i];
+      }
+    }
+    for (int i = 0; i < 3; ++i) state[(size_t)i * B + b] = p[i];
+    for (int i = 0; i < 9; ++i) state[(size_t)(3 + i) * B + b] = R[i];
+    for (int i = 0; i < 6; ++i) state[(size_t)(12 + i) * B + b] = dq[i];
+    if (out) for (int i = 0; i < 3; ++i) out[(size_t)i * B + b] = u[i];
+    if (stats) { stats[b] = s_err; stats[(size_t)B + b] = s_eff; }
+  }
+}
+
+/* ====================================================================== */
 /* Wrench-linearisation step: funapprox.c                    */
 /* ====================================================================== */
 #define NDELU 4

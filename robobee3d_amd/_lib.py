@@ -24,7 +24,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
-           "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights",
+           "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPUseTables", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
            "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
@@ -124,6 +124,8 @@ def lib():
         L.umpcBatchInitCtrl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.umpcBatchRollout.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 11
         L.umpcBatchUpdate.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+        L.umpcBatchReactive.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8
+        L.umpcBatchTaskReference.argtypes = [C.c_void_p, C.c_double] + [C.c_void_p] * 3
         L.umpcBatchPlant.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.umpcBatchAssemble.argtypes = [C.c_void_p] + [C.c_void_p] * 10
         L.umpcLastError.restype = C.c_char_p

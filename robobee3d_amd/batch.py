@@ -121,6 +121,7 @@ class BatchUprightMPC:
         if kw:
             raise TypeError("unknown task parameter(s) %r" % sorted(kw))
         arr = (C.c_double * 4)(*vals)
+        self._task = (tid, arr)
         self._check(self.L.umpcBatchSetTask(self.h, tid, arr, float(t_ms)))
 
     def set_weights(self, weights):
@@ -144,6 +145,81 @@ class BatchUprightMPC:
             self._check(self.L.umpcBatchRollout(self.h, int(K), _ptr(self.state), _ptr(self.ctrl), _ptr(self.ref),
                                                 _ptr(self.actualT0), _ptr(self.Ib), _ptr(self.gain), _ptr(self.out),
                                                 _ptr(self.stats), _ptr(self.status), _ptr(self.info), self._stream()))
+
+    def reactive_rollout(self, nsteps, gains=None, every=1):
+        """controlTest(useMPC=False) (template/uprightmpc2.py:121-151) for every robot: `nsteps` plant substeps with
+        reactiveController (template/template_controllers.py:282-296) evaluated every `every` substeps. gains:
+        [6, B] tensor (kpos0, kpos1, kz0, kz1, ks0, ks1) or None for the reference's defaults. Last command in
+        self.out[0:3]; statistics accumulate in self.stats."""
+        if gains is not None:
+            gains = torch.as_tensor(gains, dtype=self.dtype, device=self.device).contiguous()
+            assert gains.shape == (6, self.B)
+        with torch.cuda.device(self.device):
+            self._check(self.L.umpcBatchReactive(self.h, int(nsteps), int(every), _ptr(self.state), _ptr(self.ref),
+                                                 _ptr(gains), _ptr(self.Ib), _ptr(self.gain), _ptr(self.out),
+                                                 _ptr(self.stats), self._stream()))
+
+    def task_reference(self, t_ms):
+        """(pdes, dpdes, sdes) [9, B] of the current task at time t_ms (template/flight_tasks.py:6-49)."""
+        out = torch.empty((9, self.B), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.L.umpcBatchTaskReference(self.h, float(t_ms), _ptr(self.ref), _ptr(out), self._stream()))
+        return out
+
+    def control_test_log(self, tend, robots=(0,), use_mpc=True, gains=None):
+        """The log of controlTest (template/uprightmpc2.py:113,150-159) for the selected robots, in the reference's
+        layout -- a dict {'t' [Nt], 'y' [Nt, 12] = (p, Rb[:, 2], dq), 'u' [Nt, 3], 'pdes' [Nt, 3], 'accdes' [Nt, 6]}
+        per robot that viewControlTestLog / logMetric (:14-84, :161-175) take as is -- plus 'metric'. The loop runs
+        from the current state at the fixed fire schedule (every nsub substeps), one launch per substep: this is
+        the logging path, not the throughput path. Returns {robot: log}."""
+        nsub, dts = int(self.prm.nsub), float(self.prm.dtsim)
+        Nt = int(np.ceil(tend / dts - 1e-9))
+        idx = torch.as_tensor(list(robots), device=self.device)
+        rec = {k: [] for k in ("y", "u", "pdes", "accdes")}
+        t_start = self.time_ms
+        acc_now = torch.zeros((6, len(robots)), dtype=self.dtype, device=self.device)
+        tl = float(self.prm.taulim)
+        for ti in range(Nt):
+            t = t_start + ti * dts
+            fire = ti % nsub == 0
+            if use_mpc and fire:
+                self._check(self.L.umpcBatchSetTask(self.h, self._task_id(), self._task_params(), t))
+                self.update()
+                u = self.out[0:3].clone()
+                acc_now = self.out[3:9][:, idx].clone()
+            elif not use_mpc:
+                u = None
+            pd = self.task_reference(t)[0:3][:, idx]
+            if use_mpc:
+                u[1:3].clamp_(-tl, tl)
+                self.plant(u, 1)
+                ulog = u[:, idx]
+            else:
+                self.reactive_rollout(1, gains)
+                ulog = self.out[0:3][:, idx]
+            st = self.state[:, idx]
+            rec["y"].append(torch.cat((st[0:3], st[9:12], st[12:18]), 0).T.cpu().numpy().copy())
+            rec["u"].append(ulog.T.cpu().numpy().copy())
+            rec["pdes"].append(pd.T.cpu().numpy().copy())
+            rec["accdes"].append((acc_now if (use_mpc and fire) else torch.zeros_like(acc_now)).T.cpu().numpy().copy())
+        if use_mpc:   # leave the handle's clock where the loop ended
+            self._check(self.L.umpcBatchSetTask(self.h, self._task_id(), self._task_params(), t_start + Nt * dts))
+        logs = {}
+        tt = np.arange(Nt) * dts
+        for c, r in enumerate(robots):
+            lg = {"t": tt.copy()}
+            for k in rec:
+                lg[k] = np.stack([a[c] for a in rec[k]]).astype(np.float64)
+            perr, tau = lg["y"][:, :3], lg["u"][:, 1:3]
+            lg["metric"] = (float((perr ** 2).sum() / Nt), float((tau ** 2).sum() / Nt))
+            logs[r] = lg
+        return logs
+
+    def _task_id(self):
+        return getattr(self, "_task", (0, (C.c_double * 4)()))[0]
+
+    def _task_params(self):
+        return getattr(self, "_task", (0, (C.c_double * 4)()))[1]
 
     def update(self):
         """One controller step on the current state (= umpcUpdate for every robot); no plant."""

@@ -129,6 +129,101 @@ __global__ __launch_bounds__(kBlock) void umpc_assemble_kernel(DevParams<T> prm,
     for (int i = 0; i < 6; ++i) Ax[(size_t)(o++) * B + b] = qp.Btaudt[i];
 }
 
+// reactiveController (template/template_controllers.py:282-296) in the closed loop of controlTest with
+// useMPC=False (template/uprightmpc2.py:121-151): the reference evaluates it at every plant substep
+// (hlInterval=None); `every` > 1 holds the command for that many substeps (fixed schedule).
+// gains rows: kpos[2], kz[2], ks[2] (defaults 5e-3, 5e-1 | 1e-1, 1 | 10, 1e2).
+template <typename T>
+__device__ __forceinline__ void reactive_controller(const T (&p)[3], const T (&R)[9], const T (&dq)[6],
+                                                    const T (&pdes)[3], const T (&k)[6], T (&u)[3]) {
+  T sdes[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    sdes[i] = umpc::umpc_min(umpc::umpc_max(k[0] * (pdes[i] - p[i]) - k[1] * dq[i], T(-0.5)), T(0.5));
+  sdes[2] = T(1);
+  T ds[3], fT[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    ds[r] = -(R[r] * (-dq[4]) + R[r + 3] * dq[3]);      // -Rb e3h omega
+    fT[r] = k[4] * (R[6 + r] - sdes[r]) + k[5] * ds[r];
+  }
+  fT[2] = T(0);
+  // fAorn = -e3h Rb' fTorn = ((Rb' f)_y, -(Rb' f)_x, 0)
+  const T wx = (R[0] * fT[0] + R[1] * fT[1]) + R[2] * fT[2];
+  const T wy = (R[3] * fT[0] + R[4] * fT[1]) + R[5] * fT[2];
+  u[0] = k[2] * (pdes[2] - p[2]) - k[3] * dq[2];
+  u[1] = wy;
+  u[2] = -wx;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void umpc_reactive_kernel(DevParams<T> prm, int B_, int nsteps, int every, T t0,
+                                                              T *state, const T *ref, const T *gains, const T *IbA,
+                                                              const T *gainA, T *out, T *stats) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B_) return;
+  const size_t B = (size_t)B_;
+  T p[3], R[9], dq[6], Ib[3], rf0[9], k[6] = {T(5e-3), T(5e-1), T(1e-1), T(1e0), T(10e0), T(1e2)}, u[3] = {T(0), T(0), T(0)};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = state[(size_t)i * B + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = state[(size_t)(3 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dq[i] = state[(size_t)(12 + i) * B + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rf0[i] = ref[(size_t)i * B + b];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Ib[i] = IbA ? IbA[(size_t)i * B + b] : prm.Ib[i];
+  if (gains) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) k[i] = gains[(size_t)i * B + b];
+  }
+  const T gain = gainA ? gainA[b] : T(1);
+  const T Ibinv[3] = {T(1) / Ib[0], T(1) / Ib[1], T(1) / Ib[2]};
+  T s_err = stats ? stats[b] : T(0), s_eff = stats ? stats[B + b] : T(0);
+#pragma nounroll
+  for (int ti = 0; ti < nsteps; ++ti) {
+    if (ti % every == 0) {
+      T rf[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rf[i] = rf0[i];
+      umpc::task_reference(prm.task, prm.task_p, t0 + T(ti) * prm.dtsim, rf);
+      const T pdes[3] = {rf[0], rf[1], rf[2]};
+      reactive_controller(p, R, dq, pdes, k, u);
+      u[1] = umpc::umpc_min(umpc::umpc_max(u[1], -prm.taulim), prm.taulim);
+      u[2] = umpc::umpc_min(umpc::umpc_max(u[2], -prm.taulim), prm.taulim);
+    }
+    umpc::plant_step(p, R, dq, u, prm.dtsim, Ib, Ibinv, gain, prm.plant_mode);
+    s_err += p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    s_eff += u[1] * u[1] + u[2] * u[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) state[(size_t)i * B + b] = p[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) state[(size_t)(3 + i) * B + b] = R[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) state[(size_t)(12 + i) * B + b] = dq[i];
+  if (out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[(size_t)i * B + b] = u[i];
+  }
+  if (stats) { stats[b] = s_err; stats[B + b] = s_eff; }
+}
+
+// (pdes, dpdes, sdes) of the handle's task at time t for every robot (what the step kernel evaluates at a fire)
+template <typename T>
+__global__ void umpc_taskref_kernel(DevParams<T> prm, int B_, T t, const T *ref, T *out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B_) return;
+  const size_t B = (size_t)B_;
+  T r[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r[i] = ref[(size_t)i * B + b];
+  umpc::task_reference(prm.task, prm.task_p, t, r);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[(size_t)i * B + b] = r[i];
+}
+
 template <typename T>
 __global__ void umpc_init_ctrl_kernel(int B_, T *ctrl) {
   const size_t B = (size_t)B_;
@@ -191,6 +286,21 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
 }
 
 void umpc_set_error(const char *msg) { g_err = msg; }
+
+template <typename T>
+static int launch_reactive(umpc_batch_t *h, int nsteps, int every, void *state, const void *ref, const void *gains,
+                           const void *Ib, const void *gain, void *out, void *stats, void *stream) {
+  DevParams<T> prm = make_dev<T>(h->prm);
+  prm.task = h->task;
+  for (int i = 0; i < 4; ++i) prm.task_p[i] = (T)h->task_p[i];
+  const int grid = (h->B + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(umpc_reactive_kernel<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, prm, h->B, nsteps, every,
+                     (T)h->t_ms, (T *)state, (const T *)ref, (const T *)gains, (const T *)Ib, (const T *)gain, (T *)out,
+                     (T *)stats);
+  h->t_ms += (double)nsteps * h->prm.dtsim;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchReactive");
+}
 
 extern "C" {
 
@@ -263,6 +373,33 @@ int umpcBatchRollout(umpc_batch_t *h, int K, void *state, void *ctrl, const void
   return h->dtype == UMPC_F32
              ? launch_rollout<float>(h, K, h->prm.nsub, state, ctrl, ref, actualT0, Ib, gain, out, stats, status, info, stream)
              : launch_rollout<double>(h, K, h->prm.nsub, state, ctrl, ref, actualT0, Ib, gain, out, stats, status, info, stream);
+}
+
+int umpcBatchTaskReference(umpc_batch_t *h, double t_ms, const void *ref, void *out, void *stream) {
+  if (!h || !ref || !out) { g_err = "umpcBatchTaskReference: bad argument"; return -1; }
+  const int grid = (h->B + 255) / 256;
+  if (h->dtype == UMPC_F32) {
+    DevParams<float> prm = make_dev<float>(h->prm);
+    prm.task = h->task;
+    for (int i = 0; i < 4; ++i) prm.task_p[i] = (float)h->task_p[i];
+    hipLaunchKernelGGL(umpc_taskref_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, prm, h->B, (float)t_ms,
+                       (const float *)ref, (float *)out);
+  } else {
+    DevParams<double> prm = make_dev<double>(h->prm);
+    prm.task = h->task;
+    for (int i = 0; i < 4; ++i) prm.task_p[i] = h->task_p[i];
+    hipLaunchKernelGGL(umpc_taskref_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, prm, h->B, t_ms,
+                       (const double *)ref, (double *)out);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(e, "umpcBatchTaskReference");
+}
+
+int umpcBatchReactive(umpc_batch_t *h, int nsteps, int every, void *state, const void *ref, const void *gains,
+                      const void *Ib, const void *gain, void *out, void *stats, void *stream) {
+  if (!h || nsteps < 0 || every < 1 || !state || !ref) { g_err = "umpcBatchReactive: bad argument"; return -1; }
+  return h->dtype == UMPC_F32 ? launch_reactive<float>(h, nsteps, every, state, ref, gains, Ib, gain, out, stats, stream)
+                              : launch_reactive<double>(h, nsteps, every, state, ref, gains, Ib, gain, out, stats, stream);
 }
 
 int umpcBatchUpdate(umpc_batch_t *h, const void *state, void *ctrl, const void *ref, const void *actualT0,

@@ -332,10 +332,35 @@ def planar_p5f():
           sorted(set(zip(*[a.tolist() for a in np.nonzero(np.abs(np.stack(Ads)).sum(0))]))))
 
 
+
+def reactive(mods):
+    """reactiveController samples (template_controllers.py:282-296) and the reference's own
+    controlTest(None, 100, useMPC=False, taulim=10) log (uprightmpc2.py:87-159, the call of gainTuningSims :297)."""
+    genqp, tc, ft, um2 = mods
+    rng = np.random.default_rng(33)
+    rec = {k: [] for k in "p R dq pdes k u".split()}
+    for _ in range(64):
+        p, R, dq = rng.normal(size=3) * 20, rand_rot(rng, 0.6), np.hstack((rng.normal(size=3) * 0.3, rng.normal(size=3) * 0.02))
+        pdes = p + rng.normal(size=3) * 50
+        k = rng.uniform(0.2, 3, 6) * np.array([5e-3, 5e-1, 1e-1, 1e0, 10e0, 1e2])
+        u = tc.reactiveController(p, R, dq, pdes, kpos=list(k[0:2]), kz=list(k[2:4]), ks=list(k[4:6]))
+        for key, v in zip(rec, (p, R, dq, pdes, k, u)):
+            rec[key].append(np.array(v, np.float64))
+    log = um2.controlTest(None, 100, useMPC=False, showPlots=False, taulim=10, ks=[15.0, 1.2e2])
+    err, eff = um2.logMetric({k: (v.copy() if hasattr(v, "copy") else v) for k, v in log.items()})
+    np.savez_compressed(os.path.join(HERE, "reactive.npz"), log_t=log["t"], log_y=log["y"], log_u=log["u"],
+                        log_ks=np.array([15.0, 1.2e2]), metric=np.array([err, eff]),
+                        **{k: np.stack(v) for k, v in rec.items()})
+    print("reactive.npz: 64 samples, log", log["y"].shape, "metric", err, eff)
+
+
 if __name__ == "__main__":
     assert refbind.available(), "build oracle/_ref first: make -C oracle ref"
     if len(sys.argv) > 1 and sys.argv[1] == "wl":
         wl_step()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "reactive":
+        reactive(import_reference_python())
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "qp":
         assembly_fp64(import_reference_python(), 5, "assembly_fp64_N5.npz")
@@ -353,5 +378,6 @@ if __name__ == "__main__":
     tasks(mods)
     wl_step()
     assembly_fp64(mods, 5, "assembly_fp64_N5.npz")
+    reactive(mods)
     v1_qp(mods)
     planar_p5f()
