@@ -78,27 +78,37 @@ def build(force=False, verbose=False):
     from . import asmgen, codegen, codegen_qp
     gen, _ = codegen.write()
     gasm, _ = asmgen.write()
-    gqp, _ = codegen_qp.write()
+    greg, gqp_units = codegen_qp.write()
     hdr = os.path.join(ROOT, "include", "umpc_mi355x.h")
     csrc = os.path.join(HERE, "csrc")
     units = [(SRC, [gen, gasm, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
-             (SRC_BQP, [hdr, gqp, os.path.join(csrc, "umpc_err.h")])]
+             (SRC_BQP, [hdr, greg, os.path.join(csrc, "umpc_bqp_common.h"), os.path.join(csrc, "umpc_err.h")])]
+    units += [(u, [os.path.join(csrc, "umpc_bqp_common.h")]) for u in gqp_units]
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs, relink = [], force or not os.path.exists(SO_PATH)
-    procs = []
+    todo = []
     for src, deps in units:
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
         objs.append(obj)
         if (force or not os.path.exists(obj)
                 or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + deps)):
-            cmd = ["hipcc"] + HIPCC_FLAGS + ["-c", "-o", obj, src]
+            todo.append(["hipcc"] + HIPCC_FLAGS + ["-c", "-o", obj, src])
+            relink = True
+    for stale in set(os.listdir(OBJ_DIR)) - {os.path.basename(o) for o in objs}:
+        os.remove(os.path.join(OBJ_DIR, stale))
+    # one hipcc per translation unit, at most one per host CPU at a time
+    running, width = [], max(1, min(len(todo), os.cpu_count() or 1))
+    while todo or running:
+        while todo and len(running) < width:
+            cmd = todo.pop(0)
             if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd, cwd=csrc, stderr=None if verbose else subprocess.PIPE)))
-            relink = True
-    for cmd, p in procs:
+            running.append((cmd, subprocess.Popen(cmd, cwd=csrc, stderr=None if verbose else subprocess.PIPE)))
+        cmd, p = running.pop(0)
         _, err = p.communicate()
         if p.returncode != 0:
+            for _, q in running:
+                q.kill()
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), (err or b"").decode()[-4000:]))
     if relink or any(os.path.getmtime(SO_PATH) < os.path.getmtime(o) for o in objs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs

@@ -3,9 +3,9 @@ time: every index of the table-driven kernel becomes a literal, every per-robot 
 keep in a register or a fixed scratch slot and schedule freely. Same arithmetic, same order as
 `bqp_solve_kernel` (so fp64 results are bit-identical to the table-driven path; tests/test_bqp.py checks it).
 
-Emits csrc/umpc_bqp_gen.h: one `bqp_fixed_<name>` device function + kernel per structure and a registry keyed by
-the FNV-1a hash of the structure's table blob; umpcQPCreate picks the specialisation when the blob it is handed
-matches (umpcQPUseTables switches back). Built-in structures: planar p5f N = 10, the v1
+Emits one translation unit per (structure, dtype) under csrc/gen/ (compiled in parallel by _lib.build) and the
+registry header csrc/umpc_bqp_registry.h keyed by the FNV-1a hash of the structure's table blob; umpcQPCreate picks
+the specialisation when the blob it is handed matches (umpcQPUseTables switches back). Built-in structures: planar p5f N = 10, the v1
 template QP N = 3, UprightMPC2 N = 5.
 """
 import os
@@ -13,7 +13,6 @@ import os
 from . import batchqp, qpstruct
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "csrc", "umpc_bqp_gen.h")
 
 
 def fnv1a(words):
@@ -226,39 +225,62 @@ def emit_structure(name, s):
     E("  if (b >= a.B) return;")
     E("  bqp_fixed_%s<T>(a, b);" % name)
     E("}")
-    E("void bqp_launch_%s_f32(const QPArgs<float> &a, hipStream_t s) { hipLaunchKernelGGL(bqp_fixed_%s_kernel<float>, "
-      "dim3((a.B + 63) / 64), dim3(64), 0, s, a); }" % (name, name))
-    E("void bqp_launch_%s_f64(const QPArgs<double> &a, hipStream_t s) { hipLaunchKernelGGL(bqp_fixed_%s_kernel<double>, "
-      "dim3((a.B + 63) / 64), dim3(64), 0, s, a); }" % (name, name))
     return "\n".join(o) + "\n"
 
 
+DTYPES = (("f32", "float"), ("f64", "double"))
+
+
 def generate():
-    out = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
-           "// Straight-line specialisations of bqp_solve_kernel for the built-in structures.", ""]
-    reg = []
+    """Returns {relative path under csrc/: source}: one translation unit per (structure, dtype) so that the build can
+    compile them in parallel, plus the registry header umpc_bqp.hip includes."""
+    files = {}
+    reg, decl = [], []
     for name, s in builtin_structures():
-        out.append("// ---- %s: n = %d, m = %d, nnz(A) = %d, nnz(L) = %d ----" % (name, s.n, s.m, s.nnzA, s.nnzL))
-        out.append(emit_structure(name, s))
+        body = emit_structure(name, s)
+        for tag, ctype in DTYPES:
+            src = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
+                   "// Straight-line specialisation of bqp_solve_kernel: %s, n = %d, m = %d, nnz(A) = %d, nnz(L) = %d, %s."
+                   % (name, s.n, s.m, s.nnzA, s.nnzL, ctype),
+                   '#include "../umpc_bqp_common.h"', "", "namespace {", "using namespace umpcqp;", "", body,
+                   "}  // namespace", "",
+                   '__attribute__((visibility("hidden"))) void bqp_launch_%s_%s(const umpcqp::QPArgs<%s> &a, hipStream_t s) {'
+                   % (name, tag, ctype),
+                   "  hipLaunchKernelGGL(bqp_fixed_%s_kernel<%s>, dim3((a.B + 63) / 64), dim3(64), 0, s, a);" % (name, ctype),
+                   "}", ""]
+            files["gen/bqp_%s_%s.hip" % (name, tag)] = "\n".join(src)
+            decl.append('__attribute__((visibility("hidden"))) void bqp_launch_%s_%s(const umpcqp::QPArgs<%s> &, hipStream_t);'
+                        % (name, tag, ctype))
         reg.append('  {0x%016xull, "%s", bqp_launch_%s_f32, bqp_launch_%s_f64},' % (fnv1a(s.blob), name, name, name))
-    out.append("struct FixedKernel { uint64_t hash; const char *name; void (*f32)(const QPArgs<float> &, hipStream_t); "
-               "void (*f64)(const QPArgs<double> &, hipStream_t); };")
-    out.append("const FixedKernel kFixedKernels[] = {")
-    out += reg
-    out.append("};")
-    out.append("constexpr int kNumFixedKernels = %d;" % len(reg))
-    return "\n".join(out) + "\n"
+    hdr = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
+           "// Registry of the build-time specialisations (csrc/gen/bqp_*.hip), keyed by the FNV-1a hash of the table blob.",
+           "#pragma once", '#include "umpc_bqp_common.h"', ""] + decl + [
+           "struct FixedKernel { uint64_t hash; const char *name; void (*f32)(const umpcqp::QPArgs<float> &, hipStream_t); "
+           "void (*f64)(const umpcqp::QPArgs<double> &, hipStream_t); };",
+           "static const FixedKernel kFixedKernels[] = {"] + reg + ["};",
+           "constexpr int kNumFixedKernels = %d;" % len(reg), ""]
+    files["umpc_bqp_registry.h"] = "\n".join(hdr)
+    return files
 
 
-def write(path=OUT):
-    src = generate()
-    old = open(path).read() if os.path.exists(path) else None
-    if old != src:
-        with open(path, "w") as f:
-            f.write(src)
-    return path, src
+def write():
+    """Writes the generated files under csrc/ (only when their content changed); returns (registry path, [.hip paths])."""
+    csrc = os.path.join(HERE, "csrc")
+    os.makedirs(os.path.join(csrc, "gen"), exist_ok=True)
+    files = generate()
+    for rel, src in files.items():
+        path = os.path.join(csrc, rel)
+        old = open(path).read() if os.path.exists(path) else None
+        if old != src:
+            with open(path, "w") as f:
+                f.write(src)
+    keep = {os.path.basename(r) for r in files if r.startswith("gen/")}
+    for fn in os.listdir(os.path.join(csrc, "gen")):
+        if fn not in keep:
+            os.remove(os.path.join(csrc, "gen", fn))
+    return os.path.join(csrc, "umpc_bqp_registry.h"), sorted(os.path.join(csrc, r) for r in files if r.endswith(".hip"))
 
 
 if __name__ == "__main__":
-    p, src = write()
-    print(p, len(src.splitlines()), "lines")
+    reg, hips = write()
+    print(reg, *hips, sep="\n")

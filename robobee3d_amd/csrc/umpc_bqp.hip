@@ -23,59 +23,13 @@
 #include <string>
 
 #include "../../include/umpc_mi355x.h"
+#include "umpc_bqp_common.h"
+#include "umpc_bqp_registry.h"
 #include "umpc_err.h"
 
 namespace {
 
-constexpr double QP_INFTY = 1e30, QP_MIN_SCALING = 1e-4, QP_MAX_SCALING = 1e4;
-constexpr double QP_RHO_MIN = 1e-6, QP_RHO_TOL = 1e-4, QP_RHO_EQ_OVER_RHO_INEQ = 1e3;
-constexpr int HEADER_WORDS = 64;
-// header word indices (qpstruct.py)
-enum { H_N, H_M, H_NK, H_NNZP, H_NNZA, H_NNZL, H_NROWS, H_PAD, H_TAB0 };
-enum { T_PINV, T_PIDX, T_AP, T_AI, T_ARP, T_ARJ, T_ARK, T_FIP, T_FIB, T_FIS, T_FEP, T_FEC, T_FEN, T_LP, T_LI, T_LRP,
-       T_LRJ, T_LRK, T_COUNT };
-enum { R_PS, R_AS, R_QS, R_LS, R_US, R_D, R_E, R_DT, R_ET, R_RHO, R_RINV, R_KD, R_LX, R_DI, R_YV, R_WV, R_XP, R_DY,
-       R_T1, R_T2, R_T3, R_SC, R_COUNT };
-
-template <typename T>
-struct QPArgs {
-  const int32_t *tab;
-  int B;
-  T *W;
-  const T *Pv, *Av, *q, *l, *u;
-  T *x, *y, *z, *Eprev, *sol_x, *sol_y;
-  int32_t *status;
-  T *info;
-  T sigma, alpha, rho, eps_abs, eps_rel, eps_pinf, eps_dinf;
-  int max_iter, scaling;
-};
-
-template <typename T> __device__ __forceinline__ T qabs(T v) { return v < T(0) ? -v : v; }
-template <> __device__ __forceinline__ float qabs<float>(float v) { return __builtin_fabsf(v); }
-template <> __device__ __forceinline__ double qabs<double>(double v) { return __builtin_fabs(v); }
-// c_max / c_min of the reference: (a > b) ? a : b
-template <typename T> __device__ __forceinline__ T qmax(T a, T b) { return a > b ? a : b; }
-template <typename T> __device__ __forceinline__ T qmin(T a, T b) { return a < b ? a : b; }
-__device__ __forceinline__ float qsqrt(float v) { return __fsqrt_rn(v); }
-__device__ __forceinline__ double qsqrt(double v) { return __dsqrt_rn(v); }
-// limit_scaling, scaling.c:7-14 (comparisons in double)
-template <typename T> __device__ __forceinline__ T limit_scaling(T v) {
-  v = (double)v < QP_MIN_SCALING ? T(1.0) : v;
-  v = (double)v > QP_MAX_SCALING ? T(QP_MAX_SCALING) : v;
-  return v;
-}
-
-// update_rho_vec, auxil.c:103-145 (ls, us: bounds scaled by the previous E; comparisons in double)
-template <typename T>
-__device__ __forceinline__ void qp_classify(T ls, T us, T rho0, T rho_eq, T &r, T &ri) {
-  if (((double)ls < -QP_INFTY * QP_MIN_SCALING) && ((double)us > QP_INFTY * QP_MIN_SCALING)) {
-    r = T(QP_RHO_MIN); ri = T(1. / QP_RHO_MIN);
-  } else if ((double)(us - ls) < QP_RHO_TOL) {
-    r = rho_eq; ri = T(1. / (double)rho_eq);
-  } else {
-    r = rho0; ri = T(1. / (double)rho0);
-  }
-}
+using namespace umpcqp;
 
 template <typename T>
 __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
@@ -493,7 +447,6 @@ __global__ void umpcn_extract_kernel(int Bn, int N, T dt, const T *__restrict__ 
 #undef O
 }
 
-#include "umpc_bqp_gen.h"
 
 struct qp_batch {
   int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows, fixed, use_tables;
