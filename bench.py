@@ -222,6 +222,9 @@ def main():
         total_steps = world * B * args.steps
         value = total_steps / elapsed
         bps = ALG_BYTES_PER_STEP_FP32 * (2 if args.dtype == "f64" else 1)
+        # instructions one wavefront issues per closed-loop step (fp32 kernel; counted in the ISA):
+        # phase A 1.2k + 10 Ruiz passes x 1.37k + LDL'/hand-off 2.5k, 1.03k per ADMM iteration, phase C 5k, plant substeps
+        ninstr = 17400 + 1030 * args.max_iter + 5000 + args.nsub * (330 if plant_mode == 1 else 120)
         achieved = bps * B * spl / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -249,8 +252,17 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": _lib.lib().umpcKernelName(0 if args.dtype == "f32" else 1, plant_mode).decode(),
                          "kernel_ms": kern_ms, "steps_per_launch": spl, "alg_bytes_per_launch": bps * B * spl,
-                         "note": "path is VALU-issue/latency bound, not HBM bound (DESIGN.md): ~1.1e5 flop per "
-                                 "1208 B; achieved fp32 rate %.1f TFLOP/s" % (1.1e5 * B * spl / (kern_ms * 1e-3) / 1e12)},
+                         # SURVEY 8d asks for all three rooflines; the one that binds is vector issue
+                         "flops": {"achieved": 1.1e5 * B * spl / (kern_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                   "peak": 157.3, "note": "~1.1e5 flop per robot-step (SURVEY 8d); MI355X fp32 vector peak"},
+                         "lds": {"achieved": (50 * 76 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
+                                 "unit": "GB/s", "peak": 256 * 128 * 2.4,
+                                 "note": "76 ds_read_b128 per ADMM iteration per lane + hand-off; peak 128 B/clk/CU"},
+                         "valu_issue": {"instr_per_wave_step": ninstr, "achieved": ninstr * (B / 64) * spl / (kern_ms * 1e-3) / 1e9,
+                                        "peak": 1024 * 2.4 / 4, "unit": "G wave-instr/s",
+                                        "note": "static instruction counts x loop trips (DESIGN.md 2); peak = 1024 SIMDs, one "
+                                                "wave64 VALU op per 4 cycles at 2.4 GHz"} if args.dtype == "f32" else None,
+                         "note": "path is VALU-issue bound, not HBM bound (DESIGN.md): ~1.1e5 flop per 1208 B"},
             "check": {"nonfinite_state_values": nbad,
                       "mean_pos_err_mm2": float(metric[0].mean().item()),
                       "status_solved_frac": float((status > 0).float().mean().item())},
