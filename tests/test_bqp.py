@@ -425,3 +425,60 @@ def test_gpu_specialised_kernels_equal_the_table_driven_kernel():
                               T(g["snom"]), torch.as_tensor(g["vT0"].astype(ndt)).cuda())
             res.append(x.cpu().numpy().copy())
         assert np.array_equal(res[0], res[1], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_full_size_properties():
+    """Config 4 at its full batch (B = 16 384, fp32): every robot solved and finite after three ticks; robots that
+    start from the same state produce the same bits wherever they sit in the batch (lane / block independence)."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    B = 16384
+    mpc = PlanarP5fMPC(B, torch.float32)
+    rng = np.random.default_rng(20201119)
+    pert = rng.uniform(-0.1, 0.1, (2, B // 2)).astype(np.float32)
+    pert = np.concatenate((pert, pert[:, ::-1]), 1)                  # robot b and robot B-1-b are twins
+    mpc.y[0] = torch.as_tensor(pert[0]).cuda()
+    mpc.y[3] = torch.as_tensor(pert[1]).cuda()
+    for ti in range(2, 5):
+        mpc.tick(0.002 * ti)
+    torch.cuda.synchronize()
+    y = mpc.y.cpu().numpy()
+    x = mpc.qp.sol_x.cpu().numpy()
+    assert np.isfinite(y).all() and np.isfinite(x).all()
+    assert (mpc.qp.status.cpu().numpy() > 0).all()
+    assert np.array_equal(y, y[:, ::-1]) and np.array_equal(x, x[:, ::-1])
+    # the dynamics equalities hold at the solution to the ADMM tolerance: A_eq x = 0 (l = u = 0 on those rows)
+    st = mpc.st
+    Av = mpc.Av.cpu().numpy().astype(np.float64)[:, :64]
+    Ax = np.zeros((st["m"], 64))
+    for j in range(st["n"]):
+        for p in range(st["A_p"][j], st["A_p"][j + 1]):
+            Ax[st["A_i"][p]] += Av[p] * x[j, :64]
+    assert np.abs(Ax[:77]).max() < 5e-3 * max(1.0, np.abs(x[:, :64]).max())
+
+
+@pytest.mark.gpu
+def test_gpu_table_kernel_on_a_large_structure_matches_oracle():
+    """UprightMPC2 at N = 10 (n = 150, m = 130, nnz(L) ~ 1.5e3) has no build-time specialisation: the table-driven
+    kernel, fp64, against the table oracle."""
+    import torch
+    import osqp_table
+    from robobee3d_amd.batchqp import UprightMPC2N
+    seq = golden("seq_iter50.npz")
+    idx = np.arange(12)
+    st, ref, T0 = _state_ref_from_seq(seq, idx, np.float64)
+    mpc = UprightMPC2N(len(idx), 10, dtype=torch.float64)
+    assert mpc.qp.kernel_name == "tables"
+    mpc.T0.copy_(torch.as_tensor(T0).cuda())
+    mpc.update(torch.as_tensor(st).cuda(), torch.as_tensor(ref).cuda())
+    torch.cuda.synchronize()
+    f = lambda t: t.cpu().numpy()
+    s = mpc.st
+    z = lambda r: np.zeros((r, len(idx)))
+    r = osqp_table.solve(s["n"], s["m"], s["A_p"], s["A_i"], s["P_cols"], mpc.qp.s.perm, f(mpc.Pv), f(mpc.Av), f(mpc.q),
+                         f(mpc.l), f(mpc.u), z(s["n"]), z(s["m"]), z(s["m"]), np.ones((s["m"], len(idx))),
+                         osqp_table.Settings(max_iter=50))
+    assert np.allclose(f(mpc.qp.x), r["x"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(f(mpc.qp.sol_x), r["sol_x"], rtol=1e-8, atol=1e-10, equal_nan=True)
+    assert np.array_equal(f(mpc.qp.status), r["status"])
