@@ -58,7 +58,17 @@ def cpu_baseline(args, plant_mode):
     c1 = np.zeros((127, n1), np.float32); c1[124:] = 1
     oraclebind.batch_rollout(st1, c1, ref1, Ks, dtype=np.float32, plant_mode=plant_mode, nthreads=1)
     dt1 = time.perf_counter() - t1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": Bs * Ks / dt, "unit": "closed-loop MPC steps/s", "cores": ncores, "kind": "port",
+            "cpu_model": model, "host_threads_visible": len(os.sched_getaffinity(0)),
             "sample": "%d robots x %d steps of the same workload (oracle/umpc_oracle.c, fp32, OpenMP over robots)"
                       % (Bs, Ks),
             "single_thread_value": n1 * Ks / dt1}
