@@ -84,6 +84,130 @@ def _adv(e, sreg):
     e("s_addc_u32", "s%d" % (sreg + 1), "s%d" % (sreg + 1), 0)
 
 
+# ---------------------------------------------------------------------------
+# Register slots and L storage order
+# ---------------------------------------------------------------------------
+def slot_maps(s):
+    """x / constraint-row index -> register slot. The KKT pattern is invariant under the cyclic relabelling of the
+    (x, y, z) components of every position / orientation triple, so the solve applies the same operation to the x and
+    the y member of a triple with partner operands: the slots put those two members on an even-aligned register
+    pair (v_pk_fma_f32 operands); the z member and the inputs keep single slots."""
+    def one(n, ntrip):
+        sl = list(range(n))
+        for t in range(ntrip):
+            st = 3 * t
+            if st % 2:  # (x, y) must start on an even slot: rotate the triple to (z, x, y)
+                sl[st], sl[st + 1], sl[st + 2] = st + 1, st + 2, st
+        return sl
+    ntrip = 4 * s.N  # 2N blocks of (p, s) per part
+    xs, zs = one(s.nx, ntrip), one(s.nc, ntrip)
+    xinv, zinv = [0] * s.nx, [0] * s.nc
+    for j, p in enumerate(xs):
+        xinv[p] = j
+    for i, p in enumerate(zs):
+        zinv[p] = i
+    return xs, zs, xinv, zinv
+
+
+def w_reg(s, k, xs, zs):
+    """VGPR of the permuted KKT unknown k (W is stored by slot of its ORIGINAL index)."""
+    o = s.perm[k]
+    return V_W + xs[o] if o < s.nx else V_WZ + zs[o - s.nx]
+
+
+def solve_schedule(s, reg, direction, allowed=None):
+    """List-schedules one triangular solve. Ops are the L entries j = (row r, column c): forward W[r] -= L_j W[c]
+    (ready once W[c] is final), backward W[c] -= L_j W[r] (ready once W[r] is final). Two ready ops whose destination
+    registers AND source registers each form an aligned pair are issued as one packed instruction; an op whose
+    structural partner is not ready yet waits for it. Returns [(op,) | (op_lo, op_hi)] with op = (dst_k, src_k, j),
+    op_lo the member whose destination register is even. Operation order inside one unknown differs from QDLDL's
+    column sweep (rounding only)."""
+    nk = s.nk
+    ops = [(s.L_i[j], c, j) for c in range(nk) for j in range(s.L_p[c], s.L_p[c + 1])]
+    if direction == "bwd":
+        ops = [(c, r, j) for (r, c, j) in ops]
+
+    def ok(o, o2):
+        return (o2[2] != o[2] and reg[o2[0]] == (reg[o[0]] ^ 1) and reg[o2[1]] == (reg[o[1]] ^ 1)
+                and (allowed is None or frozenset((o[2], o2[2])) in allowed))
+    indeg = {k: 0 for k in range(nk)}
+    for (d, _, _) in ops:
+        indeg[d] += 1
+    final = {k for k in range(nk) if indeg[k] == 0}
+    remaining, out = list(ops), []
+    while remaining:
+        ready = [o for o in remaining if o[1] in final]
+        used, emitted = set(), []
+        for o in ready:
+            if o[2] in used:
+                continue
+            for o2 in ready:
+                if o2[2] not in used and ok(o, o2):
+                    used.update((o[2], o2[2]))
+                    emitted.append((o, o2) if reg[o[0]] % 2 == 0 else (o2, o))
+                    break
+        deferred = []
+        for o in ready:
+            if o[2] in used:
+                continue
+            if any(ok(o, o2) for o2 in remaining if o2[1] not in final and o2[2] not in used):
+                deferred.append(o)
+            else:
+                used.add(o[2])
+                emitted.append((o,))
+        if not emitted:
+            used.add(deferred[0][2])
+            emitted.append((deferred[0],))
+        out += emitted
+        for o in remaining:
+            if o[2] in used:
+                indeg[o[0]] -= 1
+                if indeg[o[0]] == 0:
+                    final.add(o[0])
+        remaining = [o for o in remaining if o[2] not in used]
+    return out
+
+
+def solve_plan(s):
+    """Forward / backward schedules with the SAME entry pairs (so that one storage order serves both) and the
+    storage position of every L entry: in order of first use by the forward solve, paired entries adjacent on an
+    even position (an LDS float4 holds two pairs; an AGPR pair is fetched with two v_accvgpr_read)."""
+    xs, zs, _, _ = slot_maps(s)
+    reg = [w_reg(s, k, xs, zs) for k in range(s.nk)]
+    fwd = solve_schedule(s, reg, "fwd")
+    # The reversed forward order with the roles of row and column swapped is a legal backward order (an entry of
+    # column r follows every entry of row r in the forward solve) with the same pairs, and it walks the storage
+    # backwards: each LDS float4 is fetched once per solve.
+    bwd = []
+    for g in reversed(fwd):
+        h = [(sr, d, j) for (d, sr, j) in g]
+        if len(h) == 2 and reg[h[0][0]] % 2:
+            h.reverse()
+        bwd.append(tuple(h))
+    order, pending = [], []
+    for g in fwd:
+        if len(g) == 2 and len(order) % 2:
+            pending.append(g)      # wait for a single to restore the parity
+            continue
+        order += [o[2] for o in g]
+        while pending and len(order) % 2 == 0:
+            order += [o[2] for o in pending.pop(0)]
+    assert not pending, "odd number of single entries before a trailing pair"
+    pos = [0] * len(s.L_i)
+    for p_, j in enumerate(order):
+        pos[j] = p_
+    for g in fwd:
+        if len(g) == 2:
+            a, b = pos[g[0][2]], pos[g[1][2]]
+            assert a // 2 == b // 2, "paired entries must share an aligned pair"
+    return fwd, bwd, pos
+
+
+def l_positions(N=3, perm=None):
+    """Storage position (LDS word < NLDS, else workspace row FAC_L + pos -> AGPR) of every L entry, by CSC index."""
+    return solve_plan(symbolic.analyse(N, perm))[2]
+
+
 def prologue(e, s):
     import numpy as np
     for reg, val in ((S_ALPHA, 1.6), (S_OMA, float(np.float32(1.0) - np.float32(1.6))), (S_SIGMA, 1e-6),
@@ -102,9 +226,10 @@ def prologue(e, s):
         _adv(e, S_P)
     # x, y, z
     e("s_mov_b64", "s[%d:%d]" % (S_P, S_P + 1), "s[%d:%d]" % (S_CTRL, S_CTRL + 1))
-    for base, n in ((V_X, s.nx), (V_Y, s.nc), (V_Z, s.nc)):
+    xs, zs, _, _ = slot_maps(s)
+    for base, n, sl in ((V_X, s.nx, xs), (V_Y, s.nc, zs), (V_Z, s.nc, zs)):
         for r in range(n):
-            e("global_load_dword", "v%d" % (base + r), "v0", "s[%d:%d]" % (S_P, S_P + 1))
+            e("global_load_dword", "v%d" % (base + sl[r]), "v0", "s[%d:%d]" % (S_P, S_P + 1))
             _adv(e, S_P)
     e("s_waitcnt", "vmcnt(0)")
 
@@ -114,9 +239,10 @@ def epilogue(e, s):
     # Registers are [x 45 | pad | y 39 | pad | z 39]; LDS words are contiguous, so y and z are written one
     # word at a time where they straddle a pad.
     w = 0
-    for base, n in ((V_X, s.nx), (V_Y, s.nc), (V_Z, s.nc)):
+    xs, zs, _, _ = slot_maps(s)
+    for base, n, sl in ((V_X, s.nx, xs), (V_Y, s.nc, zs), (V_Z, s.nc, zs)):
         for r in range(n):
-            e("ds_write_b32", "v1", "v%d" % (base + r), (w // 4) * 1024 + (w % 4) * 4)
+            e("ds_write_b32", "v1", "v%d" % (base + sl[r]), (w // 4) * 1024 + (w % 4) * 4)
             w += 1
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
@@ -198,10 +324,6 @@ class Fetcher:
                 op["emit"](V_RING + 4 * it["slot"] + op["src"][1] % 4)
 
 
-def l_src(eidx):
-    return ("L", eidx) if eidx < NLDS else ("A", A_L + eidx - NLDS)
-
-
 # ---- packed (VOP3P) operand helpers: every operand is a 64-bit register pair plus a half select ----
 def _vp(n):   # both halves of the aligned VGPR pair starting at even n
     assert n % 2 == 0
@@ -226,19 +348,23 @@ def pk(e, mnem, dst, srcs, neg=None):
     e(mnem, "v[%d:%d]" % (dst, dst + 1), *[s_[0] for s_ in srcs], mods)
 
 
-def body(e, s, first, capture):
+def body(e, s, first, capture, plan):
     nx, nc, nk = s.nx, s.nc, s.nk
     neq = 2 * s.N * symbolic.NY
+    xs, zs, xinv, zinv = slot_maps(s)
+    fwd, bwd, lpos = plan
 
-    def wreg(k):  # W is stored by ORIGINAL KKT index so that rows j, j+1 of x / y / z pair up with it
-        o = s.perm[k]
-        return V_W + o if o < nx else V_WZ + (o - nx)
+    def wreg(k):
+        return w_reg(s, k, xs, zs)
     W = lambda k: "v%d" % wreg(k)
-    WX = lambda j: V_W + j            # register of the KKT unknown paired with x_j
-    WZ = lambda i: V_WZ + i           # ... with constraint row i
-    X = lambda j: "v%d" % (V_X + j)
-    Y = lambda i: "v%d" % (V_Y + i)
-    Z = lambda i: "v%d" % (V_Z + i)
+    WX = lambda j: V_W + xs[j]        # register of the KKT unknown paired with x_j
+    WZ = lambda i: V_WZ + zs[i]       # ... with constraint row i
+    XR = lambda j: V_X + xs[j]
+    YR = lambda i: V_Y + zs[i]
+    ZR = lambda i: V_Z + zs[i]
+    X = lambda j: "v%d" % XR(j)
+    Y = lambda i: "v%d" % YR(i)
+    Z = lambda i: "v%d" % ZR(i)
     v = lambda n: "v%d" % n
     sA, sO, sS, sRi, sRh = ("s%d" % r for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO))
     ptr = "s[%d:%d]" % (S_P2, S_P2 + 1)
@@ -248,25 +374,51 @@ def body(e, s, first, capture):
     def op(src, fn):
         ops.append(dict(src=src, emit=fn))
 
+    def l_src(j):
+        return ("L", lpos[j]) if lpos[j] < NLDS else ("A", A_L + lpos[j] - NLDS)
+
     if capture:  # x_prev of this iteration -> workspace
         _row_ptr(e, S_P2, S_WS, WS_XPREV)
         for j in range(nx):
             e("global_store_dword", "v0", X(j), ptr)
             _adv(e, S_P2)
-    # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178)
-    for j in range(0, nx - 1, 2):
-        op(("A2", A_Q + j, A_Q + j + 1),
-           lambda t, j=j: pk(e, "v_pk_fma_f32", WX(j), [_sb(S_SIGMA), _vp(V_X + j), _vp(t)], [0, 0, 1]))
-    op(("A", A_Q + nx - 1), lambda t: e("v_fma_f32", v(WX(nx - 1)), sS, X(nx - 1), "-" + v(t)))
-    for i in range(0, neq, 2):
-        op(None, lambda t, i=i: pk(e, "v_pk_fma_f32", WZ(i), [_sb(S_RINV), _vp(V_Y + i), _vp(V_Z + i)], [1, 0, 0]))
+    # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178), two slots per instruction
+    for p_ in range(0, nx - 1, 2):
+        j0, j1 = xinv[p_], xinv[p_ + 1]
+        op(("A2", A_Q + j0, A_Q + j1),
+           lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_W + p_, [_sb(S_SIGMA), _vp(V_X + p_), _vp(t)], [0, 0, 1]))
+    if nx % 2:
+        jl = xinv[nx - 1]
+        op(("A", A_Q + jl), lambda t, jl=jl: e("v_fma_f32", v(WX(jl)), sS, X(jl), "-" + v(t)))
+    assert all(zinv[p_] < neq for p_ in range(neq)) and neq % 2 == 0
+    for p_ in range(0, neq, 2):
+        op(None, lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(V_Z + p_)], [1, 0, 0]))
     for i in range(neq, nc):
         op(("A", A_M + 9 + i - neq), lambda t, i=i: e("v_fma_f32", v(WZ(i)), "-" + v(t), Y(i), Z(i)))
-    # ---- forward substitution (qdldl.c:250-262)
-    for c in range(nk):
-        for j in range(s.L_p[c], s.L_p[c + 1]):
-            r_ = s.L_i[j]
-            op(l_src(j), lambda t, r_=r_, c=c: e("v_fma_f32", W(r_), "-" + v(t), W(c), W(r_)))
+
+    # ---- triangular solves (qdldl.c:250-277) from the list schedule: dst -= L * src, packed where both the
+    # destination and the source registers of two ready entries form aligned pairs
+    def solve_ops(sched):
+        for g in sched:
+            if len(g) == 1:
+                d, sr, j = g[0]
+                op(l_src(j), lambda t, d=d, sr=sr: e("v_fma_f32", W(d), "-" + v(t), W(sr), W(d)))
+                continue
+            (d0, s0_, j0), (d1, s1_, j1) = g          # d0 has the even destination register
+            rd, r0, r1 = wreg(d0), wreg(s0_), wreg(s1_)
+            assert rd % 2 == 0 and wreg(d1) == rd + 1 and r0 // 2 == r1 // 2 and lpos[j0] // 2 == lpos[j1] // 2
+            srcp = ("v[%d:%d]" % (r0 - r0 % 2, r0 - r0 % 2 + 1), r0 % 2, r1 % 2)
+            pe = lpos[j0] - lpos[j0] % 2
+            if pe < NLDS:
+                src = ("L", pe)
+                lsel = (lpos[j0] % 2, lpos[j1] % 2)
+                op(src, lambda t, rd=rd, srcp=srcp, lsel=lsel:
+                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]))
+            else:
+                src = ("A2", A_L + lpos[j0] - NLDS, A_L + lpos[j1] - NLDS)
+                op(src, lambda t, rd=rd, srcp=srcp: pk(e, "v_pk_fma_f32", rd, [_vp(t), srcp, _vp(rd)], [1, 0, 0]))
+
+    solve_ops(fwd)
     # ---- diagonal (qdldl.c:289): two unknowns per instruction, paired by register
     kof = {wreg(k): k for k in range(nk)}
     for r0 in range(V_W, V_Z, 2):
@@ -276,36 +428,34 @@ def body(e, s, first, capture):
         elif k0 is not None or k1 is not None:
             k, r = (k0, r0) if k0 is not None else (k1, r0 + 1)
             op(("A", A_D + k), lambda t, r=r: e("v_mul_f32", v(r), v(t), v(r)))
-    # ---- backward substitution (qdldl.c:265-277)
-    for c in range(nk - 1, -1, -1):
-        for j in range(s.L_p[c], s.L_p[c + 1]):
-            r_ = s.L_i[j]
-            op(l_src(j), lambda t, r_=r_, c=c: e("v_fma_f32", W(c), "-" + v(t), W(r_), W(c)))
+    solve_ops(bwd)
     f.run(ops)
     # ---- x <- alpha x~ + (1 - alpha) x   (auxil.c:188-201)
-    for j in range(0, nx - 1, 2):
-        t = V_TT + 2 * ((j // 2) % 4)
-        pk(e, "v_pk_mul_f32", t, [_sb(S_OMA), _vp(V_X + j)])
-        pk(e, "v_pk_fma_f32", V_X + j, [_sb(S_ALPHA), _vp(WX(j)), _vp(t)])
-    e("v_mul_f32", v(V_TT), sO, X(nx - 1))
-    e("v_fma_f32", X(nx - 1), sA, v(WX(nx - 1)), v(V_TT))
+    for p_ in range(0, nx - 1, 2):
+        t = V_TT + 2 * ((p_ // 2) % 4)
+        pk(e, "v_pk_mul_f32", t, [_sb(S_OMA), _vp(V_X + p_)])
+        pk(e, "v_pk_fma_f32", V_X + p_, [_sb(S_ALPHA), _vp(V_W + p_), _vp(t)])
+    if nx % 2:
+        jl = xinv[nx - 1]
+        e("v_mul_f32", v(V_TT), sO, X(jl))
+        e("v_fma_f32", X(jl), sA, v(WX(jl)), v(V_TT))
     # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
-    if capture:
+    if capture and first:
         _row_ptr(e, S_P2, S_WS, WS_DY)
     if not first:
         # Dynamics rows after the first iteration: z == l == u, so z stays and
         #   delta_y = rho (alpha z~ + (1-alpha) z - z) = rho alpha (z~ - z) = rho alpha rinv (nu - y) = alpha (nu - y)
         # (rho rinv = 1). Two packed instructions per two rows instead of seven per row; same value up to the
         # rounding of the longer chain.
-        for i in range(0, neq, 2):
-            t = V_TT + 2 * ((i // 2) % 2)
-            pk(e, "v_pk_add_f32", t, [_vp(WZ(i)), _vp(V_Y + i)], [0, 1])
+        for p_ in range(0, neq, 2):
+            t = V_TT + 2 * ((p_ // 2) % 2)
+            pk(e, "v_pk_add_f32", t, [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1])
             if capture:
                 pk(e, "v_pk_mul_f32", t + 4, [_sb(S_ALPHA), _vp(t)])
                 for h in range(2):
+                    _row_ptr(e, S_P2, S_WS, WS_DY + zinv[p_ + h])
                     e("global_store_dword", "v0", v(t + 4 + h), ptr)
-                    _adv(e, S_P2)
-            pk(e, "v_pk_fma_f32", V_Y + i, [_sb(S_ALPHA), _vp(t), _vp(V_Y + i)])
+            pk(e, "v_pk_fma_f32", V_Y + p_, [_sb(S_ALPHA), _vp(t), _vp(V_Y + p_)])
     for i in range(nc):
         eq = i < neq
         if eq and not first:
@@ -342,29 +492,33 @@ def body(e, s, first, capture):
         e("v_mul_f32", t2, rho, t2)                       # delta_y
         e("v_add_f32", Y(i), Y(i), t2)
         if capture:
+            if not first:
+                _row_ptr(e, S_P2, S_WS, WS_DY + i)
             e("global_store_dword", "v0", t2, ptr)
-            _adv(e, S_P2)
+            if first:
+                _adv(e, S_P2)
 
 
 def program(N=3, perm=None):
     s = symbolic.analyse(N, perm)
+    plan = solve_plan(s)
     e = Emit()
     prologue(e, s)
     e("s_cmp_lt_i32", "s%d" % S_ITERS, 1)
     e("s_cbranch_scc1", "9f")
-    body(e, s, first=True, capture=True)
+    body(e, s, first=True, capture=True, plan=plan)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_ITERS, 2)
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
     e("s_cbranch_scc1", "8f")
     e("label", "7")
-    body(e, s, first=False, capture=False)
+    body(e, s, first=False, capture=False, plan=plan)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
     e("label", "8")
     e("s_cmp_lt_i32", "s%d" % S_ITERS, 2)
     e("s_cbranch_scc1", "9f")
-    body(e, s, first=False, capture=True)
+    body(e, s, first=False, capture=True, plan=plan)
     e("label", "9")
     epilogue(e, s)
     return e.ins, s
@@ -392,6 +546,9 @@ def fmt(t):
 def write(path=None, N=3, perm=None):
     path = path or os.path.join(HERE, "csrc", "umpc_admm_asm.h")
     ins, s = program(N, perm)
+    lpos = solve_plan(s)[2]
+    store_l = " ".join("LDSW_(%d) = LX_(%d);" % (lpos[j], j) if lpos[j] < NLDS else "ROW_(%d) = LX_(%d);" % (FAC_L + lpos[j], j)
+                       for j in range(len(lpos)))
     used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1] + list(range(S_ALPHA, S_RHO + 2))
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
@@ -407,6 +564,9 @@ def write(path=None, N=3, perm=None):
            (WS_DS, WS_ES, WS_C, WS_XPREV, WS_DY, WS_ROWS),
            "constexpr int LDS_BYTES_PER_LANE = %d;" % (NLDS * 4),
            "}  // namespace umpcasm",
+           "// Phase A -> loop hand-off of the factor: entry j of L (CSC order) goes to its storage position (asmgen.solve_plan):",
+           "// LDS word LDSW_(p) for p < %d, workspace row ROW_(FAC_L + p) (-> AGPR) otherwise." % NLDS,
+           "#define UMPC_ASM_STORE_L(LDSW_, ROW_, LX_) do { %s } while (0)" % store_l,
            "// inputs: v0 = 4*robot, v1 = lane LDS address, s[4:5] = workspace, s[6:7] = ctrl, s10 = 4*B, s11 = maxIter",
            "#define UMPC_ADMM_ASM(voff, ldsaddr, ws, ctrl, stride, iters) asm volatile( \\"]
     for t in ins:

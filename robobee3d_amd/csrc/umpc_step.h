@@ -532,11 +532,13 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #undef A_
 #undef P_
     if constexpr (ASM) {
-      // L[0..160) goes straight to its loop home in LDS (float4-interleaved per lane), the rest through rows
-#pragma unroll
-      for (int e = 0; e < LDS_BYTES_PER_LANE / 4; ++e) LDSW(e) = Lx[e];
-#pragma unroll
-      for (int e = LDS_BYTES_PER_LANE / 4; e < NNZL; ++e) GLD(a.ws, FAC_L + e) = Lx[e];
+      // the first 160 storage positions of L go straight to their loop home in LDS (float4-interleaved per lane),
+      // the rest through rows; the storage order (paired entries adjacent) is the generator's
+#define UMPC_ROW_(r) GLD(a.ws, r)
+#define UMPC_LX_(j) Lx[j]
+      UMPC_ASM_STORE_L(LDSW, UMPC_ROW_, UMPC_LX_);
+#undef UMPC_ROW_
+#undef UMPC_LX_
 #pragma unroll
       for (int k = 0; k < NK; ++k) GLD(a.ws, FAC_DI + k) = Di[k];
 #pragma unroll

@@ -31,7 +31,11 @@ def _case(oracle_built, asmgen, ins, s, seq, k, iters):
     o = fresh(0)  # factorisation only
     ws = np.zeros(asmgen.WS_ROWS, np.float32)
     ctrl = np.zeros(127, np.float32)
-    ws[asmgen.FAC_L:asmgen.FAC_L + 213] = o.get("L_x")
+    # L entry j lives at storage position pos[j] (asmgen.solve_plan): LDS word if < NLDS, else workspace row
+    pos = np.array(asmgen.l_positions())
+    Lstore = np.zeros(213, np.float32)
+    Lstore[pos] = o.get("L_x")
+    ws[asmgen.FAC_L:asmgen.FAC_L + 213] = Lstore
     ws[asmgen.FAC_DI:asmgen.FAC_DI + 84] = o.get("Ddinv")
     ws[asmgen.FAC_Q:asmgen.FAC_Q + 45] = o.get("q")
     l, u = o.get("l"), o.get("u")
@@ -46,7 +50,7 @@ def _case(oracle_built, asmgen, ins, s, seq, k, iters):
         ob = fresh(iters - 1)
         x_before_last = ob.get("x") if iters > 1 else seq["pre_x"][k]
     lds = np.zeros(160, np.float32)
-    lds[:asmgen.NLDS] = o.get("L_x")[:asmgen.NLDS]   # phase A leaves L[0..160) in LDS
+    lds[:asmgen.NLDS] = Lstore[:asmgen.NLDS]   # phase A leaves storage positions 0..159 in LDS
     ws[asmgen.FAC_L:asmgen.FAC_L + asmgen.NLDS] = np.nan  # ... and the program must not read those rows
     asmgen.simulate(ins, ws, ctrl, iters, lds)
     o2 = fresh(iters)
