@@ -254,6 +254,9 @@ class Fetcher:
     def __init__(self, e, la=3):
         self.e, self.la = e, la
         self.nds = 0          # ds_reads issued so far in this body
+        self.waited = -1      # issue index of the last ds_read known to have returned
+        self.lds_ahead = int(os.environ.get("UMPC_ASM_LDS_AHEAD", "12"))  # ops between a ds_read and its first consumer
+        self.merge = 1        # also wait for this many later reads if they are already issued
 
     def run(self, ops):
         e = self.e
@@ -303,7 +306,7 @@ class Fetcher:
             while next_inst < len(insts):
                 it = insts[next_inst]
                 prev = insts[it["prev"]] if it["prev"] is not None else None
-                if it["first"] <= i + 4 * self.la and (prev is None or prev["last"] < i):
+                if it["first"] <= i + self.lds_ahead and (prev is None or prev["last"] < i):
                     issue(it)
                     next_inst += 1
                 else:
@@ -319,8 +322,12 @@ class Fetcher:
                     assert inst_of[i] == next_inst and (it["prev"] is None or insts[it["prev"]]["last"] < i)
                     issue(it)
                     next_inst += 1
-                if it["first"] == i:
-                    e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nds - 1 - it["issued"]))
+                if it["first"] == i and it["issued"] > self.waited:
+                    # one wait covers this read and, when it is already in flight, the next one too (LDS reads
+                    # return in order): half as many s_waitcnt in the instruction stream
+                    upto = min(self.nds - 1, it["issued"] + self.merge)
+                    e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nds - 1 - upto))
+                    self.waited = upto if self.nds - 1 - upto <= 15 else it["issued"]
                 op["emit"](V_RING + 4 * it["slot"] + op["src"][1] % 4)
 
 
