@@ -43,7 +43,8 @@ from . import symbolic
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-NLDS = 160  # L entries kept in LDS
+NLDS = 160  # L storage positions kept in LDS
+NVZ = 36    # positions NLDS .. NLDS+NVZ-1 move into the z registers of the dynamics rows after the first iteration
 # workspace rows shared with the C++ phases (see umpc_step.h)
 FAC_L, FAC_DI, FAC_Q, FAC_LOEQ, FAC_M = 0, 213, 297, 342, 378
 FAC_ROWS = 390
@@ -234,15 +235,22 @@ def prologue(e, s):
     e("s_waitcnt", "vmcnt(0)")
 
 
-def epilogue(e, s):
+def epilogue(e, s, z_is_l):
     # x, y, z stay on chip: the factor in LDS is dead now, phase C reads the iterates from LDS words 0..122.
     # Registers are [x 45 | pad | y 39 | pad | z 39]; LDS words are contiguous, so y and z are written one
-    # word at a time where they straddle a pad.
+    # word at a time where they straddle a pad. After >= 1 iteration z of the dynamics rows is l (AGPR A_LO) and
+    # their registers hold L entries.
     w = 0
     xs, zs, _, _ = slot_maps(s)
+    neq = 2 * s.N * symbolic.NY
     for base, n, sl in ((V_X, s.nx, xs), (V_Y, s.nc, zs), (V_Z, s.nc, zs)):
         for r in range(n):
-            e("ds_write_b32", "v1", "v%d" % (base + sl[r]), (w // 4) * 1024 + (w % 4) * 4)
+            if base == V_Z and z_is_l and r < neq:
+                t = V_RING + r % 16
+                e("v_accvgpr_read_b32", "v%d" % t, "a%d" % (A_LO + r))
+                e("ds_write_b32", "v1", "v%d" % t, (w // 4) * 1024 + (w % 4) * 4)
+            else:
+                e("ds_write_b32", "v1", "v%d" % (base + sl[r]), (w // 4) * 1024 + (w % 4) * 4)
             w += 1
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
@@ -355,7 +363,7 @@ def pk(e, mnem, dst, srcs, neg=None):
     e(mnem, "v[%d:%d]" % (dst, dst + 1), *[s_[0] for s_ in srcs], mods)
 
 
-def body(e, s, first, capture, plan):
+def body(e, s, first, capture, plan, lv=False):
     nx, nc, nk = s.nx, s.nc, s.nk
     neq = 2 * s.N * symbolic.NY
     xs, zs, xinv, zinv = slot_maps(s)
@@ -381,8 +389,14 @@ def body(e, s, first, capture, plan):
     def op(src, fn):
         ops.append(dict(src=src, emit=fn))
 
+    assert NVZ == neq and not (lv and first)
+
     def l_src(j):
-        return ("L", lpos[j]) if lpos[j] < NLDS else ("A", A_L + lpos[j] - NLDS)
+        if lpos[j] < NLDS:
+            return ("L", lpos[j])
+        if lv and lpos[j] < NLDS + NVZ:   # resident in the z registers of the dynamics rows (z == l there, kept in AGPRs)
+            return ("V", V_Z + lpos[j] - NLDS)
+        return ("A", A_L + lpos[j] - NLDS)
 
     if capture:  # x_prev of this iteration -> workspace
         _row_ptr(e, S_P2, S_WS, WS_XPREV)
@@ -399,7 +413,11 @@ def body(e, s, first, capture, plan):
         op(("A", A_Q + jl), lambda t, jl=jl: e("v_fma_f32", v(WX(jl)), sS, X(jl), "-" + v(t)))
     assert all(zinv[p_] < neq for p_ in range(neq)) and neq % 2 == 0
     for p_ in range(0, neq, 2):
-        op(None, lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(V_Z + p_)], [1, 0, 0]))
+        if lv:   # z of the dynamics rows is l (== u): read it from its AGPR home
+            op(("A2", A_LO + zinv[p_], A_LO + zinv[p_ + 1]),
+               lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(t)], [1, 0, 0]))
+        else:
+            op(None, lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(V_Z + p_)], [1, 0, 0]))
     for i in range(neq, nc):
         op(("A", A_M + 9 + i - neq), lambda t, i=i: e("v_fma_f32", v(WZ(i)), "-" + v(t), Y(i), Z(i)))
 
@@ -409,17 +427,24 @@ def body(e, s, first, capture, plan):
         for g in sched:
             if len(g) == 1:
                 d, sr, j = g[0]
-                op(l_src(j), lambda t, d=d, sr=sr: e("v_fma_f32", W(d), "-" + v(t), W(sr), W(d)))
+                src = l_src(j)
+                if src[0] == "V":
+                    op(None, lambda t, d=d, sr=sr, r=src[1]: e("v_fma_f32", W(d), "-" + v(r), W(sr), W(d)))
+                else:
+                    op(src, lambda t, d=d, sr=sr: e("v_fma_f32", W(d), "-" + v(t), W(sr), W(d)))
                 continue
             (d0, s0_, j0), (d1, s1_, j1) = g          # d0 has the even destination register
             rd, r0, r1 = wreg(d0), wreg(s0_), wreg(s1_)
             assert rd % 2 == 0 and wreg(d1) == rd + 1 and r0 // 2 == r1 // 2 and lpos[j0] // 2 == lpos[j1] // 2
             srcp = ("v[%d:%d]" % (r0 - r0 % 2, r0 - r0 % 2 + 1), r0 % 2, r1 % 2)
             pe = lpos[j0] - lpos[j0] % 2
+            lsel = (lpos[j0] % 2, lpos[j1] % 2)
             if pe < NLDS:
-                src = ("L", pe)
-                lsel = (lpos[j0] % 2, lpos[j1] % 2)
-                op(src, lambda t, rd=rd, srcp=srcp, lsel=lsel:
+                op(("L", pe), lambda t, rd=rd, srcp=srcp, lsel=lsel:
+                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]))
+            elif lv and pe < NLDS + NVZ:
+                t = V_Z + pe - NLDS
+                op(None, lambda _t, t=t, rd=rd, srcp=srcp, lsel=lsel:
                    pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]))
             else:
                 src = ("A2", A_L + lpos[j0] - NLDS, A_L + lpos[j1] - NLDS)
@@ -489,8 +514,7 @@ def body(e, s, first, capture, plan):
         e("v_fma_f32", t1, sA, t1, t2)                    # t = alpha z~ + (1-alpha) z
         if eq:
             zn = v(V_RING + i % 16)
-            e("v_sub_f32", t2, t1, zn)
-            e("v_mov_b32", Z(i), zn)
+            e("v_sub_f32", t2, t1, zn)   # z <- l: from here on z of this row is read from its AGPR (A_LO)
         else:
             e("v_fma_f32", t3, rinv, Y(i), t1)
             e("v_max_f32", t3, t3, v(V_AT + 2))
@@ -514,20 +538,28 @@ def program(N=3, perm=None):
     e("s_cmp_lt_i32", "s%d" % S_ITERS, 1)
     e("s_cbranch_scc1", "9f")
     body(e, s, first=True, capture=True, plan=plan)
+    # the z registers of the dynamics rows are free now (z == l): they take the L entries of storage positions
+    # NLDS .. NLDS+NVZ-1, read twice per iteration, out of the AGPRs
+    for p_ in range(NVZ):
+        e("v_accvgpr_read_b32", "v%d" % (V_Z + p_), "a%d" % (A_L + p_))
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_ITERS, 2)
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
     e("s_cbranch_scc1", "8f")
     e("label", "7")
-    body(e, s, first=False, capture=False, plan=plan)
+    body(e, s, first=False, capture=False, plan=plan, lv=True)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
     e("label", "8")
     e("s_cmp_lt_i32", "s%d" % S_ITERS, 2)
-    e("s_cbranch_scc1", "9f")
-    body(e, s, first=False, capture=True, plan=plan)
+    e("s_cbranch_scc1", "6f")
+    body(e, s, first=False, capture=True, plan=plan, lv=True)
+    e("label", "6")
+    epilogue(e, s, z_is_l=True)
+    e("s_branch", "5f")
     e("label", "9")
-    epilogue(e, s)
+    epilogue(e, s, z_is_l=False)
+    e("label", "5")
     return e.ins, s
 
 
@@ -678,8 +710,8 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds=None):
             a, b = sval(t[1]), sval(t[2])
             a = a - (1 << 32) if a & 0x80000000 else a
             scc = int(a < b) if m == "s_cmp_lt_i32" else int(a > b)
-        elif m == "s_cbranch_scc1":
-            if scc:
+        elif m == "s_branch" or m == "s_cbranch_scc1":
+            if m == "s_branch" or scc:
                 lab, d = t[1][:-1], t[1][-1]
                 cands = labels[lab]
                 pc = min(c for c in cands if c > pc) if d == "f" else max(c for c in cands if c < pc)
