@@ -132,6 +132,8 @@ __device__ __forceinline__ double umpc_rcp_fast(double v) { return 1.0 / v; }
 __device__ __forceinline__ float umpc_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double umpc_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float umpc_sqrt(float v) { return __fsqrt_rn(v); }
+__device__ __forceinline__ float umpc_sqrt_fast(float v) { return __builtin_amdgcn_sqrtf(v); }   // v_sqrt_f32, 1 ulp
+__device__ __forceinline__ double umpc_sqrt_fast(double v) { return __dsqrt_rn(v); }
 __device__ __forceinline__ double umpc_sqrt(double v) { return __dsqrt_rn(v); }
 __device__ __forceinline__ float umpc_sin(float v) { return sinf(v); }
 __device__ __forceinline__ double umpc_sin(double v) { return sin(v); }
@@ -425,6 +427,15 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     wt.wvr = GLD(a.weights, 4); wt.wvf = GLD(a.weights, 5); wt.wthrust = GLD(a.weights, 6); wt.wmom = GLD(a.weights, 7);
   }
 
+// raw diagonal of P for column j (umpcInit weight layout, uprightmpc2.c:27-36), from a Weights object
+#define PXRAW_OF(wt, j) ((j) < 2 * N * NY ? ((j) % NY < 3 ? ((j) < N * NY ? ((j) / NY == N - 1 ? wt.wpf : wt.wpr)                    \
+                                                                     : (((j) - N * NY) / NY == N - 1 ? wt.wvf : wt.wvr))        \
+                                                       : ((j) < N * NY ? wt.ws : wt.wds))                                       \
+                                   : (((j) - 2 * N * NY) % NU == 0 ? wt.wthrust : wt.wmom))
+#define PXRAW(j) PXRAW_OF(wt, j)
+  // reciprocals of the eight weights: D is recovered after Ruiz as sqrt(P_scaled / (P_raw c))
+  const Weights<T> wti = {T(1) / wt.ws, T(1) / wt.wds, T(1) / wt.wpr, T(1) / wt.wpf, T(1) / wt.wvr, T(1) / wt.wvf,
+                          T(1) / wt.wthrust, T(1) / wt.wmom};
   // =========================== phase A: assemble, equilibrate, factor ===========================
   UMPC_PHASE_FENCE();
   {
@@ -468,11 +479,10 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
       }
     }
     // ---- Ruiz equilibration, scaling.c:44-156 ----
+    // The accumulated D and E are not carried through the passes (84 live words and 84 multiplies per pass):
+    // they are recovered afterwards from the equilibrated data, D_j = sqrt(P_jj / (P_raw_jj c)) and
+    // E_i = |A_ip| / D_p on the +-1 entry of row i -- the same numbers up to rounding.
     T cscale = T(1);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) Ds[j] = T(1);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) Es[i] = T(1);
 #define P_(j) P[j]
 #define DT_(j) Dt[j]
 #define ET_(i) Et[i]
@@ -491,12 +501,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #pragma unroll
       for (int j = 0; j < NX; ++j) {
         q[j] = q[j] * Dt[j];
-        Ds[j] = Dt[j] * Ds[j];
         pmean += umpc_abs(P[j]);
         qn = umpc_max(qn, umpc_abs(q[j]));
       }
-#pragma unroll
-      for (int i = 0; i < NC; ++i) Es[i] = Et[i] * Es[i];
       pmean /= T(NX);
       qn = limit_scaling(qn);
       T ct = limit_scaling(umpc_max(pmean, qn));
@@ -507,6 +514,16 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     }
 #undef DT_
 #undef ET_
+    {
+      const T cinv_ = T(1) / cscale;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Ds[j] = umpc_sqrt_fast((P[j] * cinv_) * PXRAW_OF(wti, j));
+#define DS_(j) Ds[j]
+#define ES_(i) Es[i]
+      UMPC_GEN_E_FROM_A(umpc_rcp_fast);
+#undef DS_
+#undef ES_
+    }
     // hand-off rows: what phase C needs again, and what the loop consumes
 #pragma unroll
     for (int j = 0; j < NX; ++j) { GLD(a.ws, WS_DS + j) = Ds[j]; GLD(a.ws, FAC_Q + j) = q[j]; Q_(j) = q[j]; }
@@ -649,10 +666,6 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     }
 #define DT_(j) Ds[j]
 #define ET_(i) Es[i]
-#define PXRAW(j) ((j) < 2 * N * NY ? ((j) % NY < 3 ? ((j) < N * NY ? ((j) / NY == N - 1 ? wt.wpf : wt.wpr)                    \
-                                                                     : (((j) - N * NY) / NY == N - 1 ? wt.wvf : wt.wvr))        \
-                                                       : ((j) < N * NY ? wt.ws : wt.wds))                                       \
-                                   : (((j) - 2 * N * NY) % NU == 0 ? wt.wthrust : wt.wmom))
     // ---- update_info: residuals (auxil.c:243-307) ----
     T nz = T(0), nAx = T(0), nq = T(0), nAty = T(0), nPx = T(0);
     {
@@ -853,6 +866,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #undef YV
 #undef ZV
 #undef PXRAW
+#undef PXRAW_OF
 }
 
 }  // namespace umpc
