@@ -151,6 +151,9 @@ template <typename T> __device__ __forceinline__ T limit_scaling(T v) {
 template <typename T>
 __device__ __forceinline__ void plant_vf(const T (&R)[9], const T (&dq)[6], const T (&u)[3],
                                          const T (&Ib)[3], const T (&Ibinv)[3], T gain, T (&ddq)[6]) {
+  // the library is built with -ffp-contract=off (the QP phases place their FMAs explicitly); the plant is plain
+  // arithmetic where a fused multiply-add only removes a rounding
+#pragma clang fp contract(fast)
   const T wx = dq[3], wy = dq[4], wz = dq[5];
   const T Th = gain * u[0];
   ddq[0] = Th * R[6];
@@ -169,6 +172,9 @@ __device__ __forceinline__ void plant_vf(const T (&R)[9], const T (&dq)[6], cons
 // R <- R expm(skew(w) h): Rodrigues form of scipy.linalg.expm(skew(w) dt), genqp.py:39
 template <typename T>
 __device__ __forceinline__ void plant_rot(T (&R)[9], T w0, T w1, T w2, T h) {
+  // the library is built with -ffp-contract=off (the QP phases place their FMAs explicitly); the plant is plain
+  // arithmetic where a fused multiply-add only removes a rounding
+#pragma clang fp contract(fast)
   const T ax = w0 * h, ay = w1 * h, az = w2 * h;
   const T t = ax * ax + ay * ay + az * az;
   T a, b;
@@ -202,6 +208,9 @@ __device__ __forceinline__ void plant_rot(T (&R)[9], T w0, T w1, T w2, T h) {
 template <typename T>
 __device__ __forceinline__ void plant_step(T (&p)[3], T (&R)[9], T (&dq)[6], const T (&u)[3], T dt,
                                            const T (&Ib)[3], const T (&Ibinv)[3], T gain, int mode) {
+  // the library is built with -ffp-contract=off (the QP phases place their FMAs explicitly); the plant is plain
+  // arithmetic where a fused multiply-add only removes a rounding
+#pragma clang fp contract(fast)
   if (mode == 0) {
     T ddq[6];
     plant_vf(R, dq, u, Ib, Ibinv, gain, ddq);
