@@ -233,8 +233,8 @@ def main():
         value = total_steps / elapsed
         bps = ALG_BYTES_PER_STEP_FP32 * (2 if args.dtype == "f64" else 1)
         # instructions one wavefront issues per closed-loop step (fp32 kernel; counted in the ISA):
-        # phase A 1.2k + 10 Ruiz passes x 1.37k + LDL'/hand-off 2.5k, 1.03k per ADMM iteration, phase C 5k, plant substeps
-        ninstr = 17400 + 1030 * args.max_iter + 5000 + args.nsub * (330 if plant_mode == 1 else 120)
+        # phase A 1.2k + 10 Ruiz passes x 0.94k + LDL'/hand-off 3.0k, 835 per ADMM iteration, phase C 5k, plant substeps
+        ninstr = 13600 + 835 * args.max_iter + 5000 + args.nsub * (250 if plant_mode == 1 else 110)
         achieved = bps * B * spl / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -265,9 +265,9 @@ def main():
                          # SURVEY 8d asks for all three rooflines; the one that binds is vector issue
                          "flops": {"achieved": 1.1e5 * B * spl / (kern_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
                                    "peak": 157.3, "note": "~1.1e5 flop per robot-step (SURVEY 8d); MI355X fp32 vector peak"},
-                         "lds": {"achieved": (50 * 76 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
+                         "lds": {"achieved": (args.max_iter * 78 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
                                  "unit": "GB/s", "peak": 256 * 128 * 2.4,
-                                 "note": "76 ds_read_b128 per ADMM iteration per lane + hand-off; peak 128 B/clk/CU"},
+                                 "note": "78 ds_read_b128 per ADMM iteration per lane + hand-off; peak 128 B/clk/CU"},
                          "valu_issue": {"instr_per_wave_step": ninstr, "achieved": ninstr * (B / 64) * spl / (kern_ms * 1e-3) / 1e9,
                                         "peak": 1024 * 2.4 / 4, "unit": "G wave-instr/s",
                                         "note": "static instruction counts x loop trips (DESIGN.md 2); peak = 1024 SIMDs, one "
