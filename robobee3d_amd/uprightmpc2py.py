@@ -82,8 +82,43 @@ class WLCon:
         return u1, w0
 
 
+class UprightMPC2:
+    """Twin of the pure-Python class template_controllers.UprightMPC2(N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf,
+    wthrust, wmom, Ib) (template/template_controllers.py:170-258): any horizon N, fp64, one robot, on the
+    general-structure solver (robobee3d_amd.batchqp.UprightMPC2N with B = 1). The reference solves with pip osqp to
+    eps 1e-4; here the solve is the embedded step with `maxIter` fixed iterations (default 50, the C path's count)."""
+
+    def __init__(self, N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, maxIter=50):
+        import torch
+        from .batchqp import UprightMPC2N
+        self.N, self._torch = N, torch
+        self._mpc = UprightMPC2N(1, N, dt=dt, g=g, TtoWmax=TtoWmax, ws=ws, wds=wds, wpr=wpr, wpf=wpf, wvr=wvr, wvf=wvf,
+                                 wthrust=wthrust, wmom=wmom, Ib=tuple(float(v) for v in Ib), dtype=torch.float64,
+                                 max_iter=maxIter)
+
+    @property
+    def T0(self):
+        return float(self._mpc.T0[0].item())
+
+    def update(self, p0, R0, dq0, pdes, dpdes, sdes, actualT0=-1.0):
+        torch = self._torch
+        st = np.concatenate((np.asarray(p0, np.float64).ravel(), np.asarray(R0, np.float64).reshape(3, 3).T.ravel(),
+                             np.asarray(dq0, np.float64).ravel()))[:, None]
+        rf = np.concatenate((np.asarray(pdes, np.float64).ravel(), np.asarray(dpdes, np.float64).ravel(),
+                             np.asarray(sdes, np.float64).ravel()))[:, None]
+        dev = self._mpc.dev
+        aT0 = torch.full((1,), float(actualT0), dtype=torch.float64, device=dev)
+        out = self._mpc.update(torch.as_tensor(np.ascontiguousarray(st)).to(dev), torch.as_tensor(np.ascontiguousarray(rf)).to(dev),
+                               aT0).cpu().numpy()[:, 0]
+        self.prevsol = self._mpc.qp.sol_x.cpu().numpy()[:, 0]
+        return out[0:3].copy(), out[3:9].copy()
+
+
 def createMPC(N=3, ws=1e1, wds=1e3, wpr=1, wvr=1e3, wpf=5, wvf=2e3, wthrust=1e-1, wmom=1e-2, TtoWmax=2, **kwargs):
-    """C-version half of template/template_controllers.py:260-280 (same defaults)."""
-    assert N == 3, "the compiled horizon is N = 3 (template/uprightmpc2/uprightmpc2.h:20)"
-    return UprightMPC2C(5, 9.81e-3, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom,
-                        np.array([3333.0, 3333.0, 1000.0]), 50)
+    """template/template_controllers.py:260-280, same defaults and the same (pyver, cver) return pair: the Python
+    twin at horizon N and the compiled-C twin (horizon 3, uprightmpc2.h:20)."""
+    dt, g = 5, 9.81e-3
+    Ib = np.array([3333.0, 3333.0, 1000.0])
+    up = UprightMPC2(N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib)
+    upc = UprightMPC2C(dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, 50)
+    return up, upc
