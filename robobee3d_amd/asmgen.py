@@ -363,6 +363,32 @@ def pk(e, mnem, dst, srcs, neg=None):
     e(mnem, "v[%d:%d]" % (dst, dst + 1), *[s_[0] for s_ in srcs], mods)
 
 
+def despace(ops, window=int(os.environ.get("UMPC_ASM_WINDOW", "12"))):
+    """Reorders the op list so that an instruction does not read what the previous one (or the one before) wrote: a
+    lone wave issues an independent VALU instruction every ~5 cycles but waits ~9 for a dependent one
+    (tools/microbench.hip). Greedy, register-exact: an op may move ahead of earlier ops it has no RAW / WAR / WAW
+    relation with, inside a window; among the movable ones the first that is independent of the last two issued wins."""
+    pending, out = list(ops), []
+    last = [frozenset(), frozenset()]   # registers written by the previous two issued ops
+    while pending:
+        best, bscore = 0, None
+        blocked_w, blocked_r = set(), set()   # written / read by the earlier, still pending ops
+        for k, o in enumerate(pending[:window]):
+            movable = not (o["r"] & blocked_w) and not (o["w"] & blocked_w) and not (o["w"] & blocked_r)
+            if movable:
+                score = (2 if (o["r"] | o["w"]) & last[1] else 0) + (1 if (o["r"] | o["w"]) & last[0] else 0)
+                if bscore is None or score < bscore:
+                    best, bscore = k, score
+                    if score == 0:
+                        break
+            blocked_w |= o["w"]
+            blocked_r |= o["r"]
+        o = pending.pop(best)
+        out.append(o)
+        last = [last[1], o["w"]]
+    return out
+
+
 def body(e, s, first, capture, plan, lv=False):
     nx, nc, nk = s.nx, s.nc, s.nk
     neq = 2 * s.N * symbolic.NY
@@ -386,8 +412,9 @@ def body(e, s, first, capture, plan, lv=False):
     f = Fetcher(e)
     ops = []
 
-    def op(src, fn):
-        ops.append(dict(src=src, emit=fn))
+    def op(src, fn, w=(), r=()):
+        """w / r: the VGPRs this op writes / reads besides its fetched operand (for despace())."""
+        ops.append(dict(src=src, emit=fn, w=frozenset(w), r=frozenset(r)))
 
     assert NVZ == neq and not (lv and first)
 
@@ -407,19 +434,23 @@ def body(e, s, first, capture, plan, lv=False):
     for p_ in range(0, nx - 1, 2):
         j0, j1 = xinv[p_], xinv[p_ + 1]
         op(("A2", A_Q + j0, A_Q + j1),
-           lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_W + p_, [_sb(S_SIGMA), _vp(V_X + p_), _vp(t)], [0, 0, 1]))
+           lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_W + p_, [_sb(S_SIGMA), _vp(V_X + p_), _vp(t)], [0, 0, 1]),
+           w=(V_W + p_, V_W + p_ + 1), r=(V_X + p_, V_X + p_ + 1))
     if nx % 2:
         jl = xinv[nx - 1]
-        op(("A", A_Q + jl), lambda t, jl=jl: e("v_fma_f32", v(WX(jl)), sS, X(jl), "-" + v(t)))
+        op(("A", A_Q + jl), lambda t, jl=jl: e("v_fma_f32", v(WX(jl)), sS, X(jl), "-" + v(t)), w=(WX(jl),), r=(XR(jl),))
     assert all(zinv[p_] < neq for p_ in range(neq)) and neq % 2 == 0
     for p_ in range(0, neq, 2):
         if lv:   # z of the dynamics rows is l (== u): read it from its AGPR home
             op(("A2", A_LO + zinv[p_], A_LO + zinv[p_ + 1]),
-               lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(t)], [1, 0, 0]))
+               lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(t)], [1, 0, 0]),
+               w=(V_WZ + p_, V_WZ + p_ + 1), r=(V_Y + p_, V_Y + p_ + 1))
         else:
-            op(None, lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(V_Z + p_)], [1, 0, 0]))
+            op(None, lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(V_Z + p_)], [1, 0, 0]),
+               w=(V_WZ + p_, V_WZ + p_ + 1), r=(V_Y + p_, V_Y + p_ + 1, V_Z + p_, V_Z + p_ + 1))
     for i in range(neq, nc):
-        op(("A", A_M + 9 + i - neq), lambda t, i=i: e("v_fma_f32", v(WZ(i)), "-" + v(t), Y(i), Z(i)))
+        op(("A", A_M + 9 + i - neq), lambda t, i=i: e("v_fma_f32", v(WZ(i)), "-" + v(t), Y(i), Z(i)),
+           w=(WZ(i),), r=(YR(i), ZR(i)))
 
     # ---- triangular solves (qdldl.c:250-277) from the list schedule: dst -= L * src, packed where both the
     # destination and the source registers of two ready entries form aligned pairs
@@ -429,26 +460,29 @@ def body(e, s, first, capture, plan, lv=False):
                 d, sr, j = g[0]
                 src = l_src(j)
                 if src[0] == "V":
-                    op(None, lambda t, d=d, sr=sr, r=src[1]: e("v_fma_f32", W(d), "-" + v(r), W(sr), W(d)))
+                    op(None, lambda t, d=d, sr=sr, r=src[1]: e("v_fma_f32", W(d), "-" + v(r), W(sr), W(d)),
+                       w=(wreg(d),), r=(wreg(d), wreg(sr)))
                 else:
-                    op(src, lambda t, d=d, sr=sr: e("v_fma_f32", W(d), "-" + v(t), W(sr), W(d)))
+                    op(src, lambda t, d=d, sr=sr: e("v_fma_f32", W(d), "-" + v(t), W(sr), W(d)),
+                       w=(wreg(d),), r=(wreg(d), wreg(sr)))
                 continue
             (d0, s0_, j0), (d1, s1_, j1) = g          # d0 has the even destination register
             rd, r0, r1 = wreg(d0), wreg(s0_), wreg(s1_)
             assert rd % 2 == 0 and wreg(d1) == rd + 1 and r0 // 2 == r1 // 2 and lpos[j0] // 2 == lpos[j1] // 2
             srcp = ("v[%d:%d]" % (r0 - r0 % 2, r0 - r0 % 2 + 1), r0 % 2, r1 % 2)
+            rw = dict(w=(rd, rd + 1), r=(rd, rd + 1, r0, r1))
             pe = lpos[j0] - lpos[j0] % 2
             lsel = (lpos[j0] % 2, lpos[j1] % 2)
             if pe < NLDS:
                 op(("L", pe), lambda t, rd=rd, srcp=srcp, lsel=lsel:
-                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]))
+                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]), **rw)
             elif lv and pe < NLDS + NVZ:
                 t = V_Z + pe - NLDS
                 op(None, lambda _t, t=t, rd=rd, srcp=srcp, lsel=lsel:
-                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]))
+                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]), **rw)
             else:
                 src = ("A2", A_L + lpos[j0] - NLDS, A_L + lpos[j1] - NLDS)
-                op(src, lambda t, rd=rd, srcp=srcp: pk(e, "v_pk_fma_f32", rd, [_vp(t), srcp, _vp(rd)], [1, 0, 0]))
+                op(src, lambda t, rd=rd, srcp=srcp: pk(e, "v_pk_fma_f32", rd, [_vp(t), srcp, _vp(rd)], [1, 0, 0]), **rw)
 
     solve_ops(fwd)
     # ---- diagonal (qdldl.c:289): two unknowns per instruction, paired by register
@@ -456,17 +490,27 @@ def body(e, s, first, capture, plan, lv=False):
     for r0 in range(V_W, V_Z, 2):
         k0, k1 = kof.get(r0), kof.get(r0 + 1)
         if k0 is not None and k1 is not None:
-            op(("A2", A_D + k0, A_D + k1), lambda t, r0=r0: pk(e, "v_pk_mul_f32", r0, [_vp(r0), _vp(t)]))
+            op(("A2", A_D + k0, A_D + k1), lambda t, r0=r0: pk(e, "v_pk_mul_f32", r0, [_vp(r0), _vp(t)]),
+               w=(r0, r0 + 1), r=(r0, r0 + 1))
         elif k0 is not None or k1 is not None:
             k, r = (k0, r0) if k0 is not None else (k1, r0 + 1)
-            op(("A", A_D + k), lambda t, r=r: e("v_mul_f32", v(r), v(t), v(r)))
+            op(("A", A_D + k), lambda t, r=r: e("v_mul_f32", v(r), v(t), v(r)), w=(r,), r=(r,))
     solve_ops(bwd)
-    f.run(ops)
+    f.run(despace(ops) if os.environ.get("UMPC_ASM_DESPACE", "1") == "1" else ops)
     # ---- x <- alpha x~ + (1 - alpha) x   (auxil.c:188-201)
-    for p_ in range(0, nx - 1, 2):
-        t = V_TT + 2 * ((p_ // 2) % 4)
-        pk(e, "v_pk_mul_f32", t, [_sb(S_OMA), _vp(V_X + p_)])
-        pk(e, "v_pk_fma_f32", V_X + p_, [_sb(S_ALPHA), _vp(V_W + p_), _vp(t)])
+    # (software-pipelined by two so that no instruction consumes the result of the previous one)
+    def skewed(stage1, stage2, depth=2):
+        depth = depth if os.environ.get("UMPC_ASM_SKEW", "0") == "1" else 0
+        n_ = len(stage1)
+        for k in range(n_ + depth):
+            if k >= depth:
+                stage2[k - depth]()
+            if k < n_:
+                stage1[k]()
+    xp_ = list(range(0, nx - 1, 2))
+    tx = lambda k: V_TT + 2 * (k % 4)
+    skewed([lambda k=k, p_=p_: pk(e, "v_pk_mul_f32", tx(k), [_sb(S_OMA), _vp(V_X + p_)]) for k, p_ in enumerate(xp_)],
+           [lambda k=k, p_=p_: pk(e, "v_pk_fma_f32", V_X + p_, [_sb(S_ALPHA), _vp(V_W + p_), _vp(tx(k))]) for k, p_ in enumerate(xp_)])
     if nx % 2:
         jl = xinv[nx - 1]
         e("v_mul_f32", v(V_TT), sO, X(jl))
@@ -479,15 +523,19 @@ def body(e, s, first, capture, plan, lv=False):
         #   delta_y = rho (alpha z~ + (1-alpha) z - z) = rho alpha (z~ - z) = rho alpha rinv (nu - y) = alpha (nu - y)
         # (rho rinv = 1). Two packed instructions per two rows instead of seven per row; same value up to the
         # rounding of the longer chain.
-        for p_ in range(0, neq, 2):
-            t = V_TT + 2 * ((p_ // 2) % 2)
-            pk(e, "v_pk_add_f32", t, [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1])
-            if capture:
+        if capture:
+            for p_ in range(0, neq, 2):
+                t = V_TT + 2 * ((p_ // 2) % 2)
+                pk(e, "v_pk_add_f32", t, [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1])
                 pk(e, "v_pk_mul_f32", t + 4, [_sb(S_ALPHA), _vp(t)])
                 for h in range(2):
                     _row_ptr(e, S_P2, S_WS, WS_DY + zinv[p_ + h])
                     e("global_store_dword", "v0", v(t + 4 + h), ptr)
-            pk(e, "v_pk_fma_f32", V_Y + p_, [_sb(S_ALPHA), _vp(t), _vp(V_Y + p_)])
+                pk(e, "v_pk_fma_f32", V_Y + p_, [_sb(S_ALPHA), _vp(t), _vp(V_Y + p_)])
+        else:
+            yp_ = list(range(0, neq, 2))
+            skewed([lambda k=k, p_=p_: pk(e, "v_pk_add_f32", tx(k), [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1]) for k, p_ in enumerate(yp_)],
+                   [lambda k=k, p_=p_: pk(e, "v_pk_fma_f32", V_Y + p_, [_sb(S_ALPHA), _vp(tx(k)), _vp(V_Y + p_)]) for k, p_ in enumerate(yp_)])
     for i in range(nc):
         eq = i < neq
         if eq and not first:
