@@ -364,9 +364,11 @@ def pk(e, mnem, dst, srcs, neg=None):
 
 
 def despace(ops, window=int(os.environ.get("UMPC_ASM_WINDOW", "12"))):
-    """Reorders the op list so that an instruction does not read what the previous one (or the one before) wrote: a
-    lone wave issues an independent VALU instruction every ~5 cycles but waits ~9 for a dependent one
-    (tools/microbench.hip). Greedy, register-exact: an op may move ahead of earlier ops it has no RAW / WAR / WAW
+    """EXPERIMENT, off by default (UMPC_ASM_DESPACE=1): reorders the op list so that an instruction does not read what
+    the previous one (or the one before) wrote (back-to-back dependencies 124 -> 32 per iteration). Measured on the
+    MI355X it is SLOWER (0.182 vs 0.176 ms per step): in the real loop the dependent-issue penalty seen in
+    tools/microbench.hip is hidden behind the AGPR / LDS operand fetches, and the reordering costs fetch locality.
+    Greedy, register-exact: an op may move ahead of earlier ops it has no RAW / WAR / WAW
     relation with, inside a window; among the movable ones the first that is independent of the last two issued wins."""
     pending, out = list(ops), []
     last = [frozenset(), frozenset()]   # registers written by the previous two issued ops
@@ -496,21 +498,12 @@ def body(e, s, first, capture, plan, lv=False):
             k, r = (k0, r0) if k0 is not None else (k1, r0 + 1)
             op(("A", A_D + k), lambda t, r=r: e("v_mul_f32", v(r), v(t), v(r)), w=(r,), r=(r,))
     solve_ops(bwd)
-    f.run(despace(ops) if os.environ.get("UMPC_ASM_DESPACE", "1") == "1" else ops)
+    f.run(despace(ops) if os.environ.get("UMPC_ASM_DESPACE", "0") == "1" else ops)
     # ---- x <- alpha x~ + (1 - alpha) x   (auxil.c:188-201)
-    # (software-pipelined by two so that no instruction consumes the result of the previous one)
-    def skewed(stage1, stage2, depth=2):
-        depth = depth if os.environ.get("UMPC_ASM_SKEW", "0") == "1" else 0
-        n_ = len(stage1)
-        for k in range(n_ + depth):
-            if k >= depth:
-                stage2[k - depth]()
-            if k < n_:
-                stage1[k]()
-    xp_ = list(range(0, nx - 1, 2))
-    tx = lambda k: V_TT + 2 * (k % 4)
-    skewed([lambda k=k, p_=p_: pk(e, "v_pk_mul_f32", tx(k), [_sb(S_OMA), _vp(V_X + p_)]) for k, p_ in enumerate(xp_)],
-           [lambda k=k, p_=p_: pk(e, "v_pk_fma_f32", V_X + p_, [_sb(S_ALPHA), _vp(V_W + p_), _vp(tx(k))]) for k, p_ in enumerate(xp_)])
+    for p_ in range(0, nx - 1, 2):
+        t = V_TT + 2 * ((p_ // 2) % 4)
+        pk(e, "v_pk_mul_f32", t, [_sb(S_OMA), _vp(V_X + p_)])
+        pk(e, "v_pk_fma_f32", V_X + p_, [_sb(S_ALPHA), _vp(V_W + p_), _vp(t)])
     if nx % 2:
         jl = xinv[nx - 1]
         e("v_mul_f32", v(V_TT), sO, X(jl))
@@ -523,19 +516,15 @@ def body(e, s, first, capture, plan, lv=False):
         #   delta_y = rho (alpha z~ + (1-alpha) z - z) = rho alpha (z~ - z) = rho alpha rinv (nu - y) = alpha (nu - y)
         # (rho rinv = 1). Two packed instructions per two rows instead of seven per row; same value up to the
         # rounding of the longer chain.
-        if capture:
-            for p_ in range(0, neq, 2):
-                t = V_TT + 2 * ((p_ // 2) % 2)
-                pk(e, "v_pk_add_f32", t, [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1])
+        for p_ in range(0, neq, 2):
+            t = V_TT + 2 * ((p_ // 2) % 2)
+            pk(e, "v_pk_add_f32", t, [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1])
+            if capture:
                 pk(e, "v_pk_mul_f32", t + 4, [_sb(S_ALPHA), _vp(t)])
                 for h in range(2):
                     _row_ptr(e, S_P2, S_WS, WS_DY + zinv[p_ + h])
                     e("global_store_dword", "v0", v(t + 4 + h), ptr)
-                pk(e, "v_pk_fma_f32", V_Y + p_, [_sb(S_ALPHA), _vp(t), _vp(V_Y + p_)])
-        else:
-            yp_ = list(range(0, neq, 2))
-            skewed([lambda k=k, p_=p_: pk(e, "v_pk_add_f32", tx(k), [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1]) for k, p_ in enumerate(yp_)],
-                   [lambda k=k, p_=p_: pk(e, "v_pk_fma_f32", V_Y + p_, [_sb(S_ALPHA), _vp(tx(k)), _vp(V_Y + p_)]) for k, p_ in enumerate(yp_)])
+            pk(e, "v_pk_fma_f32", V_Y + p_, [_sb(S_ALPHA), _vp(t), _vp(V_Y + p_)])
     for i in range(nc):
         eq = i < neq
         if eq and not first:
