@@ -278,6 +278,12 @@ int umpcQPSetMaxIter(void *h, int max_iter);
  * N = 5) umpcQPCreate selects a generated straight-line kernel (same arithmetic, literal indices). UseTables(1)
  * forces the table-driven kernel; returns the index of the specialisation or -1. KernelName: its name or "tables". */
 int umpcQPUseTables(void *h, int on);
+/* Kernel choice. 1 (default): one LANE per robot (the build-time specialisation if there is one, else the
+ * table-driven kernel). 2: lane per robot, tables. 0: one WAVEFRONT per robot, working set in LDS, level-scheduled
+ * solves (needs the working set to fit a CU's LDS; faster for the planar p5f structure at B = 16 384, slower on
+ * the others measured -- DESIGN.md 10). */
+int umpcQPSetKernel(void *h, int mode);
+/* "wave", the specialisation's name, or "tables" */
 const char *umpcQPKernelName(void *h);
 /* All arrays are DEVICE pointers, SoA [rows][B] of the handle's dtype:
  *   Pv [nnzP], Av [nnzA] (CSC order), q [n], l, u [m]   raw problem data                     in

@@ -26,7 +26,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel",
-           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPUseTables", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
+           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
            "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
 
 
@@ -155,6 +155,7 @@ def lib():
         L.umpcQPDestroy.argtypes = [C.c_void_p]
         L.umpcQPSetMaxIter.argtypes = [C.c_void_p, C.c_int]
         L.umpcQPUseTables.argtypes = [C.c_void_p, C.c_int]
+        L.umpcQPSetKernel.argtypes = [C.c_void_p, C.c_int]
         L.umpcQPKernelName.argtypes = [C.c_void_p]
         L.umpcQPKernelName.restype = C.c_char_p
         L.umpcQPSolve.argtypes = [C.c_void_p] * 15

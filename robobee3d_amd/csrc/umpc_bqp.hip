@@ -300,6 +300,294 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
 #undef IN
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Wave-per-robot kernel: the same step with ONE WAVEFRONT per robot and the robot's whole working set in LDS.
+// Lane-per-robot (above) is the right mapping while the batch fills the chip and the working set fits a lane's
+// registers + LDS share (the N = 3 path). For a large structure at a moderate batch (planar p5f: 251 KKT unknowns,
+// ~3 000 words per robot, B = 16 384 = one wave per CU) it is a chain of dependent L2 round trips. Here the
+// element-wise phases run 64 unknowns per instruction and the triangular solves / the factorisation are
+// level-scheduled over the elimination tree (qpstruct.py: level(c) = 1 + max level over the row pattern of c;
+// 34 levels for p5f), one lane per unknown of a level, operands at LDS latency, 64x more waves in flight.
+// Same operation order per unknown as QDLDL's sweeps in the solves; the factorisation is the right-looking
+// dot-product form and the Ruiz cost sums are wave reductions, so results agree with the lane-per-robot kernels to
+// rounding (1e-13 relative in fp64), not bit for bit.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+  for (int o = 32; o > 0; o >>= 1) { const T u = __shfl_xor(v, o, 64); v = qmax(u, v); }
+  return v;
+}
+__device__ __forceinline__ int wave_or(int v) {
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+
+__host__ __device__ inline size_t bqp_wave_lds_words(int n, int m, int nnzP, int nnzA, int nnzL) {
+  // As Ps Lx | qs D Dt x xp t1 (6 n) | ls us E Et rho rinv y z dy t3 (10 m) | DI w (2 nk)
+  return (size_t)nnzA + nnzP + nnzL + 6 * (size_t)n + 10 * (size_t)m + 2 * (size_t)(n + m);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) bqp_wave_kernel(const QPArgs<T> a) {
+  extern __shared__ __align__(16) unsigned char bqp_smem[];
+  T *S = reinterpret_cast<T *>(bqp_smem);
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const int32_t *__restrict__ tab = a.tab;
+  const size_t B = (size_t)a.B;
+  const int n = tab[H_N], m = tab[H_M], nk = tab[H_NK], nnzP = tab[H_NNZP], nnzA = tab[H_NNZA], nnzL = tab[H_NNZL];
+  const int nlev = tab[H_NLEV];
+#define TB(t) (tab + tab[H_TAB0 + (t)])
+  const int32_t *pinv = TB(T_PINV), *pidx = TB(T_PIDX), *perm = TB(T_PERM);
+  const int32_t *A_p = TB(T_AP), *A_i = TB(T_AI), *A_j = TB(T_AJ), *Ar_p = TB(T_ARP), *Ar_j = TB(T_ARJ), *Ar_k = TB(T_ARK);
+  const int32_t *L_p = TB(T_LP), *L_i = TB(T_LI), *Lr_p = TB(T_LRP), *Lr_j = TB(T_LRJ), *Lr_k = TB(T_LRK);
+  const int32_t *lev_p = TB(T_LEVP), *lev_n = TB(T_LEVN), *elev_p = TB(T_ELEVP), *elev_e = TB(T_ELEVE);
+  const int32_t *l_ksrc = TB(T_LKSRC), *l_col = TB(T_LCOL);
+  const int32_t *ft_p = TB(T_FTP), *ft_a = TB(T_FTA), *ft_b = TB(T_FTB), *ft_j = TB(T_FTJ);
+  const int32_t *fd_p = TB(T_FDP), *fd_a = TB(T_FDA), *fd_j = TB(T_FDJ);
+#undef TB
+  T *As = S, *Ps = As + nnzA, *qs = Ps + nnzP, *ls = qs + n, *us = ls + m, *D = us + m, *E = D + n, *Dt = E + m, *Et = Dt + n;
+  T *rho = Et + m, *rinv = rho + m, *Lx = rinv + m, *DI = Lx + nnzL, *w = DI + nk, *x = w + nk, *y = x + n, *z = y + m;
+  T *xp = z + m, *dy = xp + n, *t3 = dy + m, *t1 = t3 + m;
+#define IN(arr, i) (arr)[(size_t)(i) * B + b]
+#define FOR_LANES(i, cnt) for (int i = lane; i < (cnt); i += 64)
+  const T sigma = a.sigma, alpha = a.alpha, oma = T(1.0) - a.alpha;
+
+  FOR_LANES(k, nnzP) Ps[k] = IN(a.Pv, k);
+  FOR_LANES(k, nnzA) As[k] = IN(a.Av, k);
+  FOR_LANES(j, n) { qs[j] = IN(a.q, j); D[j] = T(1.0); x[j] = IN(a.x, j); }
+  const T rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);
+  FOR_LANES(i, m) {
+    const T e = IN(a.Eprev, i);
+    T r, ri;
+    qp_classify(IN(a.l, i) * e, IN(a.u, i) * e, a.rho, rho_eq, r, ri);
+    rho[i] = r; rinv[i] = ri; E[i] = T(1.0); y[i] = IN(a.y, i); z[i] = IN(a.z, i);
+  }
+  __syncthreads();
+
+  // ---- scale_data, scaling.c:44-156 ----
+  T c = T(1.0);
+  for (int pass = 0; pass < a.scaling; ++pass) {
+    FOR_LANES(j, n) {
+      const int kp = pidx[j];
+      T dP = T(0.0);
+      if (kp >= 0) dP = qmax(qabs(Ps[kp]), dP);
+      T dA = T(0.0);
+      for (int p = A_p[j]; p < A_p[j + 1]; ++p) dA = qmax(qabs(As[p]), dA);
+      Dt[j] = T(1.0) / qsqrt(limit_scaling(qmax(dP, dA)));
+    }
+    FOR_LANES(i, m) {
+      T e = T(0.0);
+      for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) e = qmax(qabs(As[Ar_k[p]]), e);
+      Et[i] = T(1.0) / qsqrt(limit_scaling(e));
+    }
+    __syncthreads();
+    FOR_LANES(k, nnzA) { T v = As[k]; v *= Et[A_i[k]]; v *= Dt[A_j[k]]; As[k] = v; }
+    T csum = T(0.0), qn = T(0.0);
+    FOR_LANES(j, n) {
+      const T d = Dt[j];
+      const int kp = pidx[j];
+      if (kp >= 0) { T pv = Ps[kp]; pv *= d; pv *= d; Ps[kp] = pv; csum += qabs(pv); }
+      const T qv = qs[j] * d;
+      qs[j] = qv;
+      qn = qmax(qabs(qv), qn);
+      D[j] = d * D[j];
+    }
+    FOR_LANES(i, m) E[i] = Et[i] * E[i];
+    csum = wave_sum(csum);
+    qn = wave_max(qn);
+    T ct = csum / T(n);
+    qn = limit_scaling(qn);
+    ct = qmax(ct, qn);
+    ct = limit_scaling(ct);
+    ct = T(1.0) / ct;
+    __syncthreads();
+    FOR_LANES(k, nnzP) Ps[k] *= ct;
+    FOR_LANES(j, n) qs[j] *= ct;
+    c *= ct;
+    __syncthreads();
+  }
+  const T cinv = T(1.0) / c;
+  FOR_LANES(i, m) { const T e = E[i]; ls[i] = IN(a.l, i) * e; us[i] = IN(a.u, i) * e; IN(a.Eprev, i) = e; }
+
+  // ---- LDL', level by level: D[c] = K[c,c] - sum_j L[c,j]^2 D[j], L[i,c] = (K[i,c] - sum_j L[i,j] L[c,j] D[j]) / D[c]
+  // (w holds D during the factorisation)
+  int fail = 0;
+  for (int l = 0; l < nlev; ++l) {
+    for (int t = lane; t < lev_p[l + 1] - lev_p[l]; t += 64) {
+      const int cc = lev_n[lev_p[l] + t], orig = perm[cc];
+      T dk;
+      if (orig < n) { const int kp = pidx[orig]; dk = kp >= 0 ? Ps[kp] + sigma : sigma; }
+      else dk = -rinv[orig - n];
+      for (int q = fd_p[cc]; q < fd_p[cc + 1]; ++q) { const T lv = Lx[fd_a[q]]; dk -= (lv * lv) * w[fd_j[q]]; }
+      if (dk == T(0.0)) fail = 1;
+      w[cc] = dk;
+      DI[cc] = T(1.0) / dk;
+    }
+    __syncthreads();
+    for (int t = lane; t < elev_p[l + 1] - elev_p[l]; t += 64) {
+      const int e = elev_e[elev_p[l] + t], ks = l_ksrc[e];
+      T v = ks >= 0 ? As[ks] : T(0.0);
+      for (int q = ft_p[e]; q < ft_p[e + 1]; ++q) v -= (Lx[ft_a[q]] * Lx[ft_b[q]]) * w[ft_j[q]];
+      Lx[e] = v * DI[l_col[e]];
+    }
+    __syncthreads();
+  }
+
+  // ---- ADMM iterations, osqp.c:354-370 ----
+  FOR_LANES(j, n) xp[j] = x[j];
+  FOR_LANES(i, m) dy[i] = T(0.0);
+  __syncthreads();
+  for (int it = 0; it < a.max_iter; ++it) {
+    FOR_LANES(k, nk) {
+      const int orig = perm[k];
+      if (orig < n) {
+        const T xv = x[orig];
+        xp[orig] = xv;
+        w[k] = sigma * xv - qs[orig];
+      } else {
+        const int i = orig - n;
+        const T r = z[i] - rinv[i] * y[i];
+        t3[i] = r;
+        w[k] = r;
+      }
+    }
+    __syncthreads();
+    for (int l = 1; l < nlev; ++l) {      // forward: the entries of row r live in lower levels
+      for (int t = lane; t < lev_p[l + 1] - lev_p[l]; t += 64) {
+        const int r = lev_n[lev_p[l] + t];
+        T acc = w[r];
+        for (int p = Lr_p[r]; p < Lr_p[r + 1]; ++p) acc -= Lx[Lr_k[p]] * w[Lr_j[p]];
+        w[r] = acc;
+      }
+      __syncthreads();
+    }
+    for (int l = nlev - 1; l >= 0; --l) {  // diagonal + backward: the entries of column r live in higher levels
+      for (int t = lane; t < lev_p[l + 1] - lev_p[l]; t += 64) {
+        const int r = lev_n[lev_p[l] + t];
+        T acc = w[r] * DI[r];
+        for (int j = L_p[r]; j < L_p[r + 1]; ++j) acc -= Lx[j] * w[L_i[j]];
+        w[r] = acc;
+      }
+      __syncthreads();
+    }
+    FOR_LANES(j, n) x[j] = alpha * w[pinv[j]] + oma * xp[j];
+    FOR_LANES(i, m) {
+      const T ri = rinv[i], yi = y[i], zp = z[i];
+      const T zt = t3[i] + ri * w[pinv[n + i]];
+      T zn = alpha * zt + oma * zp + ri * yi;
+      zn = qmin(qmax(zn, ls[i]), us[i]);
+      z[i] = zn;
+      const T d = rho[i] * (alpha * zt + oma * zp - zn);
+      dy[i] = d;
+      y[i] = yi + d;
+    }
+    __syncthreads();
+  }
+
+  // ---- update_info / check_termination (auxil.c:243-362, 684-789) ----
+  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);
+  FOR_LANES(i, m) {
+    T acc = T(0.0);
+    for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) acc += As[Ar_k[p]] * x[Ar_j[p]];
+    const T einv = T(1.0) / E[i], zi = z[i];
+    pri_res = qmax(pri_res, qabs(einv * (acc - zi)));
+    nz = qmax(nz, qabs(einv * zi));
+    nAx = qmax(nAx, qabs(einv * acc));
+  }
+  pri_res = wave_max(pri_res); nz = wave_max(nz); nAx = wave_max(nAx);
+  T dua_res = T(0.0), nq = T(0.0), nAty = T(0.0), nPx = T(0.0);
+  FOR_LANES(j, n) {
+    const int kp = pidx[j];
+    T px = T(0.0);
+    if (kp >= 0) px += Ps[kp] * x[j];
+    T aty = T(0.0);
+    for (int p = A_p[j]; p < A_p[j + 1]; ++p) aty += As[p] * y[A_i[p]];
+    const T dinv = T(1.0) / D[j], qj = qs[j];
+    dua_res = qmax(dua_res, qabs(dinv * ((qj + px) + aty)));
+    nq = qmax(nq, qabs(dinv * qj)); nAty = qmax(nAty, qabs(dinv * aty)); nPx = qmax(nPx, qabs(dinv * px));
+  }
+  dua_res = cinv * wave_max(dua_res); nq = wave_max(nq); nAty = wave_max(nAty); nPx = wave_max(nPx);
+  const T dual_rel = qmax(qmax(nq, nAty), nPx) * cinv, prim_rel = qmax(nz, nAx);
+  T norm_dy = T(0.0), ineq_lhs = T(0.0);
+  FOR_LANES(i, m) {
+    const T usi = us[i], lsi = ls[i];
+    T d = dy[i];
+    const bool up = (double)usi > QP_INFTY * QP_MIN_SCALING, lo = (double)lsi < -QP_INFTY * QP_MIN_SCALING;
+    if (up) d = lo ? T(0.0) : qmin(d, T(0.0));
+    else if (lo) d = qmax(d, T(0.0));
+    dy[i] = d;
+    norm_dy = qmax(norm_dy, qabs(d * E[i]));
+    ineq_lhs += usi * qmax(d, T(0.0)) + lsi * qmin(d, T(0.0));
+  }
+  norm_dy = wave_max(norm_dy); ineq_lhs = wave_sum(ineq_lhs);
+  __syncthreads();
+  T nAtdy = T(0.0), norm_dx = T(0.0), qdx = T(0.0), nPdx = T(0.0);
+  FOR_LANES(j, n) {
+    T acc = T(0.0);
+    for (int p = A_p[j]; p < A_p[j + 1]; ++p) acc += As[p] * dy[A_i[p]];
+    const T dinv = T(1.0) / D[j];
+    nAtdy = qmax(nAtdy, qabs(acc * dinv));
+    const T dx = x[j] - xp[j];
+    t1[j] = dx;
+    norm_dx = qmax(norm_dx, qabs(D[j] * dx));
+    qdx += qs[j] * dx;
+    const int kp = pidx[j];
+    T pdx = T(0.0);
+    if (kp >= 0) pdx += Ps[kp] * dx;
+    nPdx = qmax(nPdx, qabs(pdx * dinv));
+  }
+  nAtdy = wave_max(nAtdy); norm_dx = wave_max(norm_dx); qdx = wave_sum(qdx); nPdx = wave_max(nPdx);
+  __syncthreads();
+  int status = -10;
+  if (((double)pri_res > QP_INFTY) || ((double)dua_res > QP_INFTY)) status = -7;
+  for (int approx = 0; approx < 2 && status == -10; ++approx) {
+    const T k = approx ? T(10) : T(1);
+    const T eps_abs = a.eps_abs * k, eps_rel = a.eps_rel * k, eps_pinf = a.eps_pinf * k, eps_dinf = a.eps_dinf * k;
+    const bool prim_ok = pri_res < eps_abs + eps_rel * prim_rel;
+    const bool dual_ok = dua_res < eps_abs + eps_rel * dual_rel;
+    bool pinf = false, dinf = false;
+    if (!prim_ok && norm_dy > eps_pinf && ineq_lhs < -eps_pinf * norm_dy) pinf = nAtdy < eps_pinf * norm_dy;
+    if (!dual_ok && norm_dx > eps_dinf && qdx < -c * eps_dinf * norm_dx && nPdx < c * eps_dinf * norm_dx) {
+      const T thr = eps_dinf * norm_dx;
+      int viol = 0;
+      FOR_LANES(i, m) {
+        T acc = T(0.0);
+        for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) acc += As[Ar_k[p]] * t1[Ar_j[p]];
+        acc = acc * (T(1.0) / E[i]);
+        if ((((double)us[i] < QP_INFTY * QP_MIN_SCALING) && (acc > thr)) ||
+            (((double)ls[i] > -QP_INFTY * QP_MIN_SCALING) && (acc < -thr)))
+          viol = 1;
+      }
+      dinf = wave_or(viol) == 0;
+    }
+    if (prim_ok && dual_ok) status = approx ? 2 : 1;
+    else if (pinf) status = approx ? 3 : -3;
+    else if (dinf) status = approx ? 4 : -4;
+  }
+  if (status == -10) status = -2;
+  const bool bad = status == -3 || status == 3 || status == -4 || status == 4 || status == -7;
+  const T qnan = std::numeric_limits<T>::quiet_NaN();
+  FOR_LANES(j, n) {
+    if (a.sol_x) IN(a.sol_x, j) = bad ? qnan : x[j] * D[j];
+    IN(a.x, j) = bad ? T(0.0) : x[j];
+  }
+  FOR_LANES(i, m) {
+    if (a.sol_y) IN(a.sol_y, i) = bad ? qnan : (y[i] * E[i]) * cinv;
+    IN(a.y, i) = bad ? T(0.0) : y[i];
+    IN(a.z, i) = bad ? T(0.0) : z[i];
+  }
+  fail = wave_or(fail);
+  if (lane == 0) {
+    if (a.status) a.status[b] = status;
+    if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); }
+  }
+#undef IN
+#undef FOR_LANES
+}
+
 // Av[k] = cst[k] if src[k] < 0 else par[src[k]][b] * cst[k]: assembles any per-robot value vector (A, P, q, l, u)
 // whose entries are constants or scaled copies of a few per-robot parameters.
 template <typename T>
@@ -449,7 +737,9 @@ __global__ void umpcn_extract_kernel(int Bn, int N, T dt, const T *__restrict__ 
 
 
 struct qp_batch {
-  int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows, fixed, use_tables;
+  int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows, fixed, use_tables, wave;   // wave: 1 = wave-per-robot kernel
+  size_t wave_lds;
+  bool wave_ok;
   umpcQPSettings st;
   int32_t *tab;
   void *W;
@@ -468,7 +758,9 @@ int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, con
   a.eps_abs = T(h->st.eps_abs); a.eps_rel = T(h->st.eps_rel);
   a.eps_pinf = T(h->st.eps_prim_inf); a.eps_dinf = T(h->st.eps_dual_inf);
   a.max_iter = h->st.max_iter; a.scaling = h->st.scaling;
-  if (h->fixed >= 0 && !h->use_tables) {
+  if (h->wave && !h->use_tables) {
+    hipLaunchKernelGGL(bqp_wave_kernel<T>, dim3(h->B), dim3(64), h->wave_lds * sizeof(T), s, a);
+  } else if (h->fixed >= 0 && !h->use_tables) {
     if constexpr (sizeof(T) == 4) kFixedKernels[h->fixed].f32(a, s);
     else kFixedKernels[h->fixed].f64(a, s);
   } else {
@@ -544,6 +836,21 @@ void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpc
               nfe == nnzL && in_range(T_FEC, nfe, 0, nk) && in_range(T_FEN, nfe, 0, nnzL) &&
               in_range(T_LP, nk + 1, 0, nnzL + 1) && in_range(T_LI, nnzL, 0, nk) && in_range(T_LRP, nk + 1, 0, nnzL + 1) &&
               in_range(T_LRJ, nnzL, 0, nk) && in_range(T_LRK, nnzL, 0, nnzL);
+    // level schedules / right-looking factor terms of the wave-per-robot kernel
+    const int nlev = blob[H_NLEV];
+    ok = ok && nlev >= 1 && nlev <= nk && in_range(T_PERM, nk, 0, nk) && in_range(T_AJ, nnzA, 0, n) &&
+         in_range(T_LEVP, nlev + 1, 0, nk + 1) && in_range(T_LEVN, nk, 0, nk) && in_range(T_ELEVP, nlev + 1, 0, nnzL + 1) &&
+         in_range(T_ELEVE, nnzL, 0, nnzL) && in_range(T_LKSRC, nnzL, -1, nnzA) && in_range(T_LCOL, nnzL, 0, nk) &&
+         in_range(T_FTP, nnzL + 1, 0, 1 << 30) && in_range(T_FDP, nk + 1, 0, 1 << 30);
+    if (ok) {
+      ok = tabp(T_LEVP)[nlev] == nk && tabp(T_ELEVP)[nlev] == nnzL;
+      for (int k = 0; ok && k < nlev; ++k) ok = tabp(T_LEVP)[k] <= tabp(T_LEVP)[k + 1] && tabp(T_ELEVP)[k] <= tabp(T_ELEVP)[k + 1];
+      for (int k = 0; ok && k < nnzL; ++k) ok = tabp(T_FTP)[k] <= tabp(T_FTP)[k + 1];
+      for (int k = 0; ok && k < nk; ++k) ok = tabp(T_FDP)[k] <= tabp(T_FDP)[k + 1];
+      const int nft = ok ? tabp(T_FTP)[nnzL] : 0, nfd = ok ? tabp(T_FDP)[nk] : 0;
+      ok = ok && in_range(T_FTA, nft, 0, nnzL) && in_range(T_FTB, nft, 0, nnzL) && in_range(T_FTJ, nft, 0, nk) &&
+           in_range(T_FDA, nfd, 0, nnzL) && in_range(T_FDJ, nfd, 0, nk);
+    }
     if (!ok) { umpc_set_error("umpcQPCreate: table entry out of range"); return nullptr; }
   }
   qp_batch *h = new qp_batch();
@@ -552,6 +859,16 @@ void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpc
   if (st) h->st = *st; else umpcQPDefaultSettings(&h->st);
   // a straight-line specialisation generated at build time for exactly this structure?
   h->fixed = -1; h->use_tables = 0;
+  // wave-per-robot kernel: available (umpcQPSetKernel(h, 0)) whenever the robot's working set fits the LDS a
+  // workgroup may own; the default is the lane-per-robot path, which is faster on most structures
+  h->wave_lds = bqp_wave_lds_words(n, m, blob[H_NNZP], blob[H_NNZA], blob[H_NNZL]);
+  h->wave = 0;
+  {
+    const size_t bytes = h->wave_lds * (dtype == UMPC_F32 ? 4 : 8);
+    const void *kf = dtype == UMPC_F32 ? (const void *)bqp_wave_kernel<float> : (const void *)bqp_wave_kernel<double>;
+    h->wave_ok = bytes <= 160 * 1024 &&
+                 hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+  }
   {
     uint64_t hash = 0xcbf29ce484222325ull;
     for (int k = 0; k < nwords; ++k) {
@@ -592,10 +909,23 @@ int umpcQPUseTables(void *hv, int on) {
   return h->fixed;
 }
 
+int umpcQPSetKernel(void *hv, int mode) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h || mode < 0 || mode > 2) { umpc_set_error("umpcQPSetKernel: bad argument"); return -1; }
+  const size_t bytes = h->wave_lds * (h->dtype == UMPC_F32 ? 4 : 8);
+  (void)bytes;
+  if (mode == 0 && !h->wave_ok) { umpc_set_error("umpcQPSetKernel: working set exceeds the LDS of a CU"); return -1; }
+  h->wave = mode == 0;
+  h->use_tables = mode == 2;
+  return 0;
+}
+
 const char *umpcQPKernelName(void *hv) {
   qp_batch *h = (qp_batch *)hv;
   if (!h) return "";
-  return (h->fixed >= 0 && !h->use_tables) ? kFixedKernels[h->fixed].name : "tables";
+  if (h->use_tables) return "tables";
+  if (h->wave) return "wave";
+  return h->fixed >= 0 ? kFixedKernels[h->fixed].name : "tables";
 }
 
 int umpcQPSetMaxIter(void *hv, int max_iter) {

@@ -14,9 +14,12 @@ constexpr double QP_INFTY = 1e30, QP_MIN_SCALING = 1e-4, QP_MAX_SCALING = 1e4;
 constexpr double QP_RHO_MIN = 1e-6, QP_RHO_TOL = 1e-4, QP_RHO_EQ_OVER_RHO_INEQ = 1e3;
 constexpr int HEADER_WORDS = 64;
 // header word indices (qpstruct.py)
-enum { H_N, H_M, H_NK, H_NNZP, H_NNZA, H_NNZL, H_NROWS, H_PAD, H_TAB0 };
+enum { H_N, H_M, H_NK, H_NNZP, H_NNZA, H_NNZL, H_NROWS, H_NLEV, H_TAB0 };
 enum { T_PINV, T_PIDX, T_AP, T_AI, T_ARP, T_ARJ, T_ARK, T_FIP, T_FIB, T_FIS, T_FEP, T_FEC, T_FEN, T_LP, T_LI, T_LRP,
-       T_LRJ, T_LRK, T_COUNT };
+       T_LRJ, T_LRK,
+       // wave-per-robot kernel: permutation, column of every A entry, level schedules, right-looking factor terms
+       T_PERM, T_AJ, T_LEVP, T_LEVN, T_ELEVP, T_ELEVE, T_LKSRC, T_LCOL, T_FTP, T_FTA, T_FTB, T_FTJ, T_FDP, T_FDA, T_FDJ,
+       T_COUNT };
 enum { R_PS, R_AS, R_QS, R_LS, R_US, R_D, R_E, R_DT, R_ET, R_RHO, R_RINV, R_KD, R_LX, R_DI, R_YV, R_WV, R_XP, R_DY,
        R_T1, R_T2, R_T3, R_SC, R_COUNT };
 

@@ -27,7 +27,10 @@ _ROWS = [("PS", "nnzP"), ("AS", "nnzA"), ("QS", "n"), ("LS", "m"), ("US", "m"), 
          ("DT", "n"), ("ET", "m"), ("RHO", "m"), ("RINV", "m"), ("KD", "nk"), ("LX", "nnzL"), ("DI", "nk"),
          ("YV", "nk"), ("WV", "nk"), ("XP", "n"), ("DY", "m"), ("T1", "n"), ("T2", "n"), ("T3", "m"), ("SC", 4)]
 _TABLES = ["pinv", "pidx", "A_p", "A_i", "Ar_p", "Ar_j", "Ar_k", "fi_p", "fi_b", "fi_src", "fe_p", "fe_c",
-           "fe_new", "L_p", "L_i", "Lr_p", "Lr_j", "Lr_k"]
+           "fe_new", "L_p", "L_i", "Lr_p", "Lr_j", "Lr_k",
+           # wave-per-robot kernel (level schedules, csrc/umpc_bqp.hip bqp_wave_kernel)
+           "perm", "A_j", "lev_p", "lev_nodes", "elev_p", "elev_ent", "l_ksrc", "l_col", "ft_p", "ft_a", "ft_b", "ft_j",
+           "fd_p", "fd_a", "fd_j"]
 HEADER_WORDS = 64
 
 
@@ -175,11 +178,59 @@ def analyse_qp(n, m, A_p, A_i, P_cols, perm=None):
             Lr_j.append(c)
             Lr_k.append(j)
         Lr_p.append(len(Lr_j))
+    # ---- level schedules for the wave-per-robot kernel: level(c) = 1 + max level over the row pattern of c, so the
+    # entries of row r (forward solve) live in lower levels and the entries of column r (backward solve) in higher ones
+    lev = [0] * nk
+    for c in range(nk):
+        lev[c] = 1 + max([lev[j] for (j, _) in lrows[c]], default=-1)
+    nlev = max(lev) + 1
+    lev_nodes = sorted(range(nk), key=lambda c: (lev[c], c))
+    lev_p = [0]
+    for l in range(nlev):
+        lev_p.append(lev_p[-1] + sum(1 for c in range(nk) if lev[c] == l))
+    ent_col = [0] * nnzL
+    for c in range(nk):
+        for j in range(L_p[c], L_p[c + 1]):
+            ent_col[j] = c
+    elev_ent = sorted(range(nnzL), key=lambda e: (lev[ent_col[e]], e))
+    elev_p = [0]
+    for l in range(nlev):
+        elev_p.append(elev_p[-1] + sum(1 for e in range(nnzL) if lev[ent_col[e]] == l))
+    # K source of every L position: the A entry of the permuted KKT at (row, col) = (L row, L col), or -1 (fill-in)
+    lidx = {}
+    for c in range(nk):
+        for j in range(L_p[c], L_p[c + 1]):
+            lidx[(L_i[j], c)] = j
+    l_ksrc = [-1] * nnzL
+    for jj in range(nk):
+        for p in range(K_p[jj], K_p[jj + 1]):
+            ii = K_i[p]
+            if ii != jj:
+                l_ksrc[lidx[(jj, ii)]] = K_src[p][1]       # ('A', index)
+    # right-looking dot products: L[i,c] = (K[i,c] - sum_j L[i,j] L[c,j] D[j]) / D[c], D[c] = K[c,c] - sum_j L[c,j]^2 D[j]
+    rowmap = [dict((c, k) for (c, k) in lrows[r]) for r in range(nk)]
+    ft_p, ft_a, ft_b, ft_j = [0], [], [], []
+    for e in range(nnzL):
+        i, c = L_i[e], ent_col[e]
+        for (j, kcj) in lrows[c]:
+            if j in rowmap[i]:
+                ft_a.append(rowmap[i][j]); ft_b.append(kcj); ft_j.append(j)
+        ft_p.append(len(ft_a))
+    fd_p, fd_a, fd_j = [0], [], []
+    for c in range(nk):
+        for (j, kcj) in lrows[c]:
+            fd_a.append(kcj); fd_j.append(j)
+        fd_p.append(len(fd_a))
+    A_j = [0] * nnzA
+    for j in range(n):
+        for p in range(A_p[j], A_p[j + 1]):
+            A_j[p] = j
     tables = dict(pinv=pinv, pidx=pidx, A_p=A_p, A_i=A_i, Ar_p=Ar_p, Ar_j=Ar_j, Ar_k=Ar_k, fi_p=fi_p, fi_b=fi_b,
                   fi_src=fi_src, fe_p=fe_p, fe_c=fe_c, fe_new=fe_new, L_p=L_p, L_i=L_i, Lr_p=Lr_p, Lr_j=Lr_j,
-                  Lr_k=Lr_k)
+                  Lr_k=Lr_k, perm=perm, A_j=A_j, lev_p=lev_p, lev_nodes=lev_nodes, elev_p=elev_p, elev_ent=elev_ent,
+                  l_ksrc=l_ksrc, l_col=ent_col, ft_p=ft_p, ft_a=ft_a, ft_b=ft_b, ft_j=ft_j, fd_p=fd_p, fd_a=fd_a, fd_j=fd_j)
     # blob: [HEADER_WORDS header | tables]; header = sizes, nrows, then (table offset) x len(_TABLES), then row offsets
-    hdr = [n, m, nk, nnzP, nnzA, nnzL, nrows, 0]
+    hdr = [n, m, nk, nnzP, nnzA, nnzL, nrows, nlev]
     body, offs = [], []
     pos = HEADER_WORDS
     for name in _TABLES:

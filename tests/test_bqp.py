@@ -185,7 +185,7 @@ def test_gpu_qp_on_uprightmpc2_fixture(structure, dtype):
     if dtype == np.float64:
         assert np.allclose(got["info"][0], ref["pri_res"], rtol=1e-6, atol=1e-12)
     else:   # fp32 residuals of a converged iterate are round-off
-        assert np.allclose(got["info"][0], ref["pri_res"], rtol=1e-2, atol=3e-5)
+        assert np.allclose(got["info"][0], ref["pri_res"], rtol=2e-2, atol=1e-4)
 
 
 @pytest.mark.gpu
@@ -387,7 +387,7 @@ def test_gpu_specialised_kernels_equal_the_table_driven_kernel():
         B = 96
         # p5f
         mpc = PlanarP5fMPC(B, tdt)
-        assert mpc.qp.kernel_name == "p5f10"
+        assert mpc.qp.kernel_name == "wave"          # PlanarP5fMPC's choice; the two lane-per-robot kernels are compared here
         mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
         mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
         mpc.linearise(7.0)
@@ -408,8 +408,8 @@ def test_gpu_specialised_kernels_equal_the_table_driven_kernel():
         res = []
         for tables in (False, True):
             m5 = UprightMPC2N(B, 5, dtype=tdt)
-            assert m5.qp.kernel_name == "umpc2n5"
             m5.qp.use_tables(tables)
+            assert m5.qp.kernel_name == ("tables" if tables else "umpc2n5")
             m5.T0.copy_(torch.as_tensor(T0).cuda())
             res.append(m5.update(S, R).cpu().numpy().copy())
         assert np.array_equal(res[0], res[1], equal_nan=True)
@@ -419,8 +419,8 @@ def test_gpu_specialised_kernels_equal_the_table_driven_kernel():
         res = []
         for tables in (False, True):
             v1 = UprightMPCv1(len(g["dt"]), 3, tdt, max_iter=100)
-            assert v1.qp.kernel_name == "v1n3"
             v1.qp.use_tables(tables)
+            assert v1.qp.kernel_name == ("tables" if tables else "v1n3")
             x, uu = v1.update(T(g["q0"]), T(g["qdes"]), T(g["Qf"]), T(g["Rd"]), T(g["smin"]), T(g["smax"]), 2.5,
                               T(g["snom"]), torch.as_tensor(g["vT0"].astype(ndt)).cuda())
             res.append(x.cpu().numpy().copy())
@@ -502,3 +502,47 @@ def test_gpu_createMPC_pair_cross_check():
     up5, _ = createMPC(N=5)
     u5, a5 = up5.update(p, R0, dq, pdes, dpdes, sdes)
     assert np.isfinite(u5).all() and np.isfinite(a5).all() and up5.prevsol.shape == (75,)
+
+
+@pytest.mark.gpu
+def test_gpu_wave_kernel_agrees_with_lane_kernels():
+    """One wavefront per robot (LDS-resident, level-scheduled; the default) against the lane-per-robot table kernel on
+    three structures: the same iterates to rounding (the factorisation and the Ruiz cost sums associate differently)."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC, UprightMPC2N
+    seq = golden("seq_iter50.npz")
+    for tdt, ndt, tol in ((torch.float64, np.float64, 1e-10), (torch.float32, np.float32, 2e-3)):
+        B = 70
+        mpc = PlanarP5fMPC(B, tdt)
+        mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
+        mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
+        res = []
+        for mode in ("wave", "tables"):
+            mpc.qp.reset()
+            mpc.qp.set_kernel(mode)
+            assert mpc.qp.kernel_name == mode
+            for ti in (2, 3):      # second call is warm-started and classifies with the first call's E
+                mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti))
+                mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
+            torch.cuda.synchronize()
+            res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x, mpc.qp.Eprev)]
+                       + [mpc.qp.status.cpu().numpy().copy()])
+        for a, b in zip(res[0][:5], res[1][:5]):
+            assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < tol, tdt
+        assert np.count_nonzero(res[0][5] != res[1][5]) <= (0 if tdt == torch.float64 else B // 8)
+        for N in (3, 10):
+            idx = np.arange(40)
+            st, ref, T0 = _state_ref_from_seq(seq, idx, ndt)
+            S, R = torch.as_tensor(st).cuda(), torch.as_tensor(ref).cuda()
+            outs = []
+            for mode in ("wave", "tables"):
+                m = UprightMPC2N(len(idx), N, dtype=tdt)
+                m.qp.set_kernel(mode)
+                m.T0.copy_(torch.as_tensor(T0).cuda())
+                outs.append(m.update(S, R).cpu().numpy().astype(np.float64).copy())
+            if tdt == torch.float64:
+                assert np.allclose(outs[0], outs[1], rtol=1e-8, atol=1e-10, equal_nan=True), N
+            else:   # two fp32 evaluations, each inside the fp32 parity band of the fp64 value: twice the band
+                assert np.all(np.abs(outs[0][0] - outs[1][0]) <= 6e-5)
+                assert np.all(np.abs(outs[0][1:3] - outs[1][1:3]) <= 2 * np.maximum(2e-2, 1e-3 * np.abs(outs[1][1:3])))
+                assert np.all(np.abs(outs[0][3:] - outs[1][3:]) <= 6e-5)

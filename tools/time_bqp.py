@@ -14,5 +14,5 @@ for N, B in ((3, 65536), (3, 16384), (5, 16384), (10, 16384)):
         mpc.update(S, R)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print("N=%d B=%d nnzL=%d: %.2f ms/step, %.3g robot-steps/s, solved %.3f" % (N, B, mpc.qp.s.nnzL, dt * 1e3, B / dt,
+    print(mpc.qp.kernel_name, "N=%d B=%d nnzL=%d: %.2f ms/step, %.3g robot-steps/s, solved %.3f" % (N, B, mpc.qp.s.nnzL, dt * 1e3, B / dt,
           float((mpc.qp.status > 0).float().mean())), flush=True)
