@@ -335,3 +335,37 @@ def test_monte_carlo_inertia_and_mass(torch_cuda, oracle_built):
     m.rollout(K)
     np.testing.assert_allclose(m.state.cpu().numpy(), s_o, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(m.out.cpu().numpy(), out_o, rtol=1e-6, atol=1e-8)
+
+
+def test_simulink_entry_points_equal_the_object_api(torch_cuda):
+    """umpcS (uprightmpc2.c:275-284) and wlconS (funapprox.c:171-176), the lazily initialised singletons behind the
+    Simulink S-functions (legacy_code_gen.m:6), give the same sequences as umpcInit/umpcUpdate and
+    wlConInit/wlConUpdate."""
+    import ctypes as C
+    from robobee3d_amd import _lib
+    from robobee3d_amd.uprightmpc2py import UprightMPC2C, WLCon
+    L = _lib.lib()
+    seq = golden("seq_iter50.npz")
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    prm = (5.0, 9.81e-3, 2.0, 1e1, 1e3, 1.0, 5.0, 1e3, 2e3, 1e-1, 1e-2)
+    Ib = f32([3333.0, 3333.0, 1000.0])
+    obj = UprightMPC2C(*prm, Ib, 50)
+    for k in range(6):
+        args = [f32(seq[n][k]) for n in ("p0",)] + [f32(seq["R0"][k].T.ravel())] + \
+               [f32(seq[n][k]) for n in ("dq0", "pdes", "dpdes", "sdes")]
+        u1, a1 = obj.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k], seq["sdes"][k],
+                            float(seq["actualT0"][k]))
+        u2, a2 = np.zeros(3, np.float32), np.zeros(6, np.float32)
+        L.umpcS(fp(u2), fp(a2), *[fp(a) for a in args], *[C.c_float(v) for v in prm], fp(Ib), C.c_int(50),
+                C.c_float(float(seq["actualT0"][k])))
+        assert np.array_equal(u1, u2) and np.array_equal(a1, a2), k
+    g = golden("wl_step.npz")
+    wl = WLCon(g["u0"], g["umin"], g["umax"], g["dumax"], g["Qw"], float(g["controlRate"]), g["popts"])
+    for k in range(8):
+        u1, w1 = wl.update(g["h0"][k], g["pdotdes"][k])
+        u2, w2 = np.zeros(4, np.float32), np.zeros(6, np.float32)
+        L.wlconS(fp(u2), fp(w2), fp(f32(g["u0"])), fp(f32(g["umin"])), fp(f32(g["umax"])), fp(f32(g["dumax"])),
+                 fp(f32(g["Qw"])), C.c_float(float(g["controlRate"])), fp(f32(g["popts"])), fp(f32(g["h0"][k])),
+                 fp(f32(g["pdotdes"][k])))
+        assert np.array_equal(u1, u2) and np.array_equal(w1, w2), k
