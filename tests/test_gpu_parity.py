@@ -369,3 +369,27 @@ def test_simulink_entry_points_equal_the_object_api(torch_cuda):
                  fp(f32(g["Qw"])), C.c_float(float(g["controlRate"])), fp(f32(g["popts"])), fp(f32(g["h0"][k])),
                  fp(f32(g["pdotdes"][k])))
         assert np.array_equal(u1, u2) and np.array_equal(w1, w2), k
+
+
+def test_config2_fp64_full_run_against_oracle_sample(torch_cuda, oracle_built):
+    """BASELINE configs[1] at full size: B = 4096, fp64, seed 20201117, K = 200 closed-loop
+    steps in one launch. Every 128th robot is replayed on the fp64 oracle (same elimination order): states agree to
+    1e-6 after 5 000 plant substeps; the whole batch hovers."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    from robobee3d_amd import _lib
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    B, K = 4096, 200
+    st, ref = hover_initial_conditions(B, 20201117, np.float64)
+    mpc = BatchUprightMPC(B, torch.float64)
+    mpc.set_state(st, ref)
+    mpc.rollout(K)
+    s = mpc.state.cpu().numpy()
+    assert np.isfinite(s).all() and np.linalg.norm(s[0:3], axis=0).max() < 0.05
+    idx = np.arange(0, B, 128)
+    s_o = np.ascontiguousarray(st[:, idx])
+    ctrl = np.zeros((127, len(idx))); ctrl[124:] = 1
+    out_o, stats_o, _ = oracle_built.batch_rollout(s_o, ctrl, np.ascontiguousarray(ref[:, idx]), K, dtype=np.float64, perm=perm)
+    np.testing.assert_allclose(s[:, idx], s_o, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(mpc.out.cpu().numpy()[:, idx], out_o, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(mpc.stats.cpu().numpy()[:, idx], stats_o, rtol=1e-7)
