@@ -461,11 +461,13 @@ def body(e, s, first, capture, plan, lv=False):
             if len(g) == 1:
                 d, sr, j = g[0]
                 src = l_src(j)
+                # the factor is stored NEGATED: dst += (-L) * src is the 4-byte VOP2 v_fmac_f32, which a lone wave
+                # issues every ~4.4 cycles against ~5.0 for the 8-byte VOP3 v_fma_f32 (tools/microbench.hip)
                 if src[0] == "V":
-                    op(None, lambda t, d=d, sr=sr, r=src[1]: e("v_fma_f32", W(d), "-" + v(r), W(sr), W(d)),
+                    op(None, lambda t, d=d, sr=sr, r=src[1]: e("v_fmac_f32", W(d), v(r), W(sr)),
                        w=(wreg(d),), r=(wreg(d), wreg(sr)))
                 else:
-                    op(src, lambda t, d=d, sr=sr: e("v_fma_f32", W(d), "-" + v(t), W(sr), W(d)),
+                    op(src, lambda t, d=d, sr=sr: e("v_fmac_f32", W(d), v(t), W(sr)),
                        w=(wreg(d),), r=(wreg(d), wreg(sr)))
                 continue
             (d0, s0_, j0), (d1, s1_, j1) = g          # d0 has the even destination register
@@ -477,14 +479,14 @@ def body(e, s, first, capture, plan, lv=False):
             lsel = (lpos[j0] % 2, lpos[j1] % 2)
             if pe < NLDS:
                 op(("L", pe), lambda t, rd=rd, srcp=srcp, lsel=lsel:
-                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]), **rw)
+                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [0, 0, 0]), **rw)
             elif lv and pe < NLDS + NVZ:
                 t = V_Z + pe - NLDS
                 op(None, lambda _t, t=t, rd=rd, srcp=srcp, lsel=lsel:
-                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [1, 0, 0]), **rw)
+                   pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [0, 0, 0]), **rw)
             else:
                 src = ("A2", A_L + lpos[j0] - NLDS, A_L + lpos[j1] - NLDS)
-                op(src, lambda t, rd=rd, srcp=srcp: pk(e, "v_pk_fma_f32", rd, [_vp(t), srcp, _vp(rd)], [1, 0, 0]), **rw)
+                op(src, lambda t, rd=rd, srcp=srcp: pk(e, "v_pk_fma_f32", rd, [_vp(t), srcp, _vp(rd)], [0, 0, 0]), **rw)
 
     solve_ops(fwd)
     # ---- diagonal (qdldl.c:289): two unknowns per instruction, paired by register
@@ -623,7 +625,7 @@ def write(path=None, N=3, perm=None):
     path = path or os.path.join(HERE, "csrc", "umpc_admm_asm.h")
     ins, s = program(N, perm)
     lpos = solve_plan(s)[2]
-    store_l = " ".join("LDSW_(%d) = LX_(%d);" % (lpos[j], j) if lpos[j] < NLDS else "ROW_(%d) = LX_(%d);" % (FAC_L + lpos[j], j)
+    store_l = " ".join("LDSW_(%d) = -LX_(%d);" % (lpos[j], j) if lpos[j] < NLDS else "ROW_(%d) = -LX_(%d);" % (FAC_L + lpos[j], j)
                        for j in range(len(lpos)))
     used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1] + list(range(S_ALPHA, S_RHO + 2))
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
@@ -640,7 +642,7 @@ def write(path=None, N=3, perm=None):
            (WS_DS, WS_ES, WS_C, WS_XPREV, WS_DY, WS_ROWS),
            "constexpr int LDS_BYTES_PER_LANE = %d;" % (NLDS * 4),
            "}  // namespace umpcasm",
-           "// Phase A -> loop hand-off of the factor: entry j of L (CSC order) goes to its storage position (asmgen.solve_plan):",
+           "// Phase A -> loop hand-off of the factor: entry j of L (CSC order) goes NEGATED to its storage position (asmgen.solve_plan):",
            "// LDS word LDSW_(p) for p < %d, workspace row ROW_(FAC_L + p) (-> AGPR) otherwise." % NLDS,
            "#define UMPC_ASM_STORE_L(LDSW_, ROW_, LX_) do { %s } while (0)" % store_l,
            "// inputs: v0 = 4*robot, v1 = lane LDS address, s[4:5] = workspace, s[6:7] = ctrl, s10 = 4*B, s11 = maxIter",
@@ -775,6 +777,8 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds=None):
             V[int(t[1][1:])] = fval(t[2])
         elif m == "v_fma_f32":
             V[int(t[1][1:])] = f32(np.float64(fval(t[2])) * np.float64(fval(t[3])) + np.float64(fval(t[4])))
+        elif m == "v_fmac_f32":
+            V[int(t[1][1:])] = f32(np.float64(fval(t[2])) * np.float64(fval(t[3])) + np.float64(V[int(t[1][1:])]))
         elif m == "v_mul_f32":
             V[int(t[1][1:])] = f32(fval(t[2]) * fval(t[3]))
         elif m == "v_add_f32":

@@ -34,7 +34,7 @@ def _case(oracle_built, asmgen, ins, s, seq, k, iters):
     # L entry j lives at storage position pos[j] (asmgen.solve_plan): LDS word if < NLDS, else workspace row
     pos = np.array(asmgen.l_positions())
     Lstore = np.zeros(213, np.float32)
-    Lstore[pos] = o.get("L_x")
+    Lstore[pos] = -o.get("L_x")          # the loop keeps the factor negated (v_fmac_f32)
     ws[asmgen.FAC_L:asmgen.FAC_L + 213] = Lstore
     ws[asmgen.FAC_DI:asmgen.FAC_DI + 84] = o.get("Ddinv")
     ws[asmgen.FAC_Q:asmgen.FAC_Q + 45] = o.get("q")

@@ -57,6 +57,11 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int iters) {
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("v_rsq_f32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+    } else if (MODE == 7) {  // 64 independent v_fmac_f32: the 4-byte VOP2 encoding of d += a*b
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 15]));
     } else if (MODE == 6) {  // 64 IEEE divisions (compiler sequence)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -78,10 +83,10 @@ int main() {
   CHECK(hipMalloc(&d, 4096 * 64 * sizeof(float)));
   CHECK(hipMemset(d, 0, 4096 * 64 * sizeof(float)));
   CHECK(hipMalloc(&c, blocks_full * 8 * sizeof(long long)));
-  const char *names[] = {"64 indep v_fma_f32", "32 v_pk_fma_f32 (64 FMA)", "64 dependent v_fma_f32", "64 x (accvgpr_read + fma)", "16 ds_read_b128 + 64 fma", "64 v_rsq_f32", "64 IEEE div"};
+  const char *names[] = {"64 indep v_fma_f32", "32 v_pk_fma_f32 (64 FMA)", "64 dependent v_fma_f32", "64 x (accvgpr_read + fma)", "16 ds_read_b128 + 64 fma", "64 v_rsq_f32", "64 IEEE div", "64 indep v_fmac_f32 (VOP2)"};
   for (int wavesPerCU : {1, 4, 8}) {
     int blocks = 256 * wavesPerCU;
-    for (int m = 0; m < 7; ++m) {
+    for (int m = 0; m < 8; ++m) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
@@ -93,6 +98,7 @@ int main() {
           case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(64), 0, 0, d, c, iters); break;
           case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(64), 0, 0, d, c, iters); break;
           case 6: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(64), 0, 0, d, c, iters); break;
+          case 7: hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(64), 0, 0, d, c, iters); break;
         }
         hipEventRecord(e1); CHECK(hipEventSynchronize(e1));
       }
