@@ -58,6 +58,13 @@ def cpu_baseline(args, plant_mode):
     c1 = np.zeros((127, n1), np.float32); c1[124:] = 1
     oraclebind.batch_rollout(st1, c1, ref1, Ks, dtype=np.float32, plant_mode=plant_mode, nthreads=1)
     dt1 = time.perf_counter() - t1
+    # the same sample on the fp64 build of the oracle, single thread (fp32 and fp64, 1 thread and OpenMP)
+    st2, ref2 = hover_initial_conditions(n1, 20201118, np.float64)
+    c2 = np.zeros((127, n1), np.float64); c2[124:] = 1
+    oraclebind.batch_rollout(st2.copy(), c2.copy(), ref2, 1, dtype=np.float64, plant_mode=plant_mode, nthreads=1)  # load + warm
+    t2 = time.perf_counter()
+    oraclebind.batch_rollout(st2, c2, ref2, Ks, dtype=np.float64, plant_mode=plant_mode, nthreads=1)
+    dt2 = time.perf_counter() - t2
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -71,7 +78,7 @@ def cpu_baseline(args, plant_mode):
             "cpu_model": model, "host_threads_visible": len(os.sched_getaffinity(0)),
             "sample": "%d robots x %d steps of the same workload (oracle/umpc_oracle.c, fp32, OpenMP over robots)"
                       % (Bs, Ks),
-            "single_thread_value": n1 * Ks / dt1}
+            "single_thread_value": n1 * Ks / dt1, "fp64_single_thread_value": n1 * Ks / dt2}
 
 
 def main_p5f(args):
