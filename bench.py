@@ -34,6 +34,101 @@ ALG_BYTES_PER_STEP_FP32 = 1208  # (18 plant + 124 controller + 9 ref)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def profile_json(name):
+    """A committed rocprofv3 summary under profiles/ (PMC counters cannot be read live from inside the process)."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
+        if os.path.exists(path):
+            try:
+                j = json.load(open(path))
+                j["_file"] = os.path.relpath(path, ROOT)
+                return j
+            except Exception:
+                pass
+    return None
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as CHILD processes of torch.distributed.run
+    (127.0.0.1 rendezvous on a free port) before this process has touched the GPU, pass their output through and
+    exit with their code. Nothing is exec'd from a process that has initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
+def reference_anchor():
+    """The reference's OWN umpcUpdate (oracle/_ref/libumpc_ref.so: its C sources compiled where they lie by
+    oracle/Makefile in the authoring container; the prebuilt file travels with the tree) timed on this host, single
+    thread, arguments marshalled once -- reported next to the port when the file is present."""
+    try:
+        import ctypes as C
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import refbind
+        if not refbind.available():
+            return None
+        r = refbind.RefUMPC()
+        rng = np.random.default_rng(1)
+        n = 2000
+        ab = rng.uniform(-0.5, 0.5, (n, 2))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        uq, ac = np.zeros(3, np.float32), np.zeros(6, np.float32)
+        z3, e3 = np.zeros(3, np.float32), np.array([0, 0, 1], np.float32)
+        dq = np.zeros(6, np.float32); dq[0] = 0.1
+        Rs = []
+        for a, b in ab:   # Rx(a) Ry(b), column-major (uprightmpc2.c:219)
+            ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+            Rs.append(np.array([cb, sa * sb, -ca * sb, 0, ca, sa, sb, -sa * cb, ca * cb], np.float32))
+        args = [(C.byref(r.up), fp(uq), fp(ac), fp(z3), fp(R), fp(dq), fp(z3), fp(z3), fp(e3), C.c_float(-1.0)) for R in Rs]
+        f = r.lib.umpcUpdate
+        for k in range(50):
+            f(*args[k])
+        t0 = time.perf_counter()
+        for k in range(n):
+            f(*args[k])
+        dt_call = (time.perf_counter() - t0) / n
+        g = r.lib.osqp_update_max_iter   # a trivial exported function: the cost of one ctypes call with arguments
+        ws = (C.c_void_p * 26).in_dll(r.lib, "workspace")
+        t0 = time.perf_counter()
+        for k in range(n):
+            g(C.c_void_p(C.addressof(ws)), C.c_int(50))
+        over = (time.perf_counter() - t0) / n
+        return {"umpcUpdate_us": dt_call * 1e6, "ctypes_call_us": over * 1e6, "calls": n,
+                "what": "the reference C umpcUpdate (OSQP 0.6.0 embedded, fp32, 50 it), 1 thread, random-tilt hover states; "
+                        "controller step only, no plant"}
+    except Exception as ex:  # the anchor is optional: never let it break the bench line
+        return {"error": repr(ex)[:200]}
+
+
+class DryRunMPC:
+    """--dry-run stand-in for BatchUprightMPC on CPU: no kernel, statistics = the global robot index, so the
+    launcher / rendezvous / gather path of bench.py can run under gloo in the CPU test-suite."""
+
+    def __init__(self, B, state, rank):
+        import torch
+        self.B, self.state, self.rank = B, state, rank
+        self.status = torch.ones(B, dtype=torch.int32)
+        self.Ib = self.gain = None
+        self.nsteps = 0
+
+    def rollout(self, K):
+        self.nsteps += K
+        time.sleep(1e-3 * (1 + self.rank))      # ranks finish at different times: the line reports the maximum
+
+    def metrics(self, nsteps):
+        import torch
+        assert nsteps == self.nsteps
+        idx = torch.arange(self.rank * self.B, (self.rank + 1) * self.B, dtype=torch.float32)
+        return torch.stack((idx, torch.zeros_like(idx)))
+
+
 def cpu_baseline(args, plant_mode):
     """The oracle (CPU restatement, OpenMP over robots) on a bounded sample of the
     same workload, timed on this box's host cores."""
@@ -75,6 +170,7 @@ def cpu_baseline(args, plant_mode):
     except OSError:
         pass
     return {"value": Bs * Ks / dt, "unit": "closed-loop MPC steps/s", "cores": ncores, "kind": "port",
+            "reference": reference_anchor(),
             "cpu_model": model, "host_threads_visible": len(os.sched_getaffinity(0)),
             "sample": "%d robots x %d steps of the same workload (oracle/umpc_oracle.c, fp32, OpenMP over robots)"
                       % (Bs, Ks),
@@ -171,22 +267,33 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-robots", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="TEST ONLY (tests/test_shard_gloo.py): run the launcher, rendezvous (gloo), sharding, barriers, "
+                         "max-over-ranks timing and the statistics gather on CPU with NO kernel; the line says dry_run")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (children only; this process never touches the GPU)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     if args.workload == "p5f":
         return main_p5f(args)
     import torch
     import torch.distributed as dist
-    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    from robobee3d_amd.batch import hover_initial_conditions
     from robobee3d_amd import _lib
 
     from robobee3d_amd import shard
     rank, world, local_rank = shard.world()
-    dev = torch.device("cuda", local_rank)
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        torch.cuda.set_device(local_rank)
-        shard.init("nccl", device=dev)   # "nccl" is RCCL on ROCm
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if args.dry_run:
+        dev = torch.device("cpu")
+        shard.init("gloo")
+    else:
+        from robobee3d_amd.batch import BatchUprightMPC
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            torch.cuda.set_device(local_rank)
+            shard.init("nccl", device=dev)   # "nccl" is RCCL on ROCm
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     ndt = np.float32 if args.dtype == "f32" else np.float64
     plant_mode = 0 if args.plant == "euler" else 1
@@ -195,66 +302,80 @@ def main():
     # synthetic inputs, resident in HBM before the timed region
     lo, _hi = shard.robot_range(B, rank)   # weak scaling: B robots per GPU, RNG keyed by the global index
     st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=lo)
-    mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode, maxIter=args.max_iter, nsub=args.nsub)
-    mpc.set_state(st, ref)
+    if args.dry_run:
+        mpc = DryRunMPC(B, torch.as_tensor(st), rank)
+    else:
+        mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode, maxIter=args.max_iter, nsub=args.nsub)
+        mpc.set_state(st, ref)
     if args.monte_carlo:  # Ib = Ib0 (1 + d), d ~ U(-0.2, 0.2)^3, thrust gain 1 + U(-0.2, 0.2)
-        rng = np.random.default_rng(20201120 + rank)
-        mpc.Ib = torch.as_tensor((np.array([3333.0, 3333.0, 1000.0])[:, None] *
-                                  (1 + rng.uniform(-0.2, 0.2, (3, B)))).astype(ndt)).to(dev)
-        mpc.gain = torch.as_tensor((1 + rng.uniform(-0.2, 0.2, B)).astype(ndt)).to(dev)
+        from robobee3d_amd.batch import monte_carlo_draws
+        Ib, gain = monte_carlo_draws(B, 20201120, ndt, index_offset=lo)   # keyed by the GLOBAL robot index
+        mpc.Ib = torch.as_tensor(Ib).to(dev)
+        mpc.gain = torch.as_tensor(gain).to(dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
 
     spl = args.steps if args.steps_per_launch <= 0 else max(1, min(args.steps_per_launch, args.steps))
     assert args.steps % spl == 0, "--steps must be a multiple of --steps-per-launch"
-    # warm-up steps use the timed launch shape when they divide into it (so a rocprofv3 --stats average over
-    # all dispatches of the step kernel is the timed launch's duration), one-step launches otherwise
-    wspl = spl if args.warmup % spl == 0 else 1
-    for _ in range(args.warmup // wspl):
-        mpc.rollout(wspl)
+    # EXACTLY `warmup` untimed steps, as multi-step launches like the timed ones (full launches of spl steps, then
+    # the remainder as one shorter launch): the code object, the workspace pages and the clocks are warm and no
+    # warm-up step runs in a shape the timed region does not use
+    w = args.warmup
+    while w > 0:
+        mpc.rollout(min(spl, w))
+        w -= min(spl, w)
     barrier()
     nlaunch = args.steps // spl
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
+    cuda = dev.type == "cuda"
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)] if cuda else []
     t0 = time.perf_counter()
     for k in range(nlaunch):
-        evs[k][0].record()
+        if cuda:
+            evs[k][0].record()      # on the stream the kernel is launched on (torch's current stream)
         mpc.rollout(spl)        # ONE launch = spl closed-loop steps of all B robots
-        evs[k][1].record()
-    torch.cuda.synchronize(dev)
+        if cuda:
+            evs[k][1].record()
+    if cuda:
+        torch.cuda.synchronize(dev)
     local = time.perf_counter() - t0          # this rank's K steps, start barrier -> local completion
     barrier()
     elapsed = shard.max_over_ranks(local, device=dev)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if cuda else local / nlaunch * 1e3
 
     # end-of-run trajectory statistics: the only exchange of the path (RCCL all_gather over xGMI,
     # outside the timed region; 2 floats per robot)
     metric = shard.gather_stats(mpc.metrics(args.warmup + args.steps))
     status = mpc.status
     nbad = int((~torch.isfinite(mpc.state)).sum().item())
+    if args.dry_run and rank == 0:
+        # the gather returned every rank's block in global robot order
+        assert metric.shape[1] == world * B and torch.equal(metric[0], torch.arange(world * B, dtype=metric.dtype))
 
     if rank == 0:
         total_steps = world * B * args.steps
         value = total_steps / elapsed
         bps = ALG_BYTES_PER_STEP_FP32 * (2 if args.dtype == "f64" else 1)
-        # instructions one wavefront issues per closed-loop step (fp32 kernel; counted in the ISA):
-        # phase A 1.2k + 10 Ruiz passes x 0.94k + LDL'/hand-off 3.0k, 835 per ADMM iteration, phase C 5k, plant substeps
-        ninstr = 13600 + 835 * args.max_iter + 5000 + args.nsub * (250 if plant_mode == 1 else 110)
         achieved = bps * B * spl / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                # PMC counters cannot be read live; this is the committed rocprofv3 --pmc measurement of THIS
-                # command (profiles/r01_pmc_traffic.json), used only when the configuration matches it
-                if (j.get("batch") == B and j.get("dtype") == args.dtype and j.get("plant") == args.plant
-                        and j.get("steps_per_launch") == spl and args.max_iter == 50 and args.nsub == 25):
-                    traffic = j["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        # PMC counters cannot be read from inside the process: `traffic` and the VALU instruction count are the
+        # committed rocprofv3 --pmc measurements of this kernel (profiles/), kept PER ROBOT-STEP and scaled to this
+        # launch (B x steps-per-launch); used only when the kernel configuration is the profiled one
+        traffic, traffic_src, valu_per_wave_step, valu_src = None, None, None, None
+        same_kernel = lambda j: (j is not None and j.get("dtype", "f32") == args.dtype and j.get("plant", "rk4") == args.plant
+                                 and j.get("max_iter", 50) == args.max_iter and j.get("nsub", 25) == args.nsub)
+        j = profile_json("pmc_traffic")
+        if same_kernel(j) and not args.monte_carlo:
+            per = j["per_robot_step_bytes"]
+            traffic = (per["read_corrected"] + per["written"]) * B * spl
+            traffic_src = "%s: %.0f B read + %.0f B written per robot-step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
+                          "gfx950 correction applied) x %d robots x %d steps" % (j["_file"], per["read_corrected"], per["written"], B, spl)
+        j = profile_json("sq_counters")
+        if same_kernel(j):
+            valu_per_wave_step = j["per_wave_step"]["valu_instructions"]
+            valu_src = j["_file"]
         line = {
             "metric": "closed-loop MPC steps/sec (QP+dyn)", "value": value, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -266,7 +387,7 @@ def main():
                        "plant": "Euler+expm (reference step)" if plant_mode == 0 else "RK4 (build-defined)",
                        "parallelism": "robots sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": _lib.lib().umpcKernelName(0 if args.dtype == "f32" else 1, plant_mode).decode(),
                          "kernel_ms": kern_ms, "steps_per_launch": spl, "alg_bytes_per_launch": bps * B * spl,
                          # SURVEY 8d asks for all three rooflines; the one that binds is vector issue
@@ -275,16 +396,23 @@ def main():
                          "lds": {"achieved": (args.max_iter * 78 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
                                  "unit": "GB/s", "peak": 256 * 128 * 2.4,
                                  "note": "78 ds_read_b128 per ADMM iteration per lane + hand-off; peak 128 B/clk/CU"},
-                         "valu_issue": {"instr_per_wave_step": ninstr, "achieved": ninstr * (B / 64) * spl / (kern_ms * 1e-3) / 1e9,
+                         "valu_issue": {"valu_instr_per_wave_step": valu_per_wave_step,
+                                        "achieved": valu_per_wave_step * (B / 64) * spl / (kern_ms * 1e-3) / 1e9,
                                         "peak": 1024 * 2.4 / 4, "unit": "G wave-instr/s",
-                                        "note": "static instruction counts x loop trips (DESIGN.md 2); peak = 1024 SIMDs, one "
-                                                "wave64 VALU op per 4 cycles at 2.4 GHz"} if args.dtype == "f32" else None,
+                                        "frac": valu_per_wave_step * (B / 64) * spl / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 4),
+                                        "source": valu_src,
+                                        "note": "VALU instructions only (SQ_INSTS_VALU per wave-step, profile-derived); peak = "
+                                                "1024 SIMDs x one wave64 VALU op per 4 cycles at 2.4 GHz"} if valu_per_wave_step else None,
                          "note": "path is VALU-issue bound, not HBM bound (DESIGN.md): ~1.1e5 flop per 1208 B"},
             "check": {"nonfinite_state_values": nbad,
                       "mean_pos_err_mm2": float(metric[0].mean().item()),
                       "status_solved_frac": float((status > 0).float().mean().item())},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.dry_run:
+            line["dry_run"] = True
+            line["value"] = line["ms_per_step"] = None     # no kernel ran: nothing was measured
+            line["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             line["cpu_baseline"] = cpu_baseline(args, plant_mode)
         print(json.dumps(line), flush=True)
     if world > 1:

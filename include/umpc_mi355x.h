@@ -43,7 +43,11 @@ extern "C" {
 /* Caller-allocated POD, same field layout as uprightmpc2.h:27-43 (1308 B):
  * the reference's pybind `vectors()/matrices()` read l,u,q,Px_data,Ax_data,
  * Ax_idx straight out of it (py/uprightmpc2py.cpp:46-51), so umpcUpdate keeps
- * them filled. */
+ * them filled. The two words of `smin` -- which no reference source reads or
+ * writes -- carry an opaque controller id set by umpcInit, so the POD may be
+ * copied or moved by its host (the pybind class holds it by value) without
+ * losing the warm start kept on the device. `T0` is the thrust accumulator of
+ * record, as in the reference: a host edit between calls is honoured. */
 typedef struct {
   float dt, g, Tmax;
   float Qyr[6], Qyf[6], Qdyr[6], Qdyf[6], R[3];
@@ -175,7 +179,10 @@ int umpcBatchSetTask(umpc_batch_t *h, int task, const double params[/* 4 */], do
 double umpcBatchTime(const umpc_batch_t *h);
 /* Per-robot objective weights for gain sweeps (template/uprightmpc2.py:272-303): device table
  * [8][B] = (ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom) in the handle's dtype, or NULL for the
- * batch-constant createMPC weights. The pointer is kept, not copied. */
+ * batch-constant createMPC weights. The pointer is kept, not copied: the table must stay allocated (and may be
+ * rewritten between launches) until it is replaced or the handle destroyed. Every weight must be > 0 (the step
+ * recovers the Ruiz scaling from the equilibrated diagonal of P); the table is checked once here (synchronous
+ * copy), umpcBatchCreate checks the batch-constant ones. Returns 0, -1 (bad weights) or a hipError_t. */
 int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
 
 /* Static facts */

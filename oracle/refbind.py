@@ -1,8 +1,10 @@
 """TEST INFRASTRUCTURE — ctypes view of oracle/_ref/libumpc_ref.so.
 
 That library is the REFERENCE's own C (template/uprightmpc2/*.c, OSQP 0.6.0
-embedded, fp32) compiled in place by oracle/Makefile; it exists only in the
-build container (never on the GPU box).  This module is used by
+embedded, fp32) compiled in place by oracle/Makefile in the authoring
+container (the reference's sources exist only there); the prebuilt, git-ignored
+file travels to the GPU box with the tree, so `available()` may be true there
+as well (nothing under /root/reference is read at run time).  This module is used by
 tools/make_golden.py to generate tests/golden/*.npz and by the CPU tests that
 pin oracle/umpc_oracle.c against the live reference when it is present.
 

@@ -50,6 +50,27 @@ def hover_initial_conditions(B, seed, dtype=np.float32, tilt=0.5, index_offset=0
     return state, ref
 
 
+def _u01(seed, idx, salt):
+    """Counter-based uniform in [0, 1): a hash of (seed, global robot index, salt)."""
+    with np.errstate(over="ignore"):
+        v = (idx + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(salt)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        v ^= v >> np.uint64(30); v *= np.uint64(0xBF58476D1CE4E5B9)
+        v ^= v >> np.uint64(27); v *= np.uint64(0x94D049BB133111EB)
+        v ^= v >> np.uint64(31)
+    return (v >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+def monte_carlo_draws(B, seed, dtype=np.float32, spread=0.2, index_offset=0):
+    """BASELINE configs[4] inputs: Ib = Ib0 (1 + d), d ~ U(-spread, spread)^3 for controller and
+    plant, plant thrust gain 1 + U(-spread, spread); keyed by the GLOBAL robot index like hover_initial_conditions, so
+    a sharded run draws exactly what the single-GPU run draws. Returns Ib [3, B], gain [B]."""
+    idx = np.arange(index_offset, index_offset + B, dtype=np.uint64)
+    Ib0 = np.array([3333.0, 3333.0, 1000.0])   # template/genqp.py:22
+    Ib = np.stack([Ib0[i] * (1 + (2 * _u01(seed, idx, 11 + i) - 1) * spread) for i in range(3)])
+    gain = 1 + (2 * _u01(seed, idx, 14) - 1) * spread
+    return Ib.astype(dtype), gain.astype(dtype)
+
+
 class BatchUprightMPC:
     """B independent uprightmpc2 controllers (+ plants), one GPU lane each."""
 

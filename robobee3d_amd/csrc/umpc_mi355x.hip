@@ -86,8 +86,8 @@ __global__ __launch_bounds__(kBlock) void umpc_plant_kernel(DevParams<T> prm, in
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void umpc_assemble_kernel(DevParams<T> prm, int B_, const T *state,
-                                                               const T *ctrl, const T *refA, const T *IbA, T *l,
-                                                               T *u, T *q, T *Px, T *Ax) {
+                                                               const T *ctrl, const T *refA, const T *IbA,
+                                                               const T *actualT0, T *l, T *u, T *q, T *Px, T *Ax) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= B_) return;
   const size_t B = (size_t)B_;
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void umpc_assemble_kernel(DevParams<T> prm,
   for (int i = 0; i < 9; ++i) ref[i] = refA[(size_t)i * B + b];
 #pragma unroll
   for (int i = 0; i < 3; ++i) Ibi[i] = T(1) / (IbA ? IbA[(size_t)i * B + b] : prm.Ib[i]);
-  const T T0 = ctrl[(size_t)(NX + 2 * NC) * B + b];
+  T T0 = ctrl[(size_t)(NX + 2 * NC) * B + b];
+  if (actualT0 && actualT0[b] >= T(0)) T0 = actualT0[b];  // uprightmpc2.c:215-216
   umpc::RawQP<T> qp;
   const umpc::Weights<T> wt = {prm.ws, prm.wds, prm.wpr, prm.wpf, prm.wvr, prm.wvf, prm.wthrust, prm.wmom};
   umpc::assemble(prm, wt, Ibi, T0, p, R, dq, ref, qp);
@@ -276,9 +277,10 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   a.Ib = (const T *)Ib; a.gain = (const T *)gain; a.ws = (T *)h->ws; a.out = (T *)out; a.stats = (T *)stats;
   a.status = status; a.info = (T *)info;
   const int grid = (h->B + kBlock - 1) / kBlock;
-  // stagger wave groups by ~1/4 step (measured step ~0.33 ms fp32) when a launch carries many steps
+  // stagger wave groups by ~1/4 step when a launch carries many steps: the last group ends 3 x skew later than the
+  // first, so the stagger only pays when that tail is small against the launch (off below 64 steps)
   const char *env = getenv("UMPC_SKEW_US");
-  const int skew_us = env ? atoi(env) : (K >= 8 && sizeof(T) == 4 && h->B >= 32768 ? 80 : 0);
+  const int skew_us = env ? atoi(env) : (K >= 64 && sizeof(T) == 4 && h->B >= 32768 ? 80 : 0);
   hipLaunchKernelGGL(umpc_rollout_kernel<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
                      (const T *)actualT0, skew_us * 100);
   hipError_t e = hipGetLastError();
@@ -325,6 +327,16 @@ umpc_batch_t *umpcBatchCreate(const umpc_batch_params_t *prm, int B, int dtype) 
     g_err = "umpcBatchCreate: bad argument";
     return nullptr;
   }
+  // The step recovers the Ruiz scaling D from the equilibrated diagonal of P (D_j = sqrt(P_jj / (P_raw,jj c)),
+  // DESIGN.md 3.4), which needs every objective weight > 0 (the reference's createMPC defaults are; a zero
+  // weight would give 0/0 there). Rejected here rather than producing NaN silently.
+  const double w8[8] = {prm->ws, prm->wds, prm->wpr, prm->wpf, prm->wvr, prm->wvf, prm->wthrust, prm->wmom};
+  for (double w : w8)
+    if (!(w > 0)) { g_err = "umpcBatchCreate: objective weights must be > 0"; return nullptr; }
+  if (!(prm->Ib[0] > 0 && prm->Ib[1] > 0 && prm->Ib[2] > 0 && prm->dt > 0)) {
+    g_err = "umpcBatchCreate: Ib and dt must be > 0";
+    return nullptr;
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) {
@@ -351,6 +363,18 @@ int umpcBatchSetTask(umpc_batch_t *h, int task, const double params[4], double t
 }
 int umpcBatchSetWeights(umpc_batch_t *h, const void *weights) {
   if (!h) return -1;
+  if (weights) {
+    // one-time validation (synchronous D2H copy of 8 x B scalars): every weight must be > 0, see umpcBatchCreate
+    const size_t n = (size_t)8 * h->B, esz = h->dtype == UMPC_F64 ? 8 : 4;
+    std::string buf(n * esz, '\0');
+    const hipError_t e = hipMemcpy(&buf[0], weights, n * esz, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(e, "umpcBatchSetWeights");
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; ++i)
+      ok = h->dtype == UMPC_F64 ? reinterpret_cast<const double *>(buf.data())[i] > 0
+                                : reinterpret_cast<const float *>(buf.data())[i] > 0;
+    if (!ok) { g_err = "umpcBatchSetWeights: objective weights must be > 0"; return -1; }
+  }
   h->weights = weights;
   return 0;
 }
@@ -424,40 +448,74 @@ int umpcBatchPlant(umpc_batch_t *h, int nsub, void *state, const void *u, const 
   return e == hipSuccess ? 0 : fail(e, "umpcBatchPlant");
 }
 
-int umpcBatchAssemble(umpc_batch_t *h, const void *state, const void *ctrl, const void *ref, const void *Ib,
-                      void *l, void *u, void *q, void *Px, void *Ax, void *stream) {
+static int assemble_launch(umpc_batch_t *h, const void *state, const void *ctrl, const void *ref, const void *Ib,
+                           const void *actualT0, void *l, void *u, void *q, void *Px, void *Ax, void *stream) {
   const int grid = (h->B + kBlock - 1) / kBlock;
   if (h->dtype == UMPC_F32)
     hipLaunchKernelGGL(umpc_assemble_kernel<float>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
                        make_dev<float>(h->prm), h->B, (const float *)state, (const float *)ctrl, (const float *)ref,
-                       (const float *)Ib, (float *)l, (float *)u, (float *)q, (float *)Px, (float *)Ax);
+                       (const float *)Ib, (const float *)actualT0, (float *)l, (float *)u, (float *)q, (float *)Px,
+                       (float *)Ax);
   else
     hipLaunchKernelGGL(umpc_assemble_kernel<double>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
                        make_dev<double>(h->prm), h->B, (const double *)state, (const double *)ctrl,
-                       (const double *)ref, (const double *)Ib, (double *)l, (double *)u, (double *)q, (double *)Px,
-                       (double *)Ax);
+                       (const double *)ref, (const double *)Ib, (const double *)actualT0, (double *)l, (double *)u,
+                       (double *)q, (double *)Px, (double *)Ax);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchAssemble");
+}
+
+int umpcBatchAssemble(umpc_batch_t *h, const void *state, const void *ctrl, const void *ref, const void *Ib,
+                      void *l, void *u, void *q, void *Px, void *Ax, void *stream) {
+  return assemble_launch(h, state, ctrl, ref, Ib, nullptr, l, u, q, Px, Ax, stream);
 }
 
 // ---------------------------------------------------------------------------
 // Part 1: the reference's own three symbols, B = 1 on the GPU
 // ---------------------------------------------------------------------------
 namespace {
+// Per-controller state of the drop-in. The caller's POD carries an opaque id in the two words of `smin` the
+// reference never touches (uprightmpc2.h:32; no .c file reads smin / smax), so a host that copies or moves the
+// POD -- the reference's pybind class holds it by value (py/uprightmpc2py.cpp:32) -- keeps its controller.
+// Inputs and outputs of a call travel through ONE pinned, mapped host buffer the kernels read and write
+// directly: no staging copies, one stream synchronisation per call.
 struct Single {
   umpc_batch_t *h = nullptr;
-  float *dev = nullptr;  // state18 | ctrl127 | ref9 | aT0 1 | out9 | info2 | l39 u39 q45 Px45 Ax48 | status(int)
+  float *ctrl = nullptr;   // device: the 127-word controller record
+  float *host = nullptr;   // pinned + mapped: inputs | outputs (layout below)
+  float *hdev = nullptr;   // device alias of `host`
+  hipStream_t stream = nullptr;
   int status = umpc::ST_UNSOLVED;
 };
 std::mutex g_mu;
-std::map<const UprightMPC_t *, Single> g_single;
-constexpr int O_STATE = 0, O_CTRL = 18, O_REF = O_CTRL + 127, O_AT0 = O_REF + 9, O_OUT = O_AT0 + 1,
-              O_INFO = O_OUT + 9, O_L = O_INFO + 2, O_U = O_L + 39, O_Q = O_U + 39, O_PX = O_Q + 45,
-              O_AX = O_PX + 45, O_STATUS = O_AX + 48, O_TOTAL = O_STATUS + 1;
+std::map<uint32_t, Single> g_single;
+uint32_t g_next_id = 1;
+constexpr uint32_t kMagic = 0x554d5043u;  // "UMPC"
+constexpr int O_STATE = 0, O_REF = 18, O_AT0 = O_REF + 9, O_OUT = O_AT0 + 1, O_INFO = O_OUT + 9, O_L = O_INFO + 2,
+              O_U = O_L + 39, O_Q = O_U + 39, O_PX = O_Q + 45, O_AX = O_PX + 45, O_STATUS = O_AX + 48,
+              O_TOTAL = O_STATUS + 1;
+
+uint32_t pod_id(const UprightMPC_t *up) {
+  uint32_t w[2];
+  memcpy(w, up->smin, sizeof(w));
+  return w[0] == kMagic ? w[1] : 0u;
+}
+void release_locked(uint32_t id) {
+  auto it = g_single.find(id);
+  if (it == g_single.end()) return;
+  Single &s = it->second;
+  if (s.stream) (void)hipStreamSynchronize(s.stream);
+  if (s.h) umpcBatchDestroy(s.h);
+  if (s.ctrl) (void)hipFree(s.ctrl);
+  if (s.host) (void)hipHostFree(s.host);
+  if (s.stream) (void)hipStreamDestroy(s.stream);
+  g_single.erase(it);
+}
 }  // namespace
 
 void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, float wds, float wpr, float wpf,
               float wvr, float wvf, float wthrust, float wmom, const float Ib[3], int maxIter) {
+  std::lock_guard<std::mutex> lk(g_mu);
   // host-visible part of uprightmpc2.c:19-118
   memset(up, 0, sizeof(*up));
   up->dt = dt; up->g = g; up->Tmax = TtoWmax * g;
@@ -474,9 +532,7 @@ void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, floa
   up->nAxT0dt = 3 * (UMPC_N - 2);
   up->nAxdt = up->nAxT0dt + 6 * UMPC_N;
 
-  std::lock_guard<std::mutex> lk(g_mu);
-  Single &s = g_single[up];
-  if (s.h) umpcBatchDestroy(s.h);
+  Single s;
   umpc_batch_params_t p;
   umpcBatchDefaultParams(&p);
   p.dt = dt; p.g = g; p.TtoWmax = TtoWmax; p.ws = ws; p.wds = wds; p.wpr = wpr; p.wpf = wpf; p.wvr = wvr;
@@ -484,45 +540,53 @@ void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, floa
   for (int i = 0; i < 3; ++i) p.Ib[i] = Ib[i];
   s.h = umpcBatchCreate(&p, 1, UMPC_F32);
   if (!s.h) { fprintf(stderr, "umpcInit: %s\n", g_err.c_str()); return; }
-  if (!s.dev && hipMalloc((void **)&s.dev, O_TOTAL * sizeof(float)) != hipSuccess) {
-    fprintf(stderr, "umpcInit: hipMalloc failed\n");
-    umpcBatchDestroy(s.h); s.h = nullptr; return;
+  if (hipMalloc((void **)&s.ctrl, UMPC_CTRL_ROWS * sizeof(float)) != hipSuccess ||
+      hipHostMalloc((void **)&s.host, O_TOTAL * sizeof(float), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&s.hdev, s.host, 0) != hipSuccess ||
+      hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+    fprintf(stderr, "umpcInit: device / pinned allocation failed\n");
+    if (s.ctrl) (void)hipFree(s.ctrl);
+    if (s.host) (void)hipHostFree(s.host);
+    umpcBatchDestroy(s.h);
+    return;
   }
-  umpcBatchInitCtrl(s.h, s.dev + O_CTRL, nullptr);
-  (void)hipDeviceSynchronize();
+  umpcBatchInitCtrl(s.h, s.ctrl, s.stream);
+  (void)hipStreamSynchronize(s.stream);
+  const uint32_t id = g_next_id++, w[2] = {kMagic, id};
+  memcpy(up->smin, w, sizeof(w));
+  g_single[id] = s;
 }
 
 int umpcUpdate(UprightMPC_t *up, float uquad[3], float accdes[6], const float p0[3], const float R0[9],
                const float dq0[6], const float pdes[3], const float dpdes[3], const float sdes[3],
                float actualT0) {
   std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_single.find(up);
+  auto it = g_single.find(pod_id(up));
   if (it == g_single.end() || !it->second.h) {
     fprintf(stderr, "umpcUpdate: controller not initialised or no GPU (no CPU path exists)\n");
     return 1;
   }
   Single &s = it->second;
-  float hin[18 + 9 + 1];
-  memcpy(hin, p0, 12); memcpy(hin + 3, R0, 36); memcpy(hin + 12, dq0, 24);
-  float href[10];
-  memcpy(href, pdes, 12); memcpy(href + 3, dpdes, 12); memcpy(href + 6, sdes, 12); href[9] = actualT0;
-  (void)hipMemcpy(s.dev + O_STATE, hin, 18 * sizeof(float), hipMemcpyHostToDevice);
-  (void)hipMemcpy(s.dev + O_REF, href, 10 * sizeof(float), hipMemcpyHostToDevice);
-  // the T0 the assembly will see (uprightmpc2.c:215-216) -> keep the POD's debug fields exact
-  if (actualT0 >= 0) (void)hipMemcpy(s.dev + O_CTRL + 123, &actualT0, sizeof(float), hipMemcpyHostToDevice);
-  int rc = umpcBatchAssemble(s.h, s.dev + O_STATE, s.dev + O_CTRL, s.dev + O_REF, nullptr, s.dev + O_L,
-                             s.dev + O_U, s.dev + O_Q, s.dev + O_PX, s.dev + O_AX, nullptr);
+  float *hb = s.host;
+  memcpy(hb + O_STATE, p0, 12); memcpy(hb + O_STATE + 3, R0, 36); memcpy(hb + O_STATE + 12, dq0, 24);
+  memcpy(hb + O_REF, pdes, 12); memcpy(hb + O_REF + 3, dpdes, 12); memcpy(hb + O_REF + 6, sdes, 12);
+  // The POD's T0 is the accumulator of record (uprightmpc2.c:215-216, 256-257): a host that edits up->T0
+  // between calls is honoured, and actualT0 >= 0 overrides it for this call.
+  hb[O_AT0] = actualT0 >= 0 ? actualT0 : up->T0;
+  float *d = s.hdev;
+  int rc = assemble_launch(s.h, d + O_STATE, s.ctrl, d + O_REF, nullptr, d + O_AT0, d + O_L, d + O_U, d + O_Q,
+                           d + O_PX, d + O_AX, s.stream);
   if (!rc)
-    rc = umpcBatchUpdate(s.h, s.dev + O_STATE, s.dev + O_CTRL, s.dev + O_REF, s.dev + O_AT0, nullptr,
-                         s.dev + O_OUT, (int32_t *)(s.dev + O_STATUS), s.dev + O_INFO, nullptr);
+    rc = umpcBatchUpdate(s.h, d + O_STATE, s.ctrl, d + O_REF, d + O_AT0, nullptr, d + O_OUT,
+                         (int32_t *)(d + O_STATUS), d + O_INFO, s.stream);
   if (rc) return 1;
-  float hout[O_TOTAL - O_OUT];
-  if (hipMemcpy(hout, s.dev + O_OUT, sizeof(hout), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-  memcpy(uquad, hout, 12); memcpy(accdes, hout + 3, 24);
-  memcpy(up->l, hout + (O_L - O_OUT), 39 * 4); memcpy(up->u, hout + (O_U - O_OUT), 39 * 4);
-  memcpy(up->q, hout + (O_Q - O_OUT), 45 * 4); memcpy(up->Px_data, hout + (O_PX - O_OUT), 45 * 4);
-  memcpy(up->Ax_data, hout + (O_AX - O_OUT), 48 * 4);
-  memcpy(&s.status, hout + (O_STATUS - O_OUT), 4);
+  const hipError_t e = hipStreamSynchronize(s.stream);
+  if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
+  memcpy(uquad, hb + O_OUT, 12); memcpy(accdes, hb + O_OUT + 3, 24);
+  memcpy(up->l, hb + O_L, 39 * 4); memcpy(up->u, hb + O_U, 39 * 4);
+  memcpy(up->q, hb + O_Q, 45 * 4); memcpy(up->Px_data, hb + O_PX, 45 * 4);
+  memcpy(up->Ax_data, hb + O_AX, 48 * 4);
+  memcpy(&s.status, hb + O_STATUS, 4);
   up->T0 = uquad[0];  // uprightmpc2.c:256-257
   return 0;
 }
@@ -541,16 +605,13 @@ void umpcS(float uquad[3], float accdes[6], const float p0[3], const float R0[9]
 
 int umpcLastStatus(const UprightMPC_t *up) {
   std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_single.find(up);
+  auto it = g_single.find(pod_id(up));
   return it == g_single.end() ? umpc::ST_UNSOLVED : it->second.status;
 }
 void umpcRelease(UprightMPC_t *up) {
   std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_single.find(up);
-  if (it == g_single.end()) return;
-  if (it->second.h) umpcBatchDestroy(it->second.h);
-  if (it->second.dev) (void)hipFree(it->second.dev);
-  g_single.erase(it);
+  release_locked(pod_id(up));
+  memset(up->smin, 0, 2 * sizeof(float));
 }
 
 // ---------------------------------------------------------------------------

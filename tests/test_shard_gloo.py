@@ -38,3 +38,41 @@ def test_split_ranges_cover_everything():
         assert r[0][0] == 0 and r[-1][1] == total
         assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
     assert shard.robot_range(65536, 3) == (196608, 262144)
+
+
+def _bench(args, env=None, timeout=300):
+    e = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, cwd=ROOT, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus N` (no torchrun around it, the driver's N = 1 command form) starts N ranks itself,
+    before touching any device. --dry-run keeps the kernel out (no GPU here): launcher, gloo rendezvous, sharding,
+    barriers, max-over-ranks and the statistics gather in global robot order all run; rank 0 prints ONE line."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "4", "--warmup", "3", "--batch", "96", "--dry-run", "--monte-carlo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["steps"] == 4 and j["warmup"] == 3
+    assert j["config"]["global_batch"] == 192 and j["scaling"] == "weak" and j["value"] is None
+
+
+def test_bench_launcher_propagates_failure():
+    r = _bench(["--gpus", "2", "--steps", "5", "--steps-per-launch", "2", "--dry-run"])   # 5 % 2 != 0: every rank asserts
+    assert r.returncode != 0
+
+
+def test_monte_carlo_draws_are_partition_invariant():
+    from robobee3d_amd.batch import monte_carlo_draws
+    Ib, gain = monte_carlo_draws(300, 20201120, np.float64)
+    Ib2, gain2 = monte_carlo_draws(100, 20201120, np.float64, index_offset=150)
+    np.testing.assert_array_equal(Ib[:, 150:250], Ib2)
+    np.testing.assert_array_equal(gain[150:250], gain2)
+    assert np.all(np.abs(Ib / np.array([[3333.0], [3333.0], [1000.0]]) - 1) <= 0.2) and np.all(np.abs(gain - 1) <= 0.2)
+    assert Ib.std(axis=1).min() > 50 and abs(gain.mean() - 1) < 0.02
