@@ -244,6 +244,17 @@ void wlconS(float u1_y1[/* 4 */], float w0_y2[/* 6 */], const float u0init_u1[/*
 int umpcBatchWLUpdate(const WLCon_t *wl, int B, int dtype, void *u, const void *h0, const void *pdotdes,
                       void *w0, void *stream);
 
+/* The coupling of the two steps as every real caller of the reference wires them
+ * (template/robobee_test_controllers.py:162-171, template/uprightmpc2/conn_MPC_WL.m:2-10), FUSED into the step
+ * kernel: after each MPC step of umpcBatchRollout / umpcBatchUpdate
+ *     h0 = (Rb' (0, 0, mb g), 0, 0, 0),  pdotdes = M0 accdes,  (u4, w0) = wlConUpdate(h0, pdotdes),
+ *     actualT0 = w0[2] / M0[2,2]  -> overrides the thrust accumulator of the NEXT step when >= 0
+ * with M0 = diag(Mdiag) (dynamicsTerms, template/ca6dynamics.py:5-10,44-50: (100,100,100,3333,3333,1000)) and g
+ * the handle's g. wl: parameters (umin, umax, dumax, Qw, fa; its u0 is ignored), copied to the device here
+ * (synchronous); NULL switches the coupling off. u4 [4][B]: per-robot WL input state, in/out, kept by pointer;
+ * w0 [6][B] or NULL: wrench w(u4) evaluated by the last step. */
+int umpcBatchSetWL(umpc_batch_t *h, const WLCon_t *wl, const double Mdiag[/* 6 */], void *u4, void *w0);
+
 /* ------------------------------------------------------------------ */
 /* Part 4: the reference's other rigid-body vector fields */
 /* ------------------------------------------------------------------ */

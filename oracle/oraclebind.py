@@ -137,8 +137,11 @@ def plant_step_d(L32, p, R, dq, u, dt, Ib=IB, gain=1.0, mode=0):
 
 def batch_rollout(state, ctrl, ref, K, dtype=np.float32, perm=None, Ib=None, gain=None,
                   Ib_nom=IB, maxIter=50, dtsim=0.2, taulim=100.0, nsub=25, plant_mode=0,
-                  nthreads=0, weights=None, task=0, task_p=None, t0=0.0, **kw):
+                  nthreads=0, weights=None, task=0, task_p=None, t0=0.0, wl=None, wl_u=None, wl_w=None,
+                  Mdiag=(100.0, 100.0, 100.0, 3333.0, 3333.0, 1000.0), **kw):
     """SoA arrays state[18,B], ctrl[127,B], ref[9,B] (modified in place).
+    wl: a WLOracle (parameters) switches the MPC -> WL -> actualT0 coupling on; wl_u [4,B] is the per-robot WL
+    state (in/out), wl_w [6,B] receives w0 of the last step.
     Returns (out[9,B], stats[2,B], status[B])."""
     dtype = np.dtype(dtype)
     L = lib(dtype)
@@ -171,10 +174,15 @@ def batch_rollout(state, ctrl, ref, K, dtype=np.float32, perm=None, Ib=None, gai
     tp = np.zeros(4, dtype)
     if task_p is not None:
         tp[:len(task_p)] = task_p
-    L.umpc_oracle_batch_rollout2(C.byref(ps), None if pp is None else pp.ctypes.data_as(C.POINTER(C.c_int)),
+    md = np.ascontiguousarray(Mdiag, dtype)
+    if wl is not None:
+        assert wl.dtype == dtype and wl_u.dtype == dtype and wl_u.shape == (4, B) and wl_u.flags.c_contiguous
+        assert wl_w is None or (wl_w.dtype == dtype and wl_w.shape == (6, B) and wl_w.flags.c_contiguous)
+    L.umpc_oracle_batch_rollout3(C.byref(ps), None if pp is None else pp.ctypes.data_as(C.POINTER(C.c_int)),
                                  C.c_int(B), C.c_int(K), P(state), P(ctrl), P(ref), P(Ib), P(gain), P(weights),
                                  C.c_int(task), P(tp), ct(t0), P(out), P(stats),
-                                 status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(nthreads))
+                                 status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(nthreads),
+                                 None if wl is None else wl.buf, P(md), P(wl_u), P(wl_w))
     return out, stats, status
 
 

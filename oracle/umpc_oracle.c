@@ -461,8 +461,13 @@ static int update_rho_vec(struct umpc_oracle *o, const real *ls, const real *us)
 
 /* osqp_update_bounds, osqp.c:784-833 */
 static int osqp_update_bounds_(struct umpc_oracle *o) {
-  for (int i = 0; i < NC; ++i)
-    if (o->l_new[i] > o->u_new[i]) return 1;
+  /* osqp.c:801-808: a crossed pair rejects the whole update (data untouched; umpcUpdate ignores the return,
+   * uprightmpc2.c:247). Canonical mode states the HIP kernel's semantics instead: bounds are
+   * applied as assembled -- only reachable with Tmax < 0, where the QP is infeasible and the certificate of
+   * auxil.c:362-424 fires (OSQP_NAN outputs + cold start, auxil.c:539-564). */
+  if (!o->canonical)
+    for (int i = 0; i < NC; ++i)
+      if (o->l_new[i] > o->u_new[i]) return 1;
   if (!o->canonical) {
     for (int i = 0; i < NC; ++i) { o->l[i] = o->l_new[i]; o->u[i] = o->u_new[i]; }
     for (int i = 0; i < NC; ++i) o->l[i] = o->l[i] * o->E[i];
@@ -889,6 +894,15 @@ void umpc_oracle_set_canonical(umpc_oracle_t *o, int on, const real *Eprev3) {
   if (Eprev3) for (int k = 0; k < NN; ++k) o->Eprev3[k] = Eprev3[k];
 }
 
+/* wrench-linearisation controller state (functions further down; the coupled rollout needs the type) */
+#define NDELU 4
+#define NW 6
+struct umpc_oracle_wl {
+  real u0[NDELU], umin[NDELU], umax[NDELU], dumax[NDELU];
+  real Qw[NW * NW];
+  struct { real a0, a1[NDELU], A2[NDELU * NDELU]; } fa[NW];
+};
+
 /* ====================================================================== */
 /* Plant + batched closed loop                                             */
 /* ====================================================================== */
@@ -961,6 +975,20 @@ void umpc_oracle_batch_rollout2(const umpc_oracle_params_t *prm, const int *perm
                                 const real *thrust_gain, const real *weights, int task,
                                 const real *task_p, real t0, real *out, real *stats,
                                 int *status, int nthreads) {
+  umpc_oracle_batch_rollout3(prm, perm, B, K, state, ctrl, ref, Ib, thrust_gain, weights, task, task_p, t0, out,
+                             stats, status, nthreads, NULL, NULL, NULL, NULL);
+}
+
+/* + the MPC -> WL -> actualT0 coupling (template/robobee_test_controllers.py:162-171, conn_MPC_WL.m:2-10):
+ * wl = an initialised WL controller (parameters; its u0 is replaced per robot by wlu [4][B], in/out),
+ * Mdiag = diag of M0 (template/ca6dynamics.py:5-10), wlw [6][B] or NULL = w0 of the last step. */
+void umpc_oracle_batch_rollout3(const umpc_oracle_params_t *prm, const int *perm,
+                                int B, int K, real *state, real *ctrl,
+                                const real *ref, const real *Ib,
+                                const real *thrust_gain, const real *weights, int task,
+                                const real *task_p, real t0, real *out, real *stats,
+                                int *status, int nthreads, const umpc_oracle_wl_t *wl, const real *Mdiag,
+                                real *wlu, real *wlw) {
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -1005,10 +1033,27 @@ void umpc_oracle_batch_rollout2(const umpc_oracle_params_t *prm, const int *perm
         o->Rw[0] = weights[(size_t)6 * B + b]; o->Rw[1] = o->Rw[2] = weights[(size_t)7 * B + b];
       }
       real s_err = stats ? stats[b] : 0, s_eff = stats ? stats[(size_t)B + b] : 0;
+      struct umpc_oracle_wl wlr;
+      real w0[6] = {0};
+      if (wl) {
+        memcpy(&wlr, wl, sizeof(wlr));
+        for (int j = 0; j < NDELU; ++j) wlr.u0[j] = wlu[(size_t)j * B + b];
+      }
       for (int k = 0; k < K; ++k) {
         for (int i = 0; i < 9; ++i) rf[i] = ref[(size_t)i * B + b];
         if (task) umpc_oracle_task_reference(task, task_p, t0 + (real)k * ((real)prm->nsub * prm->dtsim), rf);
         umpc_oracle_update(o, uq, acc, p, R, dq, &rf[0], &rf[3], &rf[6], (real)-1);
+        if (wl) {
+          /* accController, robobee_test_controllers.py:162-171: the NEXT update gets actualT0 = w0[2] / M0[2,2],
+           * which replaces the accumulator when >= 0 (uprightmpc2.c:215-216) */
+          real h0[6] = {0}, pd[6], u1[4];
+          const real mbg = Mdiag[2] * prm->g;
+          for (int c = 0; c < 3; ++c) h0[c] = R[2 + 3 * c] * mbg;
+          for (int i = 0; i < 6; ++i) pd[i] = Mdiag[i] * acc[i];
+          umpc_oracle_wl_update(&wlr, u1, w0, h0, pd);
+          const real aT0 = w0[2] / Mdiag[2];
+          if (aT0 >= 0) o->T0 = aT0;
+        }
         real uc[3] = {uq[0], c_min(c_max(uq[1], -prm->taulim), prm->taulim),
                       c_min(c_max(uq[2], -prm->taulim), prm->taulim)};
         for (int s = 0; s < prm->nsub; ++s) {
@@ -1031,6 +1076,10 @@ void umpc_oracle_batch_rollout2(const umpc_oracle_params_t *prm, const int *perm
       }
       if (stats) { stats[b] = s_err; stats[(size_t)B + b] = s_eff; }
       if (status) status[b] = o->status_val;
+      if (wl) {
+        for (int j = 0; j < NDELU; ++j) wlu[(size_t)j * B + b] = wlr.u0[j];
+        if (wlw) for (int i = 0; i < 6; ++i) wlw[(size_t)i * B + b] = w0[i];
+      }
     }
     free(o);
   }
@@ -1103,13 +1152,6 @@ void umpc_oracle_reactive_rollout(const umpc_oracle_params_t *prm, int B, int ns
 /* ====================================================================== */
 /* Wrench-linearisation step: funapprox.c                    */
 /* ====================================================================== */
-#define NDELU 4
-#define NW 6
-struct umpc_oracle_wl {
-  real u0[NDELU], umin[NDELU], umax[NDELU], dumax[NDELU];
-  real Qw[NW * NW];
-  struct { real a0, a1[NDELU], A2[NDELU * NDELU]; } fa[NW];
-};
 size_t umpc_oracle_wl_sizeof(void) { return sizeof(struct umpc_oracle_wl); }
 
 /* wlConInit + funApproxInit, funapprox.c:35-51, 102-116 */

@@ -25,7 +25,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchReactive", "umpcBatchTaskReference",
-           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchModel",
+           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
            "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
 
@@ -72,6 +72,44 @@ class UprightMPC_t(C.Structure):
     ]
 
 
+RESOURCE_LIMITS = os.path.join(HERE, "csrc", "resource_limits.json")
+
+
+def _check_resources(remarks):
+    """Parses hipcc's -Rpass-analysis=kernel-resource-usage remarks of the step-kernel translation unit and fails
+    the build when a kernel's register / scratch / LDS outcome is no longer the measured one (csrc/resource_limits.json):
+    the fp32 step kernel hands registers v0/v1/s[4:11] to a generated assembly block that clobbers v2-v245 and every
+    AGPR, so a compiler change that grows the scratch frame or drops the 512-register allocation must be seen here,
+    not as a silent slowdown on the GPU."""
+    import json
+    import re
+    res, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    with open(os.path.join(OBJ_DIR, "resources.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    if not os.path.exists(RESOURCE_LIMITS):
+        return res
+    limits = json.load(open(RESOURCE_LIMITS))
+    for pat, lim in limits.items():
+        hits = [k for k in res if pat in k]
+        if not hits:
+            raise RuntimeError("resource check: no kernel matches %r" % pat)
+        for k in hits:
+            r = res[k]
+            for key, op in (("VGPRs", "=="), ("AGPRs", "=="), ("LDS", "=="), ("ScratchSize", "<=")):
+                if key in lim and not (r[key] == lim[key] if op == "==" else r[key] <= lim[key]):
+                    raise RuntimeError("resource check failed for %s: %s = %d, recorded %s %d (csrc/resource_limits.json)"
+                                       % (k, key, r[key], op, lim[key]))
+    return res
+
+
 def build(force=False, verbose=False):
     """Generate umpc_gen.h / umpc_admm_asm.h and compile the HIP library for gfx950 (works without a GPU).
     One object per translation unit (recompiled only when it or its headers changed), then one link."""
@@ -92,7 +130,8 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if (force or not os.path.exists(obj)
                 or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + deps)):
-            todo.append(["hipcc"] + HIPCC_FLAGS + ["-c", "-o", obj, src])
+            extra = ["-Rpass-analysis=kernel-resource-usage"] if src == SRC else []
+            todo.append(["hipcc"] + HIPCC_FLAGS + extra + ["-c", "-o", obj, src])
             relink = True
     for stale in set(os.listdir(OBJ_DIR)) - {os.path.basename(o) for o in objs}:
         os.remove(os.path.join(OBJ_DIR, stale))
@@ -103,13 +142,19 @@ def build(force=False, verbose=False):
             cmd = todo.pop(0)
             if verbose:
                 print(" ".join(cmd))
-            running.append((cmd, subprocess.Popen(cmd, cwd=csrc, stderr=None if verbose else subprocess.PIPE)))
+            running.append((cmd, subprocess.Popen(cmd, cwd=csrc, stderr=subprocess.PIPE)))
         cmd, p = running.pop(0)
         _, err = p.communicate()
         if p.returncode != 0:
             for _, q in running:
                 q.kill()
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), (err or b"").decode()[-4000:]))
+        if cmd[-1] == SRC:
+            try:
+                _check_resources((err or b"").decode())
+            except RuntimeError:
+                os.remove(cmd[-2])     # the object must not survive a failed check
+                raise
     if relink or any(os.path.getmtime(SO_PATH) < os.path.getmtime(o) for o in objs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs
         if verbose:
@@ -148,6 +193,7 @@ def lib():
         L.umpcBatchTime.restype = C.c_double
         L.umpcBatchModel.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4
         L.umpcBatchWLUpdate.argtypes =[C.POINTER(WLCon_t), C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.umpcBatchSetWL.argtypes = [C.c_void_p, C.POINTER(WLCon_t), C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
         L.umpcUpdate.restype = C.c_int
         L.umpcQPDefaultSettings.argtypes = [C.POINTER(QPSettings)]
         L.umpcQPCreate.restype = C.c_void_p

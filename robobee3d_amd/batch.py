@@ -156,6 +156,23 @@ class BatchUprightMPC:
         self._weights = w  # keep alive: the library stores the pointer
         self._check(self.L.umpcBatchSetWeights(self.h, _ptr(w)))
 
+    M0_CA6 = (100.0, 100.0, 100.0, 3333.0, 3333.0, 1000.0)   # dynamicsTerms, template/ca6dynamics.py:5-10
+
+    def set_wl(self, wl, Mdiag=M0_CA6):
+        """Fuse the wrench-linearisation step into every MPC step (robobee_test_controllers.py:162-171):
+        accdes -> (u4, w0) = wlConUpdate(h0, M0 accdes) -> actualT0 = w0[2] / M0[2,2] for the next step.
+        wl: a BatchWLCon of the same B / dtype / device (its `u` [4,B] is the per-robot WL state, its `w0` [6,B]
+        receives the wrench), or None to switch the coupling off."""
+        if wl is None:
+            self._wl = None
+            self._check(self.L.umpcBatchSetWL(self.h, None, None, None, None))
+            return
+        assert wl.B == self.B and wl.dtype == self.dtype and wl.u.is_contiguous() and wl.w0.is_contiguous()
+        self._wl = wl   # keeps u / w0 alive: the library stores the pointers
+        md = (C.c_double * 6)(*[float(v) for v in Mdiag])
+        with torch.cuda.device(self.device):
+            self._check(self.L.umpcBatchSetWL(self.h, C.byref(wl.wl), md, _ptr(wl.u), _ptr(wl.w0)))
+
     @property
     def time_ms(self):
         return float(self.L.umpcBatchTime(self.h))

@@ -258,6 +258,8 @@ struct umpc_batch {
   double t_ms = 0;               // time of the next MPC step (advanced by every rollout)
   const void *weights = nullptr;  // [8][B] device table or null
   void *ws;  // [WS_ROWS][B] scratch the step parks Ruiz scalings / x_prev / delta_y in
+  umpc::WLDev *wl = nullptr;      // device copy of the WL parameters (umpcBatchSetWL), null = no coupling
+  void *wlu = nullptr, *wlw = nullptr;
 };
 
 template <typename T>
@@ -276,6 +278,7 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   if (nsub > 0) h->t_ms += (double)K * nsub * h->prm.dtsim;
   a.Ib = (const T *)Ib; a.gain = (const T *)gain; a.ws = (T *)h->ws; a.out = (T *)out; a.stats = (T *)stats;
   a.status = status; a.info = (T *)info;
+  a.wl = h->wl; a.wlu = (T *)h->wlu; a.wlw = (T *)h->wlw;
   const int grid = (h->B + kBlock - 1) / kBlock;
   // stagger wave groups by ~1/4 step when a launch carries many steps: the last group ends 3 x skew later than the
   // first, so the stagger only pays when that tail is small against the launch (off below 64 steps)
@@ -352,6 +355,7 @@ umpc_batch_t *umpcBatchCreate(const umpc_batch_params_t *prm, int B, int dtype) 
 void umpcBatchDestroy(umpc_batch_t *h) {
   if (!h) return;
   if (h->ws) (void)hipFree(h->ws);
+  if (h->wl) (void)hipFree(h->wl);
   delete h;
 }
 int umpcBatchSetTask(umpc_batch_t *h, int task, const double params[4], double t_ms) {
@@ -620,10 +624,7 @@ void umpcRelease(UprightMPC_t *up) {
 }  // extern "C"
 
 namespace {
-struct WLDev {  // everything wlConUpdate reads, passed by value (wave-uniform, lives in SGPRs / kernarg)
-  float umin[4], umax[4], dumax[4], Qw[6];
-  float a0[6], a1[6][4], A2[6][16];
-};
+using umpc::WLDev;
 
 // one lane = one robot: w0 = w(u0), A1 = dw/du(u0), one clipped gradient step (funapprox.c:118-165)
 template <typename T>
@@ -631,44 +632,16 @@ __global__ __launch_bounds__(256) void umpc_wl_kernel(WLDev p, int B_, T *u, con
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B_) return;
   const size_t B = (size_t)B_;
-  T u0[4], A1[6][4], a0v[6];
+  T u0[4], h[6], d[6], w[6];
 #pragma unroll
   for (int j = 0; j < 4; ++j) u0[j] = u[(size_t)j * B + b];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    // funApproxF: a0 + u.a1 + 0.5 u'(A2 u), accumulated like the reference's matMult (funapprox.c:53-65)
-    T dot = T(0), vout[4], quad = T(0);
+  for (int i = 0; i < 6; ++i) { h[i] = h0[(size_t)i * B + b]; d[i] = pd[(size_t)i * B + b]; }
+  umpc::wl_step(p, u0, h, d, w);
 #pragma unroll
-    for (int l = 0; l < 4; ++l) dot += u0[l] * T(p.a1[i][l]);
+  for (int i = 0; i < 6; ++i) w0out[(size_t)i * B + b] = w[i];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      T acc = T(0);
-#pragma unroll
-      for (int l = 0; l < 4; ++l) acc += T(p.A2[i][r + 4 * l]) * u0[l];
-      vout[r] = acc;
-    }
-#pragma unroll
-    for (int l = 0; l < 4; ++l) quad += u0[l] * vout[l];
-    const T w = (T(p.a0[i]) + dot) + T(0.5) * quad;
-    w0out[(size_t)i * B + b] = w;
-    a0v[i] = w - h0[(size_t)i * B + b] - pd[(size_t)i * B + b];
-    // funApproxDf: a1 + A2 u  (funapprox.c:67-76)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) A1[i][j] = T(p.a1[i][j]) + vout[j];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    T Lb = -T(p.dumax[j]), Ub = T(p.dumax[j]);
-    if (u0[j] < T(p.umin[j])) Lb = T(0);
-    else if (u0[j] > T(p.umax[j])) Ub = T(0);
-    T acc = T(0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc += A1[i][j] * (T(p.Qw[i]) * a0v[i]);
-    T d = T(-1e3) * acc;
-    if (d < Lb) d = Lb;
-    else if (d > Ub) d = Ub;
-    u[(size_t)j * B + b] = u0[j] + d;
-  }
+  for (int j = 0; j < 4; ++j) u[(size_t)j * B + b] = u0[j];
 }
 
 // a19 / a20 vector fields: nsub == 0 evaluates ydot (ca6 also appends wrench and bias h), nsub > 0
@@ -719,6 +692,7 @@ WLDev make_wl(const WLCon_t *wl) {
     d.a0[i] = wl->fa[i].a0;
     for (int j = 0; j < 4; ++j) d.a1[i][j] = wl->fa[i].a1[j];
     for (int j = 0; j < 16; ++j) d.A2[i][j] = wl->fa[i].A2[j];
+    d.Md[i] = 0.f;
   }
   return d;
 }
@@ -740,6 +714,24 @@ int umpcBatchWLUpdate(const WLCon_t *wl, int B, int dtype, void *u, const void *
                        (const double *)h0, (const double *)pdotdes, (double *)w0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchWLUpdate");
+}
+
+int umpcBatchSetWL(umpc_batch_t *h, const WLCon_t *wl, const double Mdiag[6], void *u4, void *w0) {
+  if (!h) return -1;
+  if (!wl) {
+    h->wlu = h->wlw = nullptr;
+    if (h->wl) { (void)hipDeviceSynchronize(); (void)hipFree(h->wl); h->wl = nullptr; }
+    return 0;
+  }
+  if (!Mdiag || !u4 || !(Mdiag[2] > 0)) { g_err = "umpcBatchSetWL: bad argument"; return -1; }
+  WLDev d = make_wl(wl);
+  for (int i = 0; i < 6; ++i) d.Md[i] = (float)Mdiag[i];
+  hipError_t e = hipSuccess;
+  if (!h->wl) e = hipMalloc((void **)&h->wl, sizeof(WLDev));
+  if (e == hipSuccess) e = hipMemcpy(h->wl, &d, sizeof(WLDev), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(e, "umpcBatchSetWL");
+  h->wlu = u4; h->wlw = w0;
+  return 0;
 }
 
 int umpcBatchModel(int model, int B, int dtype, int nsub, double dt, void *y, const void *u, void *aux, void *stream) {

@@ -365,6 +365,57 @@ __device__ __forceinline__ void assemble(const DevParams<T> &prm, const Weights<
 // ---------------------------------------------------------------------------
 using namespace umpcasm;
 
+// ---------------------------------------------------------------------------
+// Wrench-linearisation step, template/uprightmpc2/funapprox.c:118-165: w0 = w(u0), A1 = dw/du(u0),
+// one clipped gradient step on |A1 du + (w0 - h0 - pdotdes)|^2_Qw. Parameters are batch-constant.
+// ---------------------------------------------------------------------------
+struct WLDev {
+  float umin[4], umax[4], dumax[4], Qw[6];
+  float a0[6], a1[6][4], A2[6][16];
+  float Md[6];   // M0 = diag(mb, mb, mb, ixx, iyy, izz) of dynamicsTerms (template/ca6dynamics.py:5-10, 44-50)
+};
+
+// P may live in kernarg (by value) or in global memory (wave-uniform loads): u0 is updated in place.
+template <typename T>
+__device__ __forceinline__ void wl_step(const WLDev &P, T (&u0)[4], const T (&h0)[6], const T (&pd)[6], T (&w0)[6]) {
+  T A1[6][4], a0v[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    // funApproxF: a0 + u.a1 + 0.5 u'(A2 u), accumulated like the reference's matMult (funapprox.c:53-65)
+    T dot = T(0), vout[4], quad = T(0);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) dot += u0[l] * T(P.a1[i][l]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T acc = T(0);
+#pragma unroll
+      for (int l = 0; l < 4; ++l) acc += T(P.A2[i][r + 4 * l]) * u0[l];
+      vout[r] = acc;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) quad += u0[l] * vout[l];
+    const T w = (T(P.a0[i]) + dot) + T(0.5) * quad;
+    w0[i] = w;
+    a0v[i] = w - h0[i] - pd[i];
+    // funApproxDf: a1 + A2 u  (funapprox.c:67-76)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A1[i][j] = T(P.a1[i][j]) + vout[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    T Lb = -T(P.dumax[j]), Ub = T(P.dumax[j]);
+    if (u0[j] < T(P.umin[j])) Lb = T(0);
+    else if (u0[j] > T(P.umax[j])) Ub = T(0);
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc += A1[i][j] * (T(P.Qw[i]) * a0v[i]);
+    T d = T(-1e3) * acc;
+    if (d < Lb) d = Lb;
+    else if (d > Ub) d = Ub;
+    u0[j] = u0[j] + d;
+  }
+}
+
 template <typename T>
 struct StepIO {
   DevParams<T> prm;
@@ -381,6 +432,10 @@ struct StepIO {
   T *stats;        // [2][B] or null
   int32_t *status; // [B] or null
   T *info;         // [2][B] or null
+  // MPC -> WL -> actualT0 coupling (robobee_test_controllers.py:162-171, conn_MPC_WL.m:2-10), off when wl == null
+  const WLDev *wl; // device copy of the WL parameters
+  T *wlu;          // [4][B] WL input state u4, in/out
+  T *wlw;          // [6][B] w0 of the last step, or null
 };
 
 // One closed-loop step of robot b: controller step (= umpcUpdate) + nsub plant substeps.
@@ -677,6 +732,11 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #define ET_(i) Es[i]
     // ---- update_info: residuals (auxil.c:243-307) ----
     T nz = T(0), nAx = T(0), nq = T(0), nAty = T(0), nPx = T(0);
+    // The reference's inf-norm skips NaN entries (`if (abs > max)`, lin_alg.c:300-311) exactly like v_max; a NaN
+    // residual entry means an overflow (inf - inf) on finite inputs, where whether some OTHER entry is still
+    // > OSQP_INFTY is an accident of the evaluation order. `nanacc` turns every such step into OSQP_NON_CVX (what
+    // the reference reports on tests/golden/nan_branch.npz): NaN-propagating sum of the residual entries.
+    T nanacc = T(0);
     {
       T Ax[NC];
 #pragma unroll
@@ -688,6 +748,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
         const T einv = umpc_rcp_fast(Es[i]);
         const T zi = ZV(i);
         pri_res = umpc_max(pri_res, umpc_abs(einv * (Ax[i] - zi)));
+        nanacc = umpc_fma(T(0), Ax[i] - zi, nanacc);
         nz = umpc_max(nz, umpc_abs(einv * zi));
         nAx = umpc_max(nAx, umpc_abs(einv * Ax[i]));
       }
@@ -702,6 +763,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
         const T qj = GLD(a.ws, FAC_Q + j);
         const T Pxj = (((PXRAW(j) * Ds[j]) * Ds[j]) * cscale) * XV(j);
         dua_res = umpc_max(dua_res, umpc_abs(dinv * ((qj + Pxj) + Aty[j])));
+        nanacc = umpc_fma(T(0), (qj + Pxj) + Aty[j], nanacc);
         nq = umpc_max(nq, umpc_abs(dinv * qj));
         nAty = umpc_max(nAty, umpc_abs(dinv * Aty[j]));
         nPx = umpc_max(nPx, umpc_abs(dinv * Pxj));
@@ -714,7 +776,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     // finite, so is_primal_infeasible projects nothing): they are computed once, straight-line, and compared
     // against the exact and then the 10x tolerances. (A two-trip loop here made the compiler hoist ~500
     // loop-invariant words into scratch.)
-    if ((pri_res > T(UMPC_INFTY)) || (dua_res > T(UMPC_INFTY))) {
+    if ((pri_res > T(UMPC_INFTY)) || (dua_res > T(UMPC_INFTY)) || nanacc != nanacc) {
       status = ST_NON_CVX;
     } else {
       const T rel_p = umpc_max(nz, nAx), rel_d = umpc_max(umpc_max(nq, nAty), nPx) * cinv;
@@ -811,6 +873,30 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #pragma unroll
     for (int i = 0; i < NY; ++i) acc[i] = (dq1[i] - dq0[i]) / prm.dt;
   }
+  // ---- MPC -> WL -> actualT0 (robobee_test_controllers.py:162-171): h0 = (Rb' (0,0,mb g), 0), pdotdes = M0 accdes,
+  // (u4, w0) = wlConUpdate(h0, pdotdes), and the NEXT umpcUpdate gets actualT0 = w0[2] / M0[2,2], which overrides
+  // the accumulator when >= 0 (uprightmpc2.c:215-216). The command of THIS step (uq) is not touched.
+  T T0next = T0;
+  if (a.wl) {
+    const WLDev &P = *a.wl;
+    T u4[4], h0[6], pd[6], w0[6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u4[j] = GLD(a.wlu, j);
+    const T mbg = T(P.Md[2]) * prm.g;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { h0[c] = R0[2 + 3 * c] * mbg; h0[3 + c] = T(0); }
+#pragma unroll
+    for (int i = 0; i < NY; ++i) pd[i] = T(P.Md[i]) * acc[i];
+    wl_step(P, u4, h0, pd, w0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) GLD(a.wlu, j) = u4[j];
+    if (a.wlw) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) GLD(a.wlw, i) = w0[i];
+    }
+    const T aT0 = w0[2] / T(P.Md[2]);
+    if (aT0 >= T(0)) T0next = aT0;
+  }
   // controller record + outputs back to HBM (fp64: x, y, z are already in their rows unless cold-started)
   if (ASM || !has_sol) {
 #pragma unroll
@@ -820,7 +906,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #pragma unroll
     for (int i = 0; i < NC; ++i) { const T v = has_sol ? ZV(i) : T(0); GLD(a.ctrl, NX + NC + i) = v; }
   }
-  GLD(a.ctrl, NX + 2 * NC) = T0;
+  GLD(a.ctrl, NX + 2 * NC) = T0next;
 #pragma unroll
   for (int k = 0; k < N; ++k) GLD(a.ctrl, NX + 2 * NC + 1 + k) = Eprev3[k];
 #pragma unroll

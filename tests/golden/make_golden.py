@@ -70,14 +70,14 @@ def structure():
     print("structure.npz: nnzA=%d nnzKKT=%d nnzL=%d" % (len(d["A_i"]), len(d["K_i"]), len(d["L_i"])))
 
 
-def sequence(seed, n, maxIter, fname, full_every=1):
+def sequence(seed, n, maxIter, fname, full_every=1, inputs=None):
     """One controller from the pristine workspace through n calls (F1/F2)."""
     rng = np.random.default_rng(seed)
     r = refbind.RefUMPC(maxIter=maxIter)
     rec = {k: [] for k in ("p0 R0 dq0 pdes dpdes sdes actualT0 pre_x pre_y pre_z pre_T0 pre_E3 "
                            "l u q Px Ax c D E rho_vec constr_type Lx Dinv x y z sol_x sol_y uquad accdes "
                            "status pri_res dua_res T0 ret").split()}
-    for (p0, R0, dq0, pdes, dpdes, sdes, aT0) in gen_inputs(rng, n):
+    for (p0, R0, dq0, pdes, dpdes, sdes, aT0) in (inputs if inputs is not None else gen_inputs(rng, n)):
         x, y, z = r.iterates()
         rec["pre_x"].append(x); rec["pre_y"].append(y); rec["pre_z"].append(z)
         rec["pre_T0"].append(np.float32(r.up.T0))
@@ -103,6 +103,22 @@ def sequence(seed, n, maxIter, fname, full_every=1):
     np.savez_compressed(os.path.join(HERE, fname), **out)
     st, cnt = np.unique(out["status"], return_counts=True)
     print(fname, "calls", n, "status histogram", dict(zip(st.tolist(), cnt.tolist())))
+
+
+def nan_branch():
+    """the branch of the reference that stores OSQP_NAN and cold-starts the iterates (auxil.c:539-564)
+    behind a `!has_solution` status. The QP of this path is feasible and strictly convex for every input, so the
+    infeasibility certificates never fire; what does reach the branch in the reference is a residual beyond
+    OSQP_INFTY (osqp.c:536-541 -> OSQP_NON_CVX), e.g. from a state of 1e33. Sequence: normal calls, one such call,
+    then recovery calls that override the (now garbage) thrust accumulator through actualT0."""
+    rng = np.random.default_rng(14)
+    ins = gen_inputs(rng, 12)
+    for k in (4, 9):
+        p0, R0, dq0, pdes, dpdes, sdes, aT0 = ins[k]
+        ins[k] = (p0 * 0 + np.array([1e33, -2e33, 0.0]), R0, dq0, pdes, dpdes, sdes, aT0)
+        p0, R0, dq0, pdes, dpdes, sdes, aT0 = ins[k + 1]
+        ins[k + 1] = (p0, R0, dq0, pdes, dpdes, sdes, 0.0098)   # T0 <- actualT0 (uprightmpc2.c:215-216)
+    sequence(0, len(ins), 50, "nan_branch.npz", inputs=ins)
 
 
 def import_reference_python():
@@ -247,6 +263,62 @@ def wl_step():
 
 
 
+def mpc_wl_loop(mods):
+    """SURVEY 8f-1, the coupling: accController of template/robobee_test_controllers.py:162-171 (= conn_MPC_WL.m:2-10)
+    around the COMPILED reference -- per call: (uquad, accdes) = umpcUpdate(..., actualT0); h0 = (Rb'(0,0,mb g), 0),
+    pdotdes = M0 accdes with M0 = diag(100,100,100,3333,3333,1000) (dynamicsTerms, template/ca6dynamics.py:5-10,
+    44-50, read as text: the module needs autograd); (u4, w0) = wlConUpdate(h0, pdotdes); actualT0 = w0[2]/M0[2,2].
+    Between calls the state advances like controlTest (template/uprightmpc2.py:148-151): 25 substeps of the
+    reference's quadrotorNLDyn (template/genqp.py:32-41), moments clipped at +-100. WL constructor arguments and
+    popts as in wl_step()."""
+    import ctypes as C
+    import re
+    from scipy.spatial.transform import Rotation
+    genqp = mods[0]
+    src = open(os.path.join(REF_T, "robobee_test_controllers.py")).read()
+    m = re.search(r"\n\s+popts = \[(.*?)\]", src, re.S)
+    popts = np.array([float(v) for v in m.group(1).replace("\n", " ").split(",")], np.float32)
+    r = refbind.RefUMPC()
+    wl = (C.c_float * 184)()
+    f = lambda a: np.ascontiguousarray(a, np.float32).ctypes.data_as(C.POINTER(C.c_float))
+    u0 = np.array([140.0, 0, 0, 0], np.float32)
+    umin, umax = np.array([90, -0.5, -0.2, -0.1], np.float32), np.array([240, 0.5, 0.2, 0.1], np.float32)
+    dumax, Qw = np.array([5e3, 10, 10, 10], np.float32), np.array([1, 1, 1, 0.1, 0.1, 0.1], np.float32)
+    r.lib.wlConInit(wl, f(u0), f(umin), f(umax), f(dumax), f(Qw), C.c_float(1000.0), f(popts))
+    M0 = np.array([100, 100, 100, 3333, 3333, 1000.0])
+    mb, g = 100.0, 9.81e-3
+    # hover start of controlTest (template/uprightmpc2.py:101-103)
+    p, Rb = np.zeros(3), Rotation.from_euler("xyz", [0.5, -0.5, 0]).as_matrix()
+    dq = np.zeros(6); dq[0] = 0.1
+    pdes, dpdes, sdes = np.zeros(3), np.zeros(3), np.array([0, 0, 1.0])
+    aT0 = -1.0
+    rec = {k: [] for k in "p0 R0 dq0 actualT0 pre_x pre_y pre_z pre_T0 pre_E3 pre_u4 uquad accdes h0 pdotdes u4 w0 T0 status".split()}
+    for k in range(64):
+        x, y, z = r.iterates()
+        for key, v in dict(p0=p, R0=Rb, dq0=dq, actualT0=aT0, pre_x=x, pre_y=y, pre_z=z, pre_T0=np.float32(r.up.T0),
+                           pre_E3=r.scaling()["E"][36:39], pre_u4=np.array(wl[0:4], np.float32)).items():
+            rec[key].append(np.array(v))
+        uq, ac = r.update(p, Rb, dq, pdes, dpdes, sdes, aT0)
+        h0 = np.hstack((np.asarray(Rb, np.float32).T @ np.array([0, 0, np.float32(mb) * np.float32(g)], np.float32),
+                        np.zeros(3, np.float32))).astype(np.float32)
+        pd = (M0.astype(np.float32) * ac).astype(np.float32)
+        u1, w0 = np.zeros(4, np.float32), np.zeros(6, np.float32)
+        r.lib.wlConUpdate(wl, f(u1), f(w0), f(h0), f(pd))
+        aT0 = float(np.float32(w0[2]) / np.float32(M0[2]))
+        for key, v in dict(uquad=uq, accdes=ac, h0=h0, pdotdes=pd, u4=u1, w0=w0, T0=np.float32(r.up.T0),
+                           status=np.int32(r.info()["status_val"])).items():
+            rec[key].append(np.array(v))
+        u = uq.astype(np.float64)
+        u[1:] = np.clip(u[1:], -100, 100)
+        for _ in range(25):
+            p, Rb, dq = genqp.quadrotorNLDyn(p, Rb, dq, u, 0.2)
+    np.savez_compressed(os.path.join(HERE, "mpc_wl_loop.npz"), popts=popts, u0=u0, umin=umin, umax=umax, dumax=dumax,
+                        Qw=Qw, controlRate=np.float32(1000.0), Mdiag=M0, final_p=p, final_R=Rb, final_dq=dq,
+                        **{k: np.stack(v) for k, v in rec.items()})
+    print("mpc_wl_loop.npz: 64 coupled calls; actualT0 range %.5f..%.5f, final |p| = %.4f mm, u4 = %s"
+          % (min(rec["actualT0"][1:]), max(rec["actualT0"][1:]), np.linalg.norm(p), np.array(wl[0:4])))
+
+
 class _RecordingOSQP:
     """Placeholder for the absent pip `osqp` on the two assembly-only paths below: records what the reference
     hands to setup()/update() and computes NOTHING; solve() aborts the caller."""
@@ -356,6 +428,12 @@ def reactive(mods):
 
 if __name__ == "__main__":
     assert refbind.available(), "build oracle/_ref first: make -C oracle ref"
+    if len(sys.argv) > 1 and sys.argv[1] == "wlloop":
+        mpc_wl_loop(import_reference_python())
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "nan":
+        nan_branch()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wl":
         wl_step()
         sys.exit(0)
@@ -381,3 +459,5 @@ if __name__ == "__main__":
     reactive(mods)
     v1_qp(mods)
     planar_p5f()
+    nan_branch()
+    mpc_wl_loop(mods)

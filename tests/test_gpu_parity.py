@@ -10,7 +10,7 @@ fp64 kernel vs fp64 oracle: 1e-9 relative.
 import numpy as np
 import pytest
 
-from conftest import golden
+from conftest import golden, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -77,16 +77,28 @@ def test_assembly_matches_reference(torch_cuda):
 FIXTURE_SCALE = {"seq_iter1.npz": 15.0}
 
 
-def _check_outputs(out, seq, n, label, scale=1.0):
-    uq, ac = out[:3].T, out[3:].T
-    ru, ra = seq["uquad"][:n].astype(np.float64), seq["accdes"][:n].astype(np.float64)
+def _check_outputs(out, seq, n, label, scale=1.0, sel=None, tau_scale=None):
+    sel = np.arange(n) if sel is None else sel
+    uq, ac = out[:3].T[sel], out[3:].T[sel]
+    ru, ra = seq["uquad"][:n].astype(np.float64)[sel], seq["accdes"][:n].astype(np.float64)[sel]
     d0 = np.abs(uq[:, 0] - ru[:, 0]).max()
     dt_ = np.abs(uq[:, 1:] - ru[:, 1:])
     da = np.abs(ac - ra).max()
+    record_margin(label, "|d thrust|", d0, TOL_T * scale)
+    tau_scale = scale if tau_scale is None else tau_scale
+    record_margin(label, "|d moment| / max(2e-2, 1e-3|u|)", (dt_ / tol_tau(ru[:, 1:])).max(), tau_scale)
+    record_margin(label, "|d accdes|", da, TOL_A * scale)
     assert d0 <= TOL_T * scale, (label, "thrust", d0)
-    assert np.all(dt_ <= tol_tau(ru[:, 1:]) * scale), (label, "moment", dt_.max())
+    assert np.all(dt_ <= tol_tau(ru[:, 1:]) * tau_scale), (label, "moment", dt_.max())
     assert da <= TOL_A * scale, (label, "accdes", da)
     return d0, dt_.max(), da
+
+
+# Measured on the MI355X (round 2, profiles/README.md "parity margins"); every bound below is <= 3x its measured value.
+ITERATE_TOL = {"seq_iter50.npz": 1e-3, "seq_iter10.npz": 4e-4, "seq_iter2.npz": 2.5e-5, "seq_iter1.npz": 8e-5}
+STATUS_FLIPS = {"seq_iter50.npz": 32, "seq_iter10.npz": 1, "seq_iter2.npz": 1, "seq_iter1.npz": 1}
+DUA_RATIO = {"seq_iter50.npz": 5.0, "seq_iter10.npz": 1.5, "seq_iter2.npz": 1.5, "seq_iter1.npz": 1.5}
+PRI_REL = {"seq_iter50.npz": 4e-4, "seq_iter10.npz": 4e-6, "seq_iter2.npz": 1e-6, "seq_iter1.npz": 1e-6}
 
 
 @pytest.mark.parametrize("fname", ["seq_iter50.npz", "seq_iter10.npz", "seq_iter2.npz", "seq_iter1.npz"])
@@ -103,13 +115,14 @@ def test_single_step_matches_reference_golden(torch_cuda, fname):
     torch.cuda.synchronize()
     out = mpc.out.cpu().numpy().astype(np.float64)
     sc = FIXTURE_SCALE.get(fname, 1.0)
-    _check_outputs(out, seq, n, fname, sc)
+    _check_outputs(out, seq, n, fname, sc, tau_scale=1.0)
     ctrl = mpc.ctrl.cpu().numpy()
     # iterates: scaled x, y, z after the same number of iterations
     for name, sl in (("x", slice(0, 45)), ("y", slice(45, 84)), ("z", slice(84, 123))):
         ref = seq[name].T
         err = np.abs(ctrl[sl] - ref) / (1e-3 + np.abs(ref).max(axis=0, keepdims=True))
-        assert err.max() < 2e-2, (name, err.max())
+        record_margin(fname, "iterate %s: |d| / (1e-3 + max|ref|)" % name, err.max(), ITERATE_TOL[fname])
+        assert err.max() < ITERATE_TOL[fname], (name, err.max())
     np.testing.assert_allclose(ctrl[123], seq["T0"], rtol=0, atol=TOL_T * sc)
     np.testing.assert_allclose(ctrl[124:127].T, seq["E"][:, 36:39], rtol=1e-5)
     status = mpc.status.cpu().numpy()
@@ -121,12 +134,16 @@ def test_single_step_matches_reference_golden(torch_cuda, fname):
     # same family (never an infeasibility / non-convex code) and a bounded flip count.
     mismatch = int(np.sum(status != seq["status"]))
     assert set(np.unique(status)).issubset({1, 2, -2}), np.unique(status)
-    assert mismatch <= max(2, n // 8), (mismatch, n)
+    record_margin(fname, "status flips of %d" % n, mismatch, STATUS_FLIPS[fname])
+    assert mismatch <= STATUS_FLIPS[fname], (mismatch, n)
     info = mpc.info.cpu().numpy()
     rel_pri = np.abs(info[0] - seq["pri_res"]) / seq["pri_res"]
-    assert np.median(rel_pri) < 1e-2, np.median(rel_pri)
+    record_margin(fname, "median rel. error of pri_res", np.median(rel_pri), PRI_REL[fname])
+    assert np.median(rel_pri) < PRI_REL[fname], np.median(rel_pri)
     ratio = info[1] / seq["dua_res"]
-    assert 0.2 < np.median(ratio) < 5.0, np.median(ratio)
+    med = float(np.median(ratio))
+    record_margin(fname, "median dua_res ratio (max of r, 1/r)", max(med, 1 / med), DUA_RATIO[fname])
+    assert 1 / DUA_RATIO[fname] < med < DUA_RATIO[fname], med
 
 
 def test_single_step_fp32_vs_canonical_oracle_and_fp64(torch_cuda, oracle_built, structure):
@@ -260,7 +277,11 @@ def test_closed_loop_rollout_matches_oracle(torch_cuda, oracle_built, plant_mode
     # fp32 band after K = 12 closed-loop steps: the fp32 CPU oracle itself is 4.7e-4..6.1e-4 mm /
     # 0.9e-4..1.1e-4 (attitude, velocity) away from the fp64 oracle on this workload (measured with
     # both elimination orders); tolerance = 3x that band.
-    np.testing.assert_allclose(s32[0:3], s_o[0:3], rtol=0, atol=2e-3)
+    lab = "closed_loop_rollout[plant_mode=%d] K=12" % plant_mode
+    record_margin(lab, "fp32 vs fp64 oracle |dp| mm", np.abs(s32[0:3] - s_o[0:3]).max(), 1.5e-3)
+    record_margin(lab, "fp32 vs fp64 oracle |dR|,|ddq|", np.abs(s32[3:] - s_o[3:]).max(), 3e-4)
+    record_margin(lab, "fp64 vs fp64 oracle state", np.abs(m64.state.cpu().numpy() - s_o).max(), 1e-7)
+    np.testing.assert_allclose(s32[0:3], s_o[0:3], rtol=0, atol=1.5e-3)
     np.testing.assert_allclose(s32[3:], s_o[3:], rtol=0, atol=3e-4)
     np.testing.assert_allclose(m32.stats.cpu().numpy(), stats_o, rtol=1e-3)
 
@@ -393,3 +414,145 @@ def test_config2_fp64_full_run_against_oracle_sample(torch_cuda, oracle_built):
     np.testing.assert_allclose(s[:, idx], s_o, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(mpc.out.cpu().numpy()[:, idx], out_o, rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(mpc.stats.cpu().numpy()[:, idx], stats_o, rtol=1e-7)
+
+
+def test_headline_configuration_against_oracle(torch_cuda, oracle_built):
+    """EXACTLY what bench.py times (BASELINE configs[2]): B = 65 536, fp32, RK4 plant (plant_mode = 1), K closed-loop
+    steps in ONE launch -- a 20-step launch (the driver's --steps 20 shape) followed by a 180-step launch (wave skew
+    on, as in the default 500-step bench launch). Every 512th robot is replayed on the fp64 oracle and on the fp32
+    oracle (same elimination order, same RK4) from the same start.
+
+    SURVEY 8(c) states the closed-loop band as 1e-3 mm / 1e-4 after K = 200 steps for hover: asserted below at
+    K = 200. At K = 20 the robots are still in the 0.5 rad recovery transient, where round-off differences between
+    two fp32 evaluation orders of the same 50-iteration step are amplified by the closed loop: there the bound is
+    3x the band the fp32 CPU oracle itself is away from the fp64 oracle, measured in this test."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    from robobee3d_amd import _lib
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    B = 65536
+    st, ref = hover_initial_conditions(B, 20201118, np.float32)
+    mpc = BatchUprightMPC(B, torch.float32, plant_mode=1)
+    mpc.set_state(st, ref)
+    idx = np.arange(0, B, 512)
+    n = len(idx)
+
+    def oracle_run(dtype, K, s, c):
+        out, stats, status = oracle_built.batch_rollout(s, c, np.ascontiguousarray(ref[:, idx]).astype(dtype), K,
+                                                        dtype=dtype, perm=perm, plant_mode=1)
+        return out
+
+    s64 = np.ascontiguousarray(st[:, idx]).astype(np.float64); c64 = np.zeros((127, n)); c64[124:] = 1
+    s32 = np.ascontiguousarray(st[:, idx]).astype(np.float32); c32 = np.zeros((127, n), np.float32); c32[124:] = 1
+    for K, label in ((20, "K=20 (one 20-step launch)"), (180, "K=200 (+ one 180-step launch, skew on)")):
+        mpc.rollout(K)
+        o64 = oracle_run(np.float64, K, s64, c64)
+        o32 = oracle_run(np.float32, K, s32, c32)
+        g = mpc.state.cpu().numpy().astype(np.float64)[:, idx]
+        out = mpc.out.cpu().numpy().astype(np.float64)[:, idx]
+        assert np.isfinite(g).all()
+        dp, ds = np.abs(g[0:3] - s64[0:3]).max(), np.abs(g[3:] - s64[3:]).max()
+        bp, bs = np.abs(s32[0:3] - s64[0:3]).max(), np.abs(s32[3:] - s64[3:]).max()   # fp32 oracle vs fp64 oracle
+        lab = "headline B=65536 fp32 RK4 " + label
+        if K == 20:
+            record_margin(lab, "fp32 ORACLE vs fp64 oracle |dp| mm (the band)", bp, bp)
+            record_margin(lab, "fp32 ORACLE vs fp64 oracle |dR|,|ddq| (the band)", bs, bs)
+            tol_p, tol_s = max(3 * bp, 1e-3), max(3 * bs, 1e-4)
+        else:
+            tol_p, tol_s = 1e-3, 1e-4      # SURVEY 8(c)
+        record_margin(lab, "HIP vs fp64 oracle |dp| mm", dp, tol_p)
+        record_margin(lab, "HIP vs fp64 oracle |dR|,|ddq|", ds, tol_s)
+        record_margin(lab, "HIP vs fp64 oracle |d thrust|", np.abs(out[0] - o64[0]).max(), TOL_T)
+        record_margin(lab, "HIP vs fp64 oracle |d moment| / max(2e-2,1e-3|u|)",
+                      (np.abs(out[1:3] - o64[1:3]) / tol_tau(o64[1:3])).max(), 1.0)
+        record_margin(lab, "HIP vs fp64 oracle |d accdes|", np.abs(out[3:] - o64[3:]).max(), TOL_A)
+        assert dp <= tol_p and ds <= tol_s, (label, dp, ds, tol_p, tol_s)
+        assert np.abs(out[0] - o64[0]).max() <= TOL_T
+        assert np.all(np.abs(out[1:3] - o64[1:3]) <= tol_tau(o64[1:3]))
+        assert np.abs(out[3:] - o64[3:]).max() <= TOL_A
+    # the whole batch hovers
+    s = mpc.state.cpu().numpy().astype(np.float64)
+    assert np.isfinite(s).all() and np.linalg.norm(s[0:3], axis=0).max() < 0.05
+
+
+def test_nan_and_cold_start_branch_matches_reference(torch_cuda):
+    """the `!has_solution` branch (OSQP_NAN = the NUMBER 2143289344 stored into the solution, iterates
+    cold-started; auxil.c:539-564, constants.h:96) as the reference itself takes it -- tests/golden/nan_branch.npz,
+    generated from the compiled reference: calls 4 and 9 see a state of 1e33 (residual > OSQP_INFTY -> status -7),
+    the calls after them restart from zero iterates with actualT0 overriding the thrust accumulator."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC
+    seq = golden("nan_branch.npz")
+    n = len(seq["p0"])
+    mpc = BatchUprightMPC(n, torch.float32)
+    _load_seq_into(mpc, seq, torch)
+    mpc.update()
+    out = mpc.out.cpu().numpy().astype(np.float64)
+    ctrl = mpc.ctrl.cpu().numpy()
+    status = mpc.status.cpu().numpy()
+    bad = np.nonzero(seq["status"] == -7)[0]
+    assert list(bad) == [4, 9]
+    np.testing.assert_array_equal(status[bad], -7)
+    nanv = np.float32(2143289344.0)
+    for k in bad:
+        np.testing.assert_array_equal(out[1:3, k], nanv)                           # moments: the number itself
+        np.testing.assert_array_equal(out[:3, k].astype(np.float32), seq["uquad"][k])
+        np.testing.assert_allclose(out[3:, k], seq["accdes"][k], rtol=1e-6)        # (OSQP_NAN - dq0) / dt
+        np.testing.assert_array_equal(ctrl[:123, k], 0)                            # cold start (auxil.c:563)
+        np.testing.assert_array_equal(ctrl[123, k], seq["T0"][k])                  # T0 += OSQP_NAN, as the reference
+    good = np.setdiff1d(np.arange(n), bad)
+    assert set(np.unique(status[good])).issubset({1, 2, -2})
+    _check_outputs(out, seq, n, "nan_branch.npz (other calls)", sel=good)
+
+
+def test_nonpositive_weights_are_rejected(torch_cuda):
+    """The Ruiz scaling D is recovered from the equilibrated diagonal of P, which needs every weight > 0: a zero
+    weight is refused with an error instead of a silent NaN (include/umpc_mi355x.h)."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC
+    with pytest.raises(RuntimeError, match="weights must be > 0"):
+        BatchUprightMPC(64, torch.float32, wpr=0.0)
+    m = BatchUprightMPC(64, torch.float32)
+    w = torch.ones((8, 64), device="cuda")
+    w[7, 13] = 0.0
+    with pytest.raises(RuntimeError, match="weights must be > 0"):
+        m.set_weights(w)
+    w[7, 13] = 1e-2
+    m.set_weights(w)
+
+
+def test_dropin_survives_a_copied_pod_and_honours_T0_edits(torch_cuda):
+    """The reference's pybind class holds UprightMPC_t by value and the POD's T0 is the accumulator of record: a
+    host that copies the struct, or edits T0 between calls, keeps working (the controller id travels in the POD)."""
+    import ctypes as C
+    from robobee3d_amd import _lib
+    L = _lib.lib()
+    seq = golden("seq_iter50.npz")
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    Ib = f32([3333.0, 3333.0, 1000.0])
+    prm = (5.0, 9.81e-3, 2.0, 1e1, 1e3, 1.0, 5.0, 1e3, 2e3, 1e-1, 1e-2)
+
+    def call(up, k, aT0):
+        uq, ac = np.zeros(3, np.float32), np.zeros(6, np.float32)
+        args = [f32(seq["p0"][k]), f32(seq["R0"][k].T.ravel()), f32(seq["dq0"][k]), f32(seq["pdes"][k]),
+                f32(seq["dpdes"][k]), f32(seq["sdes"][k])]
+        rc = L.umpcUpdate(C.byref(up), fp(uq), fp(ac), *[fp(a) for a in args], C.c_float(aT0))
+        assert rc == 0
+        return uq, ac
+    a, b = _lib.UprightMPC_t(), _lib.UprightMPC_t()
+    for up in (a, b):
+        L.umpcInit(C.byref(up), *[C.c_float(v) for v in prm], fp(Ib), C.c_int(50))
+    ra = [call(a, k, -1.0) for k in range(3)]
+    moved = _lib.UprightMPC_t()
+    for k in range(3):                       # b is copied to a new address before every call
+        C.memmove(C.byref(moved), C.byref(b), C.sizeof(b))
+        rb = call(moved, k, -1.0)
+        C.memmove(C.byref(b), C.byref(moved), C.sizeof(b))
+        assert np.array_equal(ra[k][0], rb[0]) and np.array_equal(ra[k][1], rb[1]), k
+    # editing T0 in the POD == passing actualT0
+    a.T0 = 0.0123
+    u1, _ = call(a, 3, -1.0)
+    u2, _ = call(b, 3, 0.0123)
+    assert np.array_equal(u1, u2)
+    L.umpcRelease(C.byref(a)); L.umpcRelease(C.byref(b))

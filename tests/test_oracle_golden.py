@@ -23,7 +23,7 @@ def test_symbolic_structure_matches_reference(oracle_built, structure):
     assert len(structure["L_i"]) == 213 and len(structure["K_i"]) == 195
 
 
-@pytest.mark.parametrize("fname", ["seq_iter50.npz", "seq_iter1.npz", "seq_iter2.npz", "seq_iter10.npz"])
+@pytest.mark.parametrize("fname", ["seq_iter50.npz", "seq_iter1.npz", "seq_iter2.npz", "seq_iter10.npz", "nan_branch.npz"])
 def test_fp32_oracle_is_bit_identical_to_reference(oracle_built, structure, fname):
     """Same ADMM iterate after the same number of iterations from the same warm
     start, BIT FOR BIT, over a 256-call sequence starting at the pristine

@@ -70,3 +70,135 @@ def test_wlcon_dropin_sequence():
         assert u1.shape == (4,) and w0.shape == (6,)
         np.testing.assert_allclose(w0, g["w0"][k], rtol=5e-5, atol=5e-5)
         np.testing.assert_allclose(u1, g["u1"][k], rtol=1e-5, atol=5e-3)
+
+
+# ---------------------------------------------------------------------------
+# The coupling MPC -> WL -> actualT0 (template/robobee_test_controllers.py:162-171, conn_MPC_WL.m:2-10):
+# tests/golden/mpc_wl_loop.npz = 64 coupled calls of the COMPILED reference around the reference's Python plant.
+# ---------------------------------------------------------------------------
+def test_coupled_loop_oracle_replays_reference_bit_for_bit(oracle_built, structure):
+    """Faithful fp32 oracle + WL oracle, wired in the reference's order and fed the fixture's states: every uquad,
+    accdes, u4, w0 and the fed-back actualT0 are the reference's, bit for bit."""
+    g = golden("mpc_wl_loop.npz")
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"])
+    wl = oracle_built.WLOracle(*_args(g), dtype=np.float32)
+    M0 = g["Mdiag"].astype(np.float32)
+    aT0 = -1.0
+    z3, e3 = np.zeros(3), np.array([0, 0, 1.0])
+    for k in range(len(g["p0"])):
+        assert np.float32(aT0) == g["actualT0"][k].astype(np.float32)
+        uq, ac = o.update(g["p0"][k], g["R0"][k], g["dq0"][k], z3, z3, e3, aT0)
+        assert np.array_equal(uq, g["uquad"][k]) and np.array_equal(ac, g["accdes"][k]), k
+        Rb = g["R0"][k].astype(np.float32)
+        h0 = np.hstack((Rb.T @ np.array([0, 0, np.float32(100.0) * np.float32(9.81e-3)], np.float32), np.zeros(3, np.float32)))
+        assert np.array_equal(h0.astype(np.float32), g["h0"][k])
+        u1, w0 = wl.update(g["h0"][k], (M0 * ac).astype(np.float32))
+        assert np.array_equal(u1, g["u4"][k]) and np.array_equal(w0, g["w0"][k]), k
+        aT0 = float(np.float32(w0[2]) / M0[2])
+
+
+def _loop_inputs(g, dtype, n=1):
+    from scipy.spatial.transform import Rotation  # noqa: F401
+    st = np.zeros((18, n), dtype)
+    st[0:3] = g["p0"][0][:, None]
+    st[3:12] = g["R0"][0].T.reshape(9)[:, None]     # column-major
+    st[12:18] = g["dq0"][0][:, None]
+    ref = np.zeros((9, n), dtype); ref[8] = 1
+    ctrl = np.zeros((127, n), dtype); ctrl[124:] = 1
+    u4 = np.repeat(g["u0"].astype(dtype)[:, None], n, 1).copy()
+    return st, ref, ctrl, u4
+
+
+def test_coupled_closed_loop_oracle_tracks_reference_trajectory(oracle_built, structure):
+    """umpc_oracle_batch_rollout3 (what the GPU test checks the fused kernel against) run closed loop from the
+    fixture's start reproduces the reference's coupled trajectory within the closed-loop band."""
+    g = golden("mpc_wl_loop.npz")
+    K = len(g["p0"])
+    for dtype in (np.float64, np.float32):
+        wl = oracle_built.WLOracle(*_args(g), dtype=dtype)
+        st, ref, ctrl, u4 = _loop_inputs(g, dtype)
+        w0 = np.zeros((6, 1), dtype)
+        oracle_built.batch_rollout(st, ctrl, ref, K, dtype=dtype, perm=structure["perm"], wl=wl, wl_u=u4, wl_w=w0)
+        assert np.abs(st[0:3, 0] - g["final_p"]).max() < 2e-3
+        assert np.abs(st[3:12, 0] - g["final_R"].T.reshape(9)).max() < 3e-4
+        assert np.abs(st[12:18, 0] - g["final_dq"]).max() < 3e-4
+        np.testing.assert_allclose(u4[:, 0], g["u4"][-1], rtol=1e-4, atol=5e-3)
+        np.testing.assert_allclose(w0[:, 0], g["w0"][-1], rtol=1e-4, atol=5e-4)   # w0[4] = f(u4[1] ~ 1e-2): closed-loop band
+    # and step by step (one launch-equivalent per call) the fed-back thrust follows the reference's
+    wl = oracle_built.WLOracle(*_args(g), dtype=np.float64)
+    st, ref, ctrl, u4 = _loop_inputs(g, np.float64)
+    for k in range(12):
+        out, _, _ = oracle_built.batch_rollout(st, ctrl, ref, 1, dtype=np.float64, perm=structure["perm"], wl=wl, wl_u=u4)
+        np.testing.assert_allclose(out[0, 0], g["uquad"][k][0], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(ctrl[123, 0], g["actualT0"][k + 1], rtol=1e-4)       # accumulator := actualT0
+
+
+@pytest.mark.gpu
+def test_fused_mpc_wl_loop_on_gpu(oracle_built):
+    """The fused kernel option (umpcBatchSetWL): (a) every call of the reference's coupled sequence replayed as one
+    batch from the reference's own pre-call state, (b) the 64-step closed loop in ONE launch against the fp64 oracle
+    (fp64 tight, fp32 band) and against the reference's trajectory."""
+    import torch
+    from conftest import record_margin
+    from robobee3d_amd import _lib
+    from robobee3d_amd.batch import BatchUprightMPC, BatchWLCon
+    g = golden("mpc_wl_loop.npz")
+    n = len(g["p0"])
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    # (a) single coupled steps
+    mpc = BatchUprightMPC(n, torch.float32, nsub=0)
+    wl = BatchWLCon(n, *_args(g), dtype=torch.float32)
+    state = np.zeros((18, n), np.float32)
+    state[0:3] = g["p0"].T
+    state[3:12] = g["R0"].transpose(2, 1, 0).reshape(9, n)
+    state[12:18] = g["dq0"].T
+    ref = np.zeros((9, n), np.float32); ref[8] = 1
+    mpc.set_state(state, ref)
+    mpc.ctrl.copy_(torch.as_tensor(np.vstack((g["pre_x"].T, g["pre_y"].T, g["pre_z"].T, g["pre_T0"][None, :],
+                                              g["pre_E3"].T)).astype(np.float32)))
+    mpc.actualT0 = torch.as_tensor(g["actualT0"].astype(np.float32)).cuda()
+    wl.u.copy_(torch.as_tensor(g["pre_u4"].T.copy()))
+    mpc.set_wl(wl)
+    mpc.rollout(1)
+    out = mpc.out.cpu().numpy().astype(np.float64)
+    d_t = np.abs(out[0] - g["uquad"][:, 0]).max()
+    d_m = (np.abs(out[1:3] - g["uquad"][:, 1:].T) / np.maximum(2e-2, 1e-3 * np.abs(g["uquad"][:, 1:].T))).max()
+    d_a = np.abs(out[3:] - g["accdes"].T).max()
+    w0 = wl.w0.cpu().numpy().T
+    u4 = wl.u.cpu().numpy().T
+    d_w = np.abs(w0 - g["w0"]).max()
+    d_u = (np.abs(u4 - g["u4"]) / np.array([5.0, 0.01, 0.01, 0.01])).max()     # in units of the rate limits dumax/rate
+    aT0 = mpc.ctrl[123].cpu().numpy()
+    d_f = np.abs(aT0[:-1] - g["actualT0"][1:]).max()
+    for q, a, b in (("|d thrust|", d_t, 3e-5), ("|d moment| / max(2e-2,1e-3|u|)", d_m, 1.0), ("|d accdes|", d_a, 3e-5),
+                    ("|d w0|", d_w, 2e-3), ("|d u4| / rate limit", d_u, 1.0), ("|d actualT0 fed back|", d_f, 2e-5)):
+        record_margin("fused MPC->WL single steps (64 reference calls)", q, a, b)
+        assert a <= b, (q, a, b)
+    # (b) closed loop, one launch
+    K = n
+    st64, ref64, ctrl64, u64 = _loop_inputs(g, np.float64, 64)
+    wlo = oracle_built.WLOracle(*_args(g), dtype=np.float64)
+    w64 = np.zeros((6, 64))
+    out_o, _, _ = oracle_built.batch_rollout(st64, ctrl64, ref64, K, dtype=np.float64, perm=perm, wl=wlo, wl_u=u64, wl_w=w64)
+    for dtype, tp, ts, lab in ((torch.float64, 1e-7, 1e-8, "fp64"), (torch.float32, 2e-3, 3e-4, "fp32")):
+        m = BatchUprightMPC(64, dtype)
+        w = BatchWLCon(64, *_args(g), dtype=dtype)
+        s0, r0, _, _ = _loop_inputs(g, np.float64, 64)
+        m.set_state(s0, r0)
+        m.set_wl(w)
+        m.rollout(K)
+        s = m.state.cpu().numpy().astype(np.float64)
+        dp, ds = np.abs(s[0:3] - st64[0:3]).max(), np.abs(s[3:] - st64[3:]).max()
+        du = np.abs(w.u.cpu().numpy() - u64).max()
+        record_margin("fused MPC->WL closed loop K=64 " + lab, "|dp| mm vs fp64 oracle", dp, tp)
+        record_margin("fused MPC->WL closed loop K=64 " + lab, "|dR|,|ddq| vs fp64 oracle", ds, ts)
+        assert dp <= tp and ds <= ts, (lab, dp, ds)
+        if dtype == torch.float64:
+            # WL limits travel as float in WLCon_t (funapprox.h:37-41) -> 1e-9 class differences on limited steps
+            assert du < 1e-6, du
+            np.testing.assert_allclose(w.w0.cpu().numpy(), w64, rtol=1e-7, atol=1e-9)
+        # against the reference's own trajectory
+        assert np.abs(s[0:3, 0] - g["final_p"]).max() < 2e-3 and np.abs(s[12:18, 0] - g["final_dq"]).max() < 3e-4
+    # switching the coupling off restores the plain loop
+    m.set_wl(None)
+    m.rollout(1)
