@@ -24,7 +24,7 @@ SOLVED, SOLVED_INACC, MAX_ITER, PINF, PINF_INACC, DINF, DINF_INACC, UNSOLVED, NO
 
 class Settings:
     def __init__(self, rho=0.1, sigma=1e-6, alpha=1.6, max_iter=50, scaling=10, eps_abs=1e-4, eps_rel=1e-4,
-                 eps_prim_inf=1e-4, eps_dual_inf=1e-4):
+                 eps_prim_inf=1e-4, eps_dual_inf=1e-4, check_termination=0):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -210,7 +210,85 @@ def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, setting
     oma = T(1.0) - alpha
     dx = np.zeros((n, B), dtype)
     dy = np.zeros((m, B), dtype)
+    def evaluate(x, y, z, dx, dy):
+        # ---- update_info + check_termination + store_solution
+        def A_mul(v):
+            out = np.zeros((m, B), dtype)
+            for j in range(n):
+                for p in range(A_p[j], A_p[j + 1]):
+                    out[A_i[p]] = out[A_i[p]] + As[p] * v[j]
+            return out
+
+        def At_mul(v):
+            out = np.zeros((n, B), dtype)
+            for j in range(n):
+                for p in range(A_p[j], A_p[j + 1]):
+                    out[j] = out[j] + As[p] * v[A_i[p]]
+            return out
+
+        def P_mul(v):
+            out = np.zeros((n, B), dtype)
+            for j in range(n):
+                if pidx[j] >= 0:
+                    out[j] = out[j] + Ps[pidx[j]] * v[j]
+            return out
+
+        def ninf(v):
+            r = np.zeros(B, dtype)
+            for i in range(v.shape[0]):
+                r = np.maximum(r, np.abs(v[i]))
+            return r
+        Ax = A_mul(x)
+        pri_res = ninf(Einv * (Ax - z))
+        Px = P_mul(x)
+        Aty = At_mul(y)
+        dua_res = cinv * ninf(Dinv * ((qs + Px) + Aty))
+
+        def term(approx):
+            k = T(10) if approx else T(1)
+            eps_abs, eps_rel = T(st.eps_abs) * k, T(st.eps_rel) * k
+            eps_pinf, eps_dinf = T(st.eps_prim_inf) * k, T(st.eps_dual_inf) * k
+            eps_prim = eps_abs + eps_rel * np.maximum(ninf(Einv * z), ninf(Einv * Ax))
+            mr = np.maximum(np.maximum(ninf(Dinv * qs), ninf(Dinv * Aty)), ninf(Dinv * Px)) * cinv
+            eps_dual = eps_abs + eps_rel * mr
+            prim_ok = pri_res < eps_prim
+            dual_ok = dua_res < eps_dual
+            # is_primal_infeasible, auxil.c:362-424
+            upinf = usc.astype(np.float64) > INFTY * MIN_SCALING
+            lninf = lsc.astype(np.float64) < -INFTY * MIN_SCALING
+            dyp = np.where(upinf & lninf, T(0), np.where(upinf, np.minimum(dy, T(0)), np.where(lninf, np.maximum(dy, T(0)), dy)))
+            norm_dy = ninf(dyp * E)
+            lhs = np.zeros(B, dtype)
+            with np.errstate(invalid="ignore", over="ignore"):
+                for i in range(m):
+                    lhs = lhs + (usc[i] * np.maximum(dyp[i], T(0)) + lsc[i] * np.minimum(dyp[i], T(0)))
+                pinf = (norm_dy > eps_pinf) & (lhs < -eps_pinf * norm_dy) & (ninf(At_mul(dyp) * Dinv) < eps_pinf * norm_dy)
+            # is_dual_infeasible, auxil.c:426-512
+            norm_dx = ninf(D * dx)
+            qdx = np.zeros(B, dtype)
+            for j in range(n):
+                qdx = qdx + qs[j] * dx[j]
+            Adx = A_mul(dx) * Einv
+            thr = eps_dinf * norm_dx
+            viol = ((usc.astype(np.float64) < INFTY * MIN_SCALING) & (Adx > thr)) | \
+                   ((lsc.astype(np.float64) > -INFTY * MIN_SCALING) & (Adx < -thr))
+            dinf = (norm_dx > eps_dinf) & (qdx < -c * eps_dinf * norm_dx) & \
+                   (ninf(P_mul(dx) * Dinv) < c * eps_dinf * norm_dx) & ~viol.any(0)
+            pinf = pinf & ~prim_ok
+            dinf = dinf & ~dual_ok
+            code = np.where(prim_ok & dual_ok, SOLVED_INACC if approx else SOLVED,
+                            np.where(pinf, PINF_INACC if approx else PINF,
+                                     np.where(dinf, DINF_INACC if approx else DINF, 0)))
+            return code
+        with np.errstate(invalid="ignore"):
+            ncvx = (pri_res.astype(np.float64) > INFTY) | (dua_res.astype(np.float64) > INFTY)
+        return pri_res, dua_res, ncvx, term
+    # check_termination = k > 0 (osqp.c:411-450): every k-th iteration update_info + check_termination(exact); a
+    # robot that meets a criterion keeps its iterate from then on (the per-lane mask of the kernel)
+    done = np.zeros(B, bool)
+    iters = np.zeros(B, np.int32)
     for it in range(st.max_iter):
+        x0, y0, z0, dx0, dy0 = x, y, z, dx, dy
         xp, zp = x, z
         rhs = np.concatenate((sigma * xp - qs, zp - rinv * y), 0)
         bp = rhs[perm].copy()
@@ -234,77 +312,17 @@ def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, setting
         if trace is not None:
             trace.append((x.copy(), y.copy(), z.copy()))
 
-    # ---- update_info + check_termination + store_solution
-    def A_mul(v):
-        out = np.zeros((m, B), dtype)
-        for j in range(n):
-            for p in range(A_p[j], A_p[j + 1]):
-                out[A_i[p]] = out[A_i[p]] + As[p] * v[j]
-        return out
+        if done.any():
+            x, y, z = np.where(done, x0, x), np.where(done, y0, y), np.where(done, z0, z)
+            dx, dy = np.where(done, dx0, dx), np.where(done, dy0, dy)
+        iters = np.where(done, iters, it + 1).astype(np.int32)
+        if st.check_termination > 0 and (it + 1) % st.check_termination == 0:
+            _, _, nc, tf = evaluate(x, y, z, dx, dy)
+            done = done | nc | (tf(False) != 0)
+            if done.all():
+                break
 
-    def At_mul(v):
-        out = np.zeros((n, B), dtype)
-        for j in range(n):
-            for p in range(A_p[j], A_p[j + 1]):
-                out[j] = out[j] + As[p] * v[A_i[p]]
-        return out
-
-    def P_mul(v):
-        out = np.zeros((n, B), dtype)
-        for j in range(n):
-            if pidx[j] >= 0:
-                out[j] = out[j] + Ps[pidx[j]] * v[j]
-        return out
-
-    def ninf(v):
-        r = np.zeros(B, dtype)
-        for i in range(v.shape[0]):
-            r = np.maximum(r, np.abs(v[i]))
-        return r
-    Ax = A_mul(x)
-    pri_res = ninf(Einv * (Ax - z))
-    Px = P_mul(x)
-    Aty = At_mul(y)
-    dua_res = cinv * ninf(Dinv * ((qs + Px) + Aty))
-
-    def term(approx):
-        k = T(10) if approx else T(1)
-        eps_abs, eps_rel = T(st.eps_abs) * k, T(st.eps_rel) * k
-        eps_pinf, eps_dinf = T(st.eps_prim_inf) * k, T(st.eps_dual_inf) * k
-        eps_prim = eps_abs + eps_rel * np.maximum(ninf(Einv * z), ninf(Einv * Ax))
-        mr = np.maximum(np.maximum(ninf(Dinv * qs), ninf(Dinv * Aty)), ninf(Dinv * Px)) * cinv
-        eps_dual = eps_abs + eps_rel * mr
-        prim_ok = pri_res < eps_prim
-        dual_ok = dua_res < eps_dual
-        # is_primal_infeasible, auxil.c:362-424
-        upinf = usc.astype(np.float64) > INFTY * MIN_SCALING
-        lninf = lsc.astype(np.float64) < -INFTY * MIN_SCALING
-        dyp = np.where(upinf & lninf, T(0), np.where(upinf, np.minimum(dy, T(0)), np.where(lninf, np.maximum(dy, T(0)), dy)))
-        norm_dy = ninf(dyp * E)
-        lhs = np.zeros(B, dtype)
-        with np.errstate(invalid="ignore", over="ignore"):
-            for i in range(m):
-                lhs = lhs + (usc[i] * np.maximum(dyp[i], T(0)) + lsc[i] * np.minimum(dyp[i], T(0)))
-            pinf = (norm_dy > eps_pinf) & (lhs < -eps_pinf * norm_dy) & (ninf(At_mul(dyp) * Dinv) < eps_pinf * norm_dy)
-        # is_dual_infeasible, auxil.c:426-512
-        norm_dx = ninf(D * dx)
-        qdx = np.zeros(B, dtype)
-        for j in range(n):
-            qdx = qdx + qs[j] * dx[j]
-        Adx = A_mul(dx) * Einv
-        thr = eps_dinf * norm_dx
-        viol = ((usc.astype(np.float64) < INFTY * MIN_SCALING) & (Adx > thr)) | \
-               ((lsc.astype(np.float64) > -INFTY * MIN_SCALING) & (Adx < -thr))
-        dinf = (norm_dx > eps_dinf) & (qdx < -c * eps_dinf * norm_dx) & \
-               (ninf(P_mul(dx) * Dinv) < c * eps_dinf * norm_dx) & ~viol.any(0)
-        pinf = pinf & ~prim_ok
-        dinf = dinf & ~dual_ok
-        code = np.where(prim_ok & dual_ok, SOLVED_INACC if approx else SOLVED,
-                        np.where(pinf, PINF_INACC if approx else PINF,
-                                 np.where(dinf, DINF_INACC if approx else DINF, 0)))
-        return code
-    with np.errstate(invalid="ignore"):
-        ncvx = (pri_res.astype(np.float64) > INFTY) | (dua_res.astype(np.float64) > INFTY)
+    pri_res, dua_res, ncvx, term = evaluate(x, y, z, dx, dy)
     s1 = term(False)
     s2 = term(True)
     status = np.where(ncvx, NON_CVX, np.where(s1 != 0, s1, np.where(s2 != 0, s2, MAX_ITER))).astype(np.int32)
@@ -315,4 +333,4 @@ def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, setting
     y = np.where(bad, T(0), y)
     z = np.where(bad, T(0), z)
     return dict(x=x, y=y, z=z, E=E, D=D, c=c, sol_x=sol_x, sol_y=sol_y, status=status, pri_res=pri_res,
-                dua_res=dua_res, L=Lx, Dinv=Ddinv, L_i=L_i, L_p=L_p, As=As, Ps=Ps, qs=qs, rho=rho)
+                dua_res=dua_res, L=Lx, Dinv=Ddinv, L_i=L_i, L_p=L_p, As=As, Ps=Ps, qs=qs, rho=rho, iters=iters)

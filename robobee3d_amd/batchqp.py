@@ -52,7 +52,7 @@ class BatchQP:
         z = lambda r, dt=dtype: torch.zeros((max(r, 1), self.B), dtype=dt, device=self.device)
         self.x, self.y, self.z = z(n), z(m), z(m)
         self.Eprev = torch.ones((m, self.B), dtype=dtype, device=self.device)
-        self.sol_x, self.sol_y, self.info = z(n), z(m), z(4)
+        self.sol_x, self.sol_y, self.info = z(n), z(m), z(5)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         if os.environ.get("UMPC_QP_KERNEL"):      # diagnostics: wave | lane | tables
             self.set_kernel(os.environ["UMPC_QP_KERNEL"])
@@ -92,6 +92,14 @@ class BatchQP:
         if t.dtype != self.dtype or t.device != self.device or tuple(t.shape) != (rows, self.B) or not t.is_contiguous():
             raise ValueError("%s must be a contiguous [%d, %d] %s tensor on %s" % (name, rows, self.B, self.dtype, self.device))
         return t
+
+    def set_termination(self, check_every=25, max_iter=4000):
+        """pip-osqp semantics (template_controllers.py:190-191,216-219): test the termination criteria at the exact
+        tolerances every `check_every` iterations and stop a robot when one is met; check_every = 0 restores the
+        embedded reference's fixed iteration count. `self.info[4]` reports the iterations each robot ran."""
+        if self.L.umpcQPSetCheckTermination(self.h, int(check_every)) != 0 or \
+                self.L.umpcQPSetMaxIter(self.h, int(max_iter)) != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
 
     def solve(self, Pv, Av, q, l, u, max_iter=None):
         """One canonical-restart step on raw data; returns (sol_x, sol_y, status) (views of this object's buffers)."""

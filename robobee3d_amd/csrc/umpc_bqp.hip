@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
     for (int j = 0; j < n; ++j) WR(R_XP, j) = IN(a.x, j);
     for (int i = 0; i < m; ++i) WR(R_DY, i) = T(0.0);
   }
-  for (int it = 0; it < a.max_iter; ++it) {
+  auto admm_iteration = [&]() {
     // compute_rhs (auxil.c:164-178), permuted on the fly
     for (int j = 0; j < n; ++j) {
       const T xp = IN(a.x, j);
@@ -194,71 +194,75 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
       WR(R_DY, i) = dy;
       IN(a.y, i) = yi + dy;
     }
-  }
+  };
 
-  // ---- update_info / check_termination (auxil.c:243-362, 684-789) ----
-  // T3 <- Ax (scaled), then primal residual and tolerance
-  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);
-  for (int i = 0; i < m; ++i) {
-    T acc = T(0.0);
-    for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) acc += WR(R_AS, Ar_k[p]) * IN(a.x, Ar_j[p]);
-    WR(R_T3, i) = acc;
-    const T einv = T(1.0) / WR(R_E, i), zi = IN(a.z, i);
-    pri_res = qmax(pri_res, qabs(einv * (acc - zi)));
-    nz = qmax(nz, qabs(einv * zi));
-    nAx = qmax(nAx, qabs(einv * acc));
-  }
-  // T1 <- Px, T2 <- A'y, dual residual and tolerance
-  T dua_res = T(0.0), nq = T(0.0), nAty = T(0.0), nPx = T(0.0);
-  for (int j = 0; j < n; ++j) {
-    const int kp = pidx[j];
-    T px = T(0.0);
-    if (kp >= 0) px += WR(R_PS, kp) * IN(a.x, j);
-    T aty = T(0.0);
-    for (int p = A_p[j]; p < A_p[j + 1]; ++p) aty += WR(R_AS, p) * IN(a.y, A_i[p]);
-    WR(R_T1, j) = px; WR(R_T2, j) = aty;
-    const T dinv = T(1.0) / WR(R_D, j), qj = WR(R_QS, j);
-    dua_res = qmax(dua_res, qabs(dinv * ((qj + px) + aty)));
-    nq = qmax(nq, qabs(dinv * qj)); nAty = qmax(nAty, qabs(dinv * aty)); nPx = qmax(nPx, qabs(dinv * px));
-  }
-  dua_res = cinv * dua_res;
-  const T dual_rel = qmax(qmax(nq, nAty), nPx) * cinv, prim_rel = qmax(nz, nAx);
+  // ---- update_info (auxil.c:243-307) + the tolerance-independent parts of the infeasibility certificates
+  //      (auxil.c:362-512); decide(k) is check_termination (auxil.c:684-789) at k x the tolerances ----
+  T pri_res = T(0.0), dua_res = T(0.0), dual_rel = T(0.0), prim_rel = T(0.0);
+  T norm_dy = T(0.0), ineq_lhs = T(0.0), nAtdy = T(0.0), norm_dx = T(0.0), qdx = T(0.0), nPdx = T(0.0);
+  auto update_info = [&]() {
+    // T3 <- Ax (scaled), then primal residual and tolerance
+    pri_res = T(0.0); T nz = T(0.0), nAx = T(0.0);
+    for (int i = 0; i < m; ++i) {
+      T acc = T(0.0);
+      for (int p = Ar_p[i]; p < Ar_p[i + 1]; ++p) acc += WR(R_AS, Ar_k[p]) * IN(a.x, Ar_j[p]);
+      WR(R_T3, i) = acc;
+      const T einv = T(1.0) / WR(R_E, i), zi = IN(a.z, i);
+      pri_res = qmax(pri_res, qabs(einv * (acc - zi)));
+      nz = qmax(nz, qabs(einv * zi));
+      nAx = qmax(nAx, qabs(einv * acc));
+    }
+    // T1 <- Px, T2 <- A'y, dual residual and tolerance
+    dua_res = T(0.0); T nq = T(0.0), nAty = T(0.0), nPx = T(0.0);
+    for (int j = 0; j < n; ++j) {
+      const int kp = pidx[j];
+      T px = T(0.0);
+      if (kp >= 0) px += WR(R_PS, kp) * IN(a.x, j);
+      T aty = T(0.0);
+      for (int p = A_p[j]; p < A_p[j + 1]; ++p) aty += WR(R_AS, p) * IN(a.y, A_i[p]);
+      WR(R_T1, j) = px; WR(R_T2, j) = aty;
+      const T dinv = T(1.0) / WR(R_D, j), qj = WR(R_QS, j);
+      dua_res = qmax(dua_res, qabs(dinv * ((qj + px) + aty)));
+      nq = qmax(nq, qabs(dinv * qj)); nAty = qmax(nAty, qabs(dinv * aty)); nPx = qmax(nPx, qabs(dinv * px));
+    }
+    dua_res = cinv * dua_res;
+    dual_rel = qmax(qmax(nq, nAty), nPx) * cinv; prim_rel = qmax(nz, nAx);
 
-  // infeasibility certificates: quantities shared by the exact and the 10x-relaxed check
-  // is_primal_infeasible (auxil.c:362-424): project delta_y on the polar of the recession cone
-  T norm_dy = T(0.0), ineq_lhs = T(0.0);
-  for (int i = 0; i < m; ++i) {
-    const T us = WR(R_US, i), ls = WR(R_LS, i);
-    T dy = WR(R_DY, i);
-    const bool up = (double)us > QP_INFTY * QP_MIN_SCALING, lo = (double)ls < -QP_INFTY * QP_MIN_SCALING;
-    if (up) dy = lo ? T(0.0) : qmin(dy, T(0.0));
-    else if (lo) dy = qmax(dy, T(0.0));
-    WR(R_DY, i) = dy;
-    norm_dy = qmax(norm_dy, qabs(dy * WR(R_E, i)));
-    ineq_lhs += us * qmax(dy, T(0.0)) + ls * qmin(dy, T(0.0));
-  }
-  T nAtdy = T(0.0);
-  for (int j = 0; j < n; ++j) {
-    T acc = T(0.0);
-    for (int p = A_p[j]; p < A_p[j + 1]; ++p) acc += WR(R_AS, p) * WR(R_DY, A_i[p]);
-    nAtdy = qmax(nAtdy, qabs(acc * (T(1.0) / WR(R_D, j))));
-  }
-  // is_dual_infeasible (auxil.c:426-512)
-  T norm_dx = T(0.0), qdx = T(0.0), nPdx = T(0.0);
-  for (int j = 0; j < n; ++j) {
-    const T dx = IN(a.x, j) - WR(R_XP, j);
-    WR(R_T1, j) = dx;
-    norm_dx = qmax(norm_dx, qabs(WR(R_D, j) * dx));
-    qdx += WR(R_QS, j) * dx;
-    const int kp = pidx[j];
-    T pdx = T(0.0);
-    if (kp >= 0) pdx += WR(R_PS, kp) * dx;
-    nPdx = qmax(nPdx, qabs(pdx * (T(1.0) / WR(R_D, j))));
-  }
-  int status = -10;  // OSQP_UNSOLVED
-  if (((double)pri_res > QP_INFTY) || ((double)dua_res > QP_INFTY)) status = -7;  // OSQP_NON_CVX
-  for (int approx = 0; approx < 2 && status == -10; ++approx) {
-    const T k = approx ? T(10) : T(1);
+    // infeasibility certificates: quantities shared by the exact and the 10x-relaxed check
+    // is_primal_infeasible (auxil.c:362-424): project delta_y on the polar of the recession cone
+    norm_dy = T(0.0); ineq_lhs = T(0.0);
+    for (int i = 0; i < m; ++i) {
+      const T us = WR(R_US, i), ls = WR(R_LS, i);
+      T dy = WR(R_DY, i);
+      const bool up = (double)us > QP_INFTY * QP_MIN_SCALING, lo = (double)ls < -QP_INFTY * QP_MIN_SCALING;
+      if (up) dy = lo ? T(0.0) : qmin(dy, T(0.0));
+      else if (lo) dy = qmax(dy, T(0.0));
+      WR(R_DY, i) = dy;
+      norm_dy = qmax(norm_dy, qabs(dy * WR(R_E, i)));
+      ineq_lhs += us * qmax(dy, T(0.0)) + ls * qmin(dy, T(0.0));
+    }
+    nAtdy = T(0.0);
+    for (int j = 0; j < n; ++j) {
+      T acc = T(0.0);
+      for (int p = A_p[j]; p < A_p[j + 1]; ++p) acc += WR(R_AS, p) * WR(R_DY, A_i[p]);
+      nAtdy = qmax(nAtdy, qabs(acc * (T(1.0) / WR(R_D, j))));
+    }
+    // is_dual_infeasible (auxil.c:426-512)
+    norm_dx = T(0.0); qdx = T(0.0); nPdx = T(0.0);
+    for (int j = 0; j < n; ++j) {
+      const T dx = IN(a.x, j) - WR(R_XP, j);
+      WR(R_T1, j) = dx;
+      norm_dx = qmax(norm_dx, qabs(WR(R_D, j) * dx));
+      qdx += WR(R_QS, j) * dx;
+      const int kp = pidx[j];
+      T pdx = T(0.0);
+      if (kp >= 0) pdx += WR(R_PS, kp) * dx;
+      nPdx = qmax(nPdx, qabs(pdx * (T(1.0) / WR(R_D, j))));
+    }
+  };
+  auto decide = [&](T k) -> int {
+    if (((double)pri_res > QP_INFTY) || ((double)dua_res > QP_INFTY)) return -7;  // OSQP_NON_CVX
+    const bool approx = k > T(1);
     const T eps_abs = a.eps_abs * k, eps_rel = a.eps_rel * k, eps_pinf = a.eps_pinf * k, eps_dinf = a.eps_dinf * k;
     const bool prim_ok = pri_res < eps_abs + eps_rel * prim_rel;
     const bool dual_ok = dua_res < eps_abs + eps_rel * dual_rel;
@@ -276,9 +280,35 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
           dinf = false;
       }
     }
-    if (prim_ok && dual_ok) status = approx ? 2 : 1;
-    else if (pinf) status = approx ? 3 : -3;
-    else if (dinf) status = approx ? 4 : -4;
+    if (prim_ok && dual_ok) return approx ? 2 : 1;
+    if (pinf) return approx ? 3 : -3;
+    if (dinf) return approx ? 4 : -4;
+    return -10;  // OSQP_UNSOLVED
+  };
+
+  // Main loop (osqp.c:354-450). check_termination == 0 (the embedded reference, uprightmpc2.c:116-117): exactly
+  // max_iter iterations. check_termination = k > 0 (pip-osqp semantics of the reference's Python twin,
+  // template_controllers.py:190-191,216-219): every k-th iteration update_info + check_termination(exact); a robot
+  // that meets a criterion stops iterating (per-lane mask), the wave leaves the loop when all of its robots have.
+  int status = -10, iters = 0;
+  bool info_fresh = false;
+  for (int it = 1; it <= a.max_iter; ++it) {
+    if (status == -10) {
+      admm_iteration();
+      iters = it;
+      info_fresh = false;
+      if (a.check_termination > 0 && it % a.check_termination == 0) {
+        update_info();
+        info_fresh = true;
+        status = decide(T(1));
+      }
+    }
+    if (a.check_termination > 0 && __all(status != -10)) break;
+  }
+  // osqp.c:524-573: info + exact check if the last iteration did not do them, then the approximate check
+  if (status == -10) {
+    if (!info_fresh) { update_info(); status = decide(T(1)); }
+    if (status == -10) status = decide(T(10));
   }
   if (status == -10) status = -2;  // OSQP_MAX_ITER_REACHED
   (void)fail;
@@ -294,7 +324,7 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
     if (bad) { IN(a.y, i) = T(0.0); IN(a.z, i) = T(0.0); }
   }
   if (a.status) a.status[b] = status;
-  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); }
+  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(iters); }
 #undef WR
 #undef WROW
 #undef IN
@@ -758,9 +788,11 @@ int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, con
   a.eps_abs = T(h->st.eps_abs); a.eps_rel = T(h->st.eps_rel);
   a.eps_pinf = T(h->st.eps_prim_inf); a.eps_dinf = T(h->st.eps_dual_inf);
   a.max_iter = h->st.max_iter; a.scaling = h->st.scaling;
-  if (h->wave && !h->use_tables) {
+  a.check_termination = h->st.check_termination;
+  const bool tables = h->use_tables || h->st.check_termination > 0;   // early termination lives in the table kernel
+  if (h->wave && !tables) {
     hipLaunchKernelGGL(bqp_wave_kernel<T>, dim3(h->B), dim3(64), h->wave_lds * sizeof(T), s, a);
-  } else if (h->fixed >= 0 && !h->use_tables) {
+  } else if (h->fixed >= 0 && !tables) {
     if constexpr (sizeof(T) == 4) kFixedKernels[h->fixed].f32(a, s);
     else kFixedKernels[h->fixed].f64(a, s);
   } else {
@@ -800,6 +832,7 @@ void umpcQPDefaultSettings(umpcQPSettings *s) {
   s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6;
   s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
   s->max_iter = 50; s->scaling = 10;
+  s->check_termination = 0;
 }
 
 void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpcQPSettings *st) {
@@ -923,7 +956,7 @@ int umpcQPSetKernel(void *hv, int mode) {
 const char *umpcQPKernelName(void *hv) {
   qp_batch *h = (qp_batch *)hv;
   if (!h) return "";
-  if (h->use_tables) return "tables";
+  if (h->use_tables || h->st.check_termination > 0) return "tables";
   if (h->wave) return "wave";
   return h->fixed >= 0 ? kFixedKernels[h->fixed].name : "tables";
 }
@@ -932,6 +965,13 @@ int umpcQPSetMaxIter(void *hv, int max_iter) {
   qp_batch *h = (qp_batch *)hv;
   if (!h || max_iter < 0) { umpc_set_error("umpcQPSetMaxIter: bad argument"); return -1; }
   h->st.max_iter = max_iter;
+  return 0;
+}
+
+int umpcQPSetCheckTermination(void *hv, int every) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h || every < 0) { umpc_set_error("umpcQPSetCheckTermination: bad argument"); return -1; }
+  h->st.check_termination = every;
   return 0;
 }
 

@@ -85,16 +85,22 @@ class WLCon:
 class UprightMPC2:
     """Twin of the pure-Python class template_controllers.UprightMPC2(N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf,
     wthrust, wmom, Ib) (template/template_controllers.py:170-258): any horizon N, fp64, one robot, on the
-    general-structure solver (robobee3d_amd.batchqp.UprightMPC2N with B = 1). The reference solves with pip osqp to
-    eps 1e-4; here the solve is the embedded step with `maxIter` fixed iterations (default 50, the C path's count)."""
+    general-structure solver (robobee3d_amd.batchqp.UprightMPC2N with B = 1).
 
-    def __init__(self, N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, maxIter=50):
+    Solve semantics = the reference's: `osqp.OSQP().setup(..., eps_rel=1e-4, eps_abs=1e-4)` + `solve()`
+    (template_controllers.py:190-191, 216-219), i.e. pip-osqp defaults -- iterate until the termination criteria
+    hold at eps 1e-4, tested every 25 iterations, at most 4000 -- and a message when the status is not "solved"
+    (:218-219). pip osqp's adaptive_rho is not reproduced (its schedule depends on wall-clock timings), so the
+    iterate path differs from pip osqp's while the converged solution is the same QP optimum to eps.
+    maxIter = k gives the embedded C path's semantics instead (exactly k iterations, uprightmpc2.c:116-117)."""
+
+    def __init__(self, N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, maxIter=None):
         import torch
         from .batchqp import UprightMPC2N
         self.N, self._torch = N, torch
+        st = dict(max_iter=maxIter) if maxIter is not None else dict(max_iter=4000, check_termination=25)
         self._mpc = UprightMPC2N(1, N, dt=dt, g=g, TtoWmax=TtoWmax, ws=ws, wds=wds, wpr=wpr, wpf=wpf, wvr=wvr, wvf=wvf,
-                                 wthrust=wthrust, wmom=wmom, Ib=tuple(float(v) for v in Ib), dtype=torch.float64,
-                                 max_iter=maxIter)
+                                 wthrust=wthrust, wmom=wmom, Ib=tuple(float(v) for v in Ib), dtype=torch.float64, **st)
 
     @property
     def T0(self):
@@ -111,6 +117,12 @@ class UprightMPC2:
         out = self._mpc.update(torch.as_tensor(np.ascontiguousarray(st)).to(dev), torch.as_tensor(np.ascontiguousarray(rf)).to(dev),
                                aT0).cpu().numpy()[:, 0]
         self.prevsol = self._mpc.qp.sol_x.cpu().numpy()[:, 0]
+        self.status_val = int(self._mpc.qp.status[0].item())
+        self.iterations = int(self._mpc.qp.info[4, 0].item())
+        if self.status_val not in (1, 2):     # template_controllers.py:218-219
+            print({-2: "maximum iterations reached", -3: "primal infeasible", 3: "primal infeasible inaccurate",
+                   -4: "dual infeasible", 4: "dual infeasible inaccurate", -7: "problem non convex"}.get(
+                       self.status_val, "status %d" % self.status_val))
         return out[0:3].copy(), out[3:9].copy()
 
 

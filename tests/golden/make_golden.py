@@ -113,9 +113,9 @@ def nan_branch():
     then recovery calls that override the (now garbage) thrust accumulator through actualT0."""
     rng = np.random.default_rng(14)
     ins = gen_inputs(rng, 12)
-    for k in (4, 9):
+    for k, big in ((4, 1e33), (9, 1e35)):   # primal residual 5e30 and 6e31: clear of the 1e30 threshold in fp32
         p0, R0, dq0, pdes, dpdes, sdes, aT0 = ins[k]
-        ins[k] = (p0 * 0 + np.array([1e33, -2e33, 0.0]), R0, dq0, pdes, dpdes, sdes, aT0)
+        ins[k] = (p0 * 0 + np.array([big, -2 * big, 0.0]), R0, dq0, pdes, dpdes, sdes, aT0)
         p0, R0, dq0, pdes, dpdes, sdes, aT0 = ins[k + 1]
         ins[k + 1] = (p0, R0, dq0, pdes, dpdes, sdes, 0.0098)   # T0 <- actualT0 (uprightmpc2.c:215-216)
     sequence(0, len(ins), 50, "nan_branch.npz", inputs=ins)
@@ -398,8 +398,36 @@ def planar_p5f():
         Ad, Bd = ns["getLin"](a, b, c)
         Ads.append(np.asarray(Ad))
         Bds.append(np.asarray(Bd).ravel())
+    # F6: the QP data of :87-147. Every top-level statement between getLin and the tick loop is executed where it
+    # lies, one at a time; the three that cannot run here are skipped and reported: `P = sp.linalg.block_diag([..])`
+    # (:116, ValueError under this scipy: a list is passed), `prob = osqp.OSQP()` and `prob.setup(...)` (pip osqp
+    # absent). P's diagonal follows from the evaluated Q, QN, R (kron(eye(N), Q) | QN | kron(eye(N), R), :116-117).
+    import scipy as sp
+    import scipy.linalg  # noqa: F401
+    ns2 = dict(ns)
+    ns2.update(sp=sp, sys=sys)
+    seen_getlin, skipped = False, []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "getLin":
+            seen_getlin = True
+            continue
+        if not seen_getlin or isinstance(node, (ast.Import, ast.ImportFrom)):
+            continue
+        if isinstance(node, ast.For):
+            break
+        try:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns2)
+        except Exception as ex:
+            skipped.append("line %d: %s" % (node.lineno, type(ex).__name__))
+    qp = {k: np.asarray(ns2[k], np.float64) for k in ("Q", "QN", "R", "y0", "yr", "q", "leq", "ueq", "lineq", "uineq",
+                                                        "l", "u", "Aineq", "Ax", "Bu", "Aeq", "A", "xmin", "xmax",
+                                                        "umin", "umax")}
+    assert "P" not in ns2 and len(skipped) == 3, skipped
     np.savez_compressed(os.path.join(HERE, "planar_p5f.npz"), dt=ns["dt"], tf=ns["tf"], mb=ns["mb"], ib=ns["ib"],
-                        lin_u=us, lin_sigma=sg, lin_phi=ph, lin_Ad=np.stack(Ads), lin_Bd=np.stack(Bds))
+                        lin_u=us, lin_sigma=sg, lin_phi=ph, lin_Ad=np.stack(Ads), lin_Bd=np.stack(Bds),
+                        N=np.int32(ns2["N"]), nx=np.int32(ns2["nx"]), nu=np.int32(ns2["nu"]),
+                        skipped=np.array(skipped), **{"qp_" + k: v for k, v in qp.items()})
+    print("  F6: q %s l %s u %s A %s; skipped %s" % (qp["q"].shape, qp["l"].shape, qp["u"].shape, qp["A"].shape, skipped))
     print("planar_p5f.npz: %d getLin samples; Ad non-zeros at" % len(us),
           sorted(set(zip(*[a.tolist() for a in np.nonzero(np.abs(np.stack(Ads)).sum(0))]))))
 

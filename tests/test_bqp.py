@@ -113,6 +113,41 @@ def test_p5f_structure_reproduces_the_kron_construction():
     assert st["P_cols"] == [j for j in range(87) if (j < 77 and j % 7 in (1, 2, 3)) or j >= 77]
 
 
+def test_p5f_qp_data_is_the_reference_scripts(structure):
+    """q, l, u, the dense A at getLin(0, 0, 0) and the weights of planar/mpc_osqp_p5f.py:87-147,
+    evaluated from the script where it lies (tests/golden/make_golden.py planar_p5f), against p5f_structure()."""
+    from robobee3d_amd.batchqp import p5f_structure, OSQP_INFTY
+    g = golden("planar_p5f.npz")
+    N, nx, nu = int(g["N"]), int(g["nx"]), int(g["nu"])
+    st = p5f_structure(N)
+    assert (st["n"], st["m"]) == g["qp_A"].shape[::-1] == (87, 164)
+    np.testing.assert_array_equal(st["q"], g["qp_q"])
+    # the script's +-inf box rows reach OSQP as +-OSQP_INFTY (osqp's Python interface clips them at setup)
+    np.testing.assert_array_equal(st["l"], np.maximum(g["qp_l"], -OSQP_INFTY))
+    np.testing.assert_array_equal(st["u"], np.minimum(g["qp_u"], OSQP_INFTY))
+    # P = block_diag(kron(eye(N), Q), QN, kron(eye(N), R)) (:116-117; the statement itself cannot run under this
+    # scipy, its operands are the evaluated Q, QN, R)
+    Pdiag = np.hstack([np.tile(np.diag(g["qp_Q"]), N), np.diag(g["qp_QN"]), np.full(N * nu, float(g["qp_R"]))])
+    Pfull = np.zeros(st["n"])
+    Pfull[st["P_cols"]] = st["Pv"]
+    np.testing.assert_array_equal(Pfull, Pdiag)
+    assert np.count_nonzero(g["qp_Q"] - np.diag(np.diag(g["qp_Q"]))) == 0
+    # A: the script's dense kron construction at the LTI point == our pattern filled with getLin(0, 0, 0)
+    k0 = int(np.nonzero((g["lin_u"] == 0) & (np.signbit(g["lin_u"]) == False))[0][0])   # noqa: E712
+    Ad, Bd = None, None
+    A = np.zeros((st["m"], st["n"]))
+    lin0 = None
+    # getLin(0, 0, 0): entries (4,3), (5,3) of Ad and Bd[4:7] -- recover them from the script's own A
+    Ascr = g["qp_A"]
+    lin0 = np.array([Ascr[nx + 4, 3], Ascr[nx + 5, 3], Ascr[nx + 4, (N + 1) * nx], Ascr[nx + 5, (N + 1) * nx],
+                     Ascr[nx + 6, (N + 1) * nx]])
+    for j in range(st["n"]):
+        for p in range(st["A_p"][j], st["A_p"][j + 1]):
+            A[st["A_i"][p], j] = st["cst"][p] if st["src"][p] < 0 else st["cst"][p] * lin0[st["src"][p]]
+    np.testing.assert_array_equal(A, Ascr)
+    assert list(g["skipped"]) == ["line 116: ValueError", "line 136: NameError", "line 147: NameError"]
+
+
 def test_table_oracle_converges_on_v1_and_p5f():
     """Self-consistency of the oracle on the two unpinned problems: run long, KKT residuals vanish."""
     import osqp_table
@@ -135,6 +170,46 @@ def test_table_oracle_converges_on_v1_and_p5f():
                 A[st["A_i"][p], j] = g["Adata"][kk][p]
         Ax = A @ x[:, c]
         assert np.all(Ax >= g["l"][kk] - 1e-5) and np.all(Ax <= g["u"][kk] + 1e-5)
+
+
+def _tiny_infeasible_qps():
+    """(name, n, m, A_p, A_i, P_cols, Pv, Av, q, l, u, expected status): primal infeasible -- x0 >= 1 and x0 <= 0;
+    dual infeasible -- min -x1 with x1 >= 0 only and no curvature in x1 (auxil.c:362-512)."""
+    inf = 1e30
+    pinf = ("primal infeasible", 2, 3, [0, 2, 3], [0, 1, 2], [0, 1], [1.0, 1.0], [1.0, 1.0, 1.0], [0.0, 0.0],
+            [1.0, -inf, -1.0], [inf, 0.0, 1.0], -3)
+    dinf = ("dual infeasible", 2, 2, [0, 1, 2], [0, 1], [0], [1.0], [1.0, 1.0], [0.0, -1.0],
+            [-1.0, 0.0], [1.0, inf], -4)
+    return [pinf, dinf]
+
+
+def test_table_oracle_termination_mode_and_certificates():
+    """check_termination = k: robots stop at the first multiple of k where a criterion holds (osqp.c:411-450), the
+    frozen iterate is the fixed-count iterate at that count; the certificates fire on the two tiny infeasible QPs
+    (status -3 / -4, NaN solution, cold-started iterates: auxil.c:539-564)."""
+    import osqp_table
+    g = golden("seq_iter50.npz")
+    idx = np.arange(16)
+    A_p, A_i, Pv, Av, q, l, u = raw_uprightmpc2_qp(g, idx, np.float64)
+    st = golden("structure.npz")
+    z = lambda r: np.zeros((r, len(idx)))
+    args = (45, 39, A_p, A_i, list(range(45)), st["perm"], Pv, Av, q, l, u, z(45), z(39), z(39), np.ones((39, len(idx))))
+    r = osqp_table.solve(*args, osqp_table.Settings(max_iter=4000, check_termination=25))
+    # (fixed rho: pip osqp's adaptive rho is not reproduced, so a few robots need thousands of iterations and the
+    # slowest end "solved inaccurate" at max_iter)
+    assert np.all(np.isin(r["status"], (1, 2))) and np.all(r["iters"] % 25 == 0) and len(set(r["iters"])) > 2
+    assert np.all((r["status"] == 1) == (r["iters"] < 4000)) and np.count_nonzero(r["status"] == 1) >= 12
+    for k in (0, 7):
+        one = [a[:, k:k + 1] if isinstance(a, np.ndarray) and a.ndim == 2 else a for a in args]
+        rf = osqp_table.solve(*one, osqp_table.Settings(max_iter=int(r["iters"][k])))
+        assert np.array_equal(rf["x"][:, 0], r["x"][:, k]) and rf["status"][0] == 1
+    for name, n, m, Ap, Ai, Pc, Pv, Av, q, l, u, want in _tiny_infeasible_qps():
+        c = lambda a: np.array(a, np.float64)[:, None]
+        r = osqp_table.solve(n, m, Ap, Ai, Pc, list(range(n + m)), c(Pv), c(Av), c(q), c(l), c(u), np.zeros((n, 1)),
+                             np.zeros((m, 1)), np.zeros((m, 1)), np.ones((m, 1)),
+                             osqp_table.Settings(max_iter=4000, check_termination=25))
+        assert r["status"][0] == want, (name, r["status"], r["iters"])
+        assert np.isnan(r["sol_x"]).all() and not r["x"].any() and not r["y"].any() and r["iters"][0] < 4000
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -488,20 +563,28 @@ def test_gpu_table_kernel_on_a_large_structure_matches_oracle():
 def test_gpu_createMPC_pair_cross_check():
     """createMPC() returns (pyver, cver) like template_controllers.py:260-280, and the two agree on the reference's
     own cross-check inputs (template_controllers.py:303-320: identity attitude, random-ish state, 6-argument update)."""
-    from robobee3d_amd.uprightmpc2py import createMPC
+    from robobee3d_amd.uprightmpc2py import createMPC, UprightMPC2
     up, upc = createMPC()
     p = np.array([0.0, 0, 0])
     R0 = np.eye(3)
     dq = np.array([0.1, 0, 0, 0, 0, 0.0])
     pdes, dpdes, sdes = np.array([0.0, 0, 10]), np.array([0.0, 0, 0.05]), np.array([0.0, 0, 1])
+    # the twin with the C path's semantics (exactly 50 iterations) tracks the compiled-C twin call by call
+    up50 = UprightMPC2(3, 5, 9.81e-3, 2, 1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2, np.array([3333.0, 3333.0, 1000.0]), maxIter=50)
     for _ in range(3):
-        u1, a1 = up.update(p, R0, dq, pdes, dpdes, sdes, -1.0)
+        u1, a1 = up50.update(p, R0, dq, pdes, dpdes, sdes, -1.0)
         u2, a2 = upc.update(p, R0, dq, pdes, dpdes, sdes)
         assert abs(u1[0] - u2[0]) <= 3e-5 and np.all(np.abs(u1[1:] - u2[1:]) <= np.maximum(2e-2, 1e-3 * np.abs(u2[1:])))
         assert np.all(np.abs(a1 - a2) <= 3e-5)
+    # the default twin has the reference's semantics (template_controllers.py:190-191,216-219): solve() runs to the
+    # termination criteria at eps 1e-4, checked every 25 iterations
+    for _ in range(3):
+        u1, a1 = up.update(p, R0, dq, pdes, dpdes, sdes, -1.0)
+        assert up.status_val in (1, 2) and up.iterations % 25 == 0 and 25 <= up.iterations <= 4000
+        assert np.isfinite(u1).all() and np.isfinite(a1).all()
     up5, _ = createMPC(N=5)
     u5, a5 = up5.update(p, R0, dq, pdes, dpdes, sdes)
-    assert np.isfinite(u5).all() and np.isfinite(a5).all() and up5.prevsol.shape == (75,)
+    assert np.isfinite(u5).all() and np.isfinite(a5).all() and up5.prevsol.shape == (75,) and up5.status_val in (1, 2)
 
 
 @pytest.mark.gpu
@@ -546,3 +629,81 @@ def test_gpu_wave_kernel_agrees_with_lane_kernels():
                 assert np.all(np.abs(outs[0][0] - outs[1][0]) <= 6e-5)
                 assert np.all(np.abs(outs[0][1:3] - outs[1][1:3]) <= 2 * np.maximum(2e-2, 1e-3 * np.abs(outs[1][1:3])))
                 assert np.all(np.abs(outs[0][3:] - outs[1][3:]) <= 6e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_eps_terminated_mode_matches_oracle(structure):
+    """check_termination = 25, max_iter = 4000 (pip-osqp defaults, the reference twin's solve()): per-robot early
+    exit. fp64: same statuses, same iteration counts, same iterates as the oracle run to the same criterion; fp32:
+    counts may differ by one check interval at a tolerance boundary."""
+    import osqp_table
+    from conftest import record_margin
+    g = golden("seq_iter50.npz")
+    idx = np.arange(96)
+    perm = structure["perm"]
+    A_p, A_i, Pv, Av, q, l, u = raw_uprightmpc2_qp(g, idx, np.float64)
+    Eprev = np.ones((39, len(idx)))
+    z = lambda r: np.zeros((r, len(idx)))
+    args = (Pv, Av, q, l, u, z(45), z(39), z(39), Eprev)
+    for dtype in (np.float64, np.float32):
+        import torch
+        from robobee3d_amd.batchqp import BatchQP
+        tdt = torch.float32 if dtype == np.float32 else torch.float64
+        ref = osqp_table.solve(45, 39, A_p, A_i, list(range(45)), perm, *args,
+                               osqp_table.Settings(max_iter=4000, check_termination=25), dtype=dtype)
+        qp = BatchQP(45, 39, A_p, A_i, list(range(45)), len(idx), tdt, perm=perm, max_iter=4000, check_termination=25)
+        assert qp.kernel_name == "tables"
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype)).cuda()
+        qp.solve(dev(Pv), dev(Av), dev(q), dev(l), dev(u))
+        it = qp.info[4].cpu().numpy().astype(int)
+        status = qp.status.cpu().numpy()
+        assert np.all(np.isin(status, (1, 2))) and np.all(it % 25 == 0) and len(set(it)) > 2
+        assert np.all((status == 1) == (it < 4000))
+        if dtype == np.float64:
+            assert np.array_equal(it, ref["iters"]) and np.array_equal(status, ref["status"])
+            np.testing.assert_allclose(qp.x.cpu().numpy(), ref["x"], rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(qp.sol_x.cpu().numpy(), ref["sol_x"], rtol=1e-9, atol=1e-11)
+        else:
+            ndiff = int(np.count_nonzero(it != ref["iters"]))
+            record_margin("eps-terminated mode fp32", "robots whose iteration count differs (of 96)", ndiff, 12)
+            assert ndiff <= 12 and np.abs(it - ref["iters"]).max() <= 25
+            same = it == ref["iters"]
+            sx = np.maximum(1.0, np.abs(ref["sol_x"][:, same]))
+            assert np.abs(qp.sol_x.cpu().numpy()[:, same] - ref["sol_x"][:, same]).max() / sx.max() < 2e-3
+        # set_termination(0) restores the fixed count
+        qp.set_termination(0, 50)
+        qp.reset()
+        qp.solve(dev(Pv), dev(Av), dev(q), dev(l), dev(u))
+        assert np.all(qp.info[4].cpu().numpy() == 50)
+
+
+@pytest.mark.gpu
+def test_gpu_infeasibility_certificates_nan_and_cold_start():
+    """The `!has_solution` path of the general solver on synthetic QPs (auxil.c:362-512, 539-564): primal / dual
+    infeasibility detected, NaN solution, iterates cold-started -- same status and same iteration count as the oracle."""
+    import torch
+    import osqp_table
+    from robobee3d_amd.batchqp import BatchQP
+    for name, n, m, Ap, Ai, Pc, Pv, Av, q, l, u, want in _tiny_infeasible_qps():
+        for dtype, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+            B = 70                      # one full wave + a ragged one; robot 3 gets a FEASIBLE variant of the data
+            c = lambda a: np.repeat(np.array(a, dtype)[:, None], B, 1)
+            lv, uv, qv = c(l), c(u), c(q)
+            if want == -3:
+                lv[0, 3] = -1.0         # x0 >= -1 and x0 <= 0: feasible
+            else:
+                uv[1, 3] = 5.0          # x1 <= 5: bounded
+            ref = osqp_table.solve(n, m, Ap, Ai, Pc, list(range(n + m)), c(Pv), c(Av), qv, lv, uv, np.zeros((n, B)),
+                                   np.zeros((m, B)), np.zeros((m, B)), np.ones((m, B)),
+                                   osqp_table.Settings(max_iter=4000, check_termination=25), dtype=dtype)
+            qp = BatchQP(n, m, Ap, Ai, Pc, B, tdt, perm=list(range(n + m)), max_iter=4000, check_termination=25)
+            dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype)).cuda()
+            qp.solve(dev(c(Pv)), dev(c(Av)), dev(qv), dev(lv), dev(uv))
+            st = qp.status.cpu().numpy()
+            assert np.array_equal(st, ref["status"]), (name, dtype, st[:5], ref["status"][:5])
+            assert st[0] == want and st[3] == 1
+            assert np.array_equal(qp.info[4].cpu().numpy().astype(int), ref["iters"])
+            sol = qp.sol_x.cpu().numpy()
+            assert np.isnan(sol[:, 0]).all() and np.isfinite(sol[:, 3]).all()
+            assert not qp.x[:, 0].any().item() and not qp.y[:, 0].any().item() and not qp.z[:, 0].any().item()
+            np.testing.assert_allclose(sol[:, 3], ref["sol_x"][:, 3], rtol=1e-4, atol=1e-5)
