@@ -289,9 +289,14 @@ typedef struct {
    * k > 0: the pip-osqp semantics of the reference's Python twin (template_controllers.py:190-191, 216-219;
    * osqp.c:411-450): every k-th iteration update_info + check_termination at the exact tolerances, a robot that
    * meets a criterion stops iterating (per-lane mask; osqp's default k = 25, max_iter = 4000). Runs on the
-   * table-driven kernel. adaptive_rho of pip osqp is NOT reproduced (its interval is derived from wall-clock
-   * timings, osqp.c:455-480, hence not reproducible). */
+   * table-driven kernel. */
   int check_termination;
+  /* 0 (default; the embedded reference has none): fixed rho. k > 0: adapt_rho (auxil.c:12-82, osqp.c:482-520,
+   * 1268-1330) every k iterations: rho <- rho sqrt(rel. primal / rel. dual residual) when it changes by more than
+   * 5x, rho_vec by constraint type, numeric refactorisation. pip osqp derives its interval from wall-clock timings
+   * (osqp.c:455-480: a multiple of check_termination), so any multiple of 25 is a behaviour the reference's
+   * Python twin can show; the twin here uses 25. */
+  int adaptive_rho_interval;
 } umpcQPSettings;
 /* the reference's generated settings (workspace.c) with umpcInit's max_iter = 50 (uprightmpc2.c:116-117) */
 void umpcQPDefaultSettings(umpcQPSettings *s);
@@ -300,6 +305,7 @@ void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpc
 void umpcQPDestroy(void *h);
 int umpcQPSetMaxIter(void *h, int max_iter);
 int umpcQPSetCheckTermination(void *h, int every);
+int umpcQPSetAdaptiveRho(void *h, int interval);
 /* For the structures known at build time (robobee3d_amd/codegen_qp.py: planar p5f N = 10, v1 N = 3, UprightMPC2
  * N = 5) umpcQPCreate selects a generated straight-line kernel (same arithmetic, literal indices). UseTables(1)
  * forces the table-driven kernel; returns the index of the specialisation or -1. KernelName: its name or "tables". */
@@ -316,8 +322,8 @@ const char *umpcQPKernelName(void *h);
  *   x [n], y [m], z [m]   OSQP's (scaled) iterates, warm start                                in/out
  *   Eprev [m]             E of the previous call (1 before the first), osqp.c:812-820          in/out
  *   sol_x [n], sol_y [m]  unscaled solution (NaN on an infeasibility status) or NULL           out
- *   status [B] int32 (OSQP codes) or NULL; info [5][B] = pri_res, dua_res, c, zero-pivot flag, iterations run
- *                         (the last row is written by the table-driven kernel only) or NULL
+ *   status [B] int32 (OSQP codes) or NULL; info [6][B] = pri_res, dua_res, c, zero-pivot flag, iterations run,
+ *                         rho updates, or NULL
  * Asynchronous on `stream`. */
 int umpcQPSolve(void *h, const void *Pv, const void *Av, const void *q, const void *l, const void *u, void *x,
                 void *y, void *z, void *Eprev, void *sol_x, void *sol_y, int32_t *status, void *info, void *stream);

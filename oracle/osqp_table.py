@@ -24,7 +24,7 @@ SOLVED, SOLVED_INACC, MAX_ITER, PINF, PINF_INACC, DINF, DINF_INACC, UNSOLVED, NO
 
 class Settings:
     def __init__(self, rho=0.1, sigma=1e-6, alpha=1.6, max_iter=50, scaling=10, eps_abs=1e-4, eps_rel=1e-4,
-                 eps_prim_inf=1e-4, eps_dual_inf=1e-4, check_termination=0):
+                 eps_prim_inf=1e-4, eps_dual_inf=1e-4, check_termination=0, adaptive_rho_interval=0):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -156,54 +156,59 @@ def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, setting
     lsc, usc = l * E, u * E
 
     # ---- KKT values + QDLDL_factor (qdldl.c:86-247), dynamic reach exactly as the reference
-    def kval(src):
-        if src[0] == 'P':
-            return (Ps[pidx[src[1]]] + sigma) if pidx[src[1]] >= 0 else np.full(B, sigma, dtype)
-        if src[0] == 'A':
-            return As[src[1]]
-        return -rinv[src[1]]
-    K_p, K_i, K_src, etree, L_p = sym.K_p, sym.K_i, sym.K_src, sym.etree, sym.L_p
-    nnzL = L_p[-1]
-    L_i = [0] * nnzL
-    Lx = np.zeros((nnzL, B), dtype)
-    Dd = np.zeros((nk, B), dtype)
-    Ddinv = np.zeros((nk, B), dtype)
-    yVals = np.zeros((nk, B), dtype)
-    yMark = [0] * nk
-    LNext = list(L_p[:-1])
-    for k in range(nk):
-        yIdx = []
-        for p in range(K_p[k], K_p[k + 1]):
-            bidx = K_i[p]
-            if bidx == k:
-                Dd[k] = kval(K_src[p])
-                continue
-            yVals[bidx] = kval(K_src[p])
-            nxt = bidx
-            if yMark[nxt] == 0:
-                yMark[nxt] = 1
-                buf = [nxt]
-                nxt = etree[bidx]
-                while nxt != -1 and nxt < k:
-                    if yMark[nxt] == 1:
-                        break
+    def factor(rinv):
+        def kval(src):
+            if src[0] == 'P':
+                return (Ps[pidx[src[1]]] + sigma) if pidx[src[1]] >= 0 else np.full(B, sigma, dtype)
+            if src[0] == 'A':
+                return As[src[1]]
+            return -rinv[src[1]]
+        K_p, K_i, K_src, etree, L_p = sym.K_p, sym.K_i, sym.K_src, sym.etree, sym.L_p
+        nnzL = L_p[-1]
+        L_i = [0] * nnzL
+        Lx = np.zeros((nnzL, B), dtype)
+        Dd = np.zeros((nk, B), dtype)
+        Ddinv = np.zeros((nk, B), dtype)
+        yVals = np.zeros((nk, B), dtype)
+        yMark = [0] * nk
+        LNext = list(L_p[:-1])
+        for k in range(nk):
+            yIdx = []
+            for p in range(K_p[k], K_p[k + 1]):
+                bidx = K_i[p]
+                if bidx == k:
+                    Dd[k] = kval(K_src[p])
+                    continue
+                yVals[bidx] = kval(K_src[p])
+                nxt = bidx
+                if yMark[nxt] == 0:
                     yMark[nxt] = 1
-                    buf.append(nxt)
-                    nxt = etree[nxt]
-                while buf:
-                    yIdx.append(buf.pop())
-        for cidx in reversed(yIdx):
-            tmp = LNext[cidx]
-            yv = yVals[cidx].copy()
-            for j in range(L_p[cidx], tmp):
-                yVals[L_i[j]] = yVals[L_i[j]] - Lx[j] * yv
-            L_i[tmp] = k
-            Lx[tmp] = yv * Ddinv[cidx]
-            Dd[k] = Dd[k] - yv * Lx[tmp]
-            LNext[cidx] += 1
-            yVals[cidx] = 0
-            yMark[cidx] = 0
-        Ddinv[k] = T(1.0) / Dd[k]
+                    buf = [nxt]
+                    nxt = etree[bidx]
+                    while nxt != -1 and nxt < k:
+                        if yMark[nxt] == 1:
+                            break
+                        yMark[nxt] = 1
+                        buf.append(nxt)
+                        nxt = etree[nxt]
+                    while buf:
+                        yIdx.append(buf.pop())
+            for cidx in reversed(yIdx):
+                tmp = LNext[cidx]
+                yv = yVals[cidx].copy()
+                for j in range(L_p[cidx], tmp):
+                    yVals[L_i[j]] = yVals[L_i[j]] - Lx[j] * yv
+                L_i[tmp] = k
+                Lx[tmp] = yv * Ddinv[cidx]
+                Dd[k] = Dd[k] - yv * Lx[tmp]
+                LNext[cidx] += 1
+                yVals[cidx] = 0
+                yMark[cidx] = 0
+            Ddinv[k] = T(1.0) / Dd[k]
+
+        return L_i, Lx, Ddinv
+    K_p, K_i, K_src, etree, L_p = sym.K_p, sym.K_i, sym.K_src, sym.etree, sym.L_p
+    L_i, Lx, Ddinv = factor(rinv)
 
     # ---- ADMM iterations (osqp.c:354-370)
     perm = sym.perm
@@ -287,6 +292,8 @@ def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, setting
     # robot that meets a criterion keeps its iterate from then on (the per-lane mask of the kernel)
     done = np.zeros(B, bool)
     iters = np.zeros(B, np.int32)
+    rho_cur = np.full(B, rho0, dtype)
+    rho_updates = np.zeros(B, np.int32)
     for it in range(st.max_iter):
         x0, y0, z0, dx0, dy0 = x, y, z, dx, dy
         xp, zp = x, z
@@ -321,6 +328,33 @@ def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, setting
             done = done | nc | (tf(False) != 0)
             if done.all():
                 break
+        if st.adaptive_rho_interval > 0 and (it + 1) % st.adaptive_rho_interval == 0:
+            # adapt_rho / compute_rho_estimate (auxil.c:12-82) on the SCALED residual vectors, osqp_update_rho
+            # (osqp.c:1268-1330): rho_vec by constraint type, KKT refactor; robots that are done keep theirs
+            ninf_ = lambda v: np.max(np.abs(v), axis=0) if v.shape[0] else np.zeros(B, dtype)
+            Ax_ = np.zeros((m, B), dtype); Aty_ = np.zeros((n, B), dtype); Px_ = np.zeros((n, B), dtype)
+            for j in range(n):
+                for p in range(A_p[j], A_p[j + 1]):
+                    Ax_[A_i[p]] = Ax_[A_i[p]] + As[p] * x[j]
+                    Aty_[j] = Aty_[j] + As[p] * y[A_i[p]]
+                if pidx[j] >= 0:
+                    Px_[j] = Px_[j] + Ps[pidx[j]] * x[j]
+            with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+                pr = ninf_(Ax_ - z) / (np.maximum(ninf_(z), ninf_(Ax_)) + T(1e-10))
+                du = ninf_((qs + Px_) + Aty_) / (np.maximum(np.maximum(ninf_(qs), ninf_(Aty_)), ninf_(Px_)) + T(1e-10))
+                rho_new = rho_cur * np.sqrt(pr / (du + T(1e-10)))
+            rho_new = np.minimum(np.maximum(rho_new, T(RHO_MIN)), T(1e6)).astype(dtype)
+            upd = ~done & ((rho_new > rho_cur * T(5.0)) | (rho_new < rho_cur / T(5.0)))
+            if upd.any():
+                rho_cur = np.where(upd, rho_new, rho_cur).astype(dtype)
+                rho_n = np.where(loose, T(RHO_MIN), np.where(eq, T(RHO_EQ_OVER_RHO_INEQ) * rho_cur, rho_cur)).astype(dtype)
+                rinv_n = (T(1.0) / rho_n).astype(dtype)
+                rho = np.where(upd, rho_n, rho)
+                rinv = np.where(upd, rinv_n, rinv)
+                _, Lx_n, Dd_n = factor(rinv)
+                Lx = np.where(upd, Lx_n, Lx)
+                Ddinv = np.where(upd, Dd_n, Ddinv)
+                rho_updates = rho_updates + upd
 
     pri_res, dua_res, ncvx, term = evaluate(x, y, z, dx, dy)
     s1 = term(False)
@@ -333,4 +367,4 @@ def solve(n, m, A_p, A_i, P_cols, perm, Pv, Av, q, l, u, x, y, z, Eprev, setting
     y = np.where(bad, T(0), y)
     z = np.where(bad, T(0), z)
     return dict(x=x, y=y, z=z, E=E, D=D, c=c, sol_x=sol_x, sol_y=sol_y, status=status, pri_res=pri_res,
-                dua_res=dua_res, L=Lx, Dinv=Ddinv, L_i=L_i, L_p=L_p, As=As, Ps=Ps, qs=qs, rho=rho, iters=iters)
+                dua_res=dua_res, L=Lx, Dinv=Ddinv, L_i=L_i, L_p=L_p, As=As, Ps=Ps, qs=qs, rho=rho, iters=iters, rho_updates=rho_updates)

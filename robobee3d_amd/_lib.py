@@ -26,7 +26,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
-           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
+           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
            "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
 
 
@@ -38,7 +38,7 @@ class NParams(C.Structure):
 class QPSettings(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf",
                                           "eps_dual_inf")] + [("max_iter", C.c_int), ("scaling", C.c_int),
-                                                              ("check_termination", C.c_int)]
+                                                              ("check_termination", C.c_int), ("adaptive_rho_interval", C.c_int)]
 
 
 class FunApprox_t(C.Structure):
@@ -202,6 +202,7 @@ def lib():
         L.umpcQPDestroy.argtypes = [C.c_void_p]
         L.umpcQPSetMaxIter.argtypes = [C.c_void_p, C.c_int]
         L.umpcQPSetCheckTermination.argtypes = [C.c_void_p, C.c_int]
+        L.umpcQPSetAdaptiveRho.argtypes = [C.c_void_p, C.c_int]
         L.umpcQPUseTables.argtypes = [C.c_void_p, C.c_int]
         L.umpcQPSetKernel.argtypes = [C.c_void_p, C.c_int]
         L.umpcQPKernelName.argtypes = [C.c_void_p]

@@ -52,7 +52,7 @@ class BatchQP:
         z = lambda r, dt=dtype: torch.zeros((max(r, 1), self.B), dtype=dt, device=self.device)
         self.x, self.y, self.z = z(n), z(m), z(m)
         self.Eprev = torch.ones((m, self.B), dtype=dtype, device=self.device)
-        self.sol_x, self.sol_y, self.info = z(n), z(m), z(5)
+        self.sol_x, self.sol_y, self.info = z(n), z(m), z(6)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         if os.environ.get("UMPC_QP_KERNEL"):      # diagnostics: wave | lane | tables
             self.set_kernel(os.environ["UMPC_QP_KERNEL"])
@@ -93,12 +93,14 @@ class BatchQP:
             raise ValueError("%s must be a contiguous [%d, %d] %s tensor on %s" % (name, rows, self.B, self.dtype, self.device))
         return t
 
-    def set_termination(self, check_every=25, max_iter=4000):
+    def set_termination(self, check_every=25, max_iter=4000, adaptive_rho_interval=0):
         """pip-osqp semantics (template_controllers.py:190-191,216-219): test the termination criteria at the exact
-        tolerances every `check_every` iterations and stop a robot when one is met; check_every = 0 restores the
-        embedded reference's fixed iteration count. `self.info[4]` reports the iterations each robot ran."""
+        tolerances every `check_every` iterations and stop a robot when one is met; adapt rho every
+        `adaptive_rho_interval` iterations (0 = fixed rho). check_every = 0 restores the embedded reference's fixed
+        iteration count. `self.info[4]` / `[5]` report the iterations each robot ran and its rho updates."""
         if self.L.umpcQPSetCheckTermination(self.h, int(check_every)) != 0 or \
-                self.L.umpcQPSetMaxIter(self.h, int(max_iter)) != 0:
+                self.L.umpcQPSetMaxIter(self.h, int(max_iter)) != 0 or \
+                self.L.umpcQPSetAdaptiveRho(self.h, int(adaptive_rho_interval)) != 0:
             raise RuntimeError(self.L.umpcLastError().decode())
 
     def solve(self, Pv, Av, q, l, u, max_iter=None):

@@ -216,7 +216,7 @@ def emit_structure(name, s):
         E("  if (a.sol_y) IN(a.sol_y, %d) = bad ? qnan : (y[%d] * Ev[%d]) * cinv; IN(a.y, %d) = bad ? T(0.0) : y[%d]; "
           "IN(a.z, %d) = bad ? T(0.0) : z[%d];" % (i, i, i, i, i, i, i))
     E("  if (a.status) a.status[b] = status;")
-    E("  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); }")
+    E("  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(a.max_iter); IN(a.info, 5) = T(0); }")
     E("#undef IN")
     E("}")
     E("template <typename T>")

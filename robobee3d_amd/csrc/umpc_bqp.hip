@@ -125,29 +125,33 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
     IN(a.Eprev, i) = e;
   }
 
-  // ---- KKT diagonal (kkt.c:184-222) and the up-looking LDL' (qdldl.c:86-247) ----
-  for (int j = 0; j < n; ++j) {
-    const int kp = pidx[j];
-    WR(R_KD, pinv[j]) = kp >= 0 ? WR(R_PS, kp) + sigma : sigma;
-  }
-  for (int i = 0; i < m; ++i) WR(R_KD, pinv[n + i]) = -WR(R_RINV, i);
-  for (int k = 0; k < nk; ++k) WR(R_YV, k) = T(0.0);
   int fail = 0;
-  for (int k = 0; k < nk; ++k) {
-    for (int p = fi_p[k]; p < fi_p[k + 1]; ++p) WR(R_YV, fi_b[p]) = WROW(fi_s[p]);
-    T dk = WR(R_KD, k);
-    for (int e = fe_p[k]; e < fe_p[k + 1]; ++e) {
-      const int cidx = fe_c[e], lnew = fe_n[e];
-      const T yv = WR(R_YV, cidx);
-      for (int j = L_p[cidx]; j < lnew; ++j) WR(R_YV, L_i[j]) -= WR(R_LX, j) * yv;
-      const T lv = yv * WR(R_DI, cidx);
-      WR(R_LX, lnew) = lv;
-      dk -= yv * lv;
-      WR(R_YV, cidx) = T(0.0);
+  auto factor = [&]() {
+    // ---- KKT diagonal (kkt.c:184-222) and the up-looking LDL' (qdldl.c:86-247) ----
+    for (int j = 0; j < n; ++j) {
+      const int kp = pidx[j];
+      WR(R_KD, pinv[j]) = kp >= 0 ? WR(R_PS, kp) + sigma : sigma;
     }
-    if (dk == T(0.0)) fail = 1;
-    WR(R_DI, k) = T(1.0) / dk;
-  }
+    for (int i = 0; i < m; ++i) WR(R_KD, pinv[n + i]) = -WR(R_RINV, i);
+    for (int k = 0; k < nk; ++k) WR(R_YV, k) = T(0.0);
+    for (int k = 0; k < nk; ++k) {
+      for (int p = fi_p[k]; p < fi_p[k + 1]; ++p) WR(R_YV, fi_b[p]) = WROW(fi_s[p]);
+      T dk = WR(R_KD, k);
+      for (int e = fe_p[k]; e < fe_p[k + 1]; ++e) {
+        const int cidx = fe_c[e], lnew = fe_n[e];
+        const T yv = WR(R_YV, cidx);
+        for (int j = L_p[cidx]; j < lnew; ++j) WR(R_YV, L_i[j]) -= WR(R_LX, j) * yv;
+        const T lv = yv * WR(R_DI, cidx);
+        WR(R_LX, lnew) = lv;
+        dk -= yv * lv;
+        WR(R_YV, cidx) = T(0.0);
+      }
+      if (dk == T(0.0)) fail = 1;
+      WR(R_DI, k) = T(1.0) / dk;
+    }
+
+  };
+  factor();
 
   // ---- ADMM iterations, osqp.c:354-370 ----
   if (a.max_iter == 0) {
@@ -200,7 +204,9 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
   //      (auxil.c:362-512); decide(k) is check_termination (auxil.c:684-789) at k x the tolerances ----
   T pri_res = T(0.0), dua_res = T(0.0), dual_rel = T(0.0), prim_rel = T(0.0);
   T norm_dy = T(0.0), ineq_lhs = T(0.0), nAtdy = T(0.0), norm_dx = T(0.0), qdx = T(0.0), nPdx = T(0.0);
+  T s_pri = T(0.0), s_nz = T(0.0), s_nAx = T(0.0), s_dua = T(0.0), s_nq = T(0.0), s_nAty = T(0.0), s_nPx = T(0.0);  // scaled
   auto update_info = [&]() {
+    s_pri = s_nz = s_nAx = s_dua = s_nq = s_nAty = s_nPx = T(0.0);
     // T3 <- Ax (scaled), then primal residual and tolerance
     pri_res = T(0.0); T nz = T(0.0), nAx = T(0.0);
     for (int i = 0; i < m; ++i) {
@@ -211,6 +217,7 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
       pri_res = qmax(pri_res, qabs(einv * (acc - zi)));
       nz = qmax(nz, qabs(einv * zi));
       nAx = qmax(nAx, qabs(einv * acc));
+      s_pri = qmax(s_pri, qabs(acc - zi)); s_nz = qmax(s_nz, qabs(zi)); s_nAx = qmax(s_nAx, qabs(acc));
     }
     // T1 <- Px, T2 <- A'y, dual residual and tolerance
     dua_res = T(0.0); T nq = T(0.0), nAty = T(0.0), nPx = T(0.0);
@@ -224,6 +231,8 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
       const T dinv = T(1.0) / WR(R_D, j), qj = WR(R_QS, j);
       dua_res = qmax(dua_res, qabs(dinv * ((qj + px) + aty)));
       nq = qmax(nq, qabs(dinv * qj)); nAty = qmax(nAty, qabs(dinv * aty)); nPx = qmax(nPx, qabs(dinv * px));
+      s_dua = qmax(s_dua, qabs((qj + px) + aty)); s_nq = qmax(s_nq, qabs(qj)); s_nAty = qmax(s_nAty, qabs(aty));
+      s_nPx = qmax(s_nPx, qabs(px));
     }
     dua_res = cinv * dua_res;
     dual_rel = qmax(qmax(nq, nAty), nPx) * cinv; prim_rel = qmax(nz, nAx);
@@ -290,8 +299,9 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
   // max_iter iterations. check_termination = k > 0 (pip-osqp semantics of the reference's Python twin,
   // template_controllers.py:190-191,216-219): every k-th iteration update_info + check_termination(exact); a robot
   // that meets a criterion stops iterating (per-lane mask), the wave leaves the loop when all of its robots have.
-  int status = -10, iters = 0;
+  int status = -10, iters = 0, rho_updates = 0;
   bool info_fresh = false;
+  T rho_cur = a.rho;
   for (int it = 1; it <= a.max_iter; ++it) {
     if (status == -10) {
       admm_iteration();
@@ -301,6 +311,30 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
         update_info();
         info_fresh = true;
         status = decide(T(1));
+      }
+      if (status == -10 && a.adaptive_rho_interval > 0 && it % a.adaptive_rho_interval == 0) {
+        // adapt_rho / compute_rho_estimate (auxil.c:12-82) on the scaled residual vectors; osqp_update_rho
+        // (osqp.c:1268-1330): rho_vec by constraint type, then the numeric refactorisation
+        if (!info_fresh) { update_info(); info_fresh = true; }
+        const T pr = s_pri / (qmax(s_nz, s_nAx) + T(1e-10));
+        const T du = s_dua / (qmax(qmax(s_nq, s_nAty), s_nPx) + T(1e-10));
+        T rho_new = rho_cur * qsqrt(pr / (du + T(1e-10)));
+        rho_new = qmin(qmax(rho_new, T(QP_RHO_MIN)), T(1e6));
+        if (rho_new > rho_cur * T(5.0) || rho_new < rho_cur / T(5.0)) {
+          // the constraint type of a row is read back from its current rho: rho_cur = inequality, RHO_MIN = loose
+          // (kept), anything else = equality (set_rho_vec, auxil.c:84-101)
+          const T rho_prev = rho_cur;
+          rho_cur = rho_new;
+          const T req = T(QP_RHO_EQ_OVER_RHO_INEQ) * rho_cur;
+          for (int i = 0; i < m; ++i) {
+            const T r0 = WR(R_RHO, i);
+            if (r0 == T(QP_RHO_MIN) && rho_prev != T(QP_RHO_MIN)) continue;
+            const T r = r0 == rho_prev ? rho_cur : req;
+            WR(R_RHO, i) = r; WR(R_RINV, i) = T(1.0) / r;
+          }
+          factor();
+          ++rho_updates;
+        }
       }
     }
     if (a.check_termination > 0 && __all(status != -10)) break;
@@ -324,7 +358,7 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
     if (bad) { IN(a.y, i) = T(0.0); IN(a.z, i) = T(0.0); }
   }
   if (a.status) a.status[b] = status;
-  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(iters); }
+  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(iters); IN(a.info, 5) = T(rho_updates); }
 #undef WR
 #undef WROW
 #undef IN
@@ -612,7 +646,7 @@ __global__ void __launch_bounds__(64) bqp_wave_kernel(const QPArgs<T> a) {
   fail = wave_or(fail);
   if (lane == 0) {
     if (a.status) a.status[b] = status;
-    if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); }
+    if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(a.max_iter); IN(a.info, 5) = T(0); }
   }
 #undef IN
 #undef FOR_LANES
@@ -789,7 +823,9 @@ int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, con
   a.eps_pinf = T(h->st.eps_prim_inf); a.eps_dinf = T(h->st.eps_dual_inf);
   a.max_iter = h->st.max_iter; a.scaling = h->st.scaling;
   a.check_termination = h->st.check_termination;
-  const bool tables = h->use_tables || h->st.check_termination > 0;   // early termination lives in the table kernel
+  a.adaptive_rho_interval = h->st.adaptive_rho_interval;
+  // early termination / adaptive rho live in the table kernel
+  const bool tables = h->use_tables || h->st.check_termination > 0 || h->st.adaptive_rho_interval > 0;
   if (h->wave && !tables) {
     hipLaunchKernelGGL(bqp_wave_kernel<T>, dim3(h->B), dim3(64), h->wave_lds * sizeof(T), s, a);
   } else if (h->fixed >= 0 && !tables) {
@@ -833,6 +869,7 @@ void umpcQPDefaultSettings(umpcQPSettings *s) {
   s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
   s->max_iter = 50; s->scaling = 10;
   s->check_termination = 0;
+  s->adaptive_rho_interval = 0;
 }
 
 void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpcQPSettings *st) {
@@ -956,7 +993,7 @@ int umpcQPSetKernel(void *hv, int mode) {
 const char *umpcQPKernelName(void *hv) {
   qp_batch *h = (qp_batch *)hv;
   if (!h) return "";
-  if (h->use_tables || h->st.check_termination > 0) return "tables";
+  if (h->use_tables || h->st.check_termination > 0 || h->st.adaptive_rho_interval > 0) return "tables";
   if (h->wave) return "wave";
   return h->fixed >= 0 ? kFixedKernels[h->fixed].name : "tables";
 }
@@ -972,6 +1009,13 @@ int umpcQPSetCheckTermination(void *hv, int every) {
   qp_batch *h = (qp_batch *)hv;
   if (!h || every < 0) { umpc_set_error("umpcQPSetCheckTermination: bad argument"); return -1; }
   h->st.check_termination = every;
+  return 0;
+}
+
+int umpcQPSetAdaptiveRho(void *hv, int interval) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h || interval < 0) { umpc_set_error("umpcQPSetAdaptiveRho: bad argument"); return -1; }
+  h->st.adaptive_rho_interval = interval;
   return 0;
 }
 

@@ -34,6 +34,7 @@ struct QPArgs {
   T *info;
   T sigma, alpha, rho, eps_abs, eps_rel, eps_pinf, eps_dinf;
   int max_iter, scaling;
+  int adaptive_rho_interval;  // 0: fixed rho; k > 0: adapt_rho every k iterations (table kernel)
   int check_termination;  // 0: exactly max_iter iterations; k > 0: exact termination test every k iterations (table kernel)
 };
 

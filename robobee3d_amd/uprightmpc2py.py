@@ -89,16 +89,17 @@ class UprightMPC2:
 
     Solve semantics = the reference's: `osqp.OSQP().setup(..., eps_rel=1e-4, eps_abs=1e-4)` + `solve()`
     (template_controllers.py:190-191, 216-219), i.e. pip-osqp defaults -- iterate until the termination criteria
-    hold at eps 1e-4, tested every 25 iterations, at most 4000 -- and a message when the status is not "solved"
-    (:218-219). pip osqp's adaptive_rho is not reproduced (its schedule depends on wall-clock timings), so the
-    iterate path differs from pip osqp's while the converged solution is the same QP optimum to eps.
+    hold at eps 1e-4, tested every 25 iterations, at most 4000, rho adapted (adapt_rho, auxil.c:62-82) -- and a
+    message when the status is not "solved" (:218-219). pip osqp derives its rho-adaptation interval from wall-clock
+    timings (a multiple of 25); 25 is used here, so the iterate path is ONE of the reference's possible paths and
+    the returned solution is the QP optimum to eps either way.
     maxIter = k gives the embedded C path's semantics instead (exactly k iterations, uprightmpc2.c:116-117)."""
 
     def __init__(self, N, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, maxIter=None):
         import torch
         from .batchqp import UprightMPC2N
         self.N, self._torch = N, torch
-        st = dict(max_iter=maxIter) if maxIter is not None else dict(max_iter=4000, check_termination=25)
+        st = dict(max_iter=maxIter) if maxIter is not None else dict(max_iter=4000, check_termination=25, adaptive_rho_interval=25)
         self._mpc = UprightMPC2N(1, N, dt=dt, g=g, TtoWmax=TtoWmax, ws=ws, wds=wds, wpr=wpr, wpf=wpf, wvr=wvr, wvf=wvf,
                                  wthrust=wthrust, wmom=wmom, Ib=tuple(float(v) for v in Ib), dtype=torch.float64, **st)
 

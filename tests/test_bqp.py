@@ -199,6 +199,9 @@ def test_table_oracle_termination_mode_and_certificates():
     # slowest end "solved inaccurate" at max_iter)
     assert np.all(np.isin(r["status"], (1, 2))) and np.all(r["iters"] % 25 == 0) and len(set(r["iters"])) > 2
     assert np.all((r["status"] == 1) == (r["iters"] < 4000)) and np.count_nonzero(r["status"] == 1) >= 12
+    ra = osqp_table.solve(*args, osqp_table.Settings(max_iter=4000, check_termination=25, adaptive_rho_interval=25))
+    assert np.all(ra["status"] == 1) and ra["iters"].max() <= 300 and ra["rho_updates"].max() >= 1     # adapt_rho converges all
+    np.testing.assert_allclose(ra["sol_x"][:, r["status"] == 1], r["sol_x"][:, r["status"] == 1], rtol=5e-3, atol=2e-2)   # both eps-optimal
     for k in (0, 7):
         one = [a[:, k:k + 1] if isinstance(a, np.ndarray) and a.ndim == 2 else a for a in args]
         rf = osqp_table.solve(*one, osqp_table.Settings(max_iter=int(r["iters"][k])))
@@ -580,11 +583,11 @@ def test_gpu_createMPC_pair_cross_check():
     # termination criteria at eps 1e-4, checked every 25 iterations
     for _ in range(3):
         u1, a1 = up.update(p, R0, dq, pdes, dpdes, sdes, -1.0)
-        assert up.status_val in (1, 2) and up.iterations % 25 == 0 and 25 <= up.iterations <= 4000
+        assert up.status_val == 1 and up.iterations % 25 == 0 and 25 <= up.iterations < 4000
         assert np.isfinite(u1).all() and np.isfinite(a1).all()
     up5, _ = createMPC(N=5)
     u5, a5 = up5.update(p, R0, dq, pdes, dpdes, sdes)
-    assert np.isfinite(u5).all() and np.isfinite(a5).all() and up5.prevsol.shape == (75,) and up5.status_val in (1, 2)
+    assert np.isfinite(u5).all() and np.isfinite(a5).all() and up5.prevsol.shape == (75,) and up5.status_val == 1 and up5.iterations < 4000
 
 
 @pytest.mark.gpu
@@ -670,6 +673,19 @@ def test_gpu_eps_terminated_mode_matches_oracle(structure):
             same = it == ref["iters"]
             sx = np.maximum(1.0, np.abs(ref["sol_x"][:, same]))
             assert np.abs(qp.sol_x.cpu().numpy()[:, same] - ref["sol_x"][:, same]).max() / sx.max() < 2e-3
+        # adaptive rho (interval 25): every robot reaches "solved" within a few hundred iterations, as in the oracle
+        refa = osqp_table.solve(45, 39, A_p, A_i, list(range(45)), perm, *args,
+                                osqp_table.Settings(max_iter=4000, check_termination=25, adaptive_rho_interval=25), dtype=dtype)
+        qp.set_termination(25, 4000, adaptive_rho_interval=25)
+        qp.reset()
+        qp.solve(dev(Pv), dev(Av), dev(q), dev(l), dev(u))
+        ita, upa = qp.info[4].cpu().numpy().astype(int), qp.info[5].cpu().numpy().astype(int)
+        assert np.all(qp.status.cpu().numpy() == 1) and ita.max() <= 400 and upa.max() >= 1
+        if dtype == np.float64:
+            assert np.array_equal(ita, refa["iters"]) and np.array_equal(upa, refa["rho_updates"])
+            np.testing.assert_allclose(qp.sol_x.cpu().numpy(), refa["sol_x"], rtol=1e-8, atol=1e-10)
+        else:
+            assert np.count_nonzero(ita != refa["iters"]) <= 12
         # set_termination(0) restores the fixed count
         qp.set_termination(0, 50)
         qp.reset()
