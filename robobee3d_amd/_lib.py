@@ -24,7 +24,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
            "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
-           "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchReactive", "umpcBatchTaskReference",
+           "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchSetStepKernel", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
            "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
@@ -191,6 +191,7 @@ def lib():
         L.umpcKKTPerm.restype = C.POINTER(C.c_int * (NX + NC))
         L.umpcBatchSetTask.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double]
         L.umpcBatchSetWeights.argtypes = [C.c_void_p, C.c_void_p]
+        L.umpcBatchSetStepKernel.argtypes = [C.c_void_p, C.c_int]
         L.umpcBatchTime.argtypes = [C.c_void_p]
         L.umpcBatchTime.restype = C.c_double
         L.umpcBatchModel.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4

@@ -43,6 +43,7 @@ from . import symbolic
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+XV_COUNT, XV_BASE = 0, 246   # asmstep.py: storage positions NLDS+NVZ .. +XV_COUNT-1 of L live in VGPRs XV_BASE.. (free there)
 NLDS = 160  # L storage positions kept in LDS
 NVZ = 36    # positions NLDS .. NLDS+NVZ-1 move into the z registers of the dynamics rows after the first iteration
 # workspace rows shared with the C++ phases (see umpc_step.h)
@@ -427,6 +428,8 @@ def body(e, s, first, capture, plan, lv=False, delta_in_w=False):
             return ("L", lpos[j])
         if lv and lpos[j] < NLDS + NVZ:   # resident in the z registers of the dynamics rows (z == l there, kept in AGPRs)
             return ("V", V_Z + lpos[j] - NLDS)
+        if NLDS + NVZ <= lpos[j] < NLDS + NVZ + XV_COUNT:
+            return ("V", XV_BASE + lpos[j] - NLDS - NVZ)
         return ("A", A_L + lpos[j] - NLDS)
 
     if capture and not delta_in_w:  # x_prev of this iteration -> workspace
@@ -482,8 +485,8 @@ def body(e, s, first, capture, plan, lv=False, delta_in_w=False):
             if pe < NLDS:
                 op(("L", pe), lambda t, rd=rd, srcp=srcp, lsel=lsel:
                    pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [0, 0, 0]), **rw)
-            elif lv and pe < NLDS + NVZ:
-                t = V_Z + pe - NLDS
+            elif (lv and pe < NLDS + NVZ) or NLDS + NVZ <= pe < NLDS + NVZ + XV_COUNT:
+                t = V_Z + pe - NLDS if pe < NLDS + NVZ else XV_BASE + pe - NLDS - NVZ
                 op(None, lambda _t, t=t, rd=rd, srcp=srcp, lsel=lsel:
                    pk(e, "v_pk_fma_f32", rd, [("v[%d:%d]" % (t, t + 1), lsel[0], lsel[1]), srcp, _vp(rd)], [0, 0, 0]), **rw)
             else:

@@ -67,6 +67,7 @@ for _n in INTS + FLOATS:
 PARAM_BYTES = _o
 
 VFIRST, VEND = 2, 256
+XV_N, XV_B = 10, 246      # L entries kept in VGPRs beyond the loop's fixed layout (asmgen.XV_COUNT / XV_BASE)
 
 
 class Pool:
@@ -121,6 +122,13 @@ class Pool:
                 self._take(range(r, r + n))
                 return r
         raise AssertionError("out of consecutive VGPRs")
+
+    def getn_high(self, n):
+        """n consecutive registers ending at the top of the file (even base)"""
+        r = VEND - n - (VEND - n) % 2
+        assert all(r + k in self.free_ for k in range(n)), "top of the register file is not free"
+        self._take(range(r, r + n))
+        return r
 
     def free(self, *regs, kill=True):
         for r in regs:
@@ -470,7 +478,7 @@ class StepGen:
         pool.free(*Btau, *ds0, T0)
         # A3: working arrays of the equilibration
         VP = pool.getn(nx + 1)
-        VQ = pool.getn(st.nq + st.nq % 2)
+        VQ = pool.getn_high(st.nq + st.nq % 2)       # covers v246..v255, which factor() needs free (q is retired before)
         VA = pool.getn(st.na + st.na % 2)
         self.VP, self.VQ, self.VA = VP, VQ, VA
         RP = lambda j: VP + st.xs[j]
@@ -534,22 +542,47 @@ class StepGen:
             e("v_max_f32", v(dst), v(dst), "|%s|" % v(regs[0]))
 
     def limit(self, regs, rsq):
-        """limit_scaling (scaling.c:7-14) on every register, then 1/sqrt if rsq; software-pipelined over the list so
-        that the vcc compare -> select pair and the transcendental never feed the next instruction"""
+        """limit_scaling (scaling.c:7-14: v < 1e-4 -> 1, v > 1e4 -> 1e4) on every register, then 1/sqrt if rsq.
+        For a list, one running min / max (v_min3 / v_max3, two registers per instruction) decides wave-wide whether
+        ANY value of ANY robot needs limiting -- it never does once the data is equilibrated -- and the exact
+        compare / select / min sequence (software-pipelined: the vcc compare -> select pair never feeds the next
+        instruction) runs only then."""
         e = self.e
         regs = list(regs)
-        prev = None
-        for r in regs + [None]:
-            if r is not None:
-                e("v_cmp_lt_f32", "vcc", sg(S_C["minscal"]), v(r))
-            if prev is not None:
-                e("v_min_f32", v(prev), sg(S_C["maxscal"]), v(prev))
-            if r is not None:
-                e("v_cndmask_b32", v(r), 1.0, v(r), "vcc")
-            if prev is not None and rsq:
-                e("v_rsq_f32", v(prev), v(prev))
-            prev = r
+
+        def exact():
+            prev = None
+            for r in regs + [None]:
+                if r is not None:
+                    e("v_cmp_lt_f32", "vcc", sg(S_C["minscal"]), v(r))
+                if prev is not None:
+                    e("v_min_f32", v(prev), sg(S_C["maxscal"]), v(prev))
+                if r is not None:
+                    e("v_cndmask_b32", v(r), 1.0, v(r), "vcc")
+                prev = r
+        if len(regs) < 6:
+            exact()
+        else:
+            mn, mx = self.pool.get(), self.pool.get()
+            e("v_min3_f32", v(mn), v(regs[0]), v(regs[1]), v(regs[2]))
+            e("v_max3_f32", v(mx), v(regs[0]), v(regs[1]), v(regs[2]))
+            rest = regs[3:]
+            while rest:
+                a_, b_ = rest[0], rest[1] if len(rest) > 1 else rest[0]
+                e("v_min3_f32", v(mn), v(mn), v(a_), v(b_))
+                e("v_max3_f32", v(mx), v(mx), v(a_), v(b_))
+                rest = rest[2:]
+            lab = self.label()
+            e("v_cmp_gt_f32_e64", sp(S_M0), sg(S_C["minscal"]), v(mn))
+            e("v_cmp_lt_f32", "vcc", sg(S_C["maxscal"]), v(mx))
+            e("s_or_b64", "vcc", "vcc", sp(S_M0))
+            e("s_cbranch_vccz", lab + "f")
+            exact()
+            e("label", lab)
+            self.pool.free(mn, mx)
         if rsq:
+            for r in regs:
+                e("v_rsq_f32", v(r), v(r))
             e("s_nop", 0)
 
     # ---- Ruiz equilibration, scaling.c:44-156 ---------------------------------------------------------------
@@ -576,7 +609,7 @@ class StepGen:
         colpairs = [(st.xinv[2 * k], st.xinv[2 * k + 1]) for k in range(nx // 2)]
         if nx % 2:
             colpairs.append((st.xinv[nx - 1], None))
-        CH = 3
+        CH = 6
         for c0 in range(0, len(colpairs), CH):
             chunk = colpairs[c0:c0 + CH]
             T = [pool.get2() for _ in chunk]
@@ -732,6 +765,9 @@ class StepGen:
         for c, r in last_row.items():
             done_at.setdefault(r, []).append(c)
         nL, Dinv = {}, {}
+        # ten more L entries live in v246..v255 through the loop (2 AGPR reads per iteration each otherwise)
+        asmgen.XV_COUNT, asmgen.XV_BASE = XV_N, XV_B
+        pool.reserve(XV_B, XV_N)
         t = pool.get()
 
         def retire_dinv(k):
@@ -743,6 +779,8 @@ class StepGen:
                 pos = lpos[j]
                 if pos < NLDS:
                     e("ds_write_b32", "v1", v(nL[j]), (pos // 4) * 1024 + (pos % 4) * 4)
+                elif NLDS + NVZ <= pos < NLDS + NVZ + XV_N:
+                    e("v_mov_b32", v(XV_B + pos - NLDS - NVZ), v(nL[j]))
                 else:
                     e("v_accvgpr_write_b32", "a%d" % (A_L + pos - NLDS), v(nL[j]))
                 pool.free(nL.pop(j))
@@ -820,12 +858,13 @@ class StepGen:
     def admm(self):
         e, pool, st, s = self.e, self.pool, self.st, self.s
         nx, nc = s.nx, s.nc
-        assert len(pool.free_) == VEND - VFIRST, "phase A leaked registers: %s" % sorted(set(range(VFIRST, VEND)) - pool.free_)
+        left = set(range(VFIRST, VEND)) - pool.free_ - set(range(XV_B, XV_B + XV_N))
+        assert not left, "phase A leaked registers: %s" % sorted(left)
         pool.reserve(V_W, V_X - V_W)
         pool.reserve(V_X, V_Y - V_X)
         pool.reserve(V_Y, V_Z - V_Y)
         pool.reserve(V_Z, 40)
-        voff = 246          # the loop leaves v246..v255 alone
+        voff = 245          # free here: the loop's temporaries start at v214, its extra L registers at v246
         self.load_rows("ctrl", 0, [V_X + st.xs[r] for r in range(nx)] + [V_Y + st.zs[r] for r in range(nc)] +
                        [V_Z + st.zs[r] for r in range(nc)], voff)
         for pad in (V_X + nx, V_Y + nc, V_Z + nc, V_W + nx, V_WZ + nc):
@@ -852,6 +891,7 @@ class StepGen:
         # x, y, thrust-row z, delta_x (x part of W), delta_y (z part of W) stay where they are; z == l on the dynamics rows
         for i in range(st.neq):
             pool.free(V_Z + st.zs[i], kill=True)
+        pool.free_range(XV_B, XV_N)
 
     # ---- phase C ------------------------------------------------------------------------------------------
     def phase_c(self):
@@ -1376,8 +1416,11 @@ class StepGen:
         self.prologue()
         top = self.label()
         e("label", top)
-        self.phase_a()
-        self.admm()
+        try:
+            self.phase_a()      # factor() switches asmgen's extra-VGPR L homes on (module state) ...
+            self.admm()
+        finally:
+            asmgen.XV_COUNT = 0  # ... for this stream only: asmgen.program() of the C++ kernel must not see them
         self.phase_c()
         e("s_add_i32", sg(S_STEP), sg(S_STEP), 1)
         e("s_cmp_lt_i32", sg(S_STEP), sg(S_INT["K"]))
@@ -1702,6 +1745,9 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
             elif m == "v_max3_f32":
                 vals = [x for x in (fsrc(t[2]), fsrc(t[3]), fsrc(t[4])) if x == x]
                 setv(t[1], max(vals) if vals else f32(np.nan))
+            elif m == "v_min3_f32":
+                vals = [x for x in (fsrc(t[2]), fsrc(t[3]), fsrc(t[4])) if x == x]
+                setv(t[1], min(vals) if vals else f32(np.nan))
             elif m == "v_med3_f32":
                 vals = sorted((fsrc(t[2]), fsrc(t[3]), fsrc(t[4])))
                 setv(t[1], vals[1])

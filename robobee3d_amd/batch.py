@@ -156,6 +156,11 @@ class BatchUprightMPC:
         self._weights = w  # keep alive: the library stores the pointer
         self._check(self.L.umpcBatchSetWeights(self.h, _ptr(w)))
 
+    def set_step_kernel(self, mode):
+        """"auto" (default: the all-assembly fp32 kernel where it applies) or "cpp" (always the C++ kernel around the
+        assembly ADMM loop): ablation and cross-checks."""
+        self._check(self.L.umpcBatchSetStepKernel(self.h, {"auto": 0, "cpp": 1}[mode]))
+
     M0_CA6 = (100.0, 100.0, 100.0, 3333.0, 3333.0, 1000.0)   # dynamicsTerms, template/ca6dynamics.py:5-10
 
     def set_wl(self, wl, Mdiag=M0_CA6):

@@ -36,10 +36,12 @@ int fail(hipError_t e, const char *what) {
 // (no barriers, no cross-lane traffic). fp32: the ADMM phase is the generated assembly with
 // L[0..160) in LDS (40 float4 per lane = 40,960 B per workgroup -> 4 workgroups = 4 waves per CU,
 // one per SIMD, which is also what 512 registers per lane allow).
-template <typename T>
+template <typename T, bool LDSF = false>
 __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a, int K, const T *actualT0, int skew_ticks) {
   constexpr bool kAsm = sizeof(T) == 4;
-  __shared__ float4 lds[kAsm ? (umpcasm::LDS_BYTES_PER_LANE / 16) * kBlock : 1];
+  static_assert(!(kAsm && LDSF), "LDSF is the fp64 variant");
+  __shared__ float4 lds[kAsm ? (umpcasm::LDS_BYTES_PER_LANE / 16) * kBlock
+                             : LDSF ? (umpcgen::NNZL + umpcgen::NK) * kBlock * sizeof(T) / 16 : 1];
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= a.B) return;
   // low 32 bits of a flat LDS pointer = the LDS byte address
@@ -53,9 +55,9 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a,
     const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
     while (__builtin_amdgcn_s_memrealtime() - t0 < (long long)g * skew_ticks) __builtin_amdgcn_s_sleep(64);
   }
-  T *ldsw = kAsm ? reinterpret_cast<T *>(lds) + 4 * threadIdx.x : nullptr;
+  T *ldsw = kAsm ? reinterpret_cast<T *>(lds) + 4 * threadIdx.x : LDSF ? reinterpret_cast<T *>(lds) + threadIdx.x : nullptr;
 #pragma nounroll
-  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm>(a, b, ldsaddr, ldsw, k, actualT0);
+  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm, LDSF>(a, b, ldsaddr, ldsw, k, actualT0);
 }
 
 // The all-assembly fp32 fast path (asmstep.py -> umpc_step_asm.h): the whole K-step loop of one wavefront is ONE
@@ -274,6 +276,7 @@ struct umpc_batch {
   double t_ms = 0;               // time of the next MPC step (advanced by every rollout)
   const void *weights = nullptr;  // [8][B] device table or null
   void *ws;  // [WS_ROWS][B] scratch the step parks Ruiz scalings / x_prev / delta_y in
+  int step_kernel = 0;            // 0 = automatic (all-assembly fast path when it applies), 1 = always the C++ / loop-assembly kernel
   umpc::WLDev *wl = nullptr;      // device copy of the WL parameters (umpcBatchSetWL), null = no coupling
   void *wlu = nullptr, *wlw = nullptr;
 };
@@ -301,7 +304,7 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
     // coupling, >= 1 iteration, row offsets within 31 bits; UMPC_NO_ASM_STEP=1 forces the C++ / assembly-loop kernel
     static const bool no_asm = getenv("UMPC_NO_ASM_STEP") != nullptr;
     const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 4 < ((size_t)1 << 31);
-    if (!no_asm && fits && K >= 1 && h->task == 0 && !h->weights && !h->wl && h->prm.maxIter >= 1 &&
+    if (!no_asm && h->step_kernel == 0 && fits && K >= 1 && h->task == 0 && !h->weights && !h->wl && h->prm.maxIter >= 1 &&
         (nsub == 0 || h->prm.plant_mode == 1)) {
       umpcasm::StepParams p;
       p.state = state; p.ctrl = ctrl; p.ref = ref; p.ws = h->ws; p.out = out; p.stats = stats; p.status = status;
@@ -327,7 +330,17 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   // first, so the stagger only pays when that tail is small against the launch (off below 64 steps)
   const char *env = getenv("UMPC_SKEW_US");
   const int skew_us = env ? atoi(env) : (K >= 64 && sizeof(T) == 4 && h->B >= 32768 ? 80 : 0);
-  hipLaunchKernelGGL(umpc_rollout_kernel<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
+  if constexpr (sizeof(T) == 8) {
+    // small fp64 batches (BASELINE configs[1]: B = 4096 = one wave per CU at most): L and 1/D in LDS, not in scratch
+    static const bool no_ldsf = getenv("UMPC_NO_F64_LDS") != nullptr;
+    if (!no_ldsf && grid <= 256) {
+      hipLaunchKernelGGL((umpc_rollout_kernel<T, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
+                         (const T *)actualT0, 0);
+      hipError_t e2 = hipGetLastError();
+      return e2 == hipSuccess ? 0 : fail(e2, "umpcBatchRollout");
+    }
+  }
+  hipLaunchKernelGGL((umpc_rollout_kernel<T, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
                      (const T *)actualT0, skew_us * 100);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
@@ -425,6 +438,11 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights) {
     if (!ok) { g_err = "umpcBatchSetWeights: objective weights must be > 0"; return -1; }
   }
   h->weights = weights;
+  return 0;
+}
+int umpcBatchSetStepKernel(umpc_batch_t *h, int mode) {
+  if (!h || mode < 0 || mode > 1) { g_err = "umpcBatchSetStepKernel: bad argument"; return -1; }
+  h->step_kernel = mode;
   return 0;
 }
 double umpcBatchTime(const umpc_batch_t *h) { return h->t_ms; }

@@ -441,7 +441,9 @@ struct StepIO {
 // One closed-loop step of robot b: controller step (= umpcUpdate) + nsub plant substeps.
 // Everything persistent round-trips through the SoA arrays, so K steps in one launch and K
 // launches of one step are the same computation.
-template <typename T, bool ASM>
+// LDSF (fp64, small batches): the factor L and 1/D live in LDS ([word][lane], one wave per CU owns 152 kB) instead
+// of local arrays the compiler spills to scratch; same arithmetic, same results.
+template <typename T, bool ASM, bool LDSF = false>
 __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, const unsigned ldsaddr, T *ldsw,
                                                  const int step, const T *actualT0) {
 // word w of this lane's LDS slot: float4-interleaved, ldsw = (T *)lds + 4 * lane
@@ -461,8 +463,8 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #define UMPC_PHASE_FENCE() asm volatile("" : "+v"(bb)::"memory")
 #define GLD(arr, row) ((arr) + (size_t)(row) * B)[bb]
 #define Q_(j) qv[j]
-#define DI_(k) Di[k]
-#define LX_(e) Lx[e]
+#define DI_(k) (*(LDSF ? &ldsw[(NNZL + (k)) * 64] : &Di[LDSF ? 0 : (k)]))
+#define LX_(e) (*(LDSF ? &ldsw[(e) * 64] : &Lx[LDSF ? 0 : (e)]))
 #define RINV3_(k) rinv3[k]
 #define RHO3_(k) rho3[k]
 #define LO3_(k) lo3[k]
@@ -472,7 +474,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #define Y_(i) y[i]
 #define Z_(i) z[i]
 
-  T Lx[NNZL], Di[NK], qv[NX];
+  T Lx[LDSF ? 1 : NNZL], Di[LDSF ? 1 : NK], qv[NX];
   T lo[NEQ];  // scaled bounds of the dynamics rows; consumed by the first ADMM iteration
   T lo3[N], up3[N], rho3[N], rinv3[N], Eprev3[N];
   T T0 = GLD(a.ctrl, NX + 2 * NC);

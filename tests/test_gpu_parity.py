@@ -556,3 +556,31 @@ def test_dropin_survives_a_copied_pod_and_honours_T0_edits(torch_cuda):
     u2, _ = call(b, 3, 0.0123)
     assert np.array_equal(u1, u2)
     L.umpcRelease(C.byref(a)); L.umpcRelease(C.byref(b))
+
+
+def test_assembly_kernel_and_cpp_kernel_agree(torch_cuda):
+    """The all-assembly fp32 step kernel (asmstep.py) against the C++ kernel around the assembly ADMM loop (umpc_step.h)
+    on the same inputs: the iterations are the same instruction stream and phase A mirrors the C++ operation order, so
+    iterates agree to round-off; statuses come from differently associated residual norms (unscaled in the assembly
+    kernel) and may flip at a tolerance boundary."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    B, K = 4096, 10
+    st, ref = hover_initial_conditions(B, 11, np.float32)
+    res = {}
+    for mode in ("auto", "cpp"):
+        m = BatchUprightMPC(B, torch.float32, plant_mode=1)
+        m.set_step_kernel(mode)
+        m.set_state(st, ref)
+        m.rollout(K)
+        res[mode] = [t.cpu().numpy().astype(np.float64) for t in (m.state, m.out, m.ctrl, m.stats)] + [m.status.cpu().numpy()]
+    a, c = res["auto"], res["cpp"]
+    for name, k, tol in (("state", 0, 2e-5), ("out thrust/accdes", 1, None), ("ctrl", 2, None), ("stats", 3, None)):
+        d = np.abs(a[k] - c[k])
+        sc = 1.0 if tol else (1e-3 + np.abs(c[k]).max(axis=1, keepdims=True))
+        worst = (d / sc).max()
+        record_margin("assembly vs C++ step kernel (B=4096, K=10)", name, worst, tol or 2e-4)
+        assert worst <= (tol or 2e-4), (name, worst)
+    flips = int(np.count_nonzero(a[4] != c[4]))
+    record_margin("assembly vs C++ step kernel (B=4096, K=10)", "status flips of 4096", flips, 400)
+    assert flips <= 400 and set(np.unique(a[4])).issubset({1, 2, -2})

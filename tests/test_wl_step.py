@@ -171,7 +171,7 @@ def test_fused_mpc_wl_loop_on_gpu(oracle_built):
     aT0 = mpc.ctrl[123].cpu().numpy()
     d_f = np.abs(aT0[:-1] - g["actualT0"][1:]).max()
     for q, a, b in (("|d thrust|", d_t, 3e-5), ("|d moment| / max(2e-2,1e-3|u|)", d_m, 1.0), ("|d accdes|", d_a, 3e-5),
-                    ("|d w0|", d_w, 2e-3), ("|d u4| / rate limit", d_u, 1.0), ("|d actualT0 fed back|", d_f, 2e-5)):
+                    ("|d w0|", d_w, 1e-6), ("|d u4| / rate limit", d_u, 2e-2), ("|d actualT0 fed back|", d_f, 1e-8)):
         record_margin("fused MPC->WL single steps (64 reference calls)", q, a, b)
         assert a <= b, (q, a, b)
     # (b) closed loop, one launch
@@ -180,7 +180,7 @@ def test_fused_mpc_wl_loop_on_gpu(oracle_built):
     wlo = oracle_built.WLOracle(*_args(g), dtype=np.float64)
     w64 = np.zeros((6, 64))
     out_o, _, _ = oracle_built.batch_rollout(st64, ctrl64, ref64, K, dtype=np.float64, perm=perm, wl=wlo, wl_u=u64, wl_w=w64)
-    for dtype, tp, ts, lab in ((torch.float64, 1e-7, 1e-8, "fp64"), (torch.float32, 2e-3, 3e-4, "fp32")):
+    for dtype, tp, ts, lab in ((torch.float64, 1e-10, 1e-11, "fp64"), (torch.float32, 1e-5, 1e-5, "fp32")):
         m = BatchUprightMPC(64, dtype)
         w = BatchWLCon(64, *_args(g), dtype=dtype)
         s0, r0, _, _ = _loop_inputs(g, np.float64, 64)
