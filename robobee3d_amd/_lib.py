@@ -174,7 +174,9 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise RuntimeError("libumpc_mi355x.so is not built (run `python -c 'import __graft_entry__ as g; "
                                "g.build()'`); robobee3d_amd has no CPU fallback")
-        L = C.CDLL(SO_PATH)
+        # UMPC_LIB: another build of the same library (A/B timing of kernel variants on ONE box; devices differ by
+        # several per cent, so variants are only comparable inside one gpurun call)
+        L = C.CDLL(os.environ.get("UMPC_LIB") or SO_PATH)
         L.umpcBatchCreate.restype = C.c_void_p
         L.umpcBatchCreate.argtypes = [C.POINTER(BatchParams), C.c_int, C.c_int]
         L.umpcBatchDestroy.argtypes = [C.c_void_p]

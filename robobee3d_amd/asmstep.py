@@ -68,6 +68,12 @@ PARAM_BYTES = _o
 
 VFIRST, VEND = 2, 256
 XV_N, XV_B = 10, 246      # L entries kept in VGPRs beyond the loop's fixed layout (asmgen.XV_COUNT / XV_BASE)
+# generator switches for A/B timing of variants on one box (tools/build_variant.py); defaults = the shipped kernel
+OPT_XV = os.environ.get("UMPC_ASM_XV", "1") == "1"
+# LIMIT_FAST: wave-wide min / max test that skips the exact limit_scaling sequence (-1 500 instructions per step).
+# Measured SLOWER on the MI355X (same box, K = 500: 0.1261 vs 0.1239 ms per step): five VALU -> SGPR -> s_cbranch_vccz
+# round trips per Ruiz pass cost more than the 150 instructions they skip. Off.
+OPT_LIMIT_FAST = os.environ.get("UMPC_ASM_LIMIT_FAST", "0") == "1"
 
 
 class Pool:
@@ -560,18 +566,33 @@ class StepGen:
                 if r is not None:
                     e("v_cndmask_b32", v(r), 1.0, v(r), "vcc")
                 prev = r
-        if len(regs) < 6:
+        if len(regs) < 6 or not OPT_LIMIT_FAST:
             exact()
         else:
-            mn, mx = self.pool.get(), self.pool.get()
-            e("v_min3_f32", v(mn), v(regs[0]), v(regs[1]), v(regs[2]))
-            e("v_max3_f32", v(mx), v(regs[0]), v(regs[1]), v(regs[2]))
-            rest = regs[3:]
-            while rest:
-                a_, b_ = rest[0], rest[1] if len(rest) > 1 else rest[0]
-                e("v_min3_f32", v(mn), v(mn), v(a_), v(b_))
-                e("v_max3_f32", v(mx), v(mx), v(a_), v(b_))
-                rest = rest[2:]
+            # two independent min chains and two max chains, interleaved: no instruction reads its predecessor's result
+            mn, mx, mn2, mx2 = [self.pool.get() for _ in range(4)]
+            halves = [regs[0::2], regs[1::2]]
+            chains = [(mn, mx), (mn2, mx2)]
+            pos = [0, 0]
+            while any(pos[h] < len(halves[h]) for h in (0, 1)):
+                for h in (0, 1):
+                    vals, p_ = halves[h], pos[h]
+                    if p_ >= len(vals):
+                        continue
+                    rmin, rmax = chains[h]
+                    if p_ == 0:
+                        take = (vals + [vals[0], vals[0]])[:3]
+                        e("v_min3_f32", v(rmin), v(take[0]), v(take[1]), v(take[2]))
+                        e("v_max3_f32", v(rmax), v(take[0]), v(take[1]), v(take[2]))
+                        pos[h] = 3
+                    else:
+                        take = (vals[p_:p_ + 2] + [vals[p_]])[:2]
+                        e("v_min3_f32", v(rmin), v(rmin), v(take[0]), v(take[1]))
+                        e("v_max3_f32", v(rmax), v(rmax), v(take[0]), v(take[1]))
+                        pos[h] = p_ + 2
+            e("v_min_f32", v(mn), v(mn), v(mn2))
+            e("v_max_f32", v(mx), v(mx), v(mx2))
+            self.pool.free(mn2, mx2)
             lab = self.label()
             e("v_cmp_gt_f32_e64", sp(S_M0), sg(S_C["minscal"]), v(mn))
             e("v_cmp_lt_f32", "vcc", sg(S_C["maxscal"]), v(mx))
@@ -609,7 +630,7 @@ class StepGen:
         colpairs = [(st.xinv[2 * k], st.xinv[2 * k + 1]) for k in range(nx // 2)]
         if nx % 2:
             colpairs.append((st.xinv[nx - 1], None))
-        CH = 6
+        CH = 6 if OPT_LIMIT_FAST else 3
         for c0 in range(0, len(colpairs), CH):
             chunk = colpairs[c0:c0 + CH]
             T = [pool.get2() for _ in chunk]
@@ -766,7 +787,7 @@ class StepGen:
             done_at.setdefault(r, []).append(c)
         nL, Dinv = {}, {}
         # ten more L entries live in v246..v255 through the loop (2 AGPR reads per iteration each otherwise)
-        asmgen.XV_COUNT, asmgen.XV_BASE = XV_N, XV_B
+        asmgen.XV_COUNT, asmgen.XV_BASE = (XV_N if OPT_XV else 0), XV_B
         pool.reserve(XV_B, XV_N)
         t = pool.get()
 
@@ -779,7 +800,7 @@ class StepGen:
                 pos = lpos[j]
                 if pos < NLDS:
                     e("ds_write_b32", "v1", v(nL[j]), (pos // 4) * 1024 + (pos % 4) * 4)
-                elif NLDS + NVZ <= pos < NLDS + NVZ + XV_N:
+                elif NLDS + NVZ <= pos < NLDS + NVZ + asmgen.XV_COUNT:
                     e("v_mov_b32", v(XV_B + pos - NLDS - NVZ), v(nL[j]))
                 else:
                     e("v_accvgpr_write_b32", "a%d" % (A_L + pos - NLDS), v(nL[j]))

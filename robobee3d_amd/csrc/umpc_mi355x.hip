@@ -12,7 +12,10 @@
 
 #include "../../include/umpc_mi355x.h"
 #include "umpc_step.h"
-#include "umpc_step_asm.h"
+#ifndef UMPC_STEP_ASM_HEADER   // tools/build_variant.py points this at another generated stream (A/B timing)
+#define UMPC_STEP_ASM_HEADER "umpc_step_asm.h"
+#endif
+#include UMPC_STEP_ASM_HEADER
 #include "umpc_models.h"
 #include "umpc_err.h"
 

@@ -110,3 +110,20 @@ def test_options_monte_carlo_actualT0_and_controller_only(program, oracle_built)
         assert abs(a["out"][0] - uq[0]) < 3e-5 * sc and np.abs(a["out"][3:] - ac).max() < 3e-5 * sc
         assert np.all(np.abs(a["out"][1:3] - uq[1:]) <= np.maximum(2e-2, 1e-3 * np.abs(uq[1:])) * sc)
         assert abs(a["ctrl"][123] - uq[0]) < 3e-5 * sc
+
+
+def test_limit_scaling_exact_path(program, oracle_built):
+    """Weights far outside [1e-4, 1e4] engage the exact limit_scaling branch of the Ruiz passes (scaling.c:7-14) that
+    the wave-wide min / max test normally skips."""
+    g, ins = program
+    st, ref = hover_initial_conditions(1, 3, np.float32)
+    kw = dict(wvf=5e5, wmom=2e-5)
+    a = _arrays(st, ref, 0)
+    asmstep.simulate(ins, a, dict(K=1, maxIter=50, nsub=0), asmstep.host_floats(**kw))
+    o = oracle_built.Oracle(np.float64, perm=g.s.perm, **kw)
+    o.set_canonical(True)
+    R = st[3:12, 0].reshape(3, 3).T
+    uq, ac = o.update(st[0:3, 0], R, st[12:18, 0], ref[0:3, 0], ref[3:6, 0], ref[6:9, 0], -1.0)
+    assert abs(a["out"][0] - uq[0]) < 1e-4 and np.abs(a["out"][3:] - ac).max() < 1e-4     # extreme weights: worse conditioning
+    assert np.all(np.abs(a["out"][1:3] - uq[1:]) <= np.maximum(5e-2, 2e-3 * np.abs(uq[1:])))
+    np.testing.assert_allclose(a["ctrl"][124:], np.asarray(o.get("E"))[36:39], rtol=1e-4)

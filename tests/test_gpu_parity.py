@@ -575,12 +575,16 @@ def test_assembly_kernel_and_cpp_kernel_agree(torch_cuda):
         m.rollout(K)
         res[mode] = [t.cpu().numpy().astype(np.float64) for t in (m.state, m.out, m.ctrl, m.stats)] + [m.status.cpu().numpy()]
     a, c = res["auto"], res["cpp"]
-    for name, k, tol in (("state", 0, 2e-5), ("out thrust/accdes", 1, None), ("ctrl", 2, None), ("stats", 3, None)):
-        d = np.abs(a[k] - c[k])
-        sc = 1.0 if tol else (1e-3 + np.abs(c[k]).max(axis=1, keepdims=True))
-        worst = (d / sc).max()
-        record_margin("assembly vs C++ step kernel (B=4096, K=10)", name, worst, tol or 2e-4)
-        assert worst <= (tol or 2e-4), (name, worst)
+    # two fp32 evaluation orders of the same closed loop: the K = 12 band of test_closed_loop_rollout_matches_oracle
+    lab = "assembly vs C++ step kernel (B=4096, K=10)"
+    dp, ds = np.abs(a[0][0:3] - c[0][0:3]).max(), np.abs(a[0][3:] - c[0][3:]).max()
+    record_margin(lab, "|dp| mm", dp, 1.5e-3)
+    record_margin(lab, "|dR|,|ddq|", ds, 3e-4)
+    assert dp <= 1.5e-3 and ds <= 3e-4
+    for name, k in (("out", 1), ("ctrl", 2), ("stats", 3)):
+        d = np.abs(a[k] - c[k]) / (1e-3 + np.abs(c[k]).max(axis=1, keepdims=True))
+        record_margin(lab, name + ": |d| / (1e-3 + max|row|)", d.max(), 2e-2)
+        assert d.max() <= 2e-2, (name, d.max())
     flips = int(np.count_nonzero(a[4] != c[4]))
     record_margin("assembly vs C++ step kernel (B=4096, K=10)", "status flips of 4096", flips, 400)
     assert flips <= 400 and set(np.unique(a[4])).issubset({1, 2, -2})
