@@ -218,7 +218,7 @@ class BatchUprightMPC:
         nsub, dts = int(self.prm.nsub), float(self.prm.dtsim)
         Nt = int(np.ceil(tend / dts - 1e-9))
         idx = torch.as_tensor(list(robots), device=self.device)
-        rec = {k: [] for k in ("y", "u", "pdes", "accdes")}
+        rec = {k: [] for k in ("y", "u", "pdes", "accdes", "R")}
         t_start = self.time_ms
         acc_now = torch.zeros((6, len(robots)), dtype=self.dtype, device=self.device)
         tl = float(self.prm.taulim)
@@ -242,6 +242,7 @@ class BatchUprightMPC:
                 ulog = self.out[0:3][:, idx]
             st = self.state[:, idx]
             rec["y"].append(torch.cat((st[0:3], st[9:12], st[12:18]), 0).T.cpu().numpy().copy())
+            rec["R"].append(st[3:12].T.cpu().numpy().copy())          # column-major Rb (for save_viewlog's quaternion)
             rec["u"].append(ulog.T.cpu().numpy().copy())
             rec["pdes"].append(pd.T.cpu().numpy().copy())
             rec["accdes"].append((acc_now if (use_mpc and fire) else torch.zeros_like(acc_now)).T.cpu().numpy().copy())
@@ -292,6 +293,32 @@ class BatchUprightMPC:
         over the nsteps*nsub plant substeps accumulated so far."""
         n = max(1, int(nsteps) * int(self.prm.nsub))
         return self.stats / n
+
+
+def save_viewlog(f1, log, timestamp=None):
+    """Writes one robot's control_test_log() as the file template/viewlog.py reads (saveLog :24-33, readFile :50-56):
+    gzip-pickled dict {'t','q','dq','u','accdes','posdes'} of arrays, one row per >= 0.999 ms like appendLog (:11-22),
+    q = (p, quaternion xyzw of Rb), named `<f1>_<YYYYmmddHHMMSS>.zip`. Returns the file name."""
+    import gzip
+    import pickle
+    import time
+    from scipy.spatial.transform import Rotation
+    t = np.asarray(log["t"], np.float64)
+    keep, last = [], -np.inf
+    for i, ti in enumerate(t):
+        if ti - last >= 0.999:
+            keep.append(i)
+            last = ti
+    keep = np.array(keep, int)
+    Rb = np.asarray(log["R"])[keep].reshape(-1, 3, 3).transpose(0, 2, 1)          # stored column-major
+    y = np.asarray(log["y"])[keep]
+    data = {"t": t[keep], "q": np.hstack((y[:, 0:3], Rotation.from_matrix(Rb).as_quat())), "dq": y[:, 6:12],
+            "u": np.asarray(log["u"])[keep], "accdes": np.asarray(log["accdes"])[keep],
+            "posdes": np.asarray(log["pdes"])[keep]}
+    fname = "%s_%s.zip" % (f1, timestamp or time.strftime("%Y%m%d%H%M%S", time.localtime()))
+    with gzip.GzipFile(fname, "wb") as zf:
+        pickle.dump(data, zf)
+    return fname
 
 
 MODELS = {"ca6": (0, 18, 6, 30), "ThrustStrokeDev": (1, 12, 4, 12)}  # id, state rows, input rows, vf output rows
