@@ -187,7 +187,7 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
 
 /* fp32 step-kernel choice. 0 (default): automatic -- the all-assembly kernel (robobee3d_amd/asmstep.py: phase A,
  * ADMM loop, phase C and the RK4 plant as one generated gfx950 stream) whenever the call is inside its scope (no task
- * generator, batch-constant weights, RK4 plant or nsub = 0, no WL coupling, maxIter >= 1), else the C++ kernel with
+ * generator, batch-constant weights, no WL coupling, maxIter >= 1), else the C++ kernel with
  * the assembly ADMM loop. 1: always the latter (ablation / cross-check). fp64 always runs the C++ kernel. */
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode);
 

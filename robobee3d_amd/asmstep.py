@@ -22,7 +22,7 @@ algebraically the reference's Einv / Dinv / cinv-weighted norms), sums are assoc
 v_rcp_f32 + one Newton step. Everything is checked on CPU by interpreting the emitted instructions
 (asmgen.simulate) against the oracle before it reaches a GPU (tests/test_asm_step.py).
 
-Scope of this fast path: fp32, task generator off, batch-constant weights, RK4 plant (or nsub = 0), no WL coupling;
+Scope of this fast path: fp32, task generator off, batch-constant weights, no WL coupling (both plant steps);
 optional per-robot Ib / thrust gain / actualT0 / stats / status / info. umpc_mi355x.hip dispatches.
 """
 import os
@@ -38,7 +38,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # Parameter block (kernarg-resident struct umpcasm::StepParams, 4-byte words; the kernel s_loads it once)
 # ----------------------------------------------------------------------------------------------------------
 PTRS = ["state", "ctrl", "ref", "ws", "out", "stats", "status", "info", "Ib", "gain", "aT0"]
-INTS = ["stride", "K", "maxIter", "nsub"]
+INTS = ["stride", "K", "maxIter", "nsub", "plant"]
 FLOATS = ["dt", "dtg", "Tmax", "wpr", "wpf", "ws_", "wvr", "wvf", "wds", "wthrust", "wmom",
           "iwpr", "iwpf", "iws", "iwvr", "iwvf", "iwds", "iwthrust", "iwmom",
           "Ib0", "Ib1", "Ib2", "Ibi0", "Ibi1", "Ibi2", "h", "hh", "h6", "taulim", "gpl", "idt", "nwpr", "nwpf", "nws",
@@ -47,13 +47,13 @@ FLOATS = ["dt", "dtg", "Tmax", "wpr", "wpf", "ws_", "wvr", "wvf", "wds", "wthrus
 # 1/rho_eq, rho_eq as even pairs); s11 = S_ITERS.
 S_PARAM = 4
 S_PTR = {n: 40 + 2 * k for k, n in enumerate(PTRS)}                  # s40..s61
-S_INT = {"stride": 10, "K": 13, "maxIter": S_ITERS, "nsub": 5}
+S_INT = {"stride": 10, "K": 13, "maxIter": S_ITERS, "nsub": 5, "plant": 39}
 S_F = {n: 64 + k for k, n in enumerate(FLOATS)}                      # s64..s99
 assert max(S_F.values()) <= 101
 S_STEP, S_SUB, S_RUIZ = 12, 15, 15          # loop counters: closed-loop step; plant substep / Ruiz pass (never nested)
 S_MBAD, S_MP0 = 62, 14                      # phase C masks: s[62:63]; s[14:15] (ADMM / Ruiz counters are dead there)
 S_M0, S_M1, S_M2, S_M3 = 30, 32, 34, 36     # lane masks (pairs)
-S_C = {"minscal": 16, "maxscal": 17, "c45": 18, "one": 19, "eps": 38, "eps10": 39, "rho": 6, "rinv": 7, "rmin": 8,
+S_C = {"minscal": 16, "maxscal": 17, "c45": 18, "eps10": 19, "eps": 38, "rho": 6, "rinv": 7, "rmin": 8,
        "rmininv": 9, "infty_ms": 100, "rhotol": 101}   # scalar constants set by the prologue
 S_TMP = 4     # s[4:5] is free once the prologue has read the parameter block
 OFF = {}
@@ -341,7 +341,7 @@ class StepGen:
         for reg, val in ((S_ALPHA, 1.6), (S_OMA, float(f32(1.0) - f32(1.6))), (S_SIGMA, 1e-6), (S_RINV, 0.01), (S_RHO, 100.0)):
             e("s_mov_b32", sg(reg), f32bits(val))
             e("s_mov_b32", sg(reg + 1), f32bits(val))
-        for name, val in (("minscal", 1e-4), ("maxscal", 1e4), ("c45", float(f32(1.0) / f32(self.s.nx))), ("one", 1.0),
+        for name, val in (("minscal", 1e-4), ("maxscal", 1e4), ("c45", float(f32(1.0) / f32(self.s.nx))),
                           ("eps", 1e-4), ("eps10", float(f32(10) * f32(1e-4))), ("rho", 0.1), ("rinv", float(f32(1.0) / f32(0.1))),
                           ("rmin", 1e-6), ("rmininv", float(f32(1.0) / f32(1e-6))),
                           ("infty_ms", float(f32(1e30) * f32(1e-4))), ("rhotol", 1e-4)):
@@ -1395,6 +1395,100 @@ class StepGen:
             e("v_sub_f32", v(b), v(u2), v(b))
             e("v_mul_f32", v(dst + 16), v(b), v(Ibi[1]))
             e("v_mul_f32", v(dst + 17), "-" + v(hz), v(Ibi[2]))
+        lab_rk4, lab_done = self.label(), self.label()
+        e("s_cmp_lg_u32", sg(S_INT["plant"]), 0)
+        e("s_cbranch_scc1", lab_rk4 + "f")
+        # ---- mode 0: the reference's own step (template/genqp.py:32-41): p += h v, R <- R expm(skew(w) h) (Rodrigues
+        # form of the scipy expm), dq += h ddq, all from the OLD state. sin(th)/th and (1 - cos th)/th^2 as 8-term
+        # series in t = th^2 (the C++ / oracle statement switches to sin / cos at t >= 1e-2; the series agree with it to
+        # fp32 round-off for |w| h < 1.5 rad per substep, far beyond any physical spin rate).
+        e("s_mov_b32", sg(S_SUB), sg(S_INT["nsub"]))
+        top0 = self.label()
+        e("label", top0)
+        R = lambda k: Y0 + 3 + k
+        wx, wy, wz = Y0 + 15, Y0 + 16, Y0 + 17
+        dd = [YS + k for k in range(6)]                      # ddq
+        e("v_mul_f32", v(dd[0]), v(Th), v(R(6)))
+        e("v_mul_f32", v(dd[1]), v(Th), v(R(7)))
+        e("v_mul_f32", v(dd[2]), v(Th), v(R(8)))
+        e("v_subrev_f32", v(dd[2]), SF("gpl"), v(dd[2]))
+        hx, hy, hz = YS + 6, YS + 7, YS + 8
+        e("v_mul_f32", v(hx), v(Ib[0]), v(wx))
+        e("v_mul_f32", v(hy), v(Ib[1]), v(wy))
+        e("v_mul_f32", v(hz), v(Ib[2]), v(wz))
+        e("v_mul_f32", v(a), v(wz), v(hy))
+        e("v_fma_f32", v(a), v(wy), v(hz), "-" + v(a))
+        e("v_mul_f32", v(b), v(wx), v(hz))
+        e("v_fma_f32", v(b), v(wz), v(hx), "-" + v(b))
+        e("v_mul_f32", v(hz), v(wy), v(hx))
+        e("v_fma_f32", v(hz), v(wx), v(hy), "-" + v(hz))
+        e("v_sub_f32", v(a), v(u1), v(a))
+        e("v_mul_f32", v(dd[3]), v(a), v(Ibi[0]))
+        e("v_sub_f32", v(b), v(u2), v(b))
+        e("v_mul_f32", v(dd[4]), v(b), v(Ibi[1]))
+        e("v_mul_f32", v(dd[5]), "-" + v(hz), v(Ibi[2]))
+        for i in range(3):
+            e("v_fmac_f32", v(Y0 + i), SF("h"), v(Y0 + 12 + i))            # p += h v (old v)
+        ax, ay, az, tt, ca, cb = [KK + k for k in range(6)]
+        e("v_mul_f32", v(ax), SF("h"), v(wx))
+        e("v_mul_f32", v(ay), SF("h"), v(wy))
+        e("v_mul_f32", v(az), SF("h"), v(wz))
+        e("v_mul_f32", v(tt), v(ax), v(ax))
+        e("v_fmac_f32", v(tt), v(ay), v(ay))
+        e("v_fmac_f32", v(tt), v(az), v(az))
+        import math
+        ca_c = [(-1.0) ** k / math.factorial(2 * k + 1) for k in range(8)]
+        cb_c = [(-1.0) ** k / math.factorial(2 * k + 2) for k in range(8)]
+        e("v_mov_b32", v(ca), f32bits(ca_c[7]))
+        e("v_mov_b32", v(cb), f32bits(cb_c[7]))
+        for k in range(6, -1, -1):
+            e("v_fmaak_f32", v(ca), v(ca), v(tt), f32bits(ca_c[k]))
+            e("v_fmaak_f32", v(cb), v(cb), v(tt), f32bits(cb_c[k]))
+        # E = I + a K + b K^2
+        E = [[KK + 6 + 3 * r + c for c in range(3)] for r in range(3)]
+        xx, yy, zz, xy, xz, yz = [AC + k for k in range(6)]
+        e("v_mul_f32", v(xx), v(ax), v(ax))
+        e("v_mul_f32", v(yy), v(ay), v(ay))
+        e("v_mul_f32", v(zz), v(az), v(az))
+        e("v_mul_f32", v(xy), v(ax), v(ay))
+        e("v_mul_f32", v(xz), v(ax), v(az))
+        e("v_mul_f32", v(yz), v(ay), v(az))
+        e("v_mul_f32", v(xy), v(cb), v(xy))
+        e("v_mul_f32", v(xz), v(cb), v(xz))
+        e("v_mul_f32", v(yz), v(cb), v(yz))
+        t1 = AC + 6
+        e("v_add_f32", v(t1), v(yy), v(zz))
+        e("v_fma_f32", v(E[0][0]), "-" + v(cb), v(t1), 1.0)
+        e("v_add_f32", v(t1), v(xx), v(zz))
+        e("v_fma_f32", v(E[1][1]), "-" + v(cb), v(t1), 1.0)
+        e("v_add_f32", v(t1), v(xx), v(yy))
+        e("v_fma_f32", v(E[2][2]), "-" + v(cb), v(t1), 1.0)
+        e("v_fma_f32", v(E[0][1]), "-" + v(ca), v(az), v(xy))
+        e("v_fma_f32", v(E[1][0]), v(ca), v(az), v(xy))
+        e("v_fma_f32", v(E[0][2]), v(ca), v(ay), v(xz))
+        e("v_fma_f32", v(E[2][0]), "-" + v(ca), v(ay), v(xz))
+        e("v_fma_f32", v(E[1][2]), "-" + v(ca), v(ax), v(yz))
+        e("v_fma_f32", v(E[2][1]), v(ca), v(ax), v(yz))
+        Rn = [AC + 7 + k for k in range(9)]
+        for c in range(3):
+            for r in range(3):
+                e("v_mul_f32", v(Rn[r + 3 * c]), v(R(r)), v(E[0][c]))
+                e("v_fmac_f32", v(Rn[r + 3 * c]), v(R(r + 3)), v(E[1][c]))
+                e("v_fmac_f32", v(Rn[r + 3 * c]), v(R(r + 6)), v(E[2][c]))
+        for k in range(9):
+            e("v_mov_b32", v(R(k)), v(Rn[k]))
+        for i in range(6):
+            e("v_fmac_f32", v(Y0 + 12 + i), SF("h"), v(dd[i]))              # dq += h ddq
+        e("v_fmac_f32", v(serr), v(Y0), v(Y0))
+        e("v_fmac_f32", v(serr), v(Y0 + 1), v(Y0 + 1))
+        e("v_fmac_f32", v(serr), v(Y0 + 2), v(Y0 + 2))
+        e("v_add_f32", v(seff), v(seff), v(einc))
+        e("s_sub_i32", sg(S_SUB), sg(S_SUB), 1)
+        e("s_cmp_gt_i32", sg(S_SUB), 0)
+        e("s_cbranch_scc1", top0 + "b")
+        e("s_branch", lab_done + "f")
+        # ---- mode 1: classical RK4 on the same vector field (build-defined)
+        e("label", lab_rk4)
         e("s_mov_b32", sg(S_SUB), sg(S_INT["nsub"]))
         top = self.label()
         e("label", top)
@@ -1421,6 +1515,7 @@ class StepGen:
         e("s_sub_i32", sg(S_SUB), sg(S_SUB), 1)
         e("s_cmp_gt_i32", sg(S_SUB), 0)
         e("s_cbranch_scc1", top + "b")
+        e("label", lab_done)
         self.store_rows("state", 0, [Y0 + i for i in range(18)], voff)
         e("s_cmp_eq_u64", sp(S_PTR["stats"]), 0)
         e("s_cbranch_scc1", lab_s2 + "f")
@@ -1751,6 +1846,8 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
                 setv(t[1], f32(np.float64(fsrc(t[2])) * np.float64(fsrc(t[3])) + np.float64(fsrc(t[4]))))
             elif m == "v_fmac_f32":
                 setv(t[1], f32(np.float64(fsrc(t[2])) * np.float64(fsrc(t[3])) + np.float64(fsrc(t[1]))))
+            elif m == "v_fmaak_f32":
+                setv(t[1], f32(np.float64(fsrc(t[2])) * np.float64(fsrc(t[3])) + np.float64(asf(u32(t[4])))))
             elif m == "v_mul_f32":
                 setv(t[1], f32(fsrc(t[2]) * fsrc(t[3])))
             elif m == "v_add_f32":

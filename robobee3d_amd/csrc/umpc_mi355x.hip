@@ -303,16 +303,15 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   a.wl = h->wl; a.wlu = (T *)h->wlu; a.wlw = (T *)h->wlw;
   const int grid = (h->B + kBlock - 1) / kBlock;
   if constexpr (sizeof(T) == 4) {
-    // all-assembly fast path: fp32, no task generator, batch-constant weights, RK4 plant or controller only, no WL
-    // coupling, >= 1 iteration, row offsets within 31 bits; UMPC_NO_ASM_STEP=1 forces the C++ / assembly-loop kernel
+    // all-assembly fast path: fp32, no task generator, batch-constant weights, no WL coupling, >= 1 iteration, row
+    // offsets within 31 bits (either plant); UMPC_NO_ASM_STEP=1 forces the C++ / assembly-loop kernel
     static const bool no_asm = getenv("UMPC_NO_ASM_STEP") != nullptr;
     const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 4 < ((size_t)1 << 31);
-    if (!no_asm && h->step_kernel == 0 && fits && K >= 1 && h->task == 0 && !h->weights && !h->wl && h->prm.maxIter >= 1 &&
-        (nsub == 0 || h->prm.plant_mode == 1)) {
+    if (!no_asm && h->step_kernel == 0 && fits && K >= 1 && h->task == 0 && !h->weights && !h->wl && h->prm.maxIter >= 1) {
       umpcasm::StepParams p;
       p.state = state; p.ctrl = ctrl; p.ref = ref; p.ws = h->ws; p.out = out; p.stats = stats; p.status = status;
       p.info = info; p.Ib = Ib; p.gain = gain; p.aT0 = actualT0;
-      p.stride = h->B * 4; p.K = K; p.maxIter = h->prm.maxIter; p.nsub = nsub;
+      p.stride = h->B * 4; p.K = K; p.maxIter = h->prm.maxIter; p.nsub = nsub; p.plant = h->prm.plant_mode;
       const umpc_batch_params_t &q = h->prm;
       const float one = 1.0f;
       p.dt = (float)q.dt; p.dtg = (float)q.dt * (float)q.g; p.Tmax = (float)q.TtoWmax * (float)q.g;
@@ -373,9 +372,10 @@ const int *umpcAxIdx(void) { return umpcgen::kAxIdx; }
 const int *umpcKKTPerm(void) { return umpcgen::kPerm; }
 int umpcNnzL(void) { return umpcgen::NNZL; }
 const char *umpcKernelName(int dtype, int plant_mode) {
-  // the kernel a default fp32 rollout dispatches to (launch_rollout): the all-assembly kernel for the RK4 plant
+  // the kernel a default fp32 rollout dispatches to (launch_rollout)
   if (dtype == UMPC_F64) return "umpc_rollout_kernel<double>";
-  return plant_mode == 1 && !getenv("UMPC_NO_ASM_STEP") ? "umpc_rollout_asm_kernel" : "umpc_rollout_kernel<float>";
+  (void)plant_mode;
+  return !getenv("UMPC_NO_ASM_STEP") ? "umpc_rollout_asm_kernel" : "umpc_rollout_kernel<float>";
 }
 
 void umpcBatchDefaultParams(umpc_batch_params_t *p) {

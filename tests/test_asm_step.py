@@ -58,7 +58,7 @@ def test_closed_loop_steps_match_the_oracle(program, oracle_built):
     got = []
     for b in range(B):
         a = _arrays(st, ref, b)
-        n = asmstep.simulate(ins, a, dict(K=K, maxIter=50, nsub=25), fl)
+        n = asmstep.simulate(ins, a, dict(K=K, maxIter=50, nsub=25, plant=1), fl)
         assert 100000 < n < 140000
         got.append(a)
     s64 = st.astype(np.float64)
@@ -87,7 +87,7 @@ def test_options_monte_carlo_actualT0_and_controller_only(program, oracle_built)
     Ib, gain = monte_carlo_draws(B, 20201120, np.float64)
     for b in range(B):
         a = _arrays(st, ref, b, Ib=Ib, gain=gain)
-        asmstep.simulate(ins, a, dict(K=1, maxIter=50, nsub=25), asmstep.host_floats())
+        asmstep.simulate(ins, a, dict(K=1, maxIter=50, nsub=25, plant=1), asmstep.host_floats())
         s64 = np.ascontiguousarray(st[:, b:b + 1]).astype(np.float64)
         c64 = np.zeros((127, 1)); c64[124:] = 1
         out_o, _, status_o = oracle_built.batch_rollout(s64, c64, np.ascontiguousarray(ref[:, b:b + 1]).astype(np.float64), 1,
@@ -100,7 +100,7 @@ def test_options_monte_carlo_actualT0_and_controller_only(program, oracle_built)
     for it in (1, 2, 3):
         a = _arrays(st, ref, 0, aT0=np.array([0.0123, -1.0]))
         before = a["state"].copy()
-        asmstep.simulate(ins, a, dict(K=1, maxIter=it, nsub=0), asmstep.host_floats())
+        asmstep.simulate(ins, a, dict(K=1, maxIter=it, nsub=0, plant=1), asmstep.host_floats())
         assert np.array_equal(a["state"], before)                      # nsub = 0: the state is only read
         o = oracle_built.Oracle(np.float64, perm=g.s.perm, maxIter=it)
         o.set_canonical(True)
@@ -119,7 +119,7 @@ def test_limit_scaling_exact_path(program, oracle_built):
     st, ref = hover_initial_conditions(1, 3, np.float32)
     kw = dict(wvf=5e5, wmom=2e-5)
     a = _arrays(st, ref, 0)
-    asmstep.simulate(ins, a, dict(K=1, maxIter=50, nsub=0), asmstep.host_floats(**kw))
+    asmstep.simulate(ins, a, dict(K=1, maxIter=50, nsub=0, plant=1), asmstep.host_floats(**kw))
     o = oracle_built.Oracle(np.float64, perm=g.s.perm, **kw)
     o.set_canonical(True)
     R = st[3:12, 0].reshape(3, 3).T
@@ -127,3 +127,22 @@ def test_limit_scaling_exact_path(program, oracle_built):
     assert abs(a["out"][0] - uq[0]) < 1e-4 and np.abs(a["out"][3:] - ac).max() < 1e-4     # extreme weights: worse conditioning
     assert np.all(np.abs(a["out"][1:3] - uq[1:]) <= np.maximum(5e-2, 2e-3 * np.abs(uq[1:])))
     np.testing.assert_allclose(a["ctrl"][124:], np.asarray(o.get("E"))[36:39], rtol=1e-4)
+
+
+def test_reference_euler_expm_plant_mode(program, oracle_built):
+    """plant = 0: the reference's own step (template/genqp.py:32-41, Euler + SO(3) exponential) inside the assembly
+    kernel, against the fp64 oracle's restatement of it (which reproduces scipy's expm to 1e-12, tests/test_oracle_golden.py)."""
+    g, ins = program
+    B, K = 2, 2
+    st, ref = hover_initial_conditions(B, 5, np.float32)
+    for b in range(B):
+        a = _arrays(st, ref, b)
+        asmstep.simulate(ins, a, dict(K=K, maxIter=50, nsub=25, plant=0), asmstep.host_floats())
+        s64 = np.ascontiguousarray(st[:, b:b + 1]).astype(np.float64)
+        c64 = np.zeros((127, 1)); c64[124:] = 1
+        out_o, stats_o, _ = oracle_built.batch_rollout(s64, c64, np.ascontiguousarray(ref[:, b:b + 1]).astype(np.float64), K,
+                                                       dtype=np.float64, perm=g.s.perm, plant_mode=0)
+        assert np.abs(a["state"][0:3] - s64[0:3, 0]).max() < 1e-4 and np.abs(a["state"][3:] - s64[3:, 0]).max() < 3e-5
+        R = a["state"][3:12].reshape(3, 3)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5
+        np.testing.assert_allclose(a["stats"], stats_o[:, 0], rtol=1e-4)

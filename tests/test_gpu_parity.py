@@ -588,3 +588,50 @@ def test_assembly_kernel_and_cpp_kernel_agree(torch_cuda):
     flips = int(np.count_nonzero(a[4] != c[4]))
     record_margin("assembly vs C++ step kernel (B=4096, K=10)", "status flips of 4096", flips, 400)
     assert flips <= 400 and set(np.unique(a[4])).issubset({1, 2, -2})
+
+
+def test_assembly_kernel_ragged_batches_and_monte_carlo(torch_cuda, oracle_built):
+    """The all-assembly kernel with exec-masked lanes (B = 1, 63, 65, 131: the last wave is partial) and with
+    per-robot inertia / thrust gain (config 5 inputs) in fp32, RK4 plant: partial batches are bit-identical slices of
+    a larger one; the Monte-Carlo rollout matches the fp64 oracle within the fp32 closed-loop band."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions, monte_carlo_draws
+    from robobee3d_amd import _lib
+    assert b"asm" in _lib.lib().umpcKernelName(0, 1)
+    st, ref = hover_initial_conditions(131, 7)
+    big = BatchUprightMPC(131, torch.float32, plant_mode=1)
+    big.set_state(st, ref)
+    big.rollout(3)
+    for n in (1, 63, 65):
+        m = BatchUprightMPC(n, torch.float32, plant_mode=1)
+        m.set_state(st[:, :n].copy(), ref[:, :n].copy())
+        m.rollout(3)
+        np.testing.assert_array_equal(m.state.cpu().numpy(), big.state[:, :n].cpu().numpy())
+        np.testing.assert_array_equal(m.out.cpu().numpy(), big.out[:, :n].cpu().numpy())
+        np.testing.assert_array_equal(m.status.cpu().numpy(), big.status[:n].cpu().numpy())
+    # K launches of one step == one launch of K steps
+    one = BatchUprightMPC(131, torch.float32, plant_mode=1)
+    one.set_state(st, ref)
+    for _ in range(3):
+        one.rollout(1)
+    np.testing.assert_array_equal(one.state.cpu().numpy(), big.state.cpu().numpy())
+    np.testing.assert_array_equal(one.stats.cpu().numpy(), big.stats.cpu().numpy())
+    # config 5 inputs
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    B, K = 320, 8
+    st, ref = hover_initial_conditions(B, 20201120, np.float64)
+    Ib, gain = monte_carlo_draws(B, 20201120, np.float64)
+    ctrl = np.zeros((127, B)); ctrl[124:] = 1
+    s_o = st.copy()
+    out_o, stats_o, _ = oracle_built.batch_rollout(s_o, ctrl, ref, K, dtype=np.float64, perm=perm, Ib=Ib, gain=gain, plant_mode=1)
+    m = BatchUprightMPC(B, torch.float32, plant_mode=1)
+    m.set_state(st.astype(np.float32), ref.astype(np.float32))
+    m.Ib = torch.as_tensor(Ib.astype(np.float32)).cuda()
+    m.gain = torch.as_tensor(gain.astype(np.float32)).cuda()
+    m.rollout(K)
+    s = m.state.cpu().numpy().astype(np.float64)
+    dp, ds = np.abs(s[0:3] - s_o[0:3]).max(), np.abs(s[3:] - s_o[3:]).max()
+    record_margin("assembly kernel, config-5 inputs (B=320, K=8) vs fp64 oracle", "|dp| mm", dp, 1.5e-3)
+    record_margin("assembly kernel, config-5 inputs (B=320, K=8) vs fp64 oracle", "|dR|,|ddq|", ds, 3e-4)
+    assert dp <= 1.5e-3 and ds <= 3e-4
+    np.testing.assert_allclose(m.stats.cpu().numpy(), stats_o, rtol=1e-3)
