@@ -1593,7 +1593,7 @@ def write(path=None, N=3, perm=None):
         out.append("  int32_t %s;" % n)
     for n in FLOATS:
         out.append("  float %s;" % n)
-    out += ["};", "static_assert(sizeof(StepParams) == %d, \"StepParams layout\");" % PARAM_BYTES,
+    out += ["};", "static_assert(sizeof(StepParams) == %d, \"StepParams layout\");" % ((PARAM_BYTES + 7) // 8 * 8),
             "constexpr int STEP_LDS_BYTES_PER_LANE = %d;" % (NLDS * 4), "}  // namespace umpcasm",
             "// inputs: v0 = 4 * robot, v1 = lane LDS address, s[4:5] = &StepParams (kernarg)",
             "#define UMPC_STEP_ASM(voff, ldsaddr, params) asm volatile( \\"]
