@@ -49,7 +49,7 @@ def _load_seq_into(mpc, seq, torch, n=None):
 def test_native_library_is_loaded(torch_cuda):
     from robobee3d_amd import _lib
     L = _lib.lib()
-    assert b"umpc_rollout_kernel" in L.umpcKernelName(0, 0)
+    assert b"umpc_rollout" in L.umpcKernelName(0, 0)
     with open("/proc/self/maps") as f:
         assert "libumpc_mi355x.so" in f.read()
 
