@@ -291,9 +291,10 @@ def main():
     else:
         from robobee3d_amd.batch import BatchUprightMPC
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        force = os.environ.get("UMPC_FORCE_DIST") == "1"    # rehearse the RCCL path with one rank on a one-GPU box
+        if world > 1 or force:
             torch.cuda.set_device(local_rank)
-            shard.init("nccl", device=dev)   # "nccl" is RCCL on ROCm
+            shard.init("nccl", device=dev, force=force)   # "nccl" is RCCL on ROCm
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     ndt = np.float32 if args.dtype == "f32" else np.float64
     plant_mode = 0 if args.plant == "euler" else 1
@@ -314,7 +315,7 @@ def main():
         mpc.gain = torch.as_tensor(gain).to(dev)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
@@ -414,8 +415,11 @@ def main():
             line["roofline"] = None
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             line["cpu_baseline"] = cpu_baseline(args, plant_mode)
+        if dist.is_initialized():
+            line["collectives"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                   "gathered_robots": int(metric.shape[1])}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

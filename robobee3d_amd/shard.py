@@ -16,9 +16,10 @@ def world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend=None, device=None):
+def init(backend=None, device=None, force=False):
+    """force: initialise the process group even for world_size 1 (rehearsal of the RCCL path on a one-GPU box)"""
     rank, ws, local_rank = world()
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -43,14 +44,14 @@ def split_range(total, rank, ws):
 
 def max_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def gather_stats(stats):
     """stats [rows, B_local] on every rank -> [rows, sum B_local] in global robot order (all ranks)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return stats
     ws = dist.get_world_size()
     n = torch.tensor([stats.shape[1]], dtype=torch.int64, device=stats.device)

@@ -635,3 +635,23 @@ def test_assembly_kernel_ragged_batches_and_monte_carlo(torch_cuda, oracle_built
     record_margin("assembly kernel, config-5 inputs (B=320, K=8) vs fp64 oracle", "|dR|,|ddq|", ds, 3e-4)
     assert dp <= 1.5e-3 and ds <= 3e-4
     np.testing.assert_allclose(m.stats.cpu().numpy(), stats_o, rtol=1e-3)
+
+
+def test_bench_rccl_path_rehearsal_one_rank(torch_cuda):
+    """The multi-GPU code of bench.py on real hardware as far as a one-GPU box allows: torch.distributed.run with ONE
+    rank and UMPC_FORCE_DIST=1 initialises RCCL ("nccl"), runs the barriers, the max-over-ranks all_reduce and the
+    end-of-run all_gather of the per-robot statistics on device tensors, and prints the contract's JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UMPC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+           "--batch", "4096", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["collectives"] == {"backend": "nccl", "world_size": 1, "gathered_robots": 4096}
+    assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["check"]["nonfinite_state_values"] == 0
