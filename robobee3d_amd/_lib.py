@@ -114,14 +114,15 @@ def _check_resources(remarks):
 def build(force=False, verbose=False):
     """Generate umpc_gen.h / umpc_admm_asm.h and compile the HIP library for gfx950 (works without a GPU).
     One object per translation unit (recompiled only when it or its headers changed), then one link."""
-    from . import asmgen, asmstep, codegen, codegen_qp
+    from . import asmgen, asmgen64, asmstep, codegen, codegen_qp
     gen, _ = codegen.write()
     gasm, _ = asmgen.write()
+    gasm64 = asmgen64.write()[0]
     gstep, _ = asmstep.write()
     greg, gqp_units = codegen_qp.write()
     hdr = os.path.join(ROOT, "include", "umpc_mi355x.h")
     csrc = os.path.join(HERE, "csrc")
-    units = [(SRC, [gen, gasm, gstep, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
+    units = [(SRC, [gen, gasm, gasm64, gstep, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
              (SRC_BQP, [hdr, greg, os.path.join(csrc, "umpc_bqp_common.h"), os.path.join(csrc, "umpc_err.h")])]
     units += [(u, [os.path.join(csrc, "umpc_bqp_common.h")]) for u in gqp_units]
     os.makedirs(OBJ_DIR, exist_ok=True)

@@ -1,0 +1,592 @@
+"""fp64 ADMM phase of the small-batch step kernel (BASELINE config 2: B = 4 096, fp64) as generated gfx950 assembly
+(robobee3d_amd/csrc/umpc_admm_asm64.h, one `asm volatile` block inside umpc_rollout_kernel<double, LDSF>).
+
+Why: the fp64 loop's working set is 561 eight-byte words per robot; hipcc keeps ~130 of them in VGPRs and streams the
+rest through scratch, one wave per CU with nothing to hide the latency behind: 37 us per ADMM iteration, 1.85 of the
+2.32 ms step (tools/f64_breakdown.sh). A lane owns 128 words of VGPR, 128 of AGPR and -- with ONE wave per CU, which is
+what a 4 096-robot batch gives anyway -- 320 words of LDS. That is 576 words, and q and l need no home at all:
+
+    v0            robot byte offset (8*b)                 input
+    v1            lane LDS address (base + 16*lane)       input;  v2 = v1 + 64 KiB, v3 = v1 + 128 KiB (DS offsets are 16 bit)
+    v4..v171      W      KKT rhs / solution, 84 words by ORIGINAL index (x part, then constraint rows)
+    v172..v201    z, lo, up, rho, 1/rho of the three thrust rows
+    v202..v229    LDS read ring (7 x 16 bytes: a quad carries two words, and ~100 cycles of LDS latency at one
+                  fp64 FMA per ~5 cycles need that many quads in flight)
+    v230..v237    AGPR read temporaries     v238..v245  arithmetic temporaries      v246..v255  left to the compiler
+                  (it needs a few for values that live across the block and for its SGPR spills)
+    a0..a167      1/D (permuted order), two v_accvgpr_read per word
+    a168..a239    z of the dynamics rows during the FIRST iteration (afterwards z == l there)
+    LDS           words 0..212 L (CSC order, written there by phase A), 213..257 x, 258..296 y;
+                  word w = byte (w >> 1) * 1024 + 16 * lane + 8 * (w & 1): a ds_read_b128 returns two words
+    q, l          never stored on chip: their 81 words are global_load_dwordx2'ed (L2 hits, 8 B x 64 lanes coalesced)
+                  straight INTO the W registers they are about to be combined with -- W_x <- q right after the x update
+                  freed it, W_z <- l after the y update -- and the rhs is formed in place (W_x = sigma x - W_x).
+                  One VMEM instruction per word where an AGPR home costs two v_accvgpr_read.
+
+Per middle iteration ~1 500 instructions (426 v_fma_f64 of the solves, 214 + 86 ds_read_b128, 168 v_accvgpr_read, 81
+global loads, 43 ds_write). Arithmetic = UMPC_GEN_ADMM_ITER of the C++ statement (csrc/umpc_gen.h) except that the
+backward solve walks each column's entries in descending order and the dynamics rows use delta_y = alpha (nu - y) after
+the first iteration (as asmgen.py; rounding only, parity band 1e-9).
+
+Reference mapping: auxil.c:164-228 (compute_rhs, update_x, update_z, update_y), qdldl_interface.c:322-369,
+qdldl.c:250-293, proj.c:4-14.
+
+`simulate()` interprets the emitted list in exact-rounded float64 for the CPU tests."""
+import os
+import struct
+
+from . import symbolic
+from .asmgen import (Emit, _row_ptr, _adv, FAC_Q, FAC_LOEQ, FAC_M, WS_XPREV, WS_DY, WS_ROWS,
+                     S_WS, S_CTRL, S_STRIDE, S_ITERS, S_P, S_CNT, S_P2, S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+V_B1, V_B2, V_W, V_C, V_RING, V_AT, V_TT, V_END = 2, 3, 4, 172, 202, 230, 238, 246
+NSLOT, N_AT, N_TT = 7, 4, 4
+A_D, A_Z = 0, 168
+NNZL = 213
+LW_X, LW_Y, LW_END = 213, 258, 297
+LDS_BYTES_PER_LANE = 2560
+
+
+def f64bits(v):
+    return struct.unpack("<Q", struct.pack("<d", v))[0]
+
+
+def vp(n):
+    return "v[%d:%d]" % (n, n + 1)
+
+
+def sp(n):
+    return "s[%d:%d]" % (n, n + 1)
+
+
+def lds_addr(word):
+    """(base VGPR, 16-bit offset) of the quad that holds LDS word `word`, and the word's half (0 / 1)"""
+    byte = (word >> 1) * 1024
+    return "v%d" % (1, V_B1, V_B2)[byte >> 16], byte & 0xFFFF, word & 1
+
+
+class Fetch:
+    """Issues LDS quad reads and AGPR reads ahead of the ops that consume them. An op is dict(srcs=[src...], emit=fn)
+    with src = ('L', lds word) | ('A', first AGPR of the word) | ('V', first VGPR of the word); emit receives the first
+    VGPR of every source word. LDS quads live in NSLOT ring slots, least recently used replaced (static analysis)."""
+
+    def __init__(self, e, ahead=14, la=2):
+        self.e, self.ahead, self.la = e, ahead, la
+
+    def run(self, ops):
+        e = self.e
+        n = len(ops)
+        insts, slots = [], [None] * NSLOT
+        inst_of = {}
+        for i, op in enumerate(ops):
+            for q, src in enumerate(op["srcs"]):
+                if src[0] != "L":
+                    continue
+                qd = src[1] >> 1
+                hit = [k for k in slots if k is not None and insts[k]["quad"] == qd]
+                if hit:
+                    insts[hit[0]]["last"] = i
+                    inst_of[(i, q)] = hit[0]
+                    continue
+                free = [sl for sl in range(NSLOT) if slots[sl] is None]
+                sl = free[0] if free else min(range(NSLOT), key=lambda z: insts[slots[z]]["last"])
+                insts.append(dict(quad=qd, first=i, last=i, slot=sl, prev=slots[sl], issued=None))
+                slots[sl] = len(insts) - 1
+                inst_of[(i, q)] = slots[sl]
+        nds, waited, next_inst, next_acc, acc_rr = 0, -1, 0, 0, 0
+        atemp = {}
+
+        def issue(it):
+            nonlocal nds
+            base, off, _ = lds_addr(2 * it["quad"])
+            r = V_RING + 4 * it["slot"]
+            e("ds_read_b128", "v[%d:%d]" % (r, r + 3), base, off)
+            it["issued"] = nds
+            nds += 1
+        for i in range(n):
+            while next_acc < n and next_acc < i + self.la:
+                for q, src in enumerate(ops[next_acc]["srcs"]):
+                    if src[0] == "A":
+                        t = V_AT + 2 * (acc_rr % N_AT)
+                        acc_rr += 1
+                        e("v_accvgpr_read_b32", "v%d" % t, "a%d" % src[1])
+                        e("v_accvgpr_read_b32", "v%d" % (t + 1), "a%d" % (src[1] + 1))
+                        atemp[(next_acc, q)] = t
+                next_acc += 1
+            while next_inst < len(insts):
+                it = insts[next_inst]
+                prev = insts[it["prev"]] if it["prev"] is not None else None
+                if it["first"] <= i + self.ahead and (prev is None or prev["last"] < i):
+                    issue(it)
+                    next_inst += 1
+                else:
+                    break
+            regs = []
+            for q, src in enumerate(ops[i]["srcs"]):
+                if src[0] == "V":
+                    regs.append(src[1])
+                elif src[0] == "A":
+                    regs.append(atemp.pop((i, q)))
+                else:
+                    it = insts[inst_of[(i, q)]]
+                    if it["issued"] is None:
+                        assert inst_of[(i, q)] == next_inst and (it["prev"] is None or insts[it["prev"]]["last"] < i)
+                        issue(it)
+                        next_inst += 1
+                    if it["issued"] > waited:
+                        upto = min(nds - 1, it["issued"] + 1)
+                        e("s_waitcnt", "lgkmcnt(%d)" % min(15, nds - 1 - upto))
+                        waited = upto if nds - 1 - upto <= 15 else it["issued"]
+                    regs.append(V_RING + 4 * it["slot"] + 2 * (src[1] & 1))
+            ops[i]["emit"](regs)
+
+
+def _words(lo, hi):
+    """LDS quads covering words [lo, hi): list of (quad, [words of the range in it])"""
+    out = []
+    for qd in range(lo >> 1, (hi + 1) >> 1):
+        out.append((qd, [w for w in (2 * qd, 2 * qd + 1) if lo <= w < hi]))
+    return out
+
+
+def _read_group(e, quads):
+    """issues the reads of up to NSLOT quads into ring slots 0.., returns {word: first VGPR}"""
+    where = {}
+    for k, (qd, ws) in enumerate(quads):
+        base, off, _ = lds_addr(2 * qd)
+        r = V_RING + 4 * k
+        e("ds_read_b128", "v[%d:%d]" % (r, r + 3), base, off)
+        for w in ws:
+            where[w] = r + 2 * (w & 1)
+    return where
+
+
+def _write_quad(e, qd, ws, reg_of):
+    """writes the words ws of quad qd back from registers reg_of[w] (adjacent registers when both halves are written);
+    returns the number of LDS instructions issued"""
+    base, off, _ = lds_addr(2 * qd)
+    if len(ws) == 2 and reg_of[ws[1]] == reg_of[ws[0]] + 2:
+        e("ds_write_b128", base, "v[%d:%d]" % (reg_of[ws[0]], reg_of[ws[0]] + 3), off)
+        return 1
+    for w in ws:
+        e("ds_write_b64", base, vp(reg_of[w]), off + 8 * (w & 1))
+    return len(ws)
+
+
+def consts(e):
+    for reg, val in ((S_ALPHA, 1.6), (S_OMA, 1.0 - 1.6), (S_SIGMA, 1e-6), (S_RINV, 1.0 / 100.0), (S_RHO, 100.0)):
+        b = f64bits(val)
+        e("s_mov_b32", "s%d" % reg, b & 0xFFFFFFFF)
+        e("s_mov_b32", "s%d" % (reg + 1), b >> 32)
+
+
+def preload_q(e, s):
+    """W_x <- q (rows FAC_Q..), in place operands of the next rhs"""
+    _row_ptr(e, S_P, S_WS, FAC_Q)
+    for j in range(s.nx):
+        e("global_load_dwordx2", vp(V_W + 2 * j), "v0", sp(S_P))
+        _adv(e, S_P)
+
+
+def preload_l(e, s, neq):
+    _row_ptr(e, S_P, S_WS, FAC_LOEQ)
+    for i in range(neq):
+        e("global_load_dwordx2", vp(V_W + 2 * (s.nx + i)), "v0", sp(S_P))
+        _adv(e, S_P)
+
+
+def prologue(e, s):
+    nx, nc, nk = s.nx, s.nc, s.nk
+    neq = 2 * s.N * symbolic.NY
+    consts(e)
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    # 1/D: phase A left it in LDS words 213.. (permuted order) -> AGPRs; then x, y take those words
+    quads = _words(NNZL, NNZL + nk)
+    for g in range(0, len(quads), NSLOT):
+        grp = quads[g:g + NSLOT]
+        where = _read_group(e, grp)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for w, r in sorted(where.items()):
+            e("v_accvgpr_write_b32", "a%d" % (A_D + 2 * (w - NNZL)), "v%d" % r)
+            e("v_accvgpr_write_b32", "a%d" % (A_D + 2 * (w - NNZL) + 1), "v%d" % (r + 1))
+    # x, y of the warm start: ctrl rows 0..83 -> W registers (landing zone) -> LDS
+    e("s_mov_b64", sp(S_P), sp(S_CTRL))
+    for o in range(nx + nc):
+        e("global_load_dwordx2", vp(V_W + 2 * o), "v0", sp(S_P))
+        _adv(e, S_P)
+    # z of the dynamics rows (first iteration) -> AGPRs; z of the thrust rows -> registers
+    for i in range(nc):
+        dst = "a[%d:%d]" % (A_Z + 2 * i, A_Z + 2 * i + 1) if i < neq else vp(V_C + 2 * (i - neq))
+        e("global_load_dwordx2", dst, "v0", sp(S_P))
+        _adv(e, S_P)
+    # thrust-row words lo3 up3 rho3 rinv3 (rows FAC_M..)
+    _row_ptr(e, S_P, S_WS, FAC_M)
+    for k in range(4 * s.N):
+        e("global_load_dwordx2", vp(V_C + 2 * s.N + 2 * k), "v0", sp(S_P))
+        _adv(e, S_P)
+    e("s_waitcnt", "vmcnt(0)")
+    reg_of = {LW_X + o: V_W + 2 * o for o in range(nx + nc)}
+    for qd, ws in _words(LW_X, LW_X + nx + nc):
+        _write_quad(e, qd, ws, reg_of)
+    preload_q(e, s)
+
+
+def body(e, s, first, capture):
+    nx, nc, nk = s.nx, s.nc, s.nk
+    N = s.N
+    neq = 2 * N * symbolic.NY
+    W = lambda o: V_W + 2 * o
+    WK = lambda k: W(s.perm[k])
+    sA, sO, sS, sRi, sRh = (sp(r) for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO))
+    Z3 = lambda k: V_C + 2 * k
+    LO3 = lambda k: V_C + 2 * N + 2 * k
+    UP3 = lambda k: V_C + 4 * N + 2 * k
+    RHO3 = lambda k: V_C + 6 * N + 2 * k
+    RINV3 = lambda k: V_C + 8 * N + 2 * k
+    ptr = sp(S_P2)
+    e("s_waitcnt", "vmcnt(0)")     # q in W_x (and l in W_z of the dynamics rows unless first)
+    ops = []
+
+    def op(srcs, fn):
+        ops.append(dict(srcs=srcs, emit=fn))
+    # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178), q / l already in W
+    for j in range(nx):
+        op([("L", LW_X + j)], lambda r, j=j: e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j))))
+    for i in range(neq):
+        if first:
+            op([("L", LW_Y + i), ("A", A_Z + 2 * i)],
+               lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])))
+        else:
+            op([("L", LW_Y + i)], lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i))))
+    for k in range(N):
+        i = neq + k
+        op([("L", LW_Y + i)], lambda r, i=i, k=k: e("v_fma_f64", vp(W(nx + i)), "-" + vp(RINV3(k)), vp(r[0]), vp(Z3(k))))
+    # ---- forward solve (qdldl.c:250-262), columns ascending, entries ascending: W[r] -= L_j W[c]
+    for c in range(nk):
+        for j in range(s.L_p[c], s.L_p[c + 1]):
+            r_ = s.L_i[j]
+            op([("L", j)], lambda r, r_=r_, c=c: e("v_fma_f64", vp(WK(r_)), "-" + vp(r[0]), vp(WK(c)), vp(WK(r_))))
+    # ---- diagonal (qdldl.c:289)
+    for k in range(nk):
+        op([("A", A_D + 2 * k)], lambda r, k=k: e("v_mul_f64", vp(WK(k)), vp(WK(k)), vp(r[0])))
+    # ---- backward solve (qdldl.c:264-277), the storage walked backwards: W[c] -= L_j W[r]
+    for c in range(nk - 1, -1, -1):
+        for j in range(s.L_p[c + 1] - 1, s.L_p[c] - 1, -1):
+            r_ = s.L_i[j]
+            op([("L", j)], lambda r, r_=r_, c=c: e("v_fma_f64", vp(WK(c)), "-" + vp(r[0]), vp(WK(r_)), vp(WK(c))))
+    Fetch(e).run(ops)
+    # ---- x <- alpha x~ + (1 - alpha) x   (auxil.c:188-201); x_prev of a capturing iteration -> workspace
+    if capture:
+        _row_ptr(e, S_P2, S_WS, WS_XPREV)
+    quads = _words(LW_X, LW_X + nx)
+    for g in range(0, len(quads), NSLOT):
+        grp = quads[g:g + NSLOT]
+        where = _read_group(e, grp)
+        nw = 0      # LDS writes issued behind the group's reads (LDS operations complete in order)
+        for k, (qd, ws) in enumerate(grp):
+            e("s_waitcnt", "lgkmcnt(%d)" % min(15, len(grp) - 1 - k + nw))
+            for w in ws:
+                j, r, t = w - LW_X, where[w], V_TT + 2 * ((w - LW_X) % N_TT)
+                if capture:
+                    e("global_store_dwordx2", "v0", vp(r), ptr)
+                    _adv(e, S_P2)
+                e("v_mul_f64", vp(t), sO, vp(r))
+                e("v_fma_f64", vp(t if capture else r), sA, vp(W(j)), vp(t))
+            nw += _write_quad(e, qd, ws, {w: (V_TT + 2 * ((w - LW_X) % N_TT) if capture else where[w]) for w in ws})
+    if capture:
+        e("s_waitcnt", "vmcnt(0)")   # the stores have read the ring registers
+    preload_q(e, s)
+    # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
+    if capture:
+        _row_ptr(e, S_P2, S_WS, WS_DY)
+    if first:
+        _row_ptr(e, S_P, S_WS, FAC_LOEQ)
+    quads = _words(LW_Y, LW_Y + nc)
+    for g in range(0, len(quads), NSLOT):
+        grp = quads[g:g + NSLOT]
+        where = _read_group(e, grp)
+        nw = 0
+        for k, (qd, ws) in enumerate(grp):
+            e("s_waitcnt", "lgkmcnt(%d)" % min(15, len(grp) - 1 - k + nw))
+            newreg = {}
+            for w in ws:
+                i, r = w - LW_Y, where[w]
+                nu = W(nx + i)
+                t1, t2, t3 = V_TT + 2 * ((2 * i) % N_TT), V_TT + 2 * ((2 * i + 1) % N_TT), V_AT + 2 * (i % 2)
+                if i < neq and not first:
+                    # dynamics rows, z == l == u: delta_y = alpha (nu - y)
+                    e("v_add_f64", vp(t1), vp(nu), "-" + vp(r))
+                    if capture:
+                        e("v_mul_f64", vp(t2), sA, vp(t1))
+                        e("global_store_dwordx2", "v0", vp(t2), ptr)
+                        _adv(e, S_P2)
+                    e("v_fma_f64", vp(r), sA, vp(t1), vp(r))
+                    newreg[w] = r
+                    continue
+                if i < neq:     # first iteration, dynamics row: z_prev from its AGPR, l (= new z) from the workspace
+                    # (one exposed L2 round trip per row, once per step)
+                    zr, lr = V_AT + 4, V_AT + 6
+                    e("v_accvgpr_read_b32", "v%d" % zr, "a%d" % (A_Z + 2 * i))
+                    e("v_accvgpr_read_b32", "v%d" % (zr + 1), "a%d" % (A_Z + 2 * i + 1))
+                    e("global_load_dwordx2", vp(lr), "v0", sp(S_P))
+                    _adv(e, S_P)
+                    rinv, rho = sRi, sRh
+                else:
+                    k3 = i - neq
+                    zr, rinv, rho = Z3(k3), vp(RINV3(k3)), vp(RHO3(k3))
+                e("v_fma_f64", vp(t1), "-" + vp(r), rinv, vp(zr))              # z - y/rho (the rhs again)
+                e("v_fma_f64", vp(t1), vp(nu), rinv, vp(t1))                   # z~
+                e("v_mul_f64", vp(t2), sO, vp(zr))
+                e("v_fma_f64", vp(t1), sA, vp(t1), vp(t2))                     # t = alpha z~ + (1-alpha) z
+                if i < neq:
+                    e("s_waitcnt", "vmcnt(0)")
+                    e("v_add_f64", vp(t2), vp(t1), "-" + vp(lr))               # z <- l
+                    e("v_mul_f64", vp(t2), vp(t2), rho)
+                else:
+                    e("v_fma_f64", vp(t3), vp(r), rinv, vp(t1))
+                    e("v_max_f64", vp(t3), vp(t3), vp(LO3(k3)))
+                    e("v_min_f64", vp(zr), vp(t3), vp(UP3(k3)))
+                    e("v_add_f64", vp(t2), vp(t1), "-" + vp(zr))
+                    e("v_mul_f64", vp(t2), vp(t2), rho)                        # delta_y
+                if capture:
+                    e("global_store_dwordx2", "v0", vp(t2), ptr)
+                    _adv(e, S_P2)
+                e("v_add_f64", vp(r), vp(r), vp(t2))
+                newreg[w] = r
+            nw += _write_quad(e, qd, ws, newreg)
+    if capture:
+        e("s_waitcnt", "vmcnt(0)")
+    preload_l(e, s, neq)
+
+
+def epilogue(e, s):
+    """x, y, z -> ctrl rows (warm start of the next step; phase C reads them from there). z of the dynamics rows is l."""
+    nx, nc = s.nx, s.nc
+    neq = 2 * s.N * symbolic.NY
+    e("s_waitcnt", "vmcnt(0)")      # the last preloads: W_z of the dynamics rows holds l
+    e("s_mov_b64", sp(S_P), sp(S_CTRL))
+    quads = _words(LW_X, LW_X + nx + nc)
+    for g in range(0, len(quads), NSLOT):
+        grp = quads[g:g + NSLOT]
+        where = _read_group(e, grp)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for qd, ws in grp:
+            for w in ws:
+                e("global_store_dwordx2", "v0", vp(where[w]), sp(S_P))
+                _adv(e, S_P)
+        e("s_waitcnt", "vmcnt(0)")
+    for i in range(nc):
+        src = V_W + 2 * (nx + i) if i < neq else V_C + 2 * (i - neq)
+        e("global_store_dwordx2", "v0", vp(src), sp(S_P))
+        _adv(e, S_P)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+
+
+def program(N=3, perm=None):
+    """maxIter >= 1 (the caller takes the C++ loop otherwise)"""
+    s = symbolic.analyse(N, perm)
+    e = Emit()
+    prologue(e, s)
+    body(e, s, first=True, capture=True)
+    e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_ITERS, 2)
+    e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
+    e("s_cbranch_scc1", "8f")
+    e("label", "7")
+    body(e, s, first=False, capture=False)
+    e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+    e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
+    e("s_cbranch_scc1", "7b")
+    e("label", "8")
+    e("s_cmp_lt_i32", "s%d" % S_ITERS, 2)
+    e("s_cbranch_scc1", "6f")
+    body(e, s, first=False, capture=True)
+    e("label", "6")
+    epilogue(e, s)
+    return e.ins, s
+
+
+def fmt(t):
+    m = t[0]
+    if m == "label":
+        return "%s:" % t[1]
+    a = [("0x%x" % x if isinstance(x, int) and m in ("s_mov_b32", "v_add_u32") else str(x)) for x in t[1:]]
+    if m.startswith("ds_read") or m.startswith("ds_write"):
+        return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
+    if m == "s_waitcnt":
+        return "s_waitcnt " + " ".join(a)
+    return "%s %s" % (m, ", ".join(a))
+
+
+def write(path=None, N=3, perm=None):
+    path = path or os.path.join(HERE, "csrc", "umpc_admm_asm64.h")
+    ins, s = program(N, perm)
+    used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1] + list(range(S_ALPHA, S_RHO + 2))
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
+           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
+    lab7 = [k for k, t in enumerate(ins) if t == ("label", "7")][0]
+    lab8 = [k for k, t in enumerate(ins) if t == ("label", "8")][0]
+    out = ["// GENERATED by robobee3d_amd/asmgen64.py -- do not edit.",
+           "// ADMM phase of the fp64 small-batch step kernel: %d instructions, middle-iteration body %d." % (len(ins), lab8 - lab7),
+           "#pragma once",
+           "namespace umpcasm64 {",
+           "constexpr int LDS_BYTES_PER_LANE = %d, LW_X = %d, LW_Y = %d;" % (LDS_BYTES_PER_LANE, LW_X, LW_Y),
+           "}  // namespace umpcasm64",
+           "// inputs: v0 = 8*robot, v1 = lane LDS address (16*lane), s[4:5] = workspace, s[6:7] = ctrl, s10 = 8*B, s11 = maxIter >= 1",
+           "#define UMPC_ADMM_ASM64(voff, ldsaddr, ws, ctrl, stride, iters) asm volatile( \\"]
+    for t in ins:
+        out.append('  "%s\\n" \\' % fmt(t))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(ws), "{s[6:7]}"(ctrl), "{s10}"(stride), "{s11}"(iters) \\')
+    out.append("  : " + ", ".join(clob) + ")")
+    txt = "\n".join(out) + "\n"
+    old = open(path).read() if os.path.exists(path) else None
+    if old != txt:
+        with open(path, "w") as fh:
+            fh.write(txt)
+    return path, len(ins), lab8 - lab7
+
+
+# ---------------------------------------------------------------------------
+# CPU interpreter (one lane), exact-rounded float64
+# ---------------------------------------------------------------------------
+def simulate(ins, mem_ws, mem_ctrl, iters, lds):
+    """mem_ws: float64[WS_ROWS], mem_ctrl: float64[123], lds: float64[320] (L in words 0..212, 1/D in 213..296 on entry).
+    Updates the memories in place; returns the executed instruction count."""
+    import numpy as np
+    from fractions import Fraction
+    V = np.zeros(256, np.uint32)
+    A = np.zeros(256, np.uint32)
+    S = {}
+    scc = 0
+    labels = {}
+    for k, t in enumerate(ins):
+        if t[0] == "label":
+            labels.setdefault(t[1], []).append(k)
+    STRIDE = 4096
+    S[S_WS], S[S_WS + 1] = 1 << 20, 0
+    S[S_CTRL], S[S_CTRL + 1] = 1 << 30, 0
+    S[S_STRIDE], S[S_ITERS] = STRIDE, iters
+    V[1] = 0
+
+    def lohi(x):
+        return int(x[2:x.index(":")])
+
+    def sval(x):
+        if isinstance(x, int):
+            return x
+        if x.startswith("s["):
+            lo = lohi(x)
+            return S.get(lo, 0) | (S.get(lo + 1, 0) << 32)
+        return S.get(int(x[1:]), 0)
+
+    def getd(x):
+        neg = x.startswith("-")
+        if neg:
+            x = x[1:]
+        lo = lohi(x)
+        bits = (int(V[lo]) | (int(V[lo + 1]) << 32)) if x[0] == "v" else (S[lo] | (S[lo + 1] << 32))
+        val = struct.unpack("<d", struct.pack("<Q", bits))[0]
+        return -val if neg else val
+
+    def setd(x, val, file=None):
+        file = V if file is None else file
+        lo = lohi(x)
+        b = f64bits(float(val))
+        file[lo], file[lo + 1] = b & 0xFFFFFFFF, b >> 32
+
+    def fma(a, b, c):
+        if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+            return a * b + c
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def mem(addr):
+        if addr >= (1 << 30):
+            return mem_ctrl, (addr - (1 << 30)) // STRIDE
+        return mem_ws, (addr - (1 << 20)) // STRIDE
+
+    def ldsword(basereg, off):
+        byte = int(V[int(basereg[1:])]) + off
+        return (byte // 1024) * 2 + (byte % 1024) // 8
+
+    pc = nexec = 0
+    while pc < len(ins):
+        t = ins[pc]
+        m = t[0]
+        nexec += 1
+        assert nexec < 2000000, "runaway program"
+        if m in ("label", "s_waitcnt"):
+            pass
+        elif m == "s_mov_b32":
+            S[int(t[1][1:])] = t[2] if isinstance(t[2], int) else sval(t[2])
+        elif m == "s_mov_b64":
+            lo = lohi(t[1])
+            val = sval(t[2])
+            S[lo], S[lo + 1] = val & 0xFFFFFFFF, val >> 32
+        elif m == "s_mul_i32":
+            S[int(t[1][1:])] = (sval(t[2]) * sval(t[3])) & 0xFFFFFFFF
+        elif m == "s_mul_hi_u32":
+            S[int(t[1][1:])] = ((sval(t[2]) * sval(t[3])) >> 32) & 0xFFFFFFFF
+        elif m == "s_add_u32":
+            r = sval(t[2]) + sval(t[3])
+            S[int(t[1][1:])] = r & 0xFFFFFFFF
+            scc = r >> 32
+        elif m == "s_addc_u32":
+            r = sval(t[2]) + sval(t[3]) + scc
+            S[int(t[1][1:])] = r & 0xFFFFFFFF
+            scc = r >> 32
+        elif m == "s_sub_i32":
+            S[int(t[1][1:])] = (sval(t[2]) - sval(t[3])) & 0xFFFFFFFF
+        elif m in ("s_cmp_lt_i32", "s_cmp_gt_i32"):
+            a, b = sval(t[1]), sval(t[2])
+            a = a - (1 << 32) if a & 0x80000000 else a
+            scc = int(a < b) if m == "s_cmp_lt_i32" else int(a > b)
+        elif m in ("s_branch", "s_cbranch_scc1"):
+            if m == "s_branch" or scc:
+                lab, d = t[1][:-1], t[1][-1]
+                cands = labels[lab]
+                pc = min(c for c in cands if c > pc) if d == "f" else max(c for c in cands if c < pc)
+        elif m == "v_add_u32":
+            V[int(t[1][1:])] = (t[2] + int(V[int(t[3][1:])])) & 0xFFFFFFFF
+        elif m == "global_load_dwordx2":
+            arr, row = mem(sval(t[3]))
+            setd(t[1], arr[row], A if t[1][0] == "a" else V)
+        elif m == "global_store_dwordx2":
+            arr, row = mem(sval(t[3]))
+            arr[row] = getd(t[2])
+        elif m == "ds_read_b128":
+            lo = lohi(t[1])
+            w = ldsword(t[2], t[3])
+            for h in range(2):
+                b = f64bits(float(lds[w + h]))
+                V[lo + 2 * h], V[lo + 2 * h + 1] = b & 0xFFFFFFFF, b >> 32
+        elif m == "ds_write_b128":
+            w = ldsword(t[1], t[3])
+            lo = lohi(t[2])
+            for h in range(2):
+                lds[w + h] = getd(vp(lo + 2 * h))
+        elif m == "ds_write_b64":
+            lds[ldsword(t[1], t[3])] = getd(t[2])
+        elif m == "v_accvgpr_read_b32":
+            V[int(t[1][1:])] = A[int(t[2][1:])]
+        elif m == "v_accvgpr_write_b32":
+            A[int(t[1][1:])] = V[int(t[2][1:])]
+        elif m == "v_fma_f64":
+            setd(t[1], fma(getd(t[2]), getd(t[3]), getd(t[4])))
+        elif m == "v_mul_f64":
+            setd(t[1], getd(t[2]) * getd(t[3]))
+        elif m == "v_add_f64":
+            setd(t[1], getd(t[2]) + getd(t[3]))
+        elif m == "v_max_f64":
+            setd(t[1], max(getd(t[2]), getd(t[3])))
+        elif m == "v_min_f64":
+            setd(t[1], min(getd(t[2]), getd(t[3])))
+        else:
+            raise ValueError("unknown instruction %r" % (t,))
+        pc += 1
+    return nexec
+
+
+if __name__ == "__main__":
+    print(write())

@@ -39,16 +39,19 @@ int fail(hipError_t e, const char *what) {
 // (no barriers, no cross-lane traffic). fp32: the ADMM phase is the generated assembly with
 // L[0..160) in LDS (40 float4 per lane = 40,960 B per workgroup -> 4 workgroups = 4 waves per CU,
 // one per SIMD, which is also what 512 registers per lane allow).
-template <typename T, bool LDSF = false>
+// fp64: the C++ loop; LDSF (a batch of at most one wave per CU) keeps L and 1/D in LDS; LDSF + ASM64 additionally runs
+// the ADMM phase as the generated fp64 assembly (umpc_admm_asm64.h), which owns the whole 160 KiB of the CU.
+template <typename T, bool LDSF = false, bool ASM64 = false>
 __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a, int K, const T *actualT0, int skew_ticks) {
   constexpr bool kAsm = sizeof(T) == 4;
-  static_assert(!(kAsm && LDSF), "LDSF is the fp64 variant");
+  static_assert(!(kAsm && LDSF) && (!ASM64 || LDSF), "LDSF / ASM64 are the fp64 variants");
   __shared__ float4 lds[kAsm ? (umpcasm::LDS_BYTES_PER_LANE / 16) * kBlock
-                             : LDSF ? (umpcgen::NNZL + umpcgen::NK) * kBlock * sizeof(T) / 16 : 1];
+                             : ASM64 ? (umpcasm64::LDS_BYTES_PER_LANE / 16) * kBlock
+                             : LDSF ? ((umpcgen::NNZL + umpcgen::NK + 1) / 2) * kBlock : 1];
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= a.B) return;
   // low 32 bits of a flat LDS pointer = the LDS byte address
-  const unsigned ldsaddr = kAsm ? (unsigned)(size_t)(&lds[threadIdx.x]) : 0u;
+  const unsigned ldsaddr = (kAsm || ASM64) ? (unsigned)(size_t)(&lds[threadIdx.x]) : 0u;
   // Every wave runs the same phases (memory-heavy hand-offs, then the ALU-only ADMM loop). Started
   // together, all 1024 resident waves hit HBM at the same instants and idle the ALUs meanwhile. For
   // multi-step launches the waves are started in `skew_groups` staggered groups so that the memory
@@ -58,9 +61,9 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a,
     const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
     while (__builtin_amdgcn_s_memrealtime() - t0 < (long long)g * skew_ticks) __builtin_amdgcn_s_sleep(64);
   }
-  T *ldsw = kAsm ? reinterpret_cast<T *>(lds) + 4 * threadIdx.x : LDSF ? reinterpret_cast<T *>(lds) + threadIdx.x : nullptr;
+  T *ldsw = kAsm ? reinterpret_cast<T *>(lds) + 4 * threadIdx.x : LDSF ? reinterpret_cast<T *>(lds) + 2 * threadIdx.x : nullptr;
 #pragma nounroll
-  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm, LDSF>(a, b, ldsaddr, ldsw, k, actualT0);
+  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm || ASM64, LDSF>(a, b, ldsaddr, ldsw, k, actualT0);
 }
 
 // The all-assembly fp32 fast path (asmstep.py -> umpc_step_asm.h): the whole K-step loop of one wavefront is ONE
@@ -335,14 +338,21 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   if constexpr (sizeof(T) == 8) {
     // small fp64 batches (BASELINE configs[1]: B = 4096 = one wave per CU at most): L and 1/D in LDS, not in scratch
     static const bool no_ldsf = getenv("UMPC_NO_F64_LDS") != nullptr;
+    static const bool no_asm64 = getenv("UMPC_NO_ASM64") != nullptr;
     if (!no_ldsf && grid <= 256) {
-      hipLaunchKernelGGL((umpc_rollout_kernel<T, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
-                         (const T *)actualT0, 0);
+      // ... and the ADMM phase as generated fp64 assembly (needs >= 1 iteration and 31-bit row offsets)
+      const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 8 < ((size_t)1 << 31);
+      if (!no_asm64 && h->step_kernel == 0 && h->prm.maxIter >= 1 && fits)
+        hipLaunchKernelGGL((umpc_rollout_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
+                           (const T *)actualT0, 0);
+      else
+        hipLaunchKernelGGL((umpc_rollout_kernel<T, true, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
+                           (const T *)actualT0, 0);
       hipError_t e2 = hipGetLastError();
       return e2 == hipSuccess ? 0 : fail(e2, "umpcBatchRollout");
     }
   }
-  hipLaunchKernelGGL((umpc_rollout_kernel<T, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
+  hipLaunchKernelGGL((umpc_rollout_kernel<T, false, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
                      (const T *)actualT0, skew_us * 100);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");

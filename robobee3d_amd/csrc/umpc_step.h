@@ -27,6 +27,7 @@
 
 #include "umpc_gen.h"
 #include "umpc_admm_asm.h"
+#include "umpc_admm_asm64.h"
 
 namespace umpc {
 
@@ -449,7 +450,10 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 // word w of this lane's LDS slot: float4-interleaved, ldsw = (T *)lds + 4 * lane
 #define LDSW(w) ldsw[((w) >> 2) * 256 + ((w) & 3)]
   const bool first_step = step == 0;
-  static_assert(!ASM || sizeof(T) == 4, "the assembly loop is fp32");
+  // ASM: the ADMM phase is generated assembly -- fp32: umpc_admm_asm.h (asmgen.py); fp64: umpc_admm_asm64.h (asmgen64.py),
+  // which needs LDSF (L and 1/D handed over in LDS) and maxIter >= 1 (the host dispatches accordingly)
+  constexpr bool ASM32 = ASM && sizeof(T) == 4, ASM64 = ASM && sizeof(T) == 8;
+  static_assert(!ASM64 || LDSF, "the fp64 assembly loop takes the factor from LDS");
   const size_t B = (size_t)a.B;
   const DevParams<T> &prm = a.prm;
   const T sigma = T(1e-6), alpha = T(1.6), oma = T(1.0) - T(1.6);
@@ -463,8 +467,11 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #define UMPC_PHASE_FENCE() asm volatile("" : "+v"(bb)::"memory")
 #define GLD(arr, row) ((arr) + (size_t)(row) * B)[bb]
 #define Q_(j) qv[j]
-#define DI_(k) (*(LDSF ? &ldsw[(NNZL + (k)) * 64] : &Di[LDSF ? 0 : (k)]))
-#define LX_(e) (*(LDSF ? &ldsw[(e) * 64] : &Lx[LDSF ? 0 : (e)]))
+// LDSF word w of this lane: 16-byte quads of two words, quads interleaved over the lanes (ldsw = (T *)lds + 2 * lane),
+// so that the assembly loop fetches two words per ds_read_b128
+#define LDSF_W(w) ldsw[((w) >> 1) * 128 + ((w) & 1)]
+#define DI_(k) (*(LDSF ? &LDSF_W(NNZL + (k)) : &Di[LDSF ? 0 : (k)]))
+#define LX_(e) (*(LDSF ? &LDSF_W(e) : &Lx[LDSF ? 0 : (e)]))
 #define RINV3_(k) rinv3[k]
 #define RHO3_(k) rho3[k]
 #define LO3_(k) lo3[k]
@@ -614,7 +621,12 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     (void)npos;
 #undef A_
 #undef P_
-    if constexpr (ASM) {
+    if constexpr (ASM64) {
+      // L and 1/D are in LDS already (LX_ / DI_); the loop streams l of the dynamics rows from its rows
+#pragma unroll
+      for (int i = 0; i < NEQ; ++i) GLD(a.ws, FAC_LOEQ + i) = lo[i];
+    }
+    if constexpr (ASM32) {
       // the first 160 storage positions of L go straight to their loop home in LDS (float4-interleaved per lane),
       // the rest through rows; the storage order (paired entries adjacent) is the generator's
 #define UMPC_ROW_(r) GLD(a.ws, r)
@@ -631,7 +643,11 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 
   // =========================== phase B: ADMM, osqp.c:354-370 ===========================
   UMPC_PHASE_FENCE();
-  if constexpr (ASM) {
+  if constexpr (ASM64) {
+    const unsigned voff = bb * 8u, stride = (unsigned)a.B * 8u;
+    const int iters = prm.maxIter;
+    UMPC_ADMM_ASM64(voff, ldsaddr, a.ws, a.ctrl, stride, iters);
+  } else if constexpr (ASM32) {
     // generated gfx950 assembly (umpc_admm_asm.h): reads FAC_* and x,y,z, runs maxIter iterations with
     // a static VGPR/AGPR/LDS placement, writes x,y,z back and x_prev / delta_y of the last iteration
     const unsigned voff = bb * 4u, stride = (unsigned)a.B * 4u;
@@ -688,9 +704,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   // x, y, z are consumed where they lie: LDS words 0..122 after the assembly loop (fp32), the ctrl rows after
   // the C++ loop (fp64). No arrays: this phase must stay under 256 live VGPRs (the assembly block clobbers
   // every AGPR, so the compiler has nowhere cheap to spill).
-#define XV(j) (ASM ? LDSW(j) : GLD(a.ctrl, j))
-#define YV(i) (ASM ? LDSW(NX + (i)) : GLD(a.ctrl, NX + (i)))
-#define ZV(i) (ASM ? LDSW(NX + NC + (i)) : GLD(a.ctrl, NX + NC + (i)))
+#define XV(j) (ASM32 ? LDSW(j) : GLD(a.ctrl, j))
+#define YV(i) (ASM32 ? LDSW(NX + (i)) : GLD(a.ctrl, NX + (i)))
+#define ZV(i) (ASM32 ? LDSW(NX + NC + (i)) : GLD(a.ctrl, NX + NC + (i)))
 #pragma unroll
   for (int k = 0; k < N; ++k) { lo3[k] = GLD(a.ws, FAC_M + k); up3[k] = GLD(a.ws, FAC_M + N + k); }
   if (prm.maxIter < 1) {  // no iteration ran: nothing was captured
@@ -900,7 +916,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     if (aT0 >= T(0)) T0next = aT0;
   }
   // controller record + outputs back to HBM (fp64: x, y, z are already in their rows unless cold-started)
-  if (ASM || !has_sol) {
+  if (ASM32 || !has_sol) {
 #pragma unroll
     for (int j = 0; j < NX; ++j) { const T v = has_sol ? XV(j) : T(0); GLD(a.ctrl, j) = v; }
 #pragma unroll

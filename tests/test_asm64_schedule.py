@@ -1,0 +1,102 @@
+"""CPU check of the generated fp64 ADMM assembly (robobee3d_amd/asmgen64.py, BASELINE config 2): the emitted instruction
+list is interpreted in exact-rounded float64 (one lane) and compared with the fp64 oracle's iterates after the same
+number of iterations from the same factorisation (reference: osqp.c:354-370 loop body, auxil.c:164-228,
+qdldl.c:250-293)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+@pytest.fixture(scope="module")
+def prog():
+    from robobee3d_amd import asmgen64
+    ins, s = asmgen64.program()
+    return asmgen64, ins, s
+
+
+def _case(oracle_built, g, ins, s, seq, k, iters):
+    from robobee3d_amd import asmgen
+    perm = np.array(s.perm, np.int32)
+    args = (seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k], seq["sdes"][k],
+            float(seq["actualT0"][k]))
+    pre = [np.asarray(seq[n][k], np.float64) for n in ("pre_x", "pre_y", "pre_z")]
+
+    def fresh(mi):
+        o = oracle_built.Oracle(np.float64, perm=perm, maxIter=mi)
+        o.set_canonical(True, np.asarray(seq["pre_E3"][k], np.float64))
+        o.set_iterates(*pre)
+        o.set_T0(float(seq["pre_T0"][k]))
+        o.update(*args)
+        return o
+
+    o = fresh(0)  # factorisation only
+    ws = np.full(asmgen.WS_ROWS, np.nan)
+    ctrl = np.zeros(123)
+    lds = np.zeros(320)
+    lds[:213] = o.get("L_x")
+    lds[213:297] = o.get("Ddinv")
+    ws[asmgen.FAC_Q:asmgen.FAC_Q + 45] = o.get("q")
+    l, u = o.get("l"), o.get("u")
+    ws[asmgen.FAC_LOEQ:asmgen.FAC_LOEQ + 36] = l[:36]
+    ws[asmgen.FAC_M:asmgen.FAC_M + 3] = l[36:]
+    ws[asmgen.FAC_M + 3:asmgen.FAC_M + 6] = u[36:]
+    ws[asmgen.FAC_M + 6:asmgen.FAC_M + 9] = o.get("rho_vec")[36:]
+    ws[asmgen.FAC_M + 9:asmgen.FAC_M + 12] = o.get("rho_inv_vec")[36:]
+    ctrl[:45], ctrl[45:84], ctrl[84:123] = pre
+    x_before_last = fresh(iters - 1).get("x") if iters > 1 else pre[0]
+    g.simulate(ins, ws, ctrl, iters, lds)
+    o2 = fresh(iters)
+    for name, sl in (("x", slice(0, 45)), ("y", slice(45, 84)), ("z", slice(84, 123))):
+        ref = o2.get(name)
+        assert np.abs(ctrl[sl] - ref).max() <= 1e-12 * max(1e-6, np.abs(ref).max()), (name, k, iters)
+    xp = ws[asmgen.WS_XPREV:asmgen.WS_XPREV + 45]
+    assert np.abs(xp - x_before_last).max() <= 1e-12 * np.abs(x_before_last).max()
+    # delta_y of the last iteration = y_new - y_prev
+    yprev = fresh(iters - 1).get("y") if iters > 1 else pre[1]
+    dy = ws[asmgen.WS_DY:asmgen.WS_DY + 39]
+    ref = o2.get("y") - yprev
+    assert np.abs(dy - ref).max() <= 1e-9 * max(1e-6, np.abs(o2.get("y")).max())
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3, 6])
+def test_generated_fp64_admm_program_matches_oracle(oracle_built, prog, iters):
+    g, ins, s = prog
+    seq = golden("seq_iter50.npz")
+    for k in (0, 11):
+        _case(oracle_built, g, ins, s, seq, k, iters)
+
+
+def test_fp64_register_and_lds_plan(prog):
+    import re
+    g, ins, s = prog
+    assert g.V_W + 2 * s.nk == g.V_C and g.V_C + 2 * 5 * s.N == g.V_RING
+    assert g.V_RING + 4 * g.NSLOT == g.V_AT and g.V_AT + 2 * g.N_AT == g.V_TT and g.V_TT + 2 * g.N_TT == g.V_END <= 256
+    assert g.A_D + 2 * s.nk == g.A_Z and g.A_Z + 2 * 2 * s.N * 6 <= 256
+    assert g.LW_X == len(s.L_i) and g.LW_Y == g.LW_X + s.nx and g.LW_END == g.LW_Y + s.nc
+    assert g.LW_END * 8 <= g.LDS_BYTES_PER_LANE and g.LDS_BYTES_PER_LANE * 64 <= 160 * 1024
+    for t in ins:
+        for x in t[1:]:
+            if isinstance(x, str):
+                for a, b in re.findall(r"v\[(\d+):(\d+)\]", x):
+                    assert int(b) < g.V_END
+                for a in re.findall(r"\bv(\d+)\b", x):
+                    assert int(a) < g.V_END
+        if t[0].startswith("ds_"):
+            assert 0 <= t[3] < 65536 and t[3] % 8 == 0
+
+
+def test_fp64_stream_assembles(prog):
+    import os, subprocess, tempfile
+    mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    g, ins, s = prog
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("\n".join(g.fmt(t) for t in ins) + "\n")
+    try:
+        r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[:3000]
+    finally:
+        os.unlink(f.name)
