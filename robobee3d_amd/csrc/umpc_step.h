@@ -124,12 +124,31 @@ __device__ __forceinline__ float umpc_min(float a, float b) { return __builtin_f
 __device__ __forceinline__ double umpc_max(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double umpc_min(double a, double b) { return __builtin_fmin(a, b); }
 // 1/sqrt(v): the reference does sqrtf then 1.0f/ (two roundings, scaling.c:98-103). fp32 uses the
-// hardware v_rsq_f32 (1 ulp, one quarter-rate instruction instead of ~20); fp64 keeps sqrt + divide.
+// hardware v_rsq_f32 (1 ulp, one quarter-rate instruction instead of ~20). fp64: v_rsq_f64 (~2^-24) + two Newton
+// steps (error squares each step -> rounding level, within ~2 ulp of the reference's two-rounding value) in 9
+// instructions where the correctly rounded sqrt followed by the IEEE divide expands to ~35; the Ruiz passes take
+// 840 of them per step. Arguments are limit_scaling()'d: finite, in [1e-4, 1e4].
 __device__ __forceinline__ float umpc_rsqrt(float v) { return __builtin_amdgcn_rsqf(v); }
-__device__ __forceinline__ double umpc_rsqrt(double v) { return 1.0 / __dsqrt_rn(v); }
+__device__ __forceinline__ double umpc_rsqrt(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double e = __builtin_fma(-(v * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+  }
+  return y;
+}
+// 1/v for finite, normal, nonzero v: fp32 IEEE divide; fp64 v_rcp_f64 + two Newton steps (5 instructions against ~25)
+__device__ __forceinline__ float umpc_recip(float v) { return 1.0f / v; }
+__device__ __forceinline__ double umpc_recip(double v) {
+  double y = __builtin_amdgcn_rcp(v);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) y = __builtin_fma(y, __builtin_fma(-v, y, 1.0), y);
+  return y;
+}
 // 1/v where only residual NORMS consume the result
 __device__ __forceinline__ float umpc_rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }
-__device__ __forceinline__ double umpc_rcp_fast(double v) { return 1.0 / v; }
+__device__ __forceinline__ double umpc_rcp_fast(double v) { return umpc_recip(v); }
 __device__ __forceinline__ float umpc_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double umpc_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float umpc_sqrt(float v) { return __fsqrt_rn(v); }
@@ -525,16 +544,20 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #pragma unroll
     for (int k = 0; k < N; ++k) Eprev3[k] = GLD(a.ctrl, NX + 2 * NC + 1 + k);
 
-    T P[NX], A[NNZA], q[NX], Ds[NX], Es[NC], lraw[NC];
+    // LDSF: q and the raw lower bounds wait in LDS words 84..167 (free until the factor is written) instead of
+    // occupying 84 live fp64 words through the ten Ruiz passes
+    T P[NX], A[NNZA], q[LDSF ? 1 : NX], Ds[NX], Es[NC], lraw[LDSF ? 1 : NC];
+#define QA_(j) (*(LDSF ? &LDSF_W(NX + NC + (j)) : &q[LDSF ? 0 : (j)]))
+#define LRAW_(i) (*(LDSF ? &LDSF_W(2 * NX + NC + (i)) : &lraw[LDSF ? 0 : (i)]))
     {
       RawQP<T> qp;
       assemble(prm, wt, Ibi, T0, p0, R0, dq0, ref, qp);
 #define A_(p) A[p]
       UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
 #pragma unroll
-      for (int j = 0; j < NX; ++j) { P[j] = qp.Px[j]; q[j] = qp.q[j]; }
+      for (int j = 0; j < NX; ++j) { P[j] = qp.Px[j]; QA_(j) = qp.q[j]; }
 #pragma unroll
-      for (int i = 0; i < NC; ++i) lraw[i] = qp.l[i];
+      for (int i = 0; i < NC; ++i) LRAW_(i) = qp.l[i];
 #pragma unroll
       for (int k = 0; k < N; ++k) up3[k] = qp.u3[k];
     }
@@ -542,7 +565,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     // Rows < NEQ have l == u bit-for-bit: always "equality".
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const T ls = lraw[NEQ + k] * Eprev3[k], us = up3[k] * Eprev3[k];
+      const T ls = LRAW_(NEQ + k) * Eprev3[k], us = up3[k] * Eprev3[k];
       if ((ls < -T(UMPC_INFTY) * T(UMPC_MIN_SCALING)) && (us > T(UMPC_INFTY) * T(UMPC_MIN_SCALING))) {
         rho3[k] = T(UMPC_RHO_MIN); rinv3[k] = T(1) / T(UMPC_RHO_MIN);
       } else if (us - ls < T(UMPC_RHO_TOL)) {
@@ -557,32 +580,35 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     // E_i = |A_ip| / D_p on the +-1 entry of row i -- the same numbers up to rounding.
     T cscale = T(1);
 #define P_(j) P[j]
-#define DT_(j) Dt[j]
-#define ET_(i) Et[i]
+// LDSF: the per-pass scalings live in LDS words 0..83 (the factor is written there only after the last pass): 84 fewer
+// live fp64 words in the most register-starved part of the kernel
+#define DT_(j) (*(LDSF ? &LDSF_W(j) : &Dt[LDSF ? 0 : (j)]))
+#define ET_(i) (*(LDSF ? &LDSF_W(NX + (i)) : &Et[LDSF ? 0 : (i)]))
 #pragma nounroll
     for (int it = 0; it < UMPC_SCALING_ITERS; ++it) {
-      T Dt[NX], Et[NC];
+      T Dt[LDSF ? 1 : NX], Et[LDSF ? 1 : NC];
       UMPC_GEN_RUIZ_NORMS();
 #pragma unroll
-      for (int j = 0; j < NX; ++j) Dt[j] = umpc_rsqrt(limit_scaling(Dt[j]));
+      for (int j = 0; j < NX; ++j) DT_(j) = umpc_rsqrt(limit_scaling(DT_(j)));
 #pragma unroll
-      for (int i = 0; i < NC; ++i) Et[i] = umpc_rsqrt(limit_scaling(Et[i]));
+      for (int i = 0; i < NC; ++i) ET_(i) = umpc_rsqrt(limit_scaling(ET_(i)));
 #pragma unroll
-      for (int j = 0; j < NX; ++j) P[j] = (P[j] * Dt[j]) * Dt[j];
+      for (int j = 0; j < NX; ++j) P[j] = (P[j] * DT_(j)) * DT_(j);
       UMPC_GEN_RUIZ_APPLY_A();
       T pmean = T(0), qn = T(0);
 #pragma unroll
       for (int j = 0; j < NX; ++j) {
-        q[j] = q[j] * Dt[j];
+        const T qj = QA_(j) * DT_(j);
+        QA_(j) = qj;
         pmean += umpc_abs(P[j]);
-        qn = umpc_max(qn, umpc_abs(q[j]));
+        qn = umpc_max(qn, umpc_abs(qj));
       }
       pmean /= T(NX);
       qn = limit_scaling(qn);
       T ct = limit_scaling(umpc_max(pmean, qn));
       ct = T(1) / ct;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) { P[j] *= ct; q[j] *= ct; }
+      for (int j = 0; j < NX; ++j) { P[j] *= ct; QA_(j) = QA_(j) * ct; }
       cscale *= ct;
     }
 #undef DT_
@@ -599,15 +625,15 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     }
     // hand-off rows: what phase C needs again, and what the loop consumes
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { GLD(a.ws, WS_DS + j) = Ds[j]; GLD(a.ws, FAC_Q + j) = q[j]; Q_(j) = q[j]; }
+    for (int j = 0; j < NX; ++j) { GLD(a.ws, WS_DS + j) = Ds[j]; const T qj = QA_(j); GLD(a.ws, FAC_Q + j) = qj; Q_(j) = qj; }
 #pragma unroll
     for (int i = 0; i < NC; ++i) GLD(a.ws, WS_ES + i) = Es[i];
     GLD(a.ws, WS_C) = cscale;
 #pragma unroll
-    for (int i = 0; i < NEQ; ++i) lo[i] = lraw[i] * Es[i];
+    for (int i = 0; i < NEQ; ++i) lo[i] = LRAW_(i) * Es[i];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      lo3[k] = lraw[NEQ + k] * Es[NEQ + k];
+      lo3[k] = LRAW_(NEQ + k) * Es[NEQ + k];
       up3[k] = up3[k] * Es[NEQ + k];
       Eprev3[k] = Es[NEQ + k];
       GLD(a.ws, FAC_M + k) = lo3[k];
@@ -704,8 +730,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   // x, y, z are consumed where they lie: LDS words 0..122 after the assembly loop (fp32), the ctrl rows after
   // the C++ loop (fp64). No arrays: this phase must stay under 256 live VGPRs (the assembly block clobbers
   // every AGPR, so the compiler has nowhere cheap to spill).
-#define XV(j) (ASM32 ? LDSW(j) : GLD(a.ctrl, j))
-#define YV(i) (ASM32 ? LDSW(NX + (i)) : GLD(a.ctrl, NX + (i)))
+// (fp64 assembly loop: x and y are still in their LDS words, and also in the ctrl rows; z only in the rows)
+#define XV(j) (ASM32 ? LDSW(j) : ASM64 ? LDSF_W(umpcasm64::LW_X + (j)) : GLD(a.ctrl, j))
+#define YV(i) (ASM32 ? LDSW(NX + (i)) : ASM64 ? LDSF_W(umpcasm64::LW_Y + (i)) : GLD(a.ctrl, NX + (i)))
 #define ZV(i) (ASM32 ? LDSW(NX + NC + (i)) : GLD(a.ctrl, NX + NC + (i)))
 #pragma unroll
   for (int k = 0; k < N; ++k) { lo3[k] = GLD(a.ws, FAC_M + k); up3[k] = GLD(a.ws, FAC_M + N + k); }
