@@ -110,7 +110,9 @@ __device__ __forceinline__ void task_reference(int task, const T (&tp)[4], T t, 
 #define UMPC_MIN_SCALING 1e-4
 #define UMPC_MAX_SCALING 1e4
 #define UMPC_INFTY 1e30
+#ifndef UMPC_SCALING_ITERS   /* tools/build_variant.py overrides it for phase timing only */
 #define UMPC_SCALING_ITERS 10
+#endif
 
 enum { ST_SOLVED = 1, ST_SOLVED_INACC = 2, ST_PINF_INACC = 3, ST_DINF_INACC = 4,
        ST_MAX_ITER = -2, ST_PINF = -3, ST_DINF = -4, ST_NON_CVX = -7, ST_UNSOLVED = -10 };
@@ -547,12 +549,14 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     // LDSF: q and the raw lower bounds wait in LDS words 84..167 (free until the factor is written) instead of
     // occupying 84 live fp64 words through the ten Ruiz passes
     T P[NX], A[NNZA], q[LDSF ? 1 : NX], Ds[NX], Es[NC], lraw[LDSF ? 1 : NC];
+    // LDSF: the matrix itself stays in LDS words 168..278 through the passes (read twice, written once per pass; LDS
+    // round trips overlap, scratch ones did not) and comes back to registers once, for the factorisation
 #define QA_(j) (*(LDSF ? &LDSF_W(NX + NC + (j)) : &q[LDSF ? 0 : (j)]))
 #define LRAW_(i) (*(LDSF ? &LDSF_W(2 * NX + NC + (i)) : &lraw[LDSF ? 0 : (i)]))
     {
       RawQP<T> qp;
       assemble(prm, wt, Ibi, T0, p0, R0, dq0, ref, qp);
-#define A_(p) A[p]
+#define A_(p) (*(LDSF ? &LDSF_W(2 * NX + 2 * NC + (p)) : &A[LDSF ? 0 : (p)]))
       UMPC_GEN_ASSEMBLE_A(prm.dt, qp.dtT0, qp.s0dt, qp.Btaudt);
 #pragma unroll
       for (int j = 0; j < NX; ++j) { P[j] = qp.Px[j]; QA_(j) = qp.q[j]; }
@@ -592,6 +596,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
       for (int j = 0; j < NX; ++j) DT_(j) = umpc_rsqrt(limit_scaling(DT_(j)));
 #pragma unroll
       for (int i = 0; i < NC; ++i) ET_(i) = umpc_rsqrt(limit_scaling(ET_(i)));
+      // LDSF: without this fence the compiler forwards the 84 scalings from the stores above to the loads below in
+      // registers, and spills the matrix to scratch instead (147 exposed scratch round trips per pass)
+      if constexpr (LDSF) asm volatile("" ::: "memory");
 #pragma unroll
       for (int j = 0; j < NX; ++j) P[j] = (P[j] * DT_(j)) * DT_(j);
       UMPC_GEN_RUIZ_APPLY_A();
@@ -642,6 +649,13 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
       GLD(a.ws, FAC_M + 3 * N + k) = rinv3[k];
     }
     // ---- KKT fill + LDL', kkt.c:184-222 + qdldl.c:86-247 ----
+    if constexpr (LDSF) {   // the factor is written over the staging words: the matrix moves to registers first
+#pragma unroll
+      for (int p = 0; p < NNZA; ++p) A[p] = A_(p);
+      asm volatile("" ::: "memory");
+    }
+#undef A_
+#define A_(p) A[p]
     int npos = 0;
     UMPC_GEN_KKT_FACTOR(npos);
     (void)npos;

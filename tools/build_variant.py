@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds robobee3d_amd/variants/libumpc_<name>.so from the current sources with generator switches taken from the
 environment (UMPC_ASM_*), for A/B timing of step-kernel variants inside ONE gpurun call (select with UMPC_LIB).
-usage: UMPC_ASM_XV=0 tools/build_variant.py noxv"""
+usage: UMPC_ASM_XV=0 tools/build_variant.py noxv
+       UMPC_VARIANT_DEFS="-DUMPC_SCALING_ITERS=1" tools/build_variant.py ruiz1     (extra compiler flags, timing diagnostics)"""
 import os
 import subprocess
 import sys
@@ -18,7 +19,7 @@ hdr = os.path.join(vdir, "umpc_step_asm.h")
 asmstep.write(hdr)
 obj = os.path.join(vdir, name + ".o")
 csrc = os.path.join(ROOT, "robobee3d_amd", "csrc")
-subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + ["-DUMPC_STEP_ASM_HEADER=\"%s\"" % hdr, "-c", "-o", obj, _lib.SRC], check=True, cwd=csrc)
+subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + os.environ.get("UMPC_VARIANT_DEFS", "").split() + ["-DUMPC_STEP_ASM_HEADER=\"%s\"" % hdr, "-c", "-o", obj, _lib.SRC], check=True, cwd=csrc)
 objs = [os.path.join(_lib.OBJ_DIR, f) for f in os.listdir(_lib.OBJ_DIR) if f.endswith(".o") and f != "umpc_mi355x.hip.o"]
 out = os.path.join(vdir, "libumpc_%s.so" % name)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj] + objs, check=True)
