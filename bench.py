@@ -235,7 +235,9 @@ def main_p5f(args):
                        "parallelism": "robots sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": alg * B / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {"tables": "bqp_solve_kernel", "wave": "bqp_wave_kernel"}.get(mpc.qp.kernel_name, "bqp_fixed_%s_kernel" % mpc.qp.kernel_name),
+                         "kernel": {"tables": "bqp_solve_kernel", "wave": "bqp_wave_kernel"}.get(
+                             mpc.qp.kernel_name, "bqp_fixed_%s_asm_kernel" % mpc.qp.kernel_name[:-4] if mpc.qp.kernel_name.endswith("+asm")
+                             else "bqp_fixed_%s_kernel" % mpc.qp.kernel_name),
                          "kernel_ms": kern_ms, "alg_bytes_per_launch": alg * B},
             "check": {"nonfinite_state_values": int((~torch.isfinite(mpc.y)).sum().item()),
                       "status_solved_frac": float((mpc.qp.status > 0).float().mean().item())}}), flush=True)

@@ -319,9 +319,10 @@ int umpcQPUseTables(void *h, int on);
 /* Kernel choice. 1 (default): one LANE per robot (the build-time specialisation if there is one, else the
  * table-driven kernel). 2: lane per robot, tables. 0: one WAVEFRONT per robot, working set in LDS, level-scheduled
  * solves (needs the working set to fit a CU's LDS; faster for the planar p5f structure at B = 16 384, slower on
- * the others measured -- DESIGN.md 10). */
+ * the others measured -- DESIGN.md 10). 3: as 1 but without the assembly loop some specialisations carry (fp32 planar
+ * p5f: the middle ADMM iterations as generated gfx950 assembly, robobee3d_amd/asmqp.py; results equal to rounding). */
 int umpcQPSetKernel(void *h, int mode);
-/* "wave", the specialisation's name, or "tables" */
+/* "wave", the specialisation's name ("+asm" appended when its assembly loop will run), or "tables" */
 const char *umpcQPKernelName(void *h);
 /* All arrays are DEVICE pointers, SoA [rows][B] of the handle's dtype:
  *   Pv [nnzP], Av [nnzA] (CSC order), q [n], l, u [m]   raw problem data                     in

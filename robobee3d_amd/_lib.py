@@ -124,7 +124,8 @@ def build(force=False, verbose=False):
     csrc = os.path.join(HERE, "csrc")
     units = [(SRC, [gen, gasm, gasm64, gstep, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
              (SRC_BQP, [hdr, greg, os.path.join(csrc, "umpc_bqp_common.h"), os.path.join(csrc, "umpc_err.h")])]
-    units += [(u, [os.path.join(csrc, "umpc_bqp_common.h")]) for u in gqp_units]
+    gen_hdrs = [os.path.join(csrc, "gen", f) for f in os.listdir(os.path.join(csrc, "gen")) if f.endswith(".h")]
+    units += [(u, [os.path.join(csrc, "umpc_bqp_common.h")] + gen_hdrs) for u in gqp_units]
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs, relink = [], force or not os.path.exists(SO_PATH)
     todo = []

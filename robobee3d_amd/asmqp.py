@@ -1,0 +1,690 @@
+"""Generated gfx950 assembly for the MIDDLE ADMM iterations of a build-time-known, chain-structured batch QP (BASELINE
+config 4: planar p5f, n = 87, m = 164, nnz(L) = 264), fp32, one lane per robot, ONE wave per CU (B <= 16 384).
+
+Why: the straight-line C++ specialisation (codegen_qp.py) keeps ~3 000 words per robot in compiler-managed storage; a
+lone wave per CU walks them as a chain of exposed scratch round trips -- 0.21 ms per iteration, 10.5 of the 12.4 ms tick
+(tools/p5f_split.sh). A lane owns 256 VGPRs + 256 AGPRs + 640 LDS words when its wave has the CU to itself:
+
+    W (KKT rhs / solution)   VGPRs, only the NON-LEAF unknowns (162 of 251): a constraint row whose KKT unknown is a leaf
+                             of the elimination tree (one L entry, nothing eliminated into it: the 84 box rows and 5
+                             single-entry dynamics rows of p5f) never gets a register -- its rhs is formed when its row is
+                             visited, pushed into its variable's unknown, and its multiplier is re-formed in the row
+                             update from the final value of that unknown (same operations, different moment)
+    1/D                      AGPRs (251), one v_accvgpr_read per use
+    L, x, y, z(inequality)   LDS, float4-interleaved (264 + 87 + 164 + 87 = 602 words); L stored NEGATED in order of use
+    q, l(dynamics rows)      never stored: loaded from the stream buffer straight INTO the W registers they are combined
+                             with (W_x <- q, W_z <- l), as asmgen64.py
+    l, u, 1/rho, rho of the inequality rows: streamed too (4 words per row per iteration, plus 1/rho once more for the
+                             rhs), through 36 landing registers filled ~8 rows ahead
+    stream buffer            [wave][item][lane] floats: one iteration's read-only words in the exact order the loop
+                             consumes them, 256 B per item, so one 64-bit base + the 12-bit instruction offset address 16
+                             items (two SALU instructions per 16 loads)
+
+Rows in `eq_rows` (p5f: the 77 dynamics rows) are taken to be equalities (l == u, rho = rho_eq): after the first iteration
+z == l there and the row update is delta_y = alpha (nu - y) (as asmgen.py). The caller (codegen_qp.py's kernel) runs the
+FIRST and the LAST iteration in C++ (warm-start z, capture of x_prev / delta_y) and checks the equality assumption on
+device, taking the C++ loop for a wave where it does not hold.
+
+Arithmetic vs the C++ statement: fused multiply-adds in the solves, leaf contributions applied before the other
+columns, the equality-row shortcut: rounding only. `simulate()` interprets the stream on numpy float32 (tests/test_asmqp.py).
+Reference mapping: osqp 0.6.0 auxil.c:164-228, qdldl.c:250-293, proj.c:4-14 (planar/mpc_osqp_p5f.py never calls
+solve(); the iteration is the build's)."""
+import os
+import struct
+
+import numpy as np
+
+from .asmgen import Emit, f32bits
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# SGPR inputs / temporaries
+S_W, S_S, S_STRIDE, S_ITERS = 4, 6, 10, 11          # s[4:5] row workspace, s[6:7] this wave's stream block, 4*B, iterations
+S_P, S_CNT, S_SP = 12, 14, 16                       # row pointer, loop counter, stream pointer
+S_ALPHA, S_OMA, S_SIGMA, S_RINVEQ = 20, 21, 22, 23  # floats (inputs)
+V_B1, V_B2, V_LANE, V_W = 2, 3, 4, 5     # inputs: v0 = 4*robot, v1 = lane LDS address (16*lane), v4 = 4*lane
+NRING, NLAND, N_AT, N_TT = 6, 36, 4, 8
+V_END = 246
+BLOCK = 16                                          # stream items per pointer bump (16 x 256 B = the offset field's reach)
+
+
+def lds_addr(word):
+    byte = (word >> 2) * 1024
+    return "v%d" % (1, V_B1, V_B2)[byte >> 16], (byte & 0xFFFF) + 4 * (word & 3)
+
+
+class Plan:
+    def __init__(self, s, eq_rows):
+        t = s.tables
+        n, m, nk = s.n, s.m, s.nk
+        self.s, self.n, self.m, self.nk = s, n, m, nk
+        pinv, L_p, L_i, Lr_p = list(t["pinv"]), list(t["L_p"]), list(t["L_i"]), list(t["Lr_p"])
+        self.pinv, self.L_p, self.L_i = pinv, L_p, L_i
+        eq = set(int(i) for i in eq_rows)
+        self.rows = []
+        leafk = set()
+        for i in range(m):
+            k = pinv[n + i]
+            leaf = (L_p[k + 1] - L_p[k] == 1) and (Lr_p[k + 1] - Lr_p[k] == 0)
+            r = dict(i=i, k=k, eq=i in eq, leaf=leaf)
+            if leaf:
+                r["j"] = L_p[k]
+                r["r"] = L_i[L_p[k]]
+                leafk.add(k)
+            self.rows.append(r)
+        for j in range(n):
+            assert pinv[j] not in leafk
+        self.nonleaf = [k for k in range(nk) if k not in leafk]
+        self.wreg = {k: V_W + q for q, k in enumerate(self.nonleaf)}
+        for r in self.rows:
+            if r["leaf"]:
+                assert r["r"] in self.wreg, "a leaf row must hang off a non-leaf unknown"
+        self.V_LEQ = V_W + len(self.nonleaf)
+        self.leafeq = [r["i"] for r in self.rows if r["leaf"] and r["eq"]]
+        self.V_RING = self.V_LEQ + len(self.leafeq)
+        self.V_LAND = self.V_RING + 4 * NRING
+        self.V_AT = self.V_LAND + NLAND
+        self.V_TT = self.V_AT + N_AT
+        assert self.V_TT + N_TT <= V_END, (self.V_TT + N_TT, V_END)
+        # L storage: leaf entries in row order, then the solve entries in forward order (walked backwards by the
+        # backward solve)
+        self.solve_entries = [(L_i[j], c, j) for c in self.nonleaf for j in range(L_p[c], L_p[c + 1])]
+        order = [r["j"] for r in self.rows if r["leaf"]] + [j for (_, _, j) in self.solve_entries]
+        assert sorted(order) == list(range(len(L_i)))
+        self.lpos = {j: p for p, j in enumerate(order)}
+        self.LW_L, self.LW_X = 0, len(L_i)
+        self.LW_Y = self.LW_X + n
+        self.LW_Z = self.LW_Y + m
+        gen = [r["i"] for r in self.rows if not r["eq"]]
+        self.zpos = {i: q for q, i in enumerate(gen)}
+        self.LW_END = self.LW_Z + len(gen)
+        assert self.LW_END <= 640
+        # stream items of one iteration, in consumption order
+        self.stream = [("rinv", i) for i in gen]
+        for i in gen:
+            self.stream += [("l", i), ("u", i), ("rinv", i), ("rho", i)]
+        self.n_land = len(self.stream)
+        self.stream += [("q", j) for j in range(n)]
+        self.stream += [("l", r["i"]) for r in self.rows if r["eq"] and not r["leaf"]]
+        self.n_stream = len(self.stream)
+        self.extra = [("l", i) for i in self.leafeq]          # loaded once (prologue), after the per-iteration items
+        # row-major hand-off rows (floats, [row][B])
+        self.R_L, self.R_DI = 0, len(L_i)
+        self.R_X = self.R_DI + nk
+        self.R_Y = self.R_X + n
+        self.R_Z = self.R_Y + m
+        self.R_END = self.R_Z + len(gen)
+
+
+class Sched:
+    """Emits a list of ops with their operand fetches: LDS quads through a ring (prefetched `ahead` ops before first use),
+    AGPR words two ops ahead, stream items through the landing registers. op = dict(srcs=[...], emit=fn(regs)),
+    src = ('L', lds word) | ('A', agpr) | ('S', stream item) | ('V', vgpr). emit may call lds_write()."""
+
+    def __init__(self, e, plan, vm_outstanding):
+        self.e, self.p = e, plan
+        self.nlds = 0                       # LDS instructions issued so far (reads and writes complete in order)
+        self.nvm = vm_outstanding           # VMEM loads issued so far; the first `vm_outstanding` are the preloads
+        self.vmpos = {}                     # stream item -> its load's issue index
+        self.s_issued = 0                   # landing items issued
+        self.sp_block = 0
+
+    def lds_write(self, word, reg):
+        base, off = lds_addr(word)
+        self.e("ds_write_b32", base, "v%d" % reg, off)
+        self.nlds += 1
+
+    def issue_stream(self, idx):
+        e, p = self.e, self.p
+        while idx // BLOCK > self.sp_block:
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_SP, BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_SP + 1), 0)
+            self.sp_block += 1
+        e("global_load_dword", "v%d" % (p.V_LAND + idx % NLAND), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1),
+          (idx % BLOCK) * 256)
+        self.vmpos[idx] = self.nvm
+        self.nvm += 1
+
+    def run(self, ops):
+        e, p = self.e, self.p
+        n = len(ops)
+        # ---- static LDS ring analysis (a 'flush' op ends every residency: later reads see the words written since)
+        insts, slots, inst_of = [], [None] * NRING, {}
+        for i, op in enumerate(ops):
+            if op.get("flush"):
+                slots = [None] * NRING
+                continue
+            for q, src in enumerate(op["srcs"]):
+                if src[0] != "L":
+                    continue
+                qd = src[1] >> 2
+                hit = [k for k in slots if k is not None and insts[k]["quad"] == qd]
+                if hit:
+                    insts[hit[0]]["last"] = i
+                    inst_of[(i, q)] = hit[0]
+                    continue
+                free = [sl for sl in range(NRING) if slots[sl] is None]
+                if free:
+                    sl, prev = free[0], None
+                    # a slot emptied by a flush still holds an older instance's registers until its last use
+                    olds = [k for k, it in enumerate(insts) if it["slot"] == sl]
+                    prev = olds[-1] if olds else None
+                else:
+                    sl = min(range(NRING), key=lambda z: insts[slots[z]]["last"])
+                    prev = slots[sl]
+                insts.append(dict(quad=qd, first=i, last=i, slot=sl, prev=prev, issued=None))
+                slots[sl] = len(insts) - 1
+                inst_of[(i, q)] = slots[sl]
+        next_inst, next_acc, acc_rr = 0, 0, 0
+        atemp = {}
+        first_item = [min([src[1] for src in op.get("srcs", []) if src[0] == "S"], default=None) for op in ops]
+        waited_vm, waited_lds = -1, -1
+
+        def issue(it):
+            base, off = lds_addr(4 * it["quad"])
+            r = p.V_RING + 4 * it["slot"]
+            e("ds_read_b128", "v[%d:%d]" % (r, r + 3), base, off)
+            it["issued"] = self.nlds
+            self.nlds += 1
+        for i in range(n):
+            op = ops[i]
+            if op.get("flush"):
+                continue
+            while next_acc < n and next_acc < i + 3:
+                for q, src in enumerate(ops[next_acc].get("srcs", [])):
+                    if src[0] == "A":
+                        t = p.V_AT + acc_rr % N_AT
+                        acc_rr += 1
+                        e("v_accvgpr_read_b32", "v%d" % t, "a%d" % src[1])
+                        atemp[(next_acc, q)] = t
+                next_acc += 1
+            # stream: keep the landing registers full ahead of the consumer
+            nxt = next((f for f in first_item[i:] if f is not None), None)
+            if nxt is not None:
+                while self.s_issued < p.n_land and self.s_issued < nxt + NLAND - 4:
+                    self.issue_stream(self.s_issued)
+                    self.s_issued += 1
+            while next_inst < len(insts):
+                it = insts[next_inst]
+                prev = insts[it["prev"]] if it["prev"] is not None else None
+                if it["first"] <= i + 10 and (prev is None or prev["last"] < i):
+                    # (never fetched across a flush: the words may be rewritten before it)
+                    if any(ops[z].get("flush") for z in range(i, it["first"])):
+                        break
+                    issue(it)
+                    next_inst += 1
+                else:
+                    break
+            regs = []
+            for q, src in enumerate(op["srcs"]):
+                if src[0] == "V":
+                    regs.append(src[1])
+                elif src[0] == "A":
+                    regs.append(atemp.pop((i, q)))
+                elif src[0] == "S":
+                    idx = src[1]
+                    assert idx in self.vmpos, idx
+                    if idx > waited_vm:
+                        # one wait also covers the other items of this op
+                        last = max(s_[1] for s_ in op["srcs"] if s_[0] == "S")
+                        e("s_waitcnt", "vmcnt(%d)" % min(63, self.nvm - 1 - self.vmpos[last]))
+                        waited_vm = last
+                    regs.append(p.V_LAND + idx % NLAND)
+                else:
+                    it = insts[inst_of[(i, q)]]
+                    if it["issued"] is None:
+                        assert inst_of[(i, q)] == next_inst
+                        issue(it)
+                        next_inst += 1
+                    if it["issued"] > waited_lds:
+                        e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nlds - 1 - it["issued"]))
+                        waited_lds = it["issued"]
+                    regs.append(p.V_RING + 4 * it["slot"] + (src[1] & 3))
+            op["emit"](regs)
+
+
+def preloads(e, p):
+    """the tail of the stream: q -> W_x, l of the non-leaf equality rows -> their W registers (in place operands)"""
+    idx = p.n_land
+    blk = None
+    for (what, q) in p.stream[p.n_land:]:
+        if idx // BLOCK != blk:
+            # pointer = this wave's block + (idx // BLOCK) * 4096
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (idx // BLOCK) * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+            blk = idx // BLOCK
+        k = p.pinv[q] if what == "q" else p.pinv[p.n + q]
+        e("global_load_dword", "v%d" % p.wreg[k], "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
+        idx += 1
+
+
+def body(e, p):
+    n, m = p.n, p.m
+    v = lambda r: "v%d" % r
+    sA, sO, sS, sRe = ("s%d" % r for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINVEQ))
+    W = lambda k: v(p.wreg[k])
+    T = lambda q: p.V_TT + q
+    npre = p.n_stream - p.n_land
+    sc = Sched(e, p, npre)
+    e("s_mov_b64", "s[%d:%d]" % (S_SP, S_SP + 1), "s[%d:%d]" % (S_S, S_S + 1))
+    ops = []
+
+    def op(srcs, fn):
+        ops.append(dict(srcs=srcs, emit=fn))
+    pre_pos = {}                         # W register preloaded -> index of its load among the preloads
+    for q, (what, idx) in enumerate(p.stream[p.n_land:]):
+        pre_pos[p.wreg[p.pinv[idx] if what == "q" else p.pinv[n + idx]]] = q
+    waited = [-1]
+
+    def wait_pre(reg):
+        q = pre_pos[reg]
+        if q > waited[0]:
+            e("s_waitcnt", "vmcnt(%d)" % min(63, sc.nvm - 1 - q))
+            waited[0] = q
+    # ---- P1: W_x = sigma x - q (q preloaded)
+    for j in range(n):
+        k = p.pinv[j]
+
+        def f(r, k=k):
+            wait_pre(p.wreg[k])
+            e("v_fma_f32", W(k), sS, v(r[0]), "-" + W(k))
+        op([("L", p.LW_X + j)], f)
+    # ---- P2/P3: rhs of the rows; leaf rows push theirs into their variable's unknown
+    land = 0
+    leafeq_reg = {i: p.V_LEQ + q for q, i in enumerate(p.leafeq)}
+    for r in p.rows:
+        i, k = r["i"], r["k"]
+        if r["eq"] and not r["leaf"]:
+            def f(g, k=k):
+                wait_pre(p.wreg[k])
+                e("v_fma_f32", W(k), "-" + v(g[0]), sRe, W(k))
+            op([("L", p.LW_Y + i)], f)
+        elif r["eq"]:
+            op([("L", p.LW_Y + i), ("L", p.lpos[r["j"]])],
+               lambda g, r=r, i=i: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(leafeq_reg[i])),
+                                    e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0)))))
+        elif not r["leaf"]:
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("S", land)],
+               lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[2]), v(g[0]), v(g[1])))
+            land += 1
+        else:
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("S", land), ("L", p.lpos[r["j"]])],
+               lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[2]), v(g[0]), v(g[1])),
+                               e("v_fmac_f32", W(r["r"]), v(g[3]), v(T(0)))))
+            land += 1
+    # ---- solves over the non-leaf unknowns (qdldl.c:250-293)
+    for (r_, c, j) in p.solve_entries:
+        op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
+    for k in p.nonleaf:
+        op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
+    for (r_, c, j) in reversed(p.solve_entries):
+        op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+    ops.append(dict(flush=True))
+    # ---- P6: row updates (auxil.c:203-228); leaf rows re-form their multiplier from the final unknown of their variable
+    for r in p.rows:
+        i, k = r["i"], r["k"]
+        yw = p.LW_Y + i
+        if r["eq"]:
+            if r["leaf"]:
+                def f(g, r=r, i=i, yw=yw):
+                    e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(leafeq_reg[i]))
+                    e("v_mul_f32", v(T(0)), v(T(0)), v(g[2]))
+                    e("v_fmac_f32", v(T(0)), v(g[1]), W(r["r"]))          # nu
+                    e("v_sub_f32", v(T(1)), v(T(0)), v(g[0]))
+                    e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
+                    sc.lds_write(yw, T(1))
+                op([("L", yw), ("L", p.lpos[r["j"]]), ("A", k)], f)
+            else:
+                def f(g, k=k, yw=yw):
+                    e("v_sub_f32", v(T(1)), W(k), v(g[0]))
+                    e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
+                    sc.lds_write(yw, T(1))
+                op([("L", yw)], f)
+            continue
+        zw = p.LW_Z + p.zpos[i]
+        srcs = [("L", yw), ("L", zw), ("S", land), ("S", land + 1), ("S", land + 2), ("S", land + 3)]
+        land += 4
+        if r["leaf"]:
+            srcs += [("L", p.lpos[r["j"]]), ("A", k)]
+
+        def f(g, r=r, k=k, yw=yw, zw=zw):
+            y, z, lo, up, rinv, rho = (v(x) for x in g[:6])
+            t3, nu, t2, tt, t4, d = (v(T(q)) for q in range(6))
+            e("v_fma_f32", t3, "-" + rinv, y, z)                          # z - y/rho (the rhs again)
+            if r["leaf"]:
+                e("v_mul_f32", nu, t3, v(g[7]))
+                e("v_fmac_f32", nu, v(g[6]), W(r["r"]))
+            else:
+                nu = W(k)
+            e("v_fma_f32", t3, rinv, nu, t3)                              # z~
+            e("v_mul_f32", t2, sO, z)
+            e("v_fma_f32", tt, sA, t3, t2)                                # alpha z~ + (1 - alpha) z
+            e("v_fma_f32", t4, rinv, y, tt)
+            e("v_max_f32", t4, t4, lo)
+            e("v_min_f32", t4, t4, up)                                    # z_new
+            e("v_sub_f32", d, tt, t4)
+            e("v_fma_f32", d, rho, d, y)                                  # y_new = y + rho (t - z_new)
+            sc.lds_write(zw, T(4))
+            sc.lds_write(yw, T(5))
+        op(srcs, f)
+    assert land == p.n_land
+    # ---- x <- alpha x~ + (1 - alpha) x
+    for j in range(n):
+        k = p.pinv[j]
+
+        def f(g, k=k, j=j):
+            t = T(6 + j % 2)
+            e("v_mul_f32", v(t), sO, v(g[0]))
+            e("v_fma_f32", v(t), sA, W(k), v(t))
+            sc.lds_write(p.LW_X + j, t)
+        op([("L", p.LW_X + j)], f)
+    sc.run(ops)
+    preloads(e, p)
+
+
+def _row_ptr(e, sreg, row):
+    e("s_mul_i32", "s%d" % sreg, "s%d" % S_STRIDE, row)
+    e("s_mul_hi_u32", "s%d" % (sreg + 1), "s%d" % S_STRIDE, row)
+    e("s_add_u32", "s%d" % sreg, "s%d" % sreg, "s%d" % S_W)
+    e("s_addc_u32", "s%d" % (sreg + 1), "s%d" % (sreg + 1), "s%d" % (S_W + 1))
+
+
+def _adv(e, sreg):
+    e("s_add_u32", "s%d" % sreg, "s%d" % sreg, "s%d" % S_STRIDE)
+    e("s_addc_u32", "s%d" % (sreg + 1), "s%d" % (sreg + 1), 0)
+
+
+def prologue(e, p):
+    """rows R_L.. (negated L in storage order), R_DI, R_X, R_Y, R_Z -> LDS / AGPRs; the once-only stream items"""
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    # L, x, y, z -> LDS through the W registers as landing zone, a group of rows at a time
+    lds_rows = [(p.R_L + q, p.LW_L + q) for q in range(p.LW_X)] + [(p.R_X + q, p.LW_X + q) for q in range(p.n)] + \
+               [(p.R_Y + q, p.LW_Y + q) for q in range(p.m)] + [(p.R_Z + q, p.LW_Z + q) for q in range(p.LW_END - p.LW_Z)]
+    nl = len(p.nonleaf)
+    for g in range(0, len(lds_rows), nl):
+        grp = lds_rows[g:g + nl]
+        last_row = None
+        for q, (row, word) in enumerate(grp):
+            if last_row is None or row != last_row + 1:
+                _row_ptr(e, S_P, row)
+            else:
+                _adv(e, S_P)
+            last_row = row
+            e("global_load_dword", "v%d" % (V_W + q), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+        e("s_waitcnt", "vmcnt(0)")
+        for q, (row, word) in enumerate(grp):
+            base, off = lds_addr(word)
+            e("ds_write_b32", base, "v%d" % (V_W + q), off)
+        e("s_waitcnt", "lgkmcnt(0)")
+    # 1/D -> AGPRs
+    _row_ptr(e, S_P, p.R_DI)
+    for k in range(p.nk):
+        e("global_load_dword", "a%d" % k, "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+        _adv(e, S_P)
+    # once-only stream items (l of the leaf equality rows) -> their registers
+    idx = p.n_stream
+    for q, (_, i) in enumerate(p.extra):
+        e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, ((idx + q) // BLOCK) * BLOCK * 256)
+        e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        e("global_load_dword", "v%d" % (p.V_LEQ + q), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), ((idx + q) % BLOCK) * 256)
+    e("s_waitcnt", "vmcnt(0)")
+    preloads(e, p)
+
+
+def epilogue(e, p):
+    """x, y, z (inequality rows) -> rows R_X, R_Y, R_Z"""
+    e("s_waitcnt", "vmcnt(0)")
+    words = [(p.R_X + q, p.LW_X + q) for q in range(p.n)] + [(p.R_Y + q, p.LW_Y + q) for q in range(p.m)] + \
+            [(p.R_Z + q, p.LW_Z + q) for q in range(p.LW_END - p.LW_Z)]
+    quads = sorted(set(w >> 2 for _, w in words))
+    rowof = {w: r for r, w in words}
+    for g in range(0, len(quads), NRING):
+        grp = quads[g:g + NRING]
+        for q, qd in enumerate(grp):
+            base, off = lds_addr(4 * qd)
+            e("ds_read_b128", "v[%d:%d]" % (p.V_RING + 4 * q, p.V_RING + 4 * q + 3), base, off)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for q, qd in enumerate(grp):
+            for h in range(4):
+                w = 4 * qd + h
+                if w in rowof:
+                    _row_ptr(e, S_P, rowof[w])
+                    e("global_store_dword", "v0", "v%d" % (p.V_RING + 4 * q + h), "s[%d:%d]" % (S_P, S_P + 1), 0)
+        e("s_waitcnt", "vmcnt(0)")
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+
+
+def program(s, eq_rows):
+    """s11 = number of middle iterations (>= 1)"""
+    p = Plan(s, eq_rows)
+    e = Emit()
+    prologue(e, p)
+    e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
+    e("label", "7")
+    body(e, p)
+    e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+    e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
+    e("s_cbranch_scc1", "7b")
+    epilogue(e, p)
+    return e.ins, p
+
+
+def fmt(t):
+    m = t[0]
+    if m == "label":
+        return "%s:" % t[1]
+    a = [("0x%x" % x if isinstance(x, int) and m in ("s_mov_b32", "v_add_u32", "v_and_b32") else str(x)) for x in t[1:]]
+    if m.startswith("ds_"):
+        return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
+    if m.startswith("global_"):
+        return "%s %s, %s, %s offset:%s" % (m, a[0], a[1], a[2], a[3])
+    if m == "s_waitcnt":
+        return "s_waitcnt " + " ".join(a)
+    return "%s %s" % (m, ", ".join(a))
+
+
+# ---------------------------------------------------------------------------
+# CPU interpreter (one lane) and a numpy statement of the same iteration
+# ---------------------------------------------------------------------------
+def simulate(ins, W, S, iters, consts):
+    """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
+    Runs the program; W rows R_X.. are updated in place. Returns the executed instruction count."""
+    f32 = np.float32
+    V = np.zeros(256, np.uint32)
+    A = np.zeros(256, np.uint32)
+    lds = np.zeros(640, f32)
+    SG = {}
+    scc = 0
+    labels = {}
+    for k, t in enumerate(ins):
+        if t[0] == "label":
+            labels.setdefault(t[1], []).append(k)
+    STRIDE = 4096
+    SG[S_W], SG[S_W + 1] = 1 << 20, 0
+    SG[S_S], SG[S_S + 1] = 1 << 30, 0
+    SG[S_STRIDE], SG[S_ITERS] = STRIDE, iters
+    alpha, sigma, rinv_eq = consts
+    for reg, val in ((S_ALPHA, f32(alpha)), (S_OMA, f32(f32(1.0) - f32(alpha))), (S_SIGMA, f32(sigma)), (S_RINVEQ, f32(rinv_eq))):
+        SG[reg] = f32bits(float(val))
+
+    def sval(x):
+        if isinstance(x, int):
+            return x
+        if x.startswith("s["):
+            lo = int(x[2:x.index(":")])
+            return SG.get(lo, 0) | (SG.get(lo + 1, 0) << 32)
+        return SG.get(int(x[1:]), 0)
+
+    def bits2f(b):
+        return np.frombuffer(struct.pack("<I", int(b) & 0xFFFFFFFF), f32)[0]
+
+    def fval(x):
+        neg = x.startswith("-")
+        if neg:
+            x = x[1:]
+        val = bits2f(V[int(x[1:])]) if x[0] == "v" else bits2f(SG[int(x[1:])])
+        return -val if neg else val
+
+    def setf(x, val):
+        V[int(x[1:])] = f32bits(float(f32(val)))
+
+    def gaddr(t):
+        """(array, index) of a global access v_off, s[base], imm"""
+        addr = sval(t[3]) + t[4]
+        if addr >= (1 << 30):
+            return S, (addr - (1 << 30)) // 256
+        return W, (addr - (1 << 20)) // STRIDE
+
+    def ldsword(basereg, off):
+        byte = int(V[int(basereg[1:])]) + off
+        return (byte // 1024) * 4 + (byte % 1024) // 4
+
+    # completion model: LDS operations and VMEM loads complete in issue order; a register that an outstanding load will
+    # write must not be read or written before an s_waitcnt has retired that load
+    pend = {"lgkmcnt": [], "vmcnt": []}
+
+    def regs_of(x):
+        if not isinstance(x, str):
+            return set()
+        x = x.lstrip("-")
+        if x.startswith("v["):
+            lo, hi = x[2:-1].split(":")
+            return {("v", r) for r in range(int(lo), int(hi) + 1)}
+        if x[0] in "va" and x[1:].isdigit():
+            return {(x[0], int(x[1:]))}
+        return set()
+
+    def check(used):
+        for q in pend.values():
+            for dst in q:
+                assert not (dst & used), ("register used before its load was waited for", ins[pc], sorted(dst & used))
+
+    pc = nexec = 0
+    while pc < len(ins):
+        t = ins[pc]
+        m = t[0]
+        nexec += 1
+        assert nexec < 3000000, "runaway program"
+        if m == "s_waitcnt":
+            for part in t[1].split():
+                name, val = part[:-1].split("(")
+                del pend[name][:max(0, len(pend[name]) - int(val))]
+        elif m[0] == "v" or m.startswith("ds_") or m.startswith("global_"):
+            used = set().union(*[regs_of(x) for x in t[1:]])
+            check(used)
+            if m == "ds_read_b128":
+                pend["lgkmcnt"].append(regs_of(t[1]))
+            elif m.startswith("ds_write"):
+                pend["lgkmcnt"].append(set())
+            elif m == "global_load_dword":
+                pend["vmcnt"].append(regs_of(t[1]))
+            elif m == "global_store_dword":
+                pend["vmcnt"].append(set())
+        if m in ("label", "s_waitcnt"):
+            pass
+        elif m == "s_mov_b32":
+            SG[int(t[1][1:])] = t[2] if isinstance(t[2], int) else sval(t[2])
+        elif m == "s_mov_b64":
+            lo = int(t[1][2:t[1].index(":")])
+            val = sval(t[2])
+            SG[lo], SG[lo + 1] = val & 0xFFFFFFFF, val >> 32
+        elif m == "s_mul_i32":
+            SG[int(t[1][1:])] = (sval(t[2]) * sval(t[3])) & 0xFFFFFFFF
+        elif m == "s_mul_hi_u32":
+            SG[int(t[1][1:])] = ((sval(t[2]) * sval(t[3])) >> 32) & 0xFFFFFFFF
+        elif m == "s_add_u32":
+            r = sval(t[2]) + sval(t[3])
+            SG[int(t[1][1:])] = r & 0xFFFFFFFF
+            scc = r >> 32
+        elif m == "s_addc_u32":
+            r = sval(t[2]) + sval(t[3]) + scc
+            SG[int(t[1][1:])] = r & 0xFFFFFFFF
+            scc = r >> 32
+        elif m == "s_sub_i32":
+            SG[int(t[1][1:])] = (sval(t[2]) - sval(t[3])) & 0xFFFFFFFF
+        elif m == "s_cmp_gt_i32":
+            a = sval(t[1])
+            a = a - (1 << 32) if a & 0x80000000 else a
+            scc = int(a > sval(t[2]))
+        elif m == "s_cbranch_scc1":
+            if scc:
+                lab, d = t[1][:-1], t[1][-1]
+                cands = labels[lab]
+                pc = min(c for c in cands if c > pc) if d == "f" else max(c for c in cands if c < pc)
+        elif m == "v_add_u32":
+            V[int(t[1][1:])] = (t[2] + int(V[int(t[3][1:])])) & 0xFFFFFFFF
+        elif m == "v_and_b32":
+            V[int(t[1][1:])] = t[2] & int(V[int(t[3][1:])])
+        elif m == "v_lshrrev_b32":
+            V[int(t[1][1:])] = int(V[int(t[3][1:])]) >> t[2]
+        elif m == "global_load_dword":
+            arr, row = gaddr(t)
+            b = f32bits(float(arr[row]))
+            if t[1][0] == "a":
+                A[int(t[1][1:])] = b
+            else:
+                V[int(t[1][1:])] = b
+        elif m == "global_store_dword":
+            arr, row = gaddr((t[0], None, t[1], t[3], t[4]))
+            arr[row] = bits2f(V[int(t[2][1:])])
+        elif m == "ds_read_b128":
+            lo = int(t[1][2:t[1].index(":")])
+            w = ldsword(t[2], t[3])
+            for h in range(4):
+                V[lo + h] = f32bits(float(lds[w + h]))
+        elif m == "ds_write_b128":
+            lo = int(t[2][2:t[2].index(":")])
+            w = ldsword(t[1], t[3])
+            for h in range(4):
+                lds[w + h] = bits2f(V[lo + h])
+        elif m == "ds_write_b32":
+            lds[ldsword(t[1], t[3])] = bits2f(V[int(t[2][1:])])
+        elif m == "v_accvgpr_read_b32":
+            V[int(t[1][1:])] = A[int(t[2][1:])]
+        elif m == "v_fma_f32":
+            setf(t[1], np.float64(fval(t[2])) * np.float64(fval(t[3])) + np.float64(fval(t[4])))
+        elif m == "v_fmac_f32":
+            setf(t[1], np.float64(fval(t[2])) * np.float64(fval(t[3])) + np.float64(fval(t[1])))
+        elif m == "v_mul_f32":
+            setf(t[1], f32(fval(t[2])) * f32(fval(t[3])))
+        elif m == "v_sub_f32":
+            setf(t[1], f32(fval(t[2])) - f32(fval(t[3])))
+        elif m == "v_max_f32":
+            setf(t[1], max(fval(t[2]), fval(t[3])))
+        elif m == "v_min_f32":
+            setf(t[1], min(fval(t[2]), fval(t[3])))
+        else:
+            raise ValueError("unknown instruction %r" % (t,))
+        pc += 1
+    return nexec
+
+
+def reference_iterations(p, d, iters, alpha, sigma):
+    """float64 statement: iterations of the general OSQP loop on (x, y, z) with factor (L, DI) in the structure's order"""
+    s = p.s
+    n, m, nk = p.n, p.m, p.nk
+    pinv, L_p, L_i = p.pinv, p.L_p, p.L_i
+    x, y, z = d["x"].copy(), d["y"].copy(), d["z"].copy()
+    for _ in range(iters):
+        w = np.zeros(nk)
+        for j in range(n):
+            w[pinv[j]] = sigma * x[j] - d["q"][j]
+        t3 = z - d["rinv"] * y
+        for i in range(m):
+            w[pinv[n + i]] = t3[i]
+        for c in range(nk):
+            for j in range(L_p[c], L_p[c + 1]):
+                w[L_i[j]] -= d["L"][j] * w[c]
+        w *= d["DI"]
+        for c in range(nk - 1, -1, -1):
+            for j in range(L_p[c], L_p[c + 1]):
+                w[c] -= d["L"][j] * w[L_i[j]]
+        xn = np.array([alpha * w[pinv[j]] + (1 - alpha) * x[j] for j in range(n)])
+        nu = np.array([w[pinv[n + i]] for i in range(m)])
+        zt = t3 + d["rinv"] * nu
+        tt = alpha * zt + (1 - alpha) * z
+        zn = np.minimum(np.maximum(tt + d["rinv"] * y, d["l"]), d["u"])
+        y = y + d["rho"] * (tt - zn)
+        x, z = xn, zn
+    return x, y, z

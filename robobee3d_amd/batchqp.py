@@ -62,11 +62,12 @@ class BatchQP:
         if h:
             self.L.umpcQPDestroy(h)
 
-    KERNELS = {"wave": 0, "lane": 1, "tables": 2}
+    KERNELS = {"wave": 0, "lane": 1, "tables": 2, "lane_cpp": 3}
 
     def set_kernel(self, mode):
         """"lane" (default; one lane per robot: the build-time specialisation if the structure has one, else the tables),
-        "tables" (lane per robot, tables), "wave" (one wavefront per robot, working set in LDS, level-scheduled)."""
+        "tables" (lane per robot, tables), "wave" (one wavefront per robot, working set in LDS, level-scheduled),
+        "lane_cpp" ("lane" without the assembly loop of the fp32 p5f specialisation)."""
         if self.L.umpcQPSetKernel(self.h, self.KERNELS[mode]) != 0:
             raise RuntimeError(self.L.umpcLastError().decode())
 
@@ -181,8 +182,9 @@ class PlanarP5fMPC:
         st = p5f_structure(N)
         self.st, self.B, self.dt, self.dtype = st, int(B), float(dt), dtype
         self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, **settings)
-        if not os.environ.get("UMPC_QP_KERNEL"):
-            self.qp.set_kernel("wave")     # measured: 10.8 ms per tick against 13.0 ms for the lane specialisation
+        if not os.environ.get("UMPC_QP_KERNEL") and dtype != torch.float32:
+            self.qp.set_kernel("wave")     # fp64: 10.8 ms per tick (fp32 figure) against 13.0 ms for the C++ lane specialisation;
+            # fp32 keeps the default "lane": the specialisation with its middle iterations in assembly (asmqp.py)
         dev = self.qp.device
         col = lambda v: torch.as_tensor(np.repeat(np.asarray(v, np.float64)[:, None], B, 1)).to(dev, dtype).contiguous()
         self.Pv, self.q, self.l, self.u = col(st["Pv"]), col(st["q"]), col(st["l"]), col(st["u"])

@@ -36,7 +36,13 @@ def builtin_structures():
     return out
 
 
-def emit_structure(name, s):
+ASM_STRUCTURES = {"p5f10": list(range(77))}   # structure -> rows assumed to be equalities by the assembly loop (asmqp.py)
+ASM_STREAM_ROW = 1024                          # the stream buffer starts at this row of the workspace
+
+
+def emit_structure(name, s, asm=None):
+    """asm: an asmqp.Plan -> emits bqp_fixed_<name>_asm (fp32 only): the middle ADMM iterations run as the generated
+    assembly (csrc/gen/bqp_<name>_asm.h), the first and the last one in C++"""
     n, m, nk = s.n, s.m, s.nk
     t = s.tables
     pinv, pidx, A_p, A_i = t["pinv"], t["pidx"], t["A_p"], t["A_i"]
@@ -45,7 +51,10 @@ def emit_structure(name, s):
     o = []
     E = o.append
     E("template <typename T>")
-    E("__device__ __forceinline__ void bqp_fixed_%s(const QPArgs<T> &a, const int b) {" % name)
+    if asm:
+        E("__device__ __forceinline__ void bqp_fixed_%s_asm(const QPArgs<T> &a, const int b, const int wave, const unsigned ldsaddr) {" % name)
+    else:
+        E("__device__ __forceinline__ void bqp_fixed_%s(const QPArgs<T> &a, const int b) {" % name)
     E("  const size_t B = (size_t)a.B;")
     E("#define IN(arr, i) (arr)[(size_t)(i) * B + b]")
     E("  const T sigma = a.sigma, alpha = a.alpha, oma = T(1.0) - a.alpha;")
@@ -127,27 +136,91 @@ def emit_structure(name, s):
         E("  xp[%d] = x[%d];" % (j, j))
     for i in range(m):
         E("  dy[%d] = T(0.0);" % i)
-    E("#pragma nounroll")
-    E("  for (int it = 0; it < a.max_iter; ++it) {")
+    it_lines = []
+    I = it_lines.append
     for j in range(n):
-        E("    xp[%d] = x[%d]; w[%d] = sigma * xp[%d] - qs[%d];" % (j, j, pinv[j], j, j))
+        I("    xp[%d] = x[%d]; w[%d] = sigma * xp[%d] - qs[%d];" % (j, j, pinv[j], j, j))
     for i in range(m):
-        E("    t3[%d] = z[%d] - rinv[%d] * y[%d]; w[%d] = t3[%d];" % (i, i, i, i, pinv[n + i], i))
+        I("    t3[%d] = z[%d] - rinv[%d] * y[%d]; w[%d] = t3[%d];" % (i, i, i, i, pinv[n + i], i))
     for r in range(nk):
         for p in range(Lr_p[r], Lr_p[r + 1]):
-            E("    w[%d] -= Lx[%d] * w[%d];" % (r, Lr_k[p], Lr_j[p]))
+            I("    w[%d] -= Lx[%d] * w[%d];" % (r, Lr_k[p], Lr_j[p]))
     for r in range(nk):
-        E("    w[%d] *= DI[%d];" % (r, r))
+        I("    w[%d] *= DI[%d];" % (r, r))
     for r in range(nk - 1, -1, -1):
         for j in range(L_p[r], L_p[r + 1]):
-            E("    w[%d] -= Lx[%d] * w[%d];" % (r, j, L_i[j]))
+            I("    w[%d] -= Lx[%d] * w[%d];" % (r, j, L_i[j]))
     for j in range(n):
-        E("    x[%d] = alpha * w[%d] + oma * xp[%d];" % (j, pinv[j], j))
+        I("    x[%d] = alpha * w[%d] + oma * xp[%d];" % (j, pinv[j], j))
     for i in range(m):
-        E("    { const T zt = t3[%d] + rinv[%d] * w[%d]; T zn = alpha * zt + oma * z[%d] + rinv[%d] * y[%d]; "
+        I("    { const T zt = t3[%d] + rinv[%d] * w[%d]; T zn = alpha * zt + oma * z[%d] + rinv[%d] * y[%d]; "
           "zn = qmin(qmax(zn, ls[%d]), us[%d]); const T d = rho[%d] * (alpha * zt + oma * z[%d] - zn); z[%d] = zn; "
           "dy[%d] = d; y[%d] = y[%d] + d; }" % (i, i, pinv[n + i], i, i, i, i, i, i, i, i, i, i, i))
-    E("  }")
+    if not asm:
+        E("#pragma nounroll")
+        E("  for (int it = 0; it < a.max_iter; ++it) {")
+        o.extend(it_lines)
+        E("  }")
+    else:
+        P = asm
+        E("  auto iterate = [&]() __attribute__((always_inline)) {")
+        o.extend(it_lines)
+        E("  };")
+        # the assembly loop takes the rows in ASM_STRUCTURES[name] for equalities: checked here, per wave
+        E("  static_assert(BQP_%s_ASM_STREAM_ITEMS <= 1024 && BQP_%s_ASM_ROWS <= %d, \"stream buffer / hand-off rows\");"
+          % (name.upper(), name.upper(), ASM_STREAM_ROW))
+        E("  bool eqok = a.asm_ok != 0;")
+        for i in sorted(r["i"] for r in P.rows if r["eq"]):
+            E("  eqok = eqok && (rho[%d] == rho_eq) && (ls[%d] == us[%d]);" % (i, i, i))
+        E("  const int mid = a.max_iter - 2;")
+        E("  const bool use_asm = mid >= 1 && __all(eqok);")
+        E("  if (a.max_iter >= 1) iterate();")
+        E("  if (use_asm) {")
+        E("    // hand-off: negated L in the loop's storage order, 1/D, x, y, z of the inequality rows -> workspace rows;")
+        E("    // one iteration's read-only words -> this wave's stream block, in consumption order (asmqp.Plan.stream)")
+        for j, pos in sorted(P.lpos.items()):
+            E("    IN(a.W, %d) = -Lx[%d];" % (P.R_L + pos, j))
+        for k in range(nk):
+            E("    IN(a.W, %d) = DI[%d];" % (P.R_DI + k, k))
+        for j in range(n):
+            E("    IN(a.W, %d) = x[%d];" % (P.R_X + j, j))
+        for i in range(m):
+            E("    IN(a.W, %d) = y[%d];" % (P.R_Y + i, i))
+        for i, q in sorted(P.zpos.items()):
+            E("    IN(a.W, %d) = z[%d];" % (P.R_Z + q, i))
+        nst = P.n_stream + len(P.extra)
+        E("    T *const sblk = a.W + (size_t)%d * B + (size_t)wave * %d;   // wave-uniform (SGPR) base" % (ASM_STREAM_ROW, nst * 64))
+        src = {"rinv": "rinv[%d]", "l": "ls[%d]", "u": "us[%d]", "rho": "rho[%d]", "q": "qs[%d]"}
+        for q, (what, i) in enumerate(P.stream + P.extra):
+            E("    sblk[%d + threadIdx.x] = %s;" % (q * 64, src[what] % i))
+        E("    {")
+        E("      const unsigned voff = (unsigned)b * 4u, lane4 = (unsigned)threadIdx.x * 4u, stride = (unsigned)a.B * 4u;")
+        E("      // float constants come straight from the kernel arguments (SGPRs): a value computed with float arithmetic lives")
+        E("      // in a VGPR and hipcc fails to copy it back (\"illegal VGPR to SGPR copy\"), so 1 - alpha and 1/rho_eq are the host's")
+        E("      const unsigned s_alpha = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.alpha));")
+        E("      const unsigned s_oma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.oma));")
+        E("      const unsigned s_sigma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.sigma));")
+        E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
+        E("      // every scalar operand is made provably wave-uniform (the values are; the compiler cannot always see it)")
+        E("      auto uni = [](unsigned long long v_) { return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v_); };")
+        E("      const unsigned long long wsp = uni((unsigned long long)a.W), ssp = uni((unsigned long long)sblk);")
+        E("      const unsigned s_stride = __builtin_amdgcn_readfirstlane(stride), s_mid = __builtin_amdgcn_readfirstlane((unsigned)mid);")
+        E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq);" % name.upper())
+        E("    }")
+        for j in range(n):
+            E("    x[%d] = IN(a.W, %d);" % (j, P.R_X + j))
+        for i in range(m):
+            E("    y[%d] = IN(a.W, %d);" % (i, P.R_Y + i))
+        for r in P.rows:
+            if r["eq"]:
+                E("    z[%d] = ls[%d];" % (r["i"], r["i"]))
+            else:
+                E("    z[%d] = IN(a.W, %d);" % (r["i"], P.R_Z + P.zpos[r["i"]]))
+        E("  } else {")
+        E("#pragma nounroll")
+        E("    for (int it = 1; it < a.max_iter - 1; ++it) iterate();")
+        E("  }")
+        E("  if (a.max_iter >= 2) iterate();")
     # ---- residuals
     E("  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);")
     for i in range(m):
@@ -219,6 +292,14 @@ def emit_structure(name, s):
     E("  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(a.max_iter); IN(a.info, 5) = T(0); }")
     E("#undef IN")
     E("}")
+    if asm:
+        E("__global__ void __launch_bounds__(64) bqp_fixed_%s_asm_kernel(const QPArgs<float> a) {" % name)
+        E("  __shared__ float4 lds[160 * 64];   // the whole CU: 640 words per lane (asmqp.py)")
+        E("  const int b = blockIdx.x * 64 + threadIdx.x;")
+        E("  if (b >= a.B) return;")
+        E("  bqp_fixed_%s_asm<float>(a, b, (int)blockIdx.x, (unsigned)(size_t)(&lds[threadIdx.x]));" % name)
+        E("}")
+        return "\n".join(o) + "\n"
     E("template <typename T>")
     E("__global__ void __launch_bounds__(64) bqp_fixed_%s_kernel(const QPArgs<T> a) {" % name)
     E("  const int b = blockIdx.x * 64 + threadIdx.x;")
@@ -231,6 +312,32 @@ def emit_structure(name, s):
 DTYPES = (("f32", "float"), ("f64", "double"))
 
 
+def asm_macro(name, ins, plan):
+    """csrc/gen/bqp_<name>_asm.h: the instruction stream of asmqp.program as one asm volatile statement"""
+    from . import asmqp
+    used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1]
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
+           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
+    lab7 = [k for k, t_ in enumerate(ins) if t_ == ("label", "7")][0]
+    out = ["// GENERATED by robobee3d_amd/asmqp.py via codegen_qp.py -- do not edit.",
+           "// Middle ADMM iterations of the %s structure, fp32, one lane per robot, one wave per CU: %d instructions, %d"
+           % (name, len(ins), sum(1 for t_ in ins[lab7:] if t_[0] != "label")),
+           "// from the loop label on (loop body + epilogue). Stream block: %d items per iteration + %d loaded once."
+           % (plan.n_stream, len(plan.extra)),
+           "#pragma once",
+           "constexpr int BQP_%s_ASM_STREAM_ITEMS = %d, BQP_%s_ASM_ROWS = %d;" % (name.upper(), plan.n_stream + len(plan.extra),
+                                                                          name.upper(), plan.R_END),
+           "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[4:5] = row workspace, s[6:7] = the wave's stream",
+           "// block, s10 = 4*B, s11 = iterations (>= 1), s20..s23 = alpha, 1 - alpha, sigma, 1/rho_eq (float bits)",
+           "#define BQP_%s_ASM(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq) asm volatile( \\" % name.upper()]
+    for t_ in ins:
+        out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(ws), "{s[6:7]}"(sblk), "{s10}"(stride), '
+               '"{s11}"(iters), "{s20}"(alpha), "{s21}"(oma), "{s22}"(sigma), "{s23}"(rinveq) \\')
+    out.append("  : " + ", ".join(clob) + ")")
+    return "\n".join(out) + "\n"
+
+
 def generate():
     """Returns {relative path under csrc/: source}: one translation unit per (structure, dtype) so that the build can
     compile them in parallel, plus the registry header umpc_bqp.hip includes."""
@@ -238,25 +345,40 @@ def generate():
     reg, decl = [], []
     for name, s in builtin_structures():
         body = emit_structure(name, s)
+        asm_body, asm_hdr = None, None
+        if name in ASM_STRUCTURES:
+            from . import asmqp
+            ins, plan = asmqp.program(s, ASM_STRUCTURES[name])
+            asm_body = emit_structure(name, s, asm=plan)
+            asm_hdr = "bqp_%s_asm.h" % name
+            files["gen/" + asm_hdr] = asm_macro(name, ins, plan)
         for tag, ctype in DTYPES:
+            with_asm = asm_body is not None and tag == "f32"
             src = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
                    "// Straight-line specialisation of bqp_solve_kernel: %s, n = %d, m = %d, nnz(A) = %d, nnz(L) = %d, %s."
                    % (name, s.n, s.m, s.nnzA, s.nnzL, ctype),
-                   '#include "../umpc_bqp_common.h"', "", "namespace {", "using namespace umpcqp;", "", body,
+                   '#include "../umpc_bqp_common.h"'] + (['#include "%s"' % asm_hdr] if with_asm else []) + [
+                   "", "namespace {", "using namespace umpcqp;", "", body] + ([asm_body] if with_asm else []) + [
                    "}  // namespace", "",
                    '__attribute__((visibility("hidden"))) void bqp_launch_%s_%s(const umpcqp::QPArgs<%s> &a, hipStream_t s) {'
-                   % (name, tag, ctype),
+                   % (name, tag, ctype)] + ([
+                   "  // middle iterations as generated assembly (asmqp.py) when the host found room for the stream buffer",
+                   "  if (a.asm_ok && a.max_iter >= 3) {",
+                   "    hipLaunchKernelGGL(bqp_fixed_%s_asm_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a);" % name,
+                   "    return;",
+                   "  }"] if with_asm else []) + [
                    "  hipLaunchKernelGGL(bqp_fixed_%s_kernel<%s>, dim3((a.B + 63) / 64), dim3(64), 0, s, a);" % (name, ctype),
                    "}", ""]
             files["gen/bqp_%s_%s.hip" % (name, tag)] = "\n".join(src)
             decl.append('__attribute__((visibility("hidden"))) void bqp_launch_%s_%s(const umpcqp::QPArgs<%s> &, hipStream_t);'
                         % (name, tag, ctype))
-        reg.append('  {0x%016xull, "%s", bqp_launch_%s_f32, bqp_launch_%s_f64},' % (fnv1a(s.blob), name, name, name))
+        reg.append('  {0x%016xull, "%s", bqp_launch_%s_f32, bqp_launch_%s_f64, %d},'
+                   % (fnv1a(s.blob), name, name, name, 1 if name in ASM_STRUCTURES else 0))
     hdr = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
            "// Registry of the build-time specialisations (csrc/gen/bqp_*.hip), keyed by the FNV-1a hash of the table blob.",
            "#pragma once", '#include "umpc_bqp_common.h"', ""] + decl + [
            "struct FixedKernel { uint64_t hash; const char *name; void (*f32)(const umpcqp::QPArgs<float> &, hipStream_t); "
-           "void (*f64)(const umpcqp::QPArgs<double> &, hipStream_t); };",
+           "void (*f64)(const umpcqp::QPArgs<double> &, hipStream_t); int asm_f32; };",
            "static const FixedKernel kFixedKernels[] = {"] + reg + ["};",
            "constexpr int kNumFixedKernels = %d;" % len(reg), ""]
     files["umpc_bqp_registry.h"] = "\n".join(hdr)

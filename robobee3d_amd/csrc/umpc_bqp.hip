@@ -802,12 +802,27 @@ __global__ void umpcn_extract_kernel(int Bn, int N, T dt, const T *__restrict__ 
 
 struct qp_batch {
   int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows, fixed, use_tables, wave;   // wave: 1 = wave-per-robot kernel
+  int no_asm;   // umpcQPSetKernel(h, 3): the lane specialisation without its assembly loop
   size_t wave_lds;
   bool wave_ok;
   umpcQPSettings st;
   int32_t *tab;
   void *W;
 };
+
+// assembly specialisations (gen/bqp_*_asm.h, fp32) keep one iteration's read-only words in a [wave][item][lane] block
+// behind row 1024 of the workspace (codegen_qp.ASM_STREAM_ROW); 1024 items bound every built-in structure.
+// UMPC_QP_NO_ASM=1 disables them.
+bool asm_room(const qp_batch *h) {
+  static const bool no_asm = getenv("UMPC_QP_NO_ASM") != nullptr;
+  const size_t need = (size_t)((h->B + 63) / 64) * 64 * 1024, have = h->nrows > 1024 ? (size_t)(h->nrows - 1024) * h->B : 0;
+  return !no_asm && !h->no_asm && need <= have;
+}
+bool asm_active(const qp_batch *h) {
+  const bool tables = h->use_tables || h->st.check_termination > 0 || h->st.adaptive_rho_interval > 0;
+  return h->fixed >= 0 && !tables && !h->wave && h->dtype == UMPC_F32 && kFixedKernels[h->fixed].asm_f32 &&
+         h->st.max_iter >= 3 && asm_room(h);
+}
 
 template <typename T>
 int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, const void *l, const void *u, void *x,
@@ -824,6 +839,11 @@ int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, con
   a.max_iter = h->st.max_iter; a.scaling = h->st.scaling;
   a.check_termination = h->st.check_termination;
   a.adaptive_rho_interval = h->st.adaptive_rho_interval;
+  {
+    a.asm_ok = asm_room(h) ? 1 : 0;
+    a.oma = T(1.0) - a.alpha;
+    a.rinv_eq = T(1. / (double)T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho));
+  }
   // early termination / adaptive rho live in the table kernel
   const bool tables = h->use_tables || h->st.check_termination > 0 || h->st.adaptive_rho_interval > 0;
   if (h->wave && !tables) {
@@ -928,7 +948,7 @@ void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpc
   h->nnzP = blob[H_NNZP]; h->nnzA = blob[H_NNZA]; h->nnzL = blob[H_NNZL]; h->nrows = nrows;
   if (st) h->st = *st; else umpcQPDefaultSettings(&h->st);
   // a straight-line specialisation generated at build time for exactly this structure?
-  h->fixed = -1; h->use_tables = 0;
+  h->fixed = -1; h->use_tables = 0; h->no_asm = 0;
   // wave-per-robot kernel: available (umpcQPSetKernel(h, 0)) whenever the robot's working set fits the LDS a
   // workgroup may own; the default is the lane-per-robot path, which is faster on most structures
   h->wave_lds = bqp_wave_lds_words(n, m, blob[H_NNZP], blob[H_NNZA], blob[H_NNZL]);
@@ -981,12 +1001,13 @@ int umpcQPUseTables(void *hv, int on) {
 
 int umpcQPSetKernel(void *hv, int mode) {
   qp_batch *h = (qp_batch *)hv;
-  if (!h || mode < 0 || mode > 2) { umpc_set_error("umpcQPSetKernel: bad argument"); return -1; }
+  if (!h || mode < 0 || mode > 3) { umpc_set_error("umpcQPSetKernel: bad argument"); return -1; }
   const size_t bytes = h->wave_lds * (h->dtype == UMPC_F32 ? 4 : 8);
   (void)bytes;
   if (mode == 0 && !h->wave_ok) { umpc_set_error("umpcQPSetKernel: working set exceeds the LDS of a CU"); return -1; }
   h->wave = mode == 0;
   h->use_tables = mode == 2;
+  h->no_asm = mode == 3;
   return 0;
 }
 
@@ -995,6 +1016,11 @@ const char *umpcQPKernelName(void *hv) {
   if (!h) return "";
   if (h->use_tables || h->st.check_termination > 0 || h->st.adaptive_rho_interval > 0) return "tables";
   if (h->wave) return "wave";
+  if (asm_active(h)) {      // "<structure>+asm": the specialisation with its middle iterations in assembly
+    static thread_local std::string nm;
+    nm = std::string(kFixedKernels[h->fixed].name) + "+asm";
+    return nm.c_str();
+  }
   return h->fixed >= 0 ? kFixedKernels[h->fixed].name : "tables";
 }
 

@@ -1,0 +1,109 @@
+"""CPU checks of the generated assembly for the middle ADMM iterations of the planar p5f structure
+(robobee3d_amd/asmqp.py): the instruction list is interpreted on numpy float32 -- with a completion model that rejects a
+register used before the s_waitcnt covering its load -- and compared with a float64 numpy statement of the OSQP
+iteration (osqp 0.6.0 auxil.c:164-228, qdldl.c:250-293) on random data of the structure."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def prog():
+    from robobee3d_amd import asmqp, batchqp, codegen_qp, qpstruct
+    st = batchqp.p5f_structure(10)
+    s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    ins, p = asmqp.program(s, codegen_qp.ASM_STRUCTURES["p5f10"])
+    return asmqp, ins, p
+
+
+def _data(p, seed, eq):
+    rng = np.random.default_rng(seed)
+    n, m, nk = p.n, p.m, p.nk
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    d = dict(x=f(rng.normal(size=n)), y=f(rng.normal(size=m)), z=f(rng.normal(size=m)), q=f(rng.normal(size=n)),
+             L=f(rng.normal(size=len(p.L_i)) * 0.3), DI=f(rng.normal(size=nk) * 0.5))
+    l = f(rng.normal(size=m) - 1.0)
+    u = l + f(np.abs(rng.normal(size=m)) + 0.1)
+    rho = np.full(m, 0.1)
+    rho[rng.random(m) < 0.2] = 1e-6          # "loose" rows
+    rho[eq] = 100.0
+    rho = f(rho)
+    u[eq] = l[eq]
+    d["z"][eq] = l[eq]                        # what the first (C++) iteration leaves
+    d.update(l=l, u=u, rho=rho, rinv=f(1.0 / rho))
+    return d
+
+
+def _run(asmqp, ins, p, d, iters, eq):
+    n, m, nk = p.n, p.m, p.nk
+    gen = [i for i in range(m) if i not in set(eq)]
+    W = np.zeros(p.R_END, np.float32)
+    for j, pos in p.lpos.items():
+        W[p.R_L + pos] = -d["L"][j]
+    W[p.R_DI:p.R_DI + nk] = d["DI"]
+    W[p.R_X:p.R_X + n] = d["x"]
+    W[p.R_Y:p.R_Y + m] = d["y"]
+    W[p.R_Z:p.R_Z + len(gen)] = d["z"][gen]
+    S = np.zeros(p.n_stream + len(p.extra), np.float32)
+    for q, (what, i) in enumerate(p.stream + p.extra):
+        S[q] = {"rinv": d["rinv"], "l": d["l"], "u": d["u"], "rho": d["rho"], "q": d["q"]}[what][i]
+    asmqp.simulate(ins, W, S, iters, (1.6, 1e-6, float(np.float32(1.0 / 100.0))))
+    return W[p.R_X:p.R_X + n], W[p.R_Y:p.R_Y + m], W[p.R_Z:p.R_Z + len(gen)], gen
+
+
+@pytest.mark.parametrize("iters", [1, 2, 5])
+def test_generated_p5f_iterations_match_numpy(prog, iters):
+    from robobee3d_amd import codegen_qp
+    asmqp, ins, p = prog
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    for seed in (0, 1):
+        d = _data(p, seed, eq)
+        gx, gy, gz, gen = _run(asmqp, ins, p, d, iters, eq)
+        xr, yr, zr = asmqp.reference_iterations(p, d, iters, 1.6, 1e-6)
+        for got, ref in ((gx, xr), (gy, yr), (gz, zr[gen])):
+            assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (iters, seed)
+
+
+def test_plan_fits_the_lane(prog):
+    asmqp, ins, p = prog
+    assert len(p.nonleaf) == 162 and sum(r["leaf"] for r in p.rows) == 89
+    assert p.V_TT + asmqp.N_TT <= asmqp.V_END <= 246 and p.nk <= 256 and p.LW_END <= 640
+    assert p.R_END <= 1024 and p.n_stream + len(p.extra) <= 1024
+    import re
+    for t in ins:
+        for x in t[1:]:
+            if isinstance(x, str):
+                for a in re.findall(r"\bv(\d+)\b", x):
+                    assert int(a) < asmqp.V_END
+                for a, b in re.findall(r"v\[(\d+):(\d+)\]", x):
+                    assert int(b) < asmqp.V_END
+        if t[0].startswith("ds_"):
+            assert 0 <= t[3] < 65536
+        if t[0].startswith("global_"):
+            assert 0 <= t[4] < 4096
+
+
+def test_completion_model_catches_a_missing_wait(prog):
+    """the interpreter's in-order completion model is what guards the s_waitcnt placement: without the waits it must object"""
+    from robobee3d_amd import codegen_qp
+    asmqp, ins, p = prog
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    d = _data(p, 3, eq)
+    stripped = [t for t in ins if t[0] != "s_waitcnt"]
+    with pytest.raises(AssertionError):
+        _run(asmqp, stripped, p, d, 1, eq)
+
+
+def test_p5f_stream_assembles(prog):
+    import os, subprocess, tempfile
+    mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    asmqp, ins, p = prog
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("\n".join(asmqp.fmt(t) for t in ins) + "\n")
+    try:
+        r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[:3000]
+    finally:
+        os.unlink(f.name)

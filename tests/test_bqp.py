@@ -465,14 +465,16 @@ def test_gpu_specialised_kernels_equal_the_table_driven_kernel():
         B = 96
         # p5f
         mpc = PlanarP5fMPC(B, tdt)
-        assert mpc.qp.kernel_name == "wave"          # PlanarP5fMPC's choice; the two lane-per-robot kernels are compared here
+        # PlanarP5fMPC's choice: fp32 the lane specialisation with its assembly loop, fp64 the wave kernel; compared here
+        # are the two lane-per-robot C++ kernels
+        assert mpc.qp.kernel_name == ("p5f10+asm" if tdt == torch.float32 else "wave")
         mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
         mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
         mpc.linearise(7.0)
         res = []
         for tables in (False, True):
             mpc.qp.reset()
-            mpc.qp.use_tables(tables)
+            mpc.qp.set_kernel("tables" if tables else "lane_cpp")
             assert mpc.qp.kernel_name == ("tables" if tables else "p5f10")
             mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
             torch.cuda.synchronize()
@@ -588,6 +590,34 @@ def test_gpu_createMPC_pair_cross_check():
     up5, _ = createMPC(N=5)
     u5, a5 = up5.update(p, R0, dq, pdes, dpdes, sdes)
     assert np.isfinite(u5).all() and np.isfinite(a5).all() and up5.prevsol.shape == (75,) and up5.status_val == 1 and up5.iterations < 4000
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_assembly_loop_agrees_with_the_table_kernel(margin):
+    """fp32 planar p5f: the specialisation whose middle ADMM iterations run as generated assembly (asmqp.py: leaf rows
+    folded, fused multiply-adds, equality-row shortcut) against the table-driven kernel, cold and warm-started calls,
+    a full-wave batch, a ragged one and one too small for the stream buffer (falls back to the C++ loop)."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    for B in (200, 64, 5):
+        mpc = PlanarP5fMPC(B, torch.float32)
+        mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
+        mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
+        res = []
+        for mode in ("lane", "tables"):
+            mpc.qp.reset()
+            mpc.qp.set_kernel(mode)
+            assert mpc.qp.kernel_name == {"lane": "p5f10+asm" if B >= 64 else "p5f10", "tables": "tables"}[mode]
+            for ti in (2, 3, 4):      # later calls are warm-started and classify with the previous call's E
+                mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti))
+                mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
+            torch.cuda.synchronize()
+            res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x, mpc.qp.Eprev)]
+                       + [mpc.qp.status.cpu().numpy().copy(), mpc.qp.info.cpu().numpy().copy()])
+        worst = max(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) for a, b in zip(res[0][:5], res[1][:5]))
+        margin("B=%d iterates / solution, |d| / max(1, |ref|)" % B, worst, 1e-3 if B >= 64 else 0.0)
+        assert np.count_nonzero(res[0][5] != res[1][5]) <= B // 8
+        assert np.all(np.isfinite(res[0][0]))
 
 
 @pytest.mark.gpu
