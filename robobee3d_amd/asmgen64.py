@@ -200,6 +200,7 @@ def preload_l(e, s, neq):
 def prologue(e, s):
     nx, nc, nk = s.nx, s.nc, s.nk
     neq = 2 * s.N * symbolic.NY
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")     # the C++ side's hand-off stores have left the wave
     consts(e)
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")

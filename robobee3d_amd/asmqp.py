@@ -396,6 +396,7 @@ def _adv(e, sreg):
 
 def prologue(e, p):
     """rows R_L.. (negated L in storage order), R_DI, R_X, R_Y, R_Z -> LDS / AGPRs; the once-only stream items"""
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")     # the C++ side's hand-off stores have left the wave
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
     # L, x, y, z -> LDS through the W registers as landing zone, a group of rows at a time

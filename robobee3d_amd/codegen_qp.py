@@ -202,7 +202,7 @@ def emit_structure(name, s, asm=None):
         E("      const unsigned s_sigma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.sigma));")
         E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
         E("      // every scalar operand is made provably wave-uniform (the values are; the compiler cannot always see it)")
-        E("      auto uni = [](unsigned long long v_) { return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v_); };")
+        E("      auto uni = [](unsigned long long v_) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v_); };  // (the builtin returns int: no sign extension)")
         E("      const unsigned long long wsp = uni((unsigned long long)a.W), ssp = uni((unsigned long long)sblk);")
         E("      const unsigned s_stride = __builtin_amdgcn_readfirstlane(stride), s_mid = __builtin_amdgcn_readfirstlane((unsigned)mid);")
         E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq);" % name.upper())

@@ -615,7 +615,7 @@ def test_gpu_p5f_assembly_loop_agrees_with_the_table_kernel(margin):
             res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x, mpc.qp.Eprev)]
                        + [mpc.qp.status.cpu().numpy().copy(), mpc.qp.info.cpu().numpy().copy()])
         worst = max(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) for a, b in zip(res[0][:5], res[1][:5]))
-        margin("B=%d iterates / solution, |d| / max(1, |ref|)" % B, worst, 1e-3 if B >= 64 else 0.0)
+        margin("B=%d iterates / solution, |d| / max(1, |ref|)" % B, worst, 3e-6 if B >= 64 else 0.0)
         assert np.count_nonzero(res[0][5] != res[1][5]) <= B // 8
         assert np.all(np.isfinite(res[0][0]))
 
