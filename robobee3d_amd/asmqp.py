@@ -113,7 +113,9 @@ class Plan:
         self.R_X = self.R_DI + nk
         self.R_Y = self.R_X + n
         self.R_Z = self.R_Y + m
-        self.R_END = self.R_Z + len(gen)
+        self.R_XP = self.R_Z + len(gen)        # x_prev and delta_y of the last (capturing) iteration
+        self.R_DY = self.R_XP + n
+        self.R_END = self.R_DY + m
 
 
 class Sched:
@@ -258,7 +260,8 @@ def preloads(e, p):
         idx += 1
 
 
-def body(e, p):
+def body(e, p, capture=False):
+    """capture: the LAST iteration -- x_prev and delta_y go to rows R_XP / R_DY (auxil.c:362-512 consumes them)"""
     n, m = p.n, p.m
     v = lambda r: "v%d" % r
     sA, sO, sS, sRe = ("s%d" % r for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINVEQ))
@@ -320,6 +323,18 @@ def body(e, p):
     for (r_, c, j) in reversed(p.solve_entries):
         op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
     ops.append(dict(flush=True))
+    sptr = "s[%d:%d]" % (S_P, S_P + 1)
+
+    def store_dy(i, compute, reg):
+        """capturing iteration: delta_y of row i (rows are visited in order) -> row R_DY + i"""
+        if not capture:
+            return
+        compute()
+        if i == 0:
+            _row_ptr(e, S_P, p.R_DY)
+        else:
+            _adv(e, S_P)
+        e("global_store_dword", "v0", v(reg), sptr, 0)
     # ---- P6: row updates (auxil.c:203-228); leaf rows re-form their multiplier from the final unknown of their variable
     for r in p.rows:
         i, k = r["i"], r["k"]
@@ -331,12 +346,14 @@ def body(e, p):
                     e("v_mul_f32", v(T(0)), v(T(0)), v(g[2]))
                     e("v_fmac_f32", v(T(0)), v(g[1]), W(r["r"]))          # nu
                     e("v_sub_f32", v(T(1)), v(T(0)), v(g[0]))
+                    store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
                     e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
                     sc.lds_write(yw, T(1))
                 op([("L", yw), ("L", p.lpos[r["j"]]), ("A", k)], f)
             else:
-                def f(g, k=k, yw=yw):
+                def f(g, k=k, yw=yw, i=i):
                     e("v_sub_f32", v(T(1)), W(k), v(g[0]))
+                    store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
                     e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
                     sc.lds_write(yw, T(1))
                 op([("L", yw)], f)
@@ -363,7 +380,12 @@ def body(e, p):
             e("v_max_f32", t4, t4, lo)
             e("v_min_f32", t4, t4, up)                                    # z_new
             e("v_sub_f32", d, tt, t4)
-            e("v_fma_f32", d, rho, d, y)                                  # y_new = y + rho (t - z_new)
+            if capture:
+                e("v_mul_f32", d, rho, d)                                 # delta_y
+                store_dy(r["i"], lambda: None, T(5))
+                e("v_add_f32", d, y, d)
+            else:
+                e("v_fma_f32", d, rho, d, y)                              # y_new = y + rho (t - z_new)
             sc.lds_write(zw, T(4))
             sc.lds_write(yw, T(5))
         op(srcs, f)
@@ -374,12 +396,19 @@ def body(e, p):
 
         def f(g, k=k, j=j):
             t = T(6 + j % 2)
+            if capture:
+                if j == 0:
+                    _row_ptr(e, S_P, p.R_XP)
+                else:
+                    _adv(e, S_P)
+                e("global_store_dword", "v0", v(g[0]), sptr, 0)
             e("v_mul_f32", v(t), sO, v(g[0]))
             e("v_fma_f32", v(t), sA, W(k), v(t))
             sc.lds_write(p.LW_X + j, t)
         op([("L", p.LW_X + j)], f)
     sc.run(ops)
-    preloads(e, p)
+    if not capture:
+        preloads(e, p)
 
 
 def _row_ptr(e, sreg, row):
@@ -457,16 +486,20 @@ def epilogue(e, p):
 
 
 def program(s, eq_rows):
-    """s11 = number of middle iterations (>= 1)"""
+    """s11 = number of non-capturing iterations (>= 0); one capturing iteration follows them"""
     p = Plan(s, eq_rows)
     e = Emit()
     prologue(e, p)
     e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
+    e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
+    e("s_cbranch_scc1", "8f")
     e("label", "7")
     body(e, p)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
+    e("label", "8")
+    body(e, p, capture=True)
     epilogue(e, p)
     return e.ins, p
 
@@ -604,10 +637,10 @@ def simulate(ins, W, S, iters, consts):
             scc = r >> 32
         elif m == "s_sub_i32":
             SG[int(t[1][1:])] = (sval(t[2]) - sval(t[3])) & 0xFFFFFFFF
-        elif m == "s_cmp_gt_i32":
+        elif m in ("s_cmp_gt_i32", "s_cmp_lt_i32"):
             a = sval(t[1])
             a = a - (1 << 32) if a & 0x80000000 else a
-            scc = int(a > sval(t[2]))
+            scc = int(a > sval(t[2])) if m == "s_cmp_gt_i32" else int(a < sval(t[2]))
         elif m == "s_cbranch_scc1":
             if scc:
                 lab, d = t[1][:-1], t[1][-1]
@@ -651,6 +684,8 @@ def simulate(ins, W, S, iters, consts):
             setf(t[1], f32(fval(t[2])) * f32(fval(t[3])))
         elif m == "v_sub_f32":
             setf(t[1], f32(fval(t[2])) - f32(fval(t[3])))
+        elif m == "v_add_f32":
+            setf(t[1], f32(fval(t[2])) + f32(fval(t[3])))
         elif m == "v_max_f32":
             setf(t[1], max(fval(t[2]), fval(t[3])))
         elif m == "v_min_f32":

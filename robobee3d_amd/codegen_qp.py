@@ -37,7 +37,7 @@ def builtin_structures():
 
 
 ASM_STRUCTURES = {"p5f10": list(range(77))}   # structure -> rows assumed to be equalities by the assembly loop (asmqp.py)
-ASM_STREAM_ROW = 1024                          # the stream buffer starts at this row of the workspace
+ASM_STREAM_ROW = 1280                          # the stream buffer starts at this row of the workspace
 
 
 def emit_structure(name, s, asm=None):
@@ -216,11 +216,15 @@ def emit_structure(name, s, asm=None):
                 E("    z[%d] = ls[%d];" % (r["i"], r["i"]))
             else:
                 E("    z[%d] = IN(a.W, %d);" % (r["i"], P.R_Z + P.zpos[r["i"]]))
+        for j in range(n):
+            E("    xp[%d] = IN(a.W, %d);" % (j, P.R_XP + j))
+        for i in range(m):
+            E("    dy[%d] = IN(a.W, %d);" % (i, P.R_DY + i))
         E("  } else {")
         E("#pragma nounroll")
         E("    for (int it = 1; it < a.max_iter - 1; ++it) iterate();")
+        E("    if (a.max_iter >= 2) iterate();")
         E("  }")
-        E("  if (a.max_iter >= 2) iterate();")
     # ---- residuals
     E("  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);")
     for i in range(m):

@@ -811,11 +811,11 @@ struct qp_batch {
 };
 
 // assembly specialisations (gen/bqp_*_asm.h, fp32) keep one iteration's read-only words in a [wave][item][lane] block
-// behind row 1024 of the workspace (codegen_qp.ASM_STREAM_ROW); 1024 items bound every built-in structure.
+// behind row 1280 of the workspace (codegen_qp.ASM_STREAM_ROW); 1024 items bound every built-in structure.
 // UMPC_QP_NO_ASM=1 disables them.
 bool asm_room(const qp_batch *h) {
   static const bool no_asm = getenv("UMPC_QP_NO_ASM") != nullptr;
-  const size_t need = (size_t)((h->B + 63) / 64) * 64 * 1024, have = h->nrows > 1024 ? (size_t)(h->nrows - 1024) * h->B : 0;
+  const size_t need = (size_t)((h->B + 63) / 64) * 64 * 1024, have = h->nrows > 1280 ? (size_t)(h->nrows - 1280) * h->B : 0;
   return !no_asm && !h->no_asm && need <= have;
 }
 bool asm_active(const qp_batch *h) {

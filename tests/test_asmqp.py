@@ -47,27 +47,31 @@ def _run(asmqp, ins, p, d, iters, eq):
     for q, (what, i) in enumerate(p.stream + p.extra):
         S[q] = {"rinv": d["rinv"], "l": d["l"], "u": d["u"], "rho": d["rho"], "q": d["q"]}[what][i]
     asmqp.simulate(ins, W, S, iters, (1.6, 1e-6, float(np.float32(1.0 / 100.0))))
-    return W[p.R_X:p.R_X + n], W[p.R_Y:p.R_Y + m], W[p.R_Z:p.R_Z + len(gen)], gen
+    return W[p.R_X:p.R_X + n], W[p.R_Y:p.R_Y + m], W[p.R_Z:p.R_Z + len(gen)], gen, W[p.R_XP:p.R_XP + n], W[p.R_DY:p.R_DY + m]
 
 
-@pytest.mark.parametrize("iters", [1, 2, 5])
+@pytest.mark.parametrize("iters", [0, 1, 2, 3])   # (the random system is not a contraction: more iterations overflow fp32)
 def test_generated_p5f_iterations_match_numpy(prog, iters):
+    """`iters` plain iterations, then the capturing one (x_prev, delta_y of the last iteration to their rows)"""
     from robobee3d_amd import codegen_qp
     asmqp, ins, p = prog
     eq = codegen_qp.ASM_STRUCTURES["p5f10"]
     for seed in (0, 1):
         d = _data(p, seed, eq)
-        gx, gy, gz, gen = _run(asmqp, ins, p, d, iters, eq)
-        xr, yr, zr = asmqp.reference_iterations(p, d, iters, 1.6, 1e-6)
-        for got, ref in ((gx, xr), (gy, yr), (gz, zr[gen])):
+        gx, gy, gz, gen, gxp, gdy = _run(asmqp, ins, p, d, iters, eq)
+        xr, yr, zr = asmqp.reference_iterations(p, d, iters + 1, 1.6, 1e-6)
+        xq, yq, _ = asmqp.reference_iterations(p, d, iters, 1.6, 1e-6)
+        for got, ref in ((gx, xr), (gy, yr), (gz, zr[gen]), (gxp, xq)):
             assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (iters, seed)
+        assert np.abs(gdy - (yr - yq)).max() <= 2e-5 * np.abs(yr).max(), (iters, seed)
 
 
 def test_plan_fits_the_lane(prog):
+    from robobee3d_amd import codegen_qp
     asmqp, ins, p = prog
     assert len(p.nonleaf) == 162 and sum(r["leaf"] for r in p.rows) == 89
     assert p.V_TT + asmqp.N_TT <= asmqp.V_END <= 246 and p.nk <= 256 and p.LW_END <= 640
-    assert p.R_END <= 1024 and p.n_stream + len(p.extra) <= 1024
+    assert p.R_END <= codegen_qp.ASM_STREAM_ROW and p.n_stream + len(p.extra) <= 1024
     import re
     for t in ins:
         for x in t[1:]:
