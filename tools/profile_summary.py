@@ -33,6 +33,9 @@ def counters(path):
 
 for k in ("kt500", "kt20"):
     shutil.copy(os.path.join(src, k, "kt_kernel_stats.csv"), os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, k[2:] and "k" + k[2:])))
+for k, name in (("ktc2", "config2_f64"), ("ktc4", "config4_p5f")):
+    if os.path.exists(os.path.join(src, k, "kt_kernel_stats.csv")):
+        shutil.copy(os.path.join(src, k, "kt_kernel_stats.csv"), os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, name)))
 with open(os.path.join(dst, "%s_kernel_trace_rollout.csv" % tag), "w") as f:
     for k in ("kt500", "kt20"):
         lines = open(os.path.join(src, k, "kt_kernel_trace.csv")).read().splitlines()
