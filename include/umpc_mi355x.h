@@ -185,10 +185,12 @@ double umpcBatchTime(const umpc_batch_t *h);
  * copy), umpcBatchCreate checks the batch-constant ones. Returns 0, -1 (bad weights) or a hipError_t. */
 int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
 
-/* fp32 step-kernel choice. 0 (default): automatic -- the all-assembly kernel (robobee3d_amd/asmstep.py: phase A,
- * ADMM loop, phase C and the RK4 plant as one generated gfx950 stream) whenever the call is inside its scope (no task
- * generator, batch-constant weights, no WL coupling, maxIter >= 1), else the C++ kernel with
- * the assembly ADMM loop. 1: always the latter (ablation / cross-check). fp64 always runs the C++ kernel. */
+/* Step-kernel choice. 0 (default): automatic. fp32: the all-assembly kernel (robobee3d_amd/asmstep.py: phase A, ADMM
+ * loop, phase C and the plant as one generated gfx950 stream) whenever the call is inside its scope (no task
+ * generator, batch-constant weights, no WL coupling, maxIter >= 1), else the C++ kernel with the assembly ADMM loop.
+ * fp64: for batches of at most 256 wavefronts (B <= 16 384) the C++ kernel with L and 1/D in LDS and the ADMM phase as
+ * generated fp64 assembly (robobee3d_amd/asmgen64.py; maxIter >= 1), else the all-C++ kernel.
+ * 1: always the C++ kernel -- fp32 around the assembly ADMM loop, fp64 with the C++ loop (ablation / cross-check). */
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode);
 
 /* Static facts */

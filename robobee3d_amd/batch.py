@@ -157,8 +157,8 @@ class BatchUprightMPC:
         self._check(self.L.umpcBatchSetWeights(self.h, _ptr(w)))
 
     def set_step_kernel(self, mode):
-        """"auto" (default: the all-assembly fp32 kernel where it applies) or "cpp" (always the C++ kernel around the
-        assembly ADMM loop): ablation and cross-checks."""
+        """"auto" (default: the all-assembly fp32 kernel / the fp64 kernel with the assembly ADMM loop where they apply)
+        or "cpp" (fp32: the C++ kernel around the assembly ADMM loop; fp64: the C++ loop): ablation and cross-checks."""
         self._check(self.L.umpcBatchSetStepKernel(self.h, {"auto": 0, "cpp": 1}[mode]))
 
     M0_CA6 = (100.0, 100.0, 100.0, 3333.0, 3333.0, 1000.0)   # dynamicsTerms, template/ca6dynamics.py:5-10
