@@ -413,7 +413,7 @@ def fmt(t):
     m = t[0]
     if m == "label":
         return "%s:" % t[1]
-    a = [("0x%x" % x if isinstance(x, int) and m in ("s_mov_b32", "v_add_u32") else str(x)) for x in t[1:]]
+    a = [("0x%x" % x if isinstance(x, int) and m in ("s_mov_b32", "v_add_u32", "v_mov_b32", "v_cndmask_b32") else str(x)) for x in t[1:]]
     if m.startswith("ds_read") or m.startswith("ds_write"):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
     if m == "s_waitcnt":
@@ -441,6 +441,22 @@ def write(path=None, N=3, perm=None):
         out.append('  "%s\\n" \\' % fmt(t))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(ws), "{s[6:7]}"(ctrl), "{s10}"(stride), "{s11}"(iters) \\')
     out.append("  : " + ", ".join(clob) + ")")
+    # the Ruiz passes
+    rins, _ = ruiz_program(N, perm)
+    rclob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + ['"a%d"' % i for i in range(256)] + \
+            ['"s%d"' % i for i in [S_CNT, S_MINS, S_MINS + 1, S_MAXS, S_MAXS + 1]]
+    rl7 = [k for k, t_ in enumerate(rins) if t_ == ("label", "7")][0]
+    out += ["// The Ruiz passes of the fp64 step (scaling.c:44-156): %d instructions, %d per pass. LDS words (LDSF_W layout):"
+            % (len(rins), sum(1 for t_ in rins[rl7:] if t_[0] in ("s_cbranch_scc1",)) and
+               [k for k, t_ in enumerate(rins) if t_[0] == "s_cbranch_scc1"][0] - rl7),
+            "// P at RZ_P.., q at RZ_Q.., A at RZ_A.. on entry and exit, the accumulated cost scaling c at RZ_C on exit.",
+            "namespace umpcasm64 { constexpr int RZ_P = %d, RZ_C = %d, RZ_Q = %d, RZ_A = %d; }" % (RZ_P, RZ_C, RZ_Q, RZ_A),
+            "// inputs: v1 = lane LDS address (16*lane), s11 = passes >= 1",
+            "#define UMPC_RUIZ_ASM64(ldsaddr, passes) asm volatile( \\"]
+    for t_ in rins:
+        out.append('  "%s\\n" \\' % fmt(t_))
+    out.append('  : : "{v1}"(ldsaddr), "{s11}"(passes) \\')
+    out.append("  : " + ", ".join(rclob) + ")")
     txt = "\n".join(out) + "\n"
     old = open(path).read() if os.path.exists(path) else None
     if old != txt:
@@ -483,9 +499,13 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds):
         return S.get(int(x[1:]), 0)
 
     def getd(x):
+        if isinstance(x, float):
+            return x                      # inline constant (1.0, 0.5)
         neg = x.startswith("-")
         if neg:
             x = x[1:]
+        if x.startswith("|"):
+            return (-1.0 if neg else 1.0) * abs(getd(x[1:-1]))
         lo = lohi(x)
         bits = (int(V[lo]) | (int(V[lo + 1]) << 32)) if x[0] == "v" else (S[lo] | (S[lo + 1] << 32))
         val = struct.unpack("<d", struct.pack("<Q", bits))[0]
@@ -517,8 +537,23 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds):
         m = t[0]
         nexec += 1
         assert nexec < 2000000, "runaway program"
-        if m in ("label", "s_waitcnt"):
+        if m in ("label", "s_waitcnt", "s_nop"):
             pass
+        elif m == "v_mov_b32":
+            V[int(t[1][1:])] = t[2] if isinstance(t[2], int) else V[int(t[2][1:])]
+        elif m == "v_cmp_nlt_f64":
+            S["vcc"] = int(not (getd(t[2]) < getd(t[3])))
+        elif m == "v_cndmask_b32":
+            src0 = t[2] if isinstance(t[2], int) else int(V[int(t[2][1:])])
+            V[int(t[1][1:])] = int(V[int(t[3][1:])]) if S["vcc"] else src0
+        elif m == "v_rsq_f64":
+            setd(t[1], 1.0 / np.sqrt(getd(t[2])))
+        elif m == "v_rcp_f64":
+            setd(t[1], 1.0 / getd(t[2]))
+        elif m == "ds_read_b64":
+            lo = lohi(t[1])
+            b = f64bits(float(lds[ldsword(t[2], t[3])]))
+            V[lo], V[lo + 1] = b & 0xFFFFFFFF, b >> 32
         elif m == "s_mov_b32":
             S[int(t[1][1:])] = t[2] if isinstance(t[2], int) else sval(t[2])
         elif m == "s_mov_b64":
@@ -591,3 +626,219 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds):
 
 if __name__ == "__main__":
     print(write())
+
+
+# ---------------------------------------------------------------------------
+# The ten Ruiz passes of the fp64 step (scaling.c:44-156) as one assembly block
+# ---------------------------------------------------------------------------
+# hipcc's fp64 pass is ~3 700 instructions with ~400 exposed LDS / scratch waits: 22 us, ten times per step, 0.22 of the
+# 0.53 ms (tools/f64_phases.sh). Here nothing leaves the register files for the ten passes:
+#
+#   v4..v225     A (CSC order), 111 words            v226:227  q[44]      v228:229  c (accumulated cost scaling)
+#   v230..v243   temporaries (7 words)              v245  high word of 1.0 (limit_scaling's select)
+#   a0..a77      Et (39)      a78..a167  P (45)       a168..a255  q[0..44)
+#   LDS words (quad layout of LDSF_W) on entry and exit: RZ_P.. P (45), RZ_C c (exit only), RZ_Q.. q (45), RZ_A.. A (111)
+#
+# The column scalings Dt are never stored: a pass first forms all row scalings Et (they need every column), then walks
+# the columns, forming Dt_j from the still untouched column j and applying it to P_j, column j of A and q_j at once.
+# Arithmetic = UMPC_GEN_RUIZ_NORMS / APPLY_A and the loop around them in csrc/umpc_step.h, operation by operation
+# (max is exact; 1/sqrt and the two divisions are v_rsq_f64 / v_rcp_f64 + two Newton steps like umpc_rsqrt / umpc_recip;
+# pmean / nx is a multiplication by the refined reciprocal with one correction step: within an ulp of the divide).
+RZ_P, RZ_C, RZ_Q, RZ_A = 0, 45, 84, 168
+RV_A, RV_QL, RV_C, RV_T = 4, 226, 228, 230
+RV_ONEHI = 245                               # high word of 1.0 (set after the prologue, which lands quads in v230..v245)
+RA_ET, RA_P, RA_Q = 0, 78, 168
+S_MINS, S_MAXS = 30, 32                      # 1e-4, 1e4 (doubles in SGPR pairs)
+
+
+def ruiz_program(N=3, perm=None):
+    """s11 = number of passes (>= 1)"""
+    s = symbolic.analyse(N, perm)
+    nx, nc = s.nx, s.nc
+    nnz = len(s.A_i)
+    assert RV_A + 2 * nnz <= RV_QL and RA_ET + 2 * nc <= RA_P and RA_P + 2 * nx <= RA_Q and RA_Q + 2 * (nx - 1) <= 256
+    e = Emit()
+    T = lambda q: RV_T + 2 * q
+    A = lambda p_: RV_A + 2 * p_
+    sMIN, sMAX = sp(S_MINS), sp(S_MAXS)
+    ONE_HI = f64bits(1.0) >> 32
+
+    def setc(reg, val):
+        b = f64bits(val)
+        e("s_mov_b32", "s%d" % reg, b & 0xFFFFFFFF)
+        e("s_mov_b32", "s%d" % (reg + 1), b >> 32)
+
+    def limit(t, t2):
+        """t <- limit_scaling(t): t < 1e-4 ? 1 : min(t, 1e4)   (t2: scratch pair)"""
+        e("v_cmp_nlt_f64", "vcc", vp(t), sMIN)
+        e("v_min_f64", vp(t2), vp(t), sMAX)
+        e("v_cndmask_b32", "v%d" % t, 0, "v%d" % t2, "vcc")
+        e("v_cndmask_b32", "v%d" % (t + 1), "v%d" % RV_ONEHI, "v%d" % (t2 + 1), "vcc")   # (a literal next to vcc exceeds the constant bus)
+
+    def rsqrt(y, t, a_, h_):
+        """y <- 1/sqrt(t): v_rsq_f64 + two Newton steps (umpc_rsqrt)"""
+        e("v_rsq_f64", vp(y), vp(t))
+        e("s_nop", 0)
+        for _ in range(2):
+            e("v_mul_f64", vp(a_), vp(t), vp(y))
+            e("v_fma_f64", vp(a_), "-" + vp(a_), vp(y), 1.0)
+            e("v_mul_f64", vp(h_), 0.5, vp(y))
+            e("v_fma_f64", vp(y), vp(h_), vp(a_), vp(y))
+
+    def recip(y, t, a_):
+        """y <- 1/t: v_rcp_f64 + two Newton steps (umpc_recip)"""
+        e("v_rcp_f64", vp(y), vp(t))
+        e("s_nop", 0)
+        for _ in range(2):
+            e("v_fma_f64", vp(a_), "-" + vp(t), vp(y), 1.0)
+            e("v_fma_f64", vp(y), vp(y), vp(a_), vp(y))
+
+    def acc_write(areg, v_):
+        e("v_accvgpr_write_b32", "a%d" % areg, "v%d" % v_)
+        e("v_accvgpr_write_b32", "a%d" % (areg + 1), "v%d" % (v_ + 1))
+
+    def acc_read(v_, areg):
+        e("v_accvgpr_read_b32", "v%d" % v_, "a%d" % areg)
+        e("v_accvgpr_read_b32", "v%d" % (v_ + 1), "a%d" % (areg + 1))
+
+    def qhome(j):
+        return ("a", RA_Q + 2 * j) if j < nx - 1 else ("v", RV_QL)
+
+    # ---- prologue: constants; A -> VGPRs, P and q -> AGPRs (through the temporaries, four quads at a time)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    setc(S_MINS, 1e-4)
+    setc(S_MAXS, 1e4)
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    b = f64bits(1.0)
+    e("v_mov_b32", "v%d" % RV_C, b & 0xFFFFFFFF)
+    e("v_mov_b32", "v%d" % (RV_C + 1), b >> 32)
+    aquads = _words(RZ_A, RZ_A + nnz)
+    for qd, ws in aquads:
+        base, off, _ = lds_addr(2 * qd)
+        if len(ws) == 2:
+            e("ds_read_b128", "v[%d:%d]" % (A(ws[0] - RZ_A), A(ws[0] - RZ_A) + 3), base, off)
+        else:
+            e("ds_read_b64", vp(A(ws[0] - RZ_A)), base, off + 8 * (ws[0] & 1))
+    for lo, home in ((RZ_P, lambda j: ("a", RA_P + 2 * j)), (RZ_Q, qhome)):
+        quads = _words(lo, lo + nx)
+        for g in range(0, len(quads), 4):
+            grp = quads[g:g + 4]
+            for k, (qd, ws) in enumerate(grp):
+                base, off, _ = lds_addr(2 * qd)
+                e("ds_read_b128", "v[%d:%d]" % (T(2 * k), T(2 * k) + 3), base, off)
+            e("s_waitcnt", "lgkmcnt(0)")
+            for k, (qd, ws) in enumerate(grp):
+                for w_ in ws:
+                    kind, reg = home(w_ - lo)
+                    r = T(2 * k) + 2 * (w_ & 1)
+                    if kind == "a":
+                        acc_write(reg, r)
+                    else:
+                        e("v_mov_b32", "v%d" % reg, "v%d" % r)
+                        e("v_mov_b32", "v%d" % (reg + 1), "v%d" % (r + 1))
+    e("s_waitcnt", "lgkmcnt(0)")
+    e("v_mov_b32", "v%d" % RV_ONEHI, ONE_HI)
+    e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
+    e("label", "7")
+    # ---- row scalings Et_i = 1/sqrt(limit(max_j |A_ij|)) -> AGPRs
+    rows = [[] for _ in range(nc)]
+    for j in range(nx):
+        for p_ in range(s.A_p[j], s.A_p[j + 1]):
+            rows[s.A_i[p_]].append(p_)
+    for i in range(nc):
+        t = T(0)
+        ps = rows[i]
+        if len(ps) == 1:
+            e("v_max_f64", vp(t), "|" + vp(A(ps[0])) + "|", "|" + vp(A(ps[0])) + "|")
+        else:
+            e("v_max_f64", vp(t), "|" + vp(A(ps[0])) + "|", "|" + vp(A(ps[1])) + "|")
+            for p_ in ps[2:]:
+                e("v_max_f64", vp(t), vp(t), "|" + vp(A(p_)) + "|")
+        limit(t, T(1))
+        rsqrt(T(1), t, T(2), T(3))
+        acc_write(RA_ET + 2 * i, T(1))
+    # ---- columns: Dt_j from the untouched column, then P_j, column j of A, q_j; pmean in T(4), qn in T(5)
+    for r in (T(4), T(5)):
+        e("v_mov_b32", "v%d" % r, 0)
+        e("v_mov_b32", "v%d" % (r + 1), 0)
+    for j in range(nx):
+        pj, t, dt = T(6), T(0), T(1)
+        acc_read(pj, RA_P + 2 * j)
+        first = True
+        for p_ in range(s.A_p[j], s.A_p[j + 1]):
+            e("v_max_f64", vp(t), "|" + vp(pj if first else t) + "|", "|" + vp(A(p_)) + "|")
+            first = False
+        if first:
+            e("v_max_f64", vp(t), "|" + vp(pj) + "|", "|" + vp(pj) + "|")
+        limit(t, dt)
+        rsqrt(dt, t, T(2), T(3))
+        e("v_mul_f64", vp(pj), vp(pj), vp(dt))
+        e("v_mul_f64", vp(pj), vp(pj), vp(dt))
+        acc_write(RA_P + 2 * j, pj)
+        e("v_add_f64", vp(T(4)), vp(T(4)), "|" + vp(pj) + "|")
+        for p_ in range(s.A_p[j], s.A_p[j + 1]):
+            acc_read(T(2), RA_ET + 2 * s.A_i[p_])
+            e("v_mul_f64", vp(A(p_)), vp(A(p_)), vp(T(2)))
+            e("v_mul_f64", vp(A(p_)), vp(A(p_)), vp(dt))
+        kind, reg = qhome(j)
+        if kind == "a":
+            acc_read(T(2), reg)
+            e("v_mul_f64", vp(T(2)), vp(T(2)), vp(dt))
+            acc_write(reg, T(2))
+            qr = T(2)
+        else:
+            e("v_mul_f64", vp(reg), vp(reg), vp(dt))
+            qr = reg
+        e("v_max_f64", vp(T(5)), vp(T(5)), "|" + vp(qr) + "|")
+    # ---- cost scaling: ct = 1 / limit(max(pmean / nx, limit(qn)))
+    b = f64bits(float(nx))
+    e("v_mov_b32", "v%d" % T(0), b & 0xFFFFFFFF)
+    e("v_mov_b32", "v%d" % (T(0) + 1), b >> 32)
+    recip(T(1), T(0), T(2))
+    e("v_mul_f64", vp(T(2)), vp(T(4)), vp(T(1)))
+    e("v_fma_f64", vp(T(3)), "-" + vp(T(0)), vp(T(2)), vp(T(4)))
+    e("v_fma_f64", vp(T(4)), vp(T(3)), vp(T(1)), vp(T(2)))              # pmean / nx
+    limit(T(5), T(0))
+    e("v_max_f64", vp(T(4)), vp(T(4)), vp(T(5)))
+    limit(T(4), T(0))
+    recip(T(5), T(4), T(0))                                              # ct
+    e("v_mul_f64", vp(RV_C), vp(RV_C), vp(T(5)))
+    for j in range(nx):
+        acc_read(T(j % 2), RA_P + 2 * j)
+        e("v_mul_f64", vp(T(j % 2)), vp(T(j % 2)), vp(T(5)))
+        acc_write(RA_P + 2 * j, T(j % 2))
+    for j in range(nx):
+        kind, reg = qhome(j)
+        if kind == "a":
+            acc_read(T(2 + j % 2), reg)
+            e("v_mul_f64", vp(T(2 + j % 2)), vp(T(2 + j % 2)), vp(T(5)))
+            acc_write(reg, T(2 + j % 2))
+        else:
+            e("v_mul_f64", vp(reg), vp(reg), vp(T(5)))
+    e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+    e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
+    e("s_cbranch_scc1", "7b")
+    # ---- epilogue: A, P, q, c back to LDS
+    for qd, ws in aquads:
+        _write_quad(e, qd, ws, {w_: A(w_ - RZ_A) for w_ in ws})
+    for lo, home in ((RZ_P, lambda j: ("a", RA_P + 2 * j)), (RZ_Q, qhome)):
+        quads = _words(lo, lo + nx)
+        for g in range(0, len(quads), 4):
+            grp = quads[g:g + 4]
+            for k, (qd, ws) in enumerate(grp):
+                regs = {}
+                for w_ in ws:
+                    kind, reg = home(w_ - lo)
+                    r = T(2 * k) + (w_ & 1) * 2
+                    if kind == "a":
+                        acc_read(r, reg)
+                    else:
+                        e("v_mov_b32", "v%d" % r, "v%d" % reg)
+                        e("v_mov_b32", "v%d" % (r + 1), "v%d" % (reg + 1))
+                    regs[w_] = r
+                _write_quad(e, qd, ws, regs)
+    base, off, _ = lds_addr(RZ_C)
+    e("ds_write_b64", base, vp(RV_C), off + 8 * (RZ_C & 1))
+    e("s_waitcnt", "lgkmcnt(0)")
+    return e.ins, s

@@ -588,6 +588,20 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 // live fp64 words in the most register-starved part of the kernel
 #define DT_(j) (*(LDSF ? &LDSF_W(j) : &Dt[LDSF ? 0 : (j)]))
 #define ET_(i) (*(LDSF ? &LDSF_W(NX + (i)) : &Et[LDSF ? 0 : (i)]))
+    if constexpr (ASM64) {
+      // the passes as generated fp64 assembly (asmgen64.ruiz_program): the matrix in VGPRs, Et / P / q in AGPRs, nothing
+      // leaves the register files for the ten passes; P joins q and A in LDS for the hand-over
+      static_assert(umpcasm64::RZ_Q == NX + NC && umpcasm64::RZ_A == 2 * NX + 2 * NC && umpcasm64::RZ_P + NX <= umpcasm64::RZ_C,
+                    "LDS staging words of the Ruiz block");
+#pragma unroll
+      for (int j = 0; j < NX; ++j) LDSF_W(umpcasm64::RZ_P + j) = P[j];
+      UMPC_PHASE_FENCE();
+      UMPC_RUIZ_ASM64(ldsaddr, UMPC_SCALING_ITERS);
+      UMPC_PHASE_FENCE();
+#pragma unroll
+      for (int j = 0; j < NX; ++j) P[j] = LDSF_W(umpcasm64::RZ_P + j);
+      cscale = LDSF_W(umpcasm64::RZ_C);
+    } else
 #pragma nounroll
     for (int it = 0; it < UMPC_SCALING_ITERS; ++it) {
       T Dt[LDSF ? 1 : NX], Et[LDSF ? 1 : NC];

@@ -100,3 +100,74 @@ def test_fp64_stream_assembles(prog):
         assert r.returncode == 0, r.stderr[:3000]
     finally:
         os.unlink(f.name)
+
+
+def _ruiz_numpy(s, P, A, q, passes):
+    """scaling.c:44-156 as csrc/umpc_step.h states it (fp64, exact sqrt and divide)"""
+    nx, nc = s.nx, s.nc
+    P, A, q = P.copy(), A.copy(), q.copy()
+    lim = lambda v: 1.0 if v < 1e-4 else min(v, 1e4)
+    col = [range(s.A_p[j], s.A_p[j + 1]) for j in range(nx)]
+    c = 1.0
+    for _ in range(passes):
+        Dt = np.array([1.0 / np.sqrt(lim(max([abs(P[j])] + [abs(A[p]) for p in col[j]]))) for j in range(nx)])
+        rows = [[] for _ in range(nc)]
+        for j in range(nx):
+            for p in col[j]:
+                rows[s.A_i[p]].append(p)
+        Et = np.array([1.0 / np.sqrt(lim(max(abs(A[p]) for p in rows[i]))) for i in range(nc)])
+        P = (P * Dt) * Dt
+        for j in range(nx):
+            for p in col[j]:
+                A[p] = (A[p] * Et[s.A_i[p]]) * Dt[j]
+        q = q * Dt
+        ct = 1.0 / lim(max(np.abs(P).sum() / nx, lim(np.abs(q).max())))
+        P, q, c = P * ct, q * ct, c * ct
+    return P, A, q, c
+
+
+@pytest.mark.parametrize("passes", [1, 10])
+def test_generated_fp64_ruiz_block_matches_numpy(passes):
+    from robobee3d_amd import asmgen64 as g
+    ins, s = g.ruiz_program()
+    rng = np.random.default_rng(passes)
+    nx, nnz = s.nx, len(s.A_i)
+    for scale in (1.0, 1e-6, 3e5):       # the last two drive limit_scaling's branches
+        P = np.abs(rng.normal(size=nx)) * 10 * scale + 1e-3 * scale
+        A = rng.normal(size=nnz) * scale
+        A[rng.random(nnz) < 0.3] = 1.0
+        q = rng.normal(size=nx) * scale
+        lds = np.zeros(320)
+        lds[g.RZ_P:g.RZ_P + nx], lds[g.RZ_Q:g.RZ_Q + nx], lds[g.RZ_A:g.RZ_A + nnz] = P, q, A
+        ws, ctrl = np.zeros(4), np.zeros(4)
+        g.simulate(ins, ws, ctrl, passes, lds)
+        Pr, Ar, qr, cr = _ruiz_numpy(s, P, A, q, passes)
+        for got, ref in ((lds[g.RZ_P:g.RZ_P + nx], Pr), (lds[g.RZ_A:g.RZ_A + nnz], Ar), (lds[g.RZ_Q:g.RZ_Q + nx], qr)):
+            assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (passes, scale)
+        assert abs(lds[g.RZ_C] - cr) <= 1e-13 * cr
+
+
+def test_fp64_ruiz_stream_assembles_and_fits():
+    import os, re, subprocess, tempfile
+    from robobee3d_amd import asmgen64 as g
+    ins, s = g.ruiz_program()
+    for t in ins:
+        for x in t[1:]:
+            if isinstance(x, str):
+                for a, b in re.findall(r"v\[(\d+):(\d+)\]", x):
+                    assert int(b) < g.V_END
+                for a in re.findall(r"\bv(\d+)\b", x):
+                    assert int(a) < g.V_END
+                for a in re.findall(r"\ba(\d+)\b", x):
+                    assert int(a) < 256
+    mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("\n".join(g.fmt(t) for t in ins) + "\n")
+    try:
+        r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[:3000]
+    finally:
+        os.unlink(f.name)
