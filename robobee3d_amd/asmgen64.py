@@ -36,7 +36,7 @@ import os
 import struct
 
 from . import symbolic
-from .asmgen import (Emit, _row_ptr, _adv, FAC_Q, FAC_LOEQ, FAC_M, WS_XPREV, WS_DY, WS_ROWS,
+from .asmgen import (Emit, _row_ptr, _adv, FAC_Q, FAC_LOEQ, FAC_M, WS_DS, WS_ES, WS_ROWS,
                      S_WS, S_CTRL, S_STRIDE, S_ITERS, S_P, S_CNT, S_P2, S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -46,6 +46,9 @@ NSLOT, N_AT, N_TT = 7, 4, 4
 A_D, A_Z = 0, 168
 NNZL = 213
 LW_X, LW_Y, LW_END = 213, 258, 297
+# what phase C reads, staged in the (by then dead) L words by the last iteration and the epilogue: the scalings D, E of
+# phase A, z, x_prev and delta_y of the last iteration, the thrust-row bounds
+PC_DS, PC_ES, PC_Z, PC_XP, PC_DY, PC_LO3, PC_UP3 = 0, 45, 84, 123, 168, 207, 210
 LDS_BYTES_PER_LANE = 2560
 
 
@@ -280,8 +283,11 @@ def body(e, s, first, capture):
             op([("L", j)], lambda r, r_=r_, c=c: e("v_fma_f64", vp(WK(c)), "-" + vp(r[0]), vp(WK(r_)), vp(WK(c))))
     Fetch(e).run(ops)
     # ---- x <- alpha x~ + (1 - alpha) x   (auxil.c:188-201); x_prev of a capturing iteration -> workspace
-    if capture:
-        _row_ptr(e, S_P2, S_WS, WS_XPREV)
+    def lds_store(word, reg):
+        """one word of a capture -> LDS (the capturing iteration is the last one: the L words are dead)"""
+        base, off, half = lds_addr(word)
+        e("ds_write_b64", base, vp(reg), off + 8 * half)
+        return 1
     quads = _words(LW_X, LW_X + nx)
     for g in range(0, len(quads), NSLOT):
         grp = quads[g:g + NSLOT]
@@ -292,19 +298,21 @@ def body(e, s, first, capture):
             for w in ws:
                 j, r, t = w - LW_X, where[w], V_TT + 2 * ((w - LW_X) % N_TT)
                 if capture:
-                    e("global_store_dwordx2", "v0", vp(r), ptr)
-                    _adv(e, S_P2)
+                    nw += lds_store(PC_XP + j, r)
                 e("v_mul_f64", vp(t), sO, vp(r))
                 e("v_fma_f64", vp(t if capture else r), sA, vp(W(j)), vp(t))
             nw += _write_quad(e, qd, ws, {w: (V_TT + 2 * ((w - LW_X) % N_TT) if capture else where[w]) for w in ws})
-    if capture:
-        e("s_waitcnt", "vmcnt(0)")   # the stores have read the ring registers
-    preload_q(e, s)
-    # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
-    if capture:
-        _row_ptr(e, S_P2, S_WS, WS_DY)
     if first:
+        # l of the dynamics rows (the new z there) -> the W_x registers the x update has just freed, one round trip for
+        # all 36 rows; q follows after the row update
         _row_ptr(e, S_P, S_WS, FAC_LOEQ)
+        for i in range(neq):
+            e("global_load_dwordx2", vp(W(i)), "v0", sp(S_P))
+            _adv(e, S_P)
+        e("s_waitcnt", "vmcnt(0)")
+    else:
+        preload_q(e, s)
+    # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
     quads = _words(LW_Y, LW_Y + nc)
     for g in range(0, len(quads), NSLOT):
         grp = quads[g:g + NSLOT]
@@ -322,18 +330,14 @@ def body(e, s, first, capture):
                     e("v_add_f64", vp(t1), vp(nu), "-" + vp(r))
                     if capture:
                         e("v_mul_f64", vp(t2), sA, vp(t1))
-                        e("global_store_dwordx2", "v0", vp(t2), ptr)
-                        _adv(e, S_P2)
+                        nw += lds_store(PC_DY + i, t2)
                     e("v_fma_f64", vp(r), sA, vp(t1), vp(r))
                     newreg[w] = r
                     continue
-                if i < neq:     # first iteration, dynamics row: z_prev from its AGPR, l (= new z) from the workspace
-                    # (one exposed L2 round trip per row, once per step)
-                    zr, lr = V_AT + 4, V_AT + 6
+                if i < neq:     # first iteration, dynamics row: z_prev from its AGPR, l (= new z) from W_x[i]
+                    zr, lr = V_AT + 4, W(i)
                     e("v_accvgpr_read_b32", "v%d" % zr, "a%d" % (A_Z + 2 * i))
                     e("v_accvgpr_read_b32", "v%d" % (zr + 1), "a%d" % (A_Z + 2 * i + 1))
-                    e("global_load_dwordx2", vp(lr), "v0", sp(S_P))
-                    _adv(e, S_P)
                     rinv, rho = sRi, sRh
                 else:
                     k3 = i - neq
@@ -343,7 +347,6 @@ def body(e, s, first, capture):
                 e("v_mul_f64", vp(t2), sO, vp(zr))
                 e("v_fma_f64", vp(t1), sA, vp(t1), vp(t2))                     # t = alpha z~ + (1-alpha) z
                 if i < neq:
-                    e("s_waitcnt", "vmcnt(0)")
                     e("v_add_f64", vp(t2), vp(t1), "-" + vp(lr))               # z <- l
                     e("v_mul_f64", vp(t2), vp(t2), rho)
                 else:
@@ -353,20 +356,21 @@ def body(e, s, first, capture):
                     e("v_add_f64", vp(t2), vp(t1), "-" + vp(zr))
                     e("v_mul_f64", vp(t2), vp(t2), rho)                        # delta_y
                 if capture:
-                    e("global_store_dwordx2", "v0", vp(t2), ptr)
-                    _adv(e, S_P2)
+                    nw += lds_store(PC_DY + i, t2)
                 e("v_add_f64", vp(r), vp(r), vp(t2))
                 newreg[w] = r
             nw += _write_quad(e, qd, ws, newreg)
-    if capture:
-        e("s_waitcnt", "vmcnt(0)")
+    if first:
+        preload_q(e, s)
     preload_l(e, s, neq)
 
 
 def epilogue(e, s):
-    """x, y, z -> ctrl rows (warm start of the next step; phase C reads them from there). z of the dynamics rows is l."""
+    """x, y, z -> ctrl rows (warm start of the next step); everything phase C reads -> LDS words PC_* (z; the thrust-row
+    bounds; D and E of phase A, fetched here in ONE round trip -- hipcc fetches them one exposed load at a time)."""
     nx, nc = s.nx, s.nc
-    neq = 2 * s.N * symbolic.NY
+    N = s.N
+    neq = 2 * N * symbolic.NY
     e("s_waitcnt", "vmcnt(0)")      # the last preloads: W_z of the dynamics rows holds l
     e("s_mov_b64", sp(S_P), sp(S_CTRL))
     quads = _words(LW_X, LW_X + nx + nc)
@@ -378,11 +382,22 @@ def epilogue(e, s):
             for w in ws:
                 e("global_store_dwordx2", "v0", vp(where[w]), sp(S_P))
                 _adv(e, S_P)
-        e("s_waitcnt", "vmcnt(0)")
+    zreg = lambda i: V_W + 2 * (nx + i) if i < neq else V_C + 2 * (i - neq)
     for i in range(nc):
-        src = V_W + 2 * (nx + i) if i < neq else V_C + 2 * (i - neq)
-        e("global_store_dwordx2", "v0", vp(src), sp(S_P))
+        e("global_store_dwordx2", "v0", vp(zreg(i)), sp(S_P))
         _adv(e, S_P)
+    for qd, ws in _words(PC_Z, PC_Z + nc):
+        _write_quad(e, qd, ws, {w: zreg(w - PC_Z) for w in ws})
+    for qd, ws in _words(PC_LO3, PC_LO3 + 2 * N):      # lo3 up3 are adjacent register pairs (V_C + 2N ..)
+        _write_quad(e, qd, ws, {w: V_C + 2 * N + 2 * (w - PC_LO3) for w in ws})
+    # D (45) -> the W_x registers, E (39) -> the W_z registers (all dead now), then LDS
+    _row_ptr(e, S_P, S_WS, WS_DS)
+    for o in range(nx + nc):
+        e("global_load_dwordx2", vp(V_W + 2 * o), "v0", sp(S_P))
+        _adv(e, S_P)
+    e("s_waitcnt", "vmcnt(0)")
+    for qd, ws in _words(PC_DS, PC_DS + nx + nc):
+        _write_quad(e, qd, ws, {w: V_W + 2 * (w - PC_DS) for w in ws})
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
 
@@ -391,7 +406,10 @@ def program(N=3, perm=None):
     s = symbolic.analyse(N, perm)
     e = Emit()
     prologue(e, s)
-    body(e, s, first=True, capture=True)
+    # the captures overwrite L in LDS, so only the LAST iteration captures: a single iteration is its own variant
+    e("s_cmp_lt_i32", "s%d" % S_ITERS, 2)
+    e("s_cbranch_scc1", "4f")
+    body(e, s, first=True, capture=False)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_ITERS, 2)
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
     e("s_cbranch_scc1", "8f")
@@ -401,9 +419,10 @@ def program(N=3, perm=None):
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
     e("label", "8")
-    e("s_cmp_lt_i32", "s%d" % S_ITERS, 2)
-    e("s_cbranch_scc1", "6f")
     body(e, s, first=False, capture=True)
+    e("s_branch", "6f")
+    e("label", "4")
+    body(e, s, first=True, capture=True)
     e("label", "6")
     epilogue(e, s)
     return e.ins, s
@@ -434,6 +453,9 @@ def write(path=None, N=3, perm=None):
            "#pragma once",
            "namespace umpcasm64 {",
            "constexpr int LDS_BYTES_PER_LANE = %d, LW_X = %d, LW_Y = %d;" % (LDS_BYTES_PER_LANE, LW_X, LW_Y),
+           "// LDS words phase C reads after the loop: D, E of phase A, z, x_prev and delta_y of the last iteration, lo3, up3",
+           "constexpr int PC_DS = %d, PC_ES = %d, PC_Z = %d, PC_XP = %d, PC_DY = %d, PC_LO3 = %d, PC_UP3 = %d;"
+           % (PC_DS, PC_ES, PC_Z, PC_XP, PC_DY, PC_LO3, PC_UP3),
            "}  // namespace umpcasm64",
            "// inputs: v0 = 8*robot, v1 = lane LDS address (16*lane), s[4:5] = workspace, s[6:7] = ctrl, s10 = 8*B, s11 = maxIter >= 1",
            "#define UMPC_ADMM_ASM64(voff, ldsaddr, ws, ctrl, stride, iters) asm volatile( \\"]

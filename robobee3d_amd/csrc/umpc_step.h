@@ -530,8 +530,17 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   // reciprocals of the eight weights: D is recovered after Ruiz as sqrt(P_scaled / (P_raw c))
   const Weights<T> wti = {T(1) / wt.ws, T(1) / wt.wds, T(1) / wt.wpr, T(1) / wt.wpf, T(1) / wt.wvr, T(1) / wt.wvf,
                           T(1) / wt.wthrust, T(1) / wt.wmom};
+// -DUMPC_PHASE_TIMING (tools/build_variant.py, diagnostics only): 100 MHz timestamps at the phase boundaries; the
+// six intervals (assemble, Ruiz, D/E + factor, ADMM, residuals/extraction, plant) replace accdes in out rows 3..8
+#ifdef UMPC_PHASE_TIMING
+  long long tmark[7];
+#define UMPC_TMARK(k) tmark[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define UMPC_TMARK(k)
+#endif
   // =========================== phase A: assemble, equilibrate, factor ===========================
   UMPC_PHASE_FENCE();
+  UMPC_TMARK(0);
   {
     T p0[3], R0[9], dq0[6], ref[9];
 #pragma unroll
@@ -578,6 +587,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
         rho3[k] = T(UMPC_RHO); rinv3[k] = T(1) / T(UMPC_RHO);
       }
     }
+    UMPC_TMARK(1);
     // ---- Ruiz equilibration, scaling.c:44-156 ----
     // The accumulated D and E are not carried through the passes (84 live words and 84 multiplies per pass):
     // they are recovered afterwards from the equilibrated data, D_j = sqrt(P_jj / (P_raw_jj c)) and
@@ -634,6 +644,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     }
 #undef DT_
 #undef ET_
+    UMPC_TMARK(2);
     {
       const T cinv_ = T(1) / cscale;
 #pragma unroll
@@ -697,6 +708,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 
   // =========================== phase B: ADMM, osqp.c:354-370 ===========================
   UMPC_PHASE_FENCE();
+  UMPC_TMARK(3);
   if constexpr (ASM64) {
     const unsigned voff = bb * 8u, stride = (unsigned)a.B * 8u;
     const int iters = prm.maxIter;
@@ -755,20 +767,30 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 
   // =========================== phase C: residuals, status, extraction, plant ===========================
   UMPC_PHASE_FENCE();
+  UMPC_TMARK(4);
   // x, y, z are consumed where they lie: LDS words 0..122 after the assembly loop (fp32), the ctrl rows after
   // the C++ loop (fp64). No arrays: this phase must stay under 256 live VGPRs (the assembly block clobbers
   // every AGPR, so the compiler has nowhere cheap to spill).
 // (fp64 assembly loop: x and y are still in their LDS words, and also in the ctrl rows; z only in the rows)
 #define XV(j) (ASM32 ? LDSW(j) : ASM64 ? LDSF_W(umpcasm64::LW_X + (j)) : GLD(a.ctrl, j))
 #define YV(i) (ASM32 ? LDSW(NX + (i)) : ASM64 ? LDSF_W(umpcasm64::LW_Y + (i)) : GLD(a.ctrl, NX + (i)))
-#define ZV(i) (ASM32 ? LDSW(NX + NC + (i)) : GLD(a.ctrl, NX + NC + (i)))
+#define ZV(i) (ASM32 ? LDSW(NX + NC + (i)) : ASM64 ? LDSF_W(umpcasm64::PC_Z + (i)) : GLD(a.ctrl, NX + NC + (i)))
+// fp64 assembly loop: its epilogue staged everything else this phase reads in LDS as well (hipcc fetches the rows one
+// exposed global load at a time, ~2 us each for a lone wave): D, E, x_prev, delta_y, the thrust-row bounds
+#define PC_DS_(j) (ASM64 ? LDSF_W(umpcasm64::PC_DS + (j)) : GLD(a.ws, WS_DS + (j)))
+#define PC_ES_(i) (ASM64 ? LDSF_W(umpcasm64::PC_ES + (i)) : GLD(a.ws, WS_ES + (i)))
+#define PC_XP_(j) (*(ASM64 ? &LDSF_W(umpcasm64::PC_XP + (j)) : &GLD(a.ws, WS_XPREV + (j))))
+#define PC_DY_(i) (*(ASM64 ? &LDSF_W(umpcasm64::PC_DY + (i)) : &GLD(a.ws, WS_DY + (i))))
 #pragma unroll
-  for (int k = 0; k < N; ++k) { lo3[k] = GLD(a.ws, FAC_M + k); up3[k] = GLD(a.ws, FAC_M + N + k); }
+  for (int k = 0; k < N; ++k) {
+    lo3[k] = ASM64 ? LDSF_W(umpcasm64::PC_LO3 + k) : GLD(a.ws, FAC_M + k);
+    up3[k] = ASM64 ? LDSF_W(umpcasm64::PC_UP3 + k) : GLD(a.ws, FAC_M + N + k);
+  }
   if (prm.maxIter < 1) {  // no iteration ran: nothing was captured
 #pragma unroll
-    for (int j = 0; j < NX; ++j) GLD(a.ws, WS_XPREV + j) = XV(j);
+    for (int j = 0; j < NX; ++j) PC_XP_(j) = XV(j);
 #pragma unroll
-    for (int i = 0; i < NC; ++i) GLD(a.ws, WS_DY + i) = T(0);
+    for (int i = 0; i < NC; ++i) PC_DY_(i) = T(0);
   }
   T p0[3], R0[9], dq0[6];
 #pragma unroll
@@ -785,9 +807,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     const T cscale = GLD(a.ws, WS_C);
     const T cinv = T(1) / cscale;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) Ds[j] = GLD(a.ws, WS_DS + j);
+    for (int j = 0; j < NX; ++j) Ds[j] = PC_DS_(j);
 #pragma unroll
-    for (int i = 0; i < NC; ++i) Es[i] = GLD(a.ws, WS_ES + i);
+    for (int i = 0; i < NC; ++i) Es[i] = PC_ES_(i);
     // raw entries of A: the scaled matrix is re-derived entry by entry as (raw * E_i) * D_j wherever it is
     // needed (the factorisation consumed the equilibrated copy); nothing of size 111 is ever live here
     T dtT0, s0dt[3], Btaudt[6];
@@ -861,7 +883,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
       if (!prim_ok0) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-          const T dyi = GLD(a.ws, WS_DY + i);
+          const T dyi = PC_DY_(i);
           const T li = i < NEQ ? ZV(i) : lo3[i < NEQ ? 0 : i - NEQ];  // z == l == u on the dynamics rows
           const T ui = i < NEQ ? li : up3[i < NEQ ? 0 : i - NEQ];
           ndy = umpc_max(ndy, umpc_abs(dyi * Es[i]));
@@ -869,7 +891,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
         }
         if (ndy > eps_pinf0 && lhs < -eps_pinf0 * ndy) {  // the 10x test implies this one
           T Atdy[NX];
-#define IN_DY(i) GLD(a.ws, WS_DY + (i))
+#define IN_DY(i) PC_DY_(i)
 #define OUT_ATDY(j) Atdy[j]
           UMPC_GEN_AT_MUL_SCALED(prm.dt, dtT0, s0dt, Btaudt, IN_DY, OUT_ATDY);
           nrm = T(0);
@@ -881,7 +903,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
         T dxv[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-          dxv[j] = XV(j) - GLD(a.ws, WS_XPREV + j);
+          dxv[j] = XV(j) - PC_XP_(j);
           ndx = umpc_max(ndx, umpc_abs(Ds[j] * dxv[j]));
           qdx += GLD(a.ws, FAC_Q + j) * dxv[j];
         }
@@ -989,6 +1011,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   if (a.status) a.status[bb] = status;
   if (a.info) { GLD(a.info, 0) = pri_res; GLD(a.info, 1) = dua_res; }
 
+  UMPC_TMARK(5);
   // ---- plant: template/uprightmpc2.py:148-151 ----
   if (prm.nsub > 0) {
     T Ib[3];
@@ -1014,6 +1037,12 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     for (int i = 0; i < 6; ++i) GLD(a.state, 12 + i) = dq0[i];
     if (a.stats) { GLD(a.stats, 0) = s_err; GLD(a.stats, 1) = s_eff; }
   }
+#ifdef UMPC_PHASE_TIMING
+  UMPC_TMARK(6);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) GLD(a.out, 3 + i) = T(tmark[i + 1] - tmark[i]);
+#endif
+#undef UMPC_TMARK
 #undef GLD
 #undef UMPC_PHASE_FENCE
 #undef UMPC_SCHED_FENCE
@@ -1033,6 +1062,10 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #undef XV
 #undef YV
 #undef ZV
+#undef PC_DS_
+#undef PC_ES_
+#undef PC_XP_
+#undef PC_DY_
 #undef PXRAW
 #undef PXRAW_OF
 }

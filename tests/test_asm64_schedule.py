@@ -44,17 +44,25 @@ def _case(oracle_built, g, ins, s, seq, k, iters):
     ws[asmgen.FAC_M + 6:asmgen.FAC_M + 9] = o.get("rho_vec")[36:]
     ws[asmgen.FAC_M + 9:asmgen.FAC_M + 12] = o.get("rho_inv_vec")[36:]
     ctrl[:45], ctrl[45:84], ctrl[84:123] = pre
+    ws[asmgen.WS_DS:asmgen.WS_DS + 45] = 100.0 + np.arange(45)      # phase A's D, E: the epilogue stages them in LDS
+    ws[asmgen.WS_ES:asmgen.WS_ES + 39] = 200.0 + np.arange(39)
     x_before_last = fresh(iters - 1).get("x") if iters > 1 else pre[0]
     g.simulate(ins, ws, ctrl, iters, lds)
     o2 = fresh(iters)
     for name, sl in (("x", slice(0, 45)), ("y", slice(45, 84)), ("z", slice(84, 123))):
         ref = o2.get(name)
         assert np.abs(ctrl[sl] - ref).max() <= 1e-12 * max(1e-6, np.abs(ref).max()), (name, k, iters)
-    xp = ws[asmgen.WS_XPREV:asmgen.WS_XPREV + 45]
+    # what phase C reads from LDS: x, y where the loop keeps them, z, D, E, the thrust-row bounds, the captures
+    assert np.array_equal(lds[g.LW_X:g.LW_X + 45], ctrl[:45]) and np.array_equal(lds[g.LW_Y:g.LW_Y + 39], ctrl[45:84])
+    assert np.array_equal(lds[g.PC_Z:g.PC_Z + 39], ctrl[84:123])
+    assert np.array_equal(lds[g.PC_DS:g.PC_DS + 45], 100.0 + np.arange(45))
+    assert np.array_equal(lds[g.PC_ES:g.PC_ES + 39], 200.0 + np.arange(39))
+    assert np.array_equal(lds[g.PC_LO3:g.PC_LO3 + 3], l[36:]) and np.array_equal(lds[g.PC_UP3:g.PC_UP3 + 3], u[36:])
+    xp = lds[g.PC_XP:g.PC_XP + 45]
     assert np.abs(xp - x_before_last).max() <= 1e-12 * np.abs(x_before_last).max()
     # delta_y of the last iteration = y_new - y_prev
     yprev = fresh(iters - 1).get("y") if iters > 1 else pre[1]
-    dy = ws[asmgen.WS_DY:asmgen.WS_DY + 39]
+    dy = lds[g.PC_DY:g.PC_DY + 39]
     ref = o2.get("y") - yprev
     assert np.abs(dy - ref).max() <= 1e-9 * max(1e-6, np.abs(o2.get("y")).max())
 
