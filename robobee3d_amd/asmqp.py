@@ -113,9 +113,12 @@ class Plan:
         self.R_X = self.R_DI + nk
         self.R_Y = self.R_X + n
         self.R_Z = self.R_Y + m
-        self.R_XP = self.R_Z + len(gen)        # x_prev and delta_y of the last (capturing) iteration
-        self.R_DY = self.R_XP + n
-        self.R_END = self.R_DY + m
+        self.R_END = self.R_Z + len(gen)
+        # x_prev and delta_y of the last (capturing) iteration go to LDS words of L that are dead by then: delta_y over
+        # the solve block (dead after the backward solve), x_prev over the leaf block (dead after the row updates)
+        self.n_leaf = sum(r["leaf"] for r in self.rows)
+        self.LW_DY, self.LW_XP = self.n_leaf, 0
+        assert self.LW_DY + m <= self.LW_X and self.LW_XP + n <= self.n_leaf + m
 
 
 class Sched:
@@ -326,15 +329,11 @@ def body(e, p, capture=False):
     sptr = "s[%d:%d]" % (S_P, S_P + 1)
 
     def store_dy(i, compute, reg):
-        """capturing iteration: delta_y of row i (rows are visited in order) -> row R_DY + i"""
+        """capturing iteration: delta_y of row i -> LDS word LW_DY + i (the solve block of L is dead by now)"""
         if not capture:
             return
         compute()
-        if i == 0:
-            _row_ptr(e, S_P, p.R_DY)
-        else:
-            _adv(e, S_P)
-        e("global_store_dword", "v0", v(reg), sptr, 0)
+        sc.lds_write(p.LW_DY + i, reg)
     # ---- P6: row updates (auxil.c:203-228); leaf rows re-form their multiplier from the final unknown of their variable
     for r in p.rows:
         i, k = r["i"], r["k"]
@@ -397,11 +396,7 @@ def body(e, p, capture=False):
         def f(g, k=k, j=j):
             t = T(6 + j % 2)
             if capture:
-                if j == 0:
-                    _row_ptr(e, S_P, p.R_XP)
-                else:
-                    _adv(e, S_P)
-                e("global_store_dword", "v0", v(g[0]), sptr, 0)
+                sc.lds_write(p.LW_XP + j, g[0])      # x_prev (every L word is dead by now)
             e("v_mul_f32", v(t), sO, v(g[0]))
             e("v_fma_f32", v(t), sA, W(k), v(t))
             sc.lds_write(p.LW_X + j, t)
@@ -463,25 +458,8 @@ def prologue(e, p):
 
 
 def epilogue(e, p):
-    """x, y, z (inequality rows) -> rows R_X, R_Y, R_Z"""
-    e("s_waitcnt", "vmcnt(0)")
-    words = [(p.R_X + q, p.LW_X + q) for q in range(p.n)] + [(p.R_Y + q, p.LW_Y + q) for q in range(p.m)] + \
-            [(p.R_Z + q, p.LW_Z + q) for q in range(p.LW_END - p.LW_Z)]
-    quads = sorted(set(w >> 2 for _, w in words))
-    rowof = {w: r for r, w in words}
-    for g in range(0, len(quads), NRING):
-        grp = quads[g:g + NRING]
-        for q, qd in enumerate(grp):
-            base, off = lds_addr(4 * qd)
-            e("ds_read_b128", "v[%d:%d]" % (p.V_RING + 4 * q, p.V_RING + 4 * q + 3), base, off)
-        e("s_waitcnt", "lgkmcnt(0)")
-        for q, qd in enumerate(grp):
-            for h in range(4):
-                w = 4 * qd + h
-                if w in rowof:
-                    _row_ptr(e, S_P, rowof[w])
-                    e("global_store_dword", "v0", "v%d" % (p.V_RING + 4 * q + h), "s[%d:%d]" % (S_P, S_P + 1), 0)
-        e("s_waitcnt", "vmcnt(0)")
+    """x, y, z of the inequality rows (words LW_X.., LW_Y.., LW_Z..), x_prev (LW_XP..) and delta_y (LW_DY..) stay in LDS: the
+    C++ side reads them there (hipcc fetches rows from global memory one exposed load at a time)"""
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
 
@@ -523,7 +501,7 @@ def fmt(t):
 # ---------------------------------------------------------------------------
 def simulate(ins, W, S, iters, consts):
     """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
-    Runs the program; W rows R_X.. are updated in place. Returns the executed instruction count."""
+    Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there)."""
     f32 = np.float32
     V = np.zeros(256, np.uint32)
     A = np.zeros(256, np.uint32)
@@ -693,7 +671,7 @@ def simulate(ins, W, S, iters, consts):
         else:
             raise ValueError("unknown instruction %r" % (t,))
         pc += 1
-    return nexec
+    return lds
 
 
 def reference_iterations(p, d, iters, alpha, sigma):

@@ -52,7 +52,7 @@ def emit_structure(name, s, asm=None):
     E = o.append
     E("template <typename T>")
     if asm:
-        E("__device__ __forceinline__ void bqp_fixed_%s_asm(const QPArgs<T> &a, const int b, const int wave, const unsigned ldsaddr) {" % name)
+        E("__device__ __forceinline__ void bqp_fixed_%s_asm(const QPArgs<T> &a, const int b, const int wave, const unsigned ldsaddr, const float *ldsf) {" % name)
     else:
         E("__device__ __forceinline__ void bqp_fixed_%s(const QPArgs<T> &a, const int b) {" % name)
     E("  const size_t B = (size_t)a.B;")
@@ -74,6 +74,11 @@ def emit_structure(name, s, asm=None):
     for i in range(m):
         E("  { const T e = IN(a.Eprev, %d); qp_classify(IN(a.l, %d) * e, IN(a.u, %d) * e, a.rho, rho_eq, rho[%d], rinv[%d]); "
           "Ev[%d] = T(1.0); y[%d] = IN(a.y, %d); z[%d] = IN(a.z, %d); }" % (i, i, i, i, i, i, i, i, i, i))
+    TIMING = asm is not None and os.environ.get("UMPC_QP_TIMING") == "1"   # diagnostic builds: phase intervals -> info rows
+    mark = (lambda k: E("  tmark[%d] = __builtin_amdgcn_s_memrealtime();" % k)) if TIMING else (lambda k: None)
+    if TIMING:
+        E("  long long tmark[8];")
+    mark(0)
     # ---- Ruiz
     E("  T c = T(1.0);")
     E("  for (int pass = 0; pass < a.scaling; ++pass) {")
@@ -110,6 +115,7 @@ def emit_structure(name, s, asm=None):
     E("  const T cinv = T(1.0) / c;")
     for i in range(m):
         E("  ls[%d] = IN(a.l, %d) * Ev[%d]; us[%d] = IN(a.u, %d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, i, i, i, i))
+    mark(1)
     # ---- factor
     for k in range(nk):
         E("  yv[%d] = T(0.0);" % k)
@@ -131,6 +137,7 @@ def emit_structure(name, s, asm=None):
             E("      const T lv = yc * DI[%d]; Lx[%d] = lv; dk -= yc * lv; yv[%d] = T(0.0); }" % (cidx, new, cidx))
         E("    if (dk == T(0.0)) fail = 1;")
         E("    DI[%d] = T(1.0) / dk; }" % k)
+    mark(2)
     # ---- ADMM
     for j in range(n):
         E("  xp[%d] = x[%d];" % (j, j))
@@ -175,6 +182,7 @@ def emit_structure(name, s, asm=None):
         E("  const int mid = a.max_iter - 2;")
         E("  const bool use_asm = mid >= 1 && __all(eqok);")
         E("  if (a.max_iter >= 1) iterate();")
+        mark(3)
         E("  if (use_asm) {")
         E("    // hand-off: negated L in the loop's storage order, 1/D, x, y, z of the inequality rows -> workspace rows;")
         E("    // one iteration's read-only words -> this wave's stream block, in consumption order (asmqp.Plan.stream)")
@@ -193,6 +201,7 @@ def emit_structure(name, s, asm=None):
         src = {"rinv": "rinv[%d]", "l": "ls[%d]", "u": "us[%d]", "rho": "rho[%d]", "q": "qs[%d]"}
         for q, (what, i) in enumerate(P.stream + P.extra):
             E("    sblk[%d + threadIdx.x] = %s;" % (q * 64, src[what] % i))
+        mark(4)
         E("    {")
         E("      const unsigned voff = (unsigned)b * 4u, lane4 = (unsigned)threadIdx.x * 4u, stride = (unsigned)a.B * 4u;")
         E("      // float constants come straight from the kernel arguments (SGPRs): a value computed with float arithmetic lives")
@@ -207,24 +216,29 @@ def emit_structure(name, s, asm=None):
         E("      const unsigned s_stride = __builtin_amdgcn_readfirstlane(stride), s_mid = __builtin_amdgcn_readfirstlane((unsigned)mid);")
         E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq);" % name.upper())
         E("    }")
+        mark(5)
+        E("    // the loop left x, y, z of the inequality rows, x_prev and delta_y in LDS (float4-interleaved words)")
+        E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
         for j in range(n):
-            E("    x[%d] = IN(a.W, %d);" % (j, P.R_X + j))
+            E("    x[%d] = LDSQ(%d);" % (j, P.LW_X + j))
         for i in range(m):
-            E("    y[%d] = IN(a.W, %d);" % (i, P.R_Y + i))
+            E("    y[%d] = LDSQ(%d);" % (i, P.LW_Y + i))
         for r in P.rows:
             if r["eq"]:
                 E("    z[%d] = ls[%d];" % (r["i"], r["i"]))
             else:
-                E("    z[%d] = IN(a.W, %d);" % (r["i"], P.R_Z + P.zpos[r["i"]]))
+                E("    z[%d] = LDSQ(%d);" % (r["i"], P.LW_Z + P.zpos[r["i"]]))
         for j in range(n):
-            E("    xp[%d] = IN(a.W, %d);" % (j, P.R_XP + j))
+            E("    xp[%d] = LDSQ(%d);" % (j, P.LW_XP + j))
         for i in range(m):
-            E("    dy[%d] = IN(a.W, %d);" % (i, P.R_DY + i))
+            E("    dy[%d] = LDSQ(%d);" % (i, P.LW_DY + i))
+        E("#undef LDSQ")
         E("  } else {")
         E("#pragma nounroll")
         E("    for (int it = 1; it < a.max_iter - 1; ++it) iterate();")
         E("    if (a.max_iter >= 2) iterate();")
         E("  }")
+    mark(6)
     # ---- residuals
     E("  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);")
     for i in range(m):
@@ -294,6 +308,10 @@ def emit_structure(name, s, asm=None):
           "IN(a.z, %d) = bad ? T(0.0) : z[%d];" % (i, i, i, i, i, i, i))
     E("  if (a.status) a.status[b] = status;")
     E("  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(a.max_iter); IN(a.info, 5) = T(0); }")
+    if TIMING:
+        E("  tmark[7] = __builtin_amdgcn_s_memrealtime();")
+        E("  if (a.info) { IN(a.info, 0) = T(tmark[1] - tmark[0]); IN(a.info, 1) = T(tmark[2] - tmark[1]); IN(a.info, 2) = T(tmark[3] - tmark[2]); "
+          "IN(a.info, 3) = T(tmark[4] - tmark[3]); IN(a.info, 4) = T(tmark[5] - tmark[4]); IN(a.info, 5) = T(tmark[7] - tmark[5]); }")
     E("#undef IN")
     E("}")
     if asm:
@@ -301,7 +319,7 @@ def emit_structure(name, s, asm=None):
         E("  __shared__ float4 lds[160 * 64];   // the whole CU: 640 words per lane (asmqp.py)")
         E("  const int b = blockIdx.x * 64 + threadIdx.x;")
         E("  if (b >= a.B) return;")
-        E("  bqp_fixed_%s_asm<float>(a, b, (int)blockIdx.x, (unsigned)(size_t)(&lds[threadIdx.x]));" % name)
+        E("  bqp_fixed_%s_asm<float>(a, b, (int)blockIdx.x, (unsigned)(size_t)(&lds[threadIdx.x]), reinterpret_cast<const float *>(lds) + 4 * threadIdx.x);" % name)
         E("}")
         return "\n".join(o) + "\n"
     E("template <typename T>")

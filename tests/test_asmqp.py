@@ -46,8 +46,9 @@ def _run(asmqp, ins, p, d, iters, eq):
     S = np.zeros(p.n_stream + len(p.extra), np.float32)
     for q, (what, i) in enumerate(p.stream + p.extra):
         S[q] = {"rinv": d["rinv"], "l": d["l"], "u": d["u"], "rho": d["rho"], "q": d["q"]}[what][i]
-    asmqp.simulate(ins, W, S, iters, (1.6, 1e-6, float(np.float32(1.0 / 100.0))))
-    return W[p.R_X:p.R_X + n], W[p.R_Y:p.R_Y + m], W[p.R_Z:p.R_Z + len(gen)], gen, W[p.R_XP:p.R_XP + n], W[p.R_DY:p.R_DY + m]
+    lds = asmqp.simulate(ins, W, S, iters, (1.6, 1e-6, float(np.float32(1.0 / 100.0))))
+    return (lds[p.LW_X:p.LW_X + n], lds[p.LW_Y:p.LW_Y + m], lds[p.LW_Z:p.LW_Z + len(gen)], gen,
+            lds[p.LW_XP:p.LW_XP + n], lds[p.LW_DY:p.LW_DY + m])
 
 
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])   # (the random system is not a contraction: more iterations overflow fp32)
