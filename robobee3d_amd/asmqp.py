@@ -486,7 +486,7 @@ def fmt(t):
     m = t[0]
     if m == "label":
         return "%s:" % t[1]
-    a = [("0x%x" % x if isinstance(x, int) and m in ("s_mov_b32", "v_add_u32", "v_and_b32") else str(x)) for x in t[1:]]
+    a = [("0x%x" % x if isinstance(x, int) and m in ("s_mov_b32", "v_add_u32", "v_and_b32", "v_mov_b32") else str(x)) for x in t[1:]]
     if m.startswith("ds_"):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
     if m.startswith("global_"):
@@ -499,7 +499,7 @@ def fmt(t):
 # ---------------------------------------------------------------------------
 # CPU interpreter (one lane) and a numpy statement of the same iteration
 # ---------------------------------------------------------------------------
-def simulate(ins, W, S, iters, consts):
+def simulate(ins, W, S, iters, consts, regions=None):
     """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
     Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there)."""
     f32 = np.float32
@@ -516,6 +516,11 @@ def simulate(ins, W, S, iters, consts):
     SG[S_W], SG[S_W + 1] = 1 << 20, 0
     SG[S_S], SG[S_S + 1] = 1 << 30, 0
     SG[S_STRIDE], SG[S_ITERS] = STRIDE, iters
+    # regions (the Ruiz block's inputs): [(SGPR pair, array)], row-major with the simulated stride, 1 << 32 apart
+    regmap = {}
+    for q, (sreg, arr) in enumerate(regions or []):
+        SG[sreg], SG[sreg + 1] = 0, q + 1
+        regmap[q + 1] = arr
     alpha, sigma, rinv_eq = consts
     for reg, val in ((S_ALPHA, f32(alpha)), (S_OMA, f32(f32(1.0) - f32(alpha))), (S_SIGMA, f32(sigma)), (S_RINVEQ, f32(rinv_eq))):
         SG[reg] = f32bits(float(val))
@@ -532,10 +537,15 @@ def simulate(ins, W, S, iters, consts):
         return np.frombuffer(struct.pack("<I", int(b) & 0xFFFFFFFF), f32)[0]
 
     def fval(x):
+        if isinstance(x, float):
+            return f32(x)                       # inline constant
         neg = x.startswith("-")
         if neg:
             x = x[1:]
-        val = bits2f(V[int(x[1:])]) if x[0] == "v" else bits2f(SG[int(x[1:])])
+        if x.startswith("|"):
+            val = abs(fval(x[1:-1]))
+        else:
+            val = bits2f(V[int(x[1:])]) if x[0] == "v" else bits2f(SG[int(x[1:])])
         return -val if neg else val
 
     def setf(x, val):
@@ -544,6 +554,8 @@ def simulate(ins, W, S, iters, consts):
     def gaddr(t):
         """(array, index) of a global access v_off, s[base], imm"""
         addr = sval(t[3]) + t[4]
+        if addr >> 32:
+            return regmap[addr >> 32], (addr & 0xFFFFFFFF) // STRIDE
         if addr >= (1 << 30):
             return S, (addr - (1 << 30)) // 256
         return W, (addr - (1 << 20)) // STRIDE
@@ -559,7 +571,7 @@ def simulate(ins, W, S, iters, consts):
     def regs_of(x):
         if not isinstance(x, str):
             return set()
-        x = x.lstrip("-")
+        x = x.lstrip("-").strip("|")
         if x.startswith("v["):
             lo, hi = x[2:-1].split(":")
             return {("v", r) for r in range(int(lo), int(hi) + 1)}
@@ -593,8 +605,21 @@ def simulate(ins, W, S, iters, consts):
                 pend["vmcnt"].append(regs_of(t[1]))
             elif m == "global_store_dword":
                 pend["vmcnt"].append(set())
-        if m in ("label", "s_waitcnt"):
+        if m in ("label", "s_waitcnt", "s_nop"):
             pass
+        elif m == "v_mov_b32":
+            V[int(t[1][1:])] = (t[2] if isinstance(t[2], int) else f32bits(t[2]) if isinstance(t[2], float) else V[int(t[2][1:])])
+        elif m == "v_cmp_nlt_f32":
+            SG["vcc"] = int(not (fval(t[2]) < fval(t[3])))
+        elif m == "v_cndmask_b32":
+            src0 = f32bits(t[2]) if isinstance(t[2], float) else int(V[int(t[2][1:])])
+            V[int(t[1][1:])] = int(V[int(t[3][1:])]) if SG["vcc"] else src0
+        elif m == "v_rsq_f32":
+            setf(t[1], 1.0 / np.sqrt(np.float64(fval(t[2]))))
+        elif m == "v_rcp_f32":
+            setf(t[1], 1.0 / np.float64(fval(t[2])))
+        elif m == "v_accvgpr_write_b32":
+            A[int(t[1][1:])] = V[int(t[2][1:])]
         elif m == "s_mov_b32":
             SG[int(t[1][1:])] = t[2] if isinstance(t[2], int) else sval(t[2])
         elif m == "s_mov_b64":
@@ -702,3 +727,221 @@ def reference_iterations(p, d, iters, alpha, sigma):
         y = y + d["rho"] * (tt - zn)
         x, z = xn, zn
     return x, y, z
+
+
+# ---------------------------------------------------------------------------
+# The Ruiz passes of a build-time-known structure (scaling.c:44-156) as one assembly block, fp32
+# ---------------------------------------------------------------------------
+# hipcc's version of this phase for p5f -- fetching Av / Pv / q one exposed global load at a time, then ten passes over
+# arrays that live in scratch -- is 0.74 of the 2.9 ms tick (tools/p5f_timing.py). Here the block fetches its own inputs in
+# batches and nothing leaves the chip for the ten passes:
+#
+#   v4..v(3+m)    Et: the row norms accumulate here while A streams by in column order, then become the row scalings
+#   AGPRs         Dt (n), P (nnzP), q (n)
+#   LDS words     A (nnzA, read twice and written once per pass through the ring), then the accumulated D (n) and E (m),
+#                 c, and on exit P and q: RZ_* below; the C++ side picks everything up from there
+#
+# Arithmetic = the pass of codegen_qp.emit_structure statement by statement, except that 1/sqrt is v_rsq_f32 + one Newton
+# step and the two divisions v_rcp_f32 + Newton (+ a correction step for csum / n): each within an ulp of the IEEE results.
+RZ_MIN, RZ_MAX = 1e-4, 1e4
+
+
+class RuizPlan:
+    def __init__(self, s):
+        t = s.tables
+        self.s, self.n, self.m, self.nnzA, self.nnzP = s, s.n, s.m, s.nnzA, s.nnzP
+        self.A_p, self.A_i, self.pidx = list(t["A_p"]), list(t["A_i"]), list(t["pidx"])
+        self.V_ET = 4
+        self.V_RING = self.V_ET + self.m
+        self.V_LAND = self.V_RING + 4 * NRING          # (no stream in this block)
+        self.V_AT = self.V_LAND
+        self.V_TT = self.V_AT + N_AT
+        self.NT = 14
+        assert self.V_TT + self.NT <= V_END
+        self.n_land = 0
+        self.A_DT, self.A_P = 0, self.n
+        self.A_Q = self.A_P + self.nnzP
+        assert self.A_Q + self.n <= 256
+        self.LW_A = 0
+        self.LW_D = self.nnzA
+        self.LW_EV = self.LW_D + self.n
+        self.LW_C = self.LW_EV + self.m
+        self.LW_P = self.LW_C + 1
+        self.LW_Q = self.LW_P + self.nnzP
+        self.LW_END = self.LW_Q + self.n
+        assert self.LW_END <= 640 and self.nnzA <= 2 * self.m
+
+
+S_AV, S_PV, S_QV = 4, 6, 8          # s[4:5] Av rows, s[6:7] Pv rows, s[8:9] q rows (the block's inputs, [k][B] floats)
+S_RMIN, S_RMAX = 20, 21            # 1e-4, 1e4 (float bits, set by the block)
+
+
+def ruiz_program(s):
+    """s11 = number of passes (>= 1). Inputs as above, v0 = 4*robot, v1 = lane LDS address, s10 = 4*B."""
+    p = RuizPlan(s)
+    n, m = p.n, p.m
+    e = Emit()
+    v = lambda r: "v%d" % r
+    T = lambda q: p.V_TT + q
+    ET = lambda i: v(p.V_ET + i)
+    sMIN, sMAX = "s%d" % S_RMIN, "s%d" % S_RMAX
+    ab = lambda x: "|" + x + "|"
+
+    def rowptr(base, row):
+        e("s_mul_i32", "s%d" % S_P, "s%d" % S_STRIDE, row)
+        e("s_mul_hi_u32", "s%d" % (S_P + 1), "s%d" % S_STRIDE, row)
+        e("s_add_u32", "s%d" % S_P, "s%d" % S_P, "s%d" % base)
+        e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_P + 1), "s%d" % (base + 1))
+
+    def limit(t, t2):
+        """t <- limit_scaling(t) (umpc_bqp_common.h): t < 1e-4 ? 1 : min(t, 1e4)"""
+        e("v_cmp_nlt_f32", "vcc", v(t), sMIN)
+        e("v_min_f32", v(t2), sMAX, v(t))
+        e("v_cndmask_b32", v(t), 1.0, v(t2), "vcc")
+
+    def rsqrt(y, t, a_):
+        e("v_rsq_f32", v(y), v(t))
+        e("s_nop", 0)
+        e("v_mul_f32", v(a_), v(t), v(y))
+        e("v_fma_f32", v(a_), "-" + v(a_), v(y), 1.0)
+        e("v_mul_f32", v(t), 0.5, v(y))
+        e("v_fma_f32", v(y), v(t), v(a_), v(y))
+
+    def recip(y, t, a_):
+        e("v_rcp_f32", v(y), v(t))
+        e("s_nop", 0)
+        e("v_fma_f32", v(a_), "-" + v(t), v(y), 1.0)
+        e("v_fma_f32", v(y), v(y), v(a_), v(y))
+
+    # ---- prologue: A rows -> LDS through the Et registers (landing zone), P and q -> AGPRs, D = E = 1 in LDS, c = 1
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    e("s_mov_b32", sMIN, f32bits(RZ_MIN))
+    e("s_mov_b32", sMAX, f32bits(RZ_MAX))
+    rowptr(S_PV, 0)
+    for k in range(p.nnzP):
+        e("global_load_dword", "a%d" % (p.A_P + k), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+        _adv(e, S_P)
+    rowptr(S_QV, 0)
+    for j in range(n):
+        e("global_load_dword", "a%d" % (p.A_Q + j), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+        _adv(e, S_P)
+    rowptr(S_AV, 0)
+    for g in range(0, p.nnzA, m):
+        cnt = min(m, p.nnzA - g)
+        for q in range(cnt):
+            e("global_load_dword", v(p.V_ET + q), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+            _adv(e, S_P)
+        e("s_waitcnt", "vmcnt(0)")
+        for q in range(cnt):
+            base, off = lds_addr(p.LW_A + g + q)
+            e("ds_write_b32", base, v(p.V_ET + q), off)
+    e("v_mov_b32", v(T(13)), 1.0)                                  # c
+    for w in range(p.LW_D, p.LW_C):
+        base, off = lds_addr(w)
+        e("ds_write_b32", base, v(T(13)), off)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
+    e("label", "7")
+    sc = Sched(e, p, 0)
+    ops = []
+
+    def op(srcs, fn):
+        ops.append(dict(srcs=srcs, emit=fn))
+    # ---- norms: columns in order; the row norms accumulate in the Et registers
+    touched = set()
+    for j in range(n):
+        cols = list(range(p.A_p[j], p.A_p[j + 1]))
+        if p.pidx[j] >= 0:
+            op([("A", p.A_P + p.pidx[j])], lambda g: e("v_max_f32", v(T(0)), ab(v(g[0])), ab(v(g[0]))))
+        else:
+            op([], lambda g: e("v_mov_b32", v(T(0)), 0))
+        for q in cols:
+            i = p.A_i[q]
+
+            def f(g, i=i, first=i not in touched):
+                e("v_max_f32", v(T(0)), v(T(0)), ab(v(g[0])))
+                e("v_max_f32", ET(i), ab(v(g[0])) if first else ET(i), ab(v(g[0])))
+            op([("L", p.LW_A + q)], f)
+            touched.add(i)
+
+        def fin(g, j=j):
+            limit(T(0), T(1))
+            rsqrt(T(1), T(0), T(2))
+            e("v_accvgpr_write_b32", "a%d" % (p.A_DT + j), v(T(1)))
+        op([], fin)
+    assert len(touched) == m
+    for i in range(m):
+        def fe(g, i=i):
+            limit(p.V_ET + i, T(1))
+            rsqrt(T(1), p.V_ET + i, T(2))
+            e("v_mov_b32", ET(i), v(T(1)))
+        op([], fe)
+    # ---- apply; csum in T(4), qn in T(5), dt of the column in T(7)
+    op([], lambda g: (e("v_mov_b32", v(T(4)), 0), e("v_mov_b32", v(T(5)), 0)))
+    for j in range(n):
+        op([("A", p.A_DT + j)], lambda g: e("v_mov_b32", v(T(7)), v(g[0])))
+        if p.pidx[j] >= 0:
+            def fp(g, k=p.pidx[j]):
+                e("v_mul_f32", v(T(6)), v(g[0]), v(T(7)))
+                e("v_mul_f32", v(T(6)), v(T(6)), v(T(7)))
+                e("v_accvgpr_write_b32", "a%d" % (p.A_P + k), v(T(6)))
+                e("v_add_f32", v(T(4)), v(T(4)), ab(v(T(6))))
+            op([("A", p.A_P + p.pidx[j])], fp)
+        for q in range(p.A_p[j], p.A_p[j + 1]):
+            def fa(g, q=q, i=p.A_i[q]):
+                t = T(8 + q % 4)
+                e("v_mul_f32", v(t), v(g[0]), ET(i))
+                e("v_mul_f32", v(t), v(t), v(T(7)))
+                sc.lds_write(p.LW_A + q, t)
+            op([("L", p.LW_A + q)], fa)
+
+        def fq(g, j=j):
+            e("v_mul_f32", v(T(6)), v(g[0]), v(T(7)))
+            e("v_accvgpr_write_b32", "a%d" % (p.A_Q + j), v(T(6)))
+            e("v_max_f32", v(T(5)), ab(v(T(6))), v(T(5)))
+            e("v_mul_f32", v(T(12)), v(T(7)), v(g[1]))
+            sc.lds_write(p.LW_D + j, T(12))
+        op([("A", p.A_Q + j), ("L", p.LW_D + j)], fq)
+    for i in range(m):
+        def fv(g, i=i):
+            t = T(8 + i % 4)
+            e("v_mul_f32", v(t), ET(i), v(g[0]))
+            sc.lds_write(p.LW_EV + i, t)
+        op([("L", p.LW_EV + i)], fv)
+
+    # ---- cost scaling: ct = 1 / limit(max(csum / n, limit(qn)))
+    def cost(g):
+        e("v_mov_b32", v(T(0)), f32bits(float(n)))
+        recip(T(1), T(0), T(2))
+        e("v_mul_f32", v(T(2)), v(T(4)), v(T(1)))
+        e("v_fma_f32", v(T(3)), "-" + v(T(0)), v(T(2)), v(T(4)))
+        e("v_fma_f32", v(T(4)), v(T(3)), v(T(1)), v(T(2)))           # csum / n
+        limit(T(5), T(0))
+        e("v_max_f32", v(T(4)), v(T(4)), v(T(5)))
+        limit(T(4), T(0))
+        recip(T(5), T(4), T(0))                                        # ct
+        e("v_mul_f32", v(T(13)), v(T(13)), v(T(5)))
+    op([], cost)
+    for k in range(p.nnzP + n):
+        def fs(g, k=k):
+            t = T(8 + k % 4)
+            e("v_mul_f32", v(t), v(g[0]), v(T(5)))
+            e("v_accvgpr_write_b32", "a%d" % (p.A_P + k), v(t))        # (q follows P in the AGPRs)
+        op([("A", p.A_P + k)], fs)
+    sc.run(ops)
+    e("s_waitcnt", "lgkmcnt(0)")
+    e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+    e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
+    e("s_cbranch_scc1", "7b")
+    # ---- epilogue: c, P, q -> LDS
+    base, off = lds_addr(p.LW_C)
+    e("ds_write_b32", base, v(T(13)), off)
+    for k in range(p.nnzP + n):
+        t = T(k % 8)
+        e("v_accvgpr_read_b32", v(t), "a%d" % (p.A_P + k))
+        base, off = lds_addr(p.LW_P + k)
+        e("ds_write_b32", base, v(t), off)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    return e.ins, p

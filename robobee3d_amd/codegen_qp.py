@@ -64,12 +64,13 @@ def emit_structure(name, s, asm=None):
       (s.nnzA, n, n, m, n, m, m, m, m, m))
     E("  T Lx[%d], DI[%d], yv[%d], w[%d], x[%d], y[%d], z[%d], xp[%d], dy[%d], t3[%d], t1[%d];" %
       (s.nnzL, nk, nk, nk, n, m, m, n, m, m, n))
-    for k in range(s.nnzP):
-        E("  Ps[%d] = IN(a.Pv, %d);" % (k, k))
-    for k in range(s.nnzA):
-        E("  As[%d] = IN(a.Av, %d);" % (k, k))
+    load_lines = ["  Ps[%d] = IN(a.Pv, %d);" % (k, k) for k in range(s.nnzP)] + \
+                 ["  As[%d] = IN(a.Av, %d);" % (k, k) for k in range(s.nnzA)] + \
+                 ["  qs[%d] = IN(a.q, %d);" % (j, j) for j in range(n)]
+    if not asm:
+        o.extend(load_lines)      # (the assembly variant's Ruiz block fetches Pv, Av, q itself)
     for j in range(n):
-        E("  qs[%d] = IN(a.q, %d); D[%d] = T(1.0); x[%d] = IN(a.x, %d);" % (j, j, j, j, j))
+        E("  D[%d] = T(1.0); x[%d] = IN(a.x, %d);" % (j, j, j))
     E("  const T rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);")
     for i in range(m):
         E("  { const T e = IN(a.Eprev, %d); qp_classify(IN(a.l, %d) * e, IN(a.u, %d) * e, a.rho, rho_eq, rho[%d], rinv[%d]); "
@@ -81,7 +82,31 @@ def emit_structure(name, s, asm=None):
     mark(0)
     # ---- Ruiz
     E("  T c = T(1.0);")
-    E("  for (int pass = 0; pass < a.scaling; ++pass) {")
+    if asm:
+        RP = asm.ruiz
+        E("  // scaling.c:44-156 as generated assembly (asmqp.ruiz_program): the block fetches Pv, Av, q in batches, keeps the row")
+        E("  // scalings in VGPRs, Dt / P / q in AGPRs, A and the accumulated D, E in LDS, and leaves everything in LDS")
+        E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
+        E("  auto uni = [](unsigned long long v_) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v_); };  // (the builtin returns int: no sign extension)")
+        E("  if (a.scaling >= 1) {")
+        E("    const unsigned voff = (unsigned)b * 4u, s_stride = __builtin_amdgcn_readfirstlane((unsigned)a.B * 4u);")
+        E("    const unsigned s_pass = __builtin_amdgcn_readfirstlane((unsigned)a.scaling);")
+        E("    const unsigned long long avp = uni((unsigned long long)a.Av), pvp = uni((unsigned long long)a.Pv), qvp = uni((unsigned long long)a.q);")
+        E("    BQP_%s_RUIZ_ASM(voff, ldsaddr, avp, pvp, qvp, s_stride, s_pass);" % name.upper())
+        for k in range(s.nnzA):
+            E("    As[%d] = LDSQ(%d);" % (k, RP.LW_A + k))
+        for k in range(s.nnzP):
+            E("    Ps[%d] = LDSQ(%d);" % (k, RP.LW_P + k))
+        for j in range(n):
+            E("    qs[%d] = LDSQ(%d); D[%d] = LDSQ(%d);" % (j, RP.LW_Q + j, j, RP.LW_D + j))
+        for i in range(m):
+            E("    Ev[%d] = LDSQ(%d);" % (i, RP.LW_EV + i))
+        E("    c = LDSQ(%d);" % RP.LW_C)
+        E("  } else {")
+        o.extend("  " + ln for ln in load_lines)
+        E("  }")
+        E("#undef LDSQ")
+    E("  for (int pass = 0; pass < (%s); ++pass) {" % ("0" if asm else "a.scaling"))
     for j in range(n):
         terms = "T(0.0)"
         dP = "qmax(qabs(Ps[%d]), T(0.0))" % pidx[j] if pidx[j] >= 0 else "T(0.0)"
@@ -211,7 +236,6 @@ def emit_structure(name, s, asm=None):
         E("      const unsigned s_sigma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.sigma));")
         E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
         E("      // every scalar operand is made provably wave-uniform (the values are; the compiler cannot always see it)")
-        E("      auto uni = [](unsigned long long v_) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v_); };  // (the builtin returns int: no sign extension)")
         E("      const unsigned long long wsp = uni((unsigned long long)a.W), ssp = uni((unsigned long long)sblk);")
         E("      const unsigned s_stride = __builtin_amdgcn_readfirstlane(stride), s_mid = __builtin_amdgcn_readfirstlane((unsigned)mid);")
         E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq);" % name.upper())
@@ -360,6 +384,22 @@ def asm_macro(name, ins, plan):
     return "\n".join(out) + "\n"
 
 
+def ruiz_macro(name, ins, rp):
+    from . import asmqp
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, asmqp.V_END)] + ['"a%d"' % i for i in range(256)] + \
+           ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_RMIN, asmqp.S_RMAX)]
+    lab7 = [k for k, t_ in enumerate(ins) if t_ == ("label", "7")][0]
+    br = [k for k, t_ in enumerate(ins) if t_[0] == "s_cbranch_scc1"][0]
+    out = ["// The Ruiz passes of the %s structure (asmqp.ruiz_program), fp32: %d instructions, %d per pass." % (name, len(ins), br - lab7),
+           "// inputs: v0 = 4*robot, v1 = lane LDS address, s[4:5] = Av rows, s[6:7] = Pv rows, s[8:9] = q rows, s10 = 4*B, s11 = passes >= 1",
+           "#define BQP_%s_RUIZ_ASM(voff, ldsaddr, av, pv, qv, stride, passes) asm volatile( \\" % name.upper()]
+    for t_ in ins:
+        out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(av), "{s[6:7]}"(pv), "{s[8:9]}"(qv), "{s10}"(stride), "{s11}"(passes) \\')
+    out.append("  : " + ", ".join(clob) + ")")
+    return "\n".join(out) + "\n"
+
+
 def generate():
     """Returns {relative path under csrc/: source}: one translation unit per (structure, dtype) so that the build can
     compile them in parallel, plus the registry header umpc_bqp.hip includes."""
@@ -371,9 +411,10 @@ def generate():
         if name in ASM_STRUCTURES:
             from . import asmqp
             ins, plan = asmqp.program(s, ASM_STRUCTURES[name])
+            rins, plan.ruiz = asmqp.ruiz_program(s)
             asm_body = emit_structure(name, s, asm=plan)
             asm_hdr = "bqp_%s_asm.h" % name
-            files["gen/" + asm_hdr] = asm_macro(name, ins, plan)
+            files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + ruiz_macro(name, rins, plan.ruiz)
         for tag, ctype in DTYPES:
             with_asm = asm_body is not None and tag == "f32"
             src = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",

@@ -112,3 +112,56 @@ def test_p5f_stream_assembles(prog):
         assert r.returncode == 0, r.stderr[:3000]
     finally:
         os.unlink(f.name)
+
+
+def _ruiz_numpy(p, P, A, q, passes):
+    """the pass of codegen_qp.emit_structure (scaling.c:44-156), float64"""
+    n, m = p.n, p.m
+    P, A, q = P.copy(), A.copy(), q.copy()
+    D, E, c = np.ones(n), np.ones(m), 1.0
+    lim = lambda v: min(1.0 if v < 1e-4 else v, 1e4)
+    for _ in range(passes):
+        Dt, Et = np.zeros(n), np.zeros(m)
+        for j in range(n):
+            Dt[j] = abs(P[p.pidx[j]]) if p.pidx[j] >= 0 else 0.0
+            for k in range(p.A_p[j], p.A_p[j + 1]):
+                Dt[j] = max(Dt[j], abs(A[k]))
+                Et[p.A_i[k]] = max(Et[p.A_i[k]], abs(A[k]))
+        Dt = np.array([1.0 / np.sqrt(lim(x)) for x in Dt])
+        Et = np.array([1.0 / np.sqrt(lim(x)) for x in Et])
+        csum, qn = 0.0, 0.0
+        for j in range(n):
+            if p.pidx[j] >= 0:
+                P[p.pidx[j]] *= Dt[j] * Dt[j]
+                csum += abs(P[p.pidx[j]])
+            for k in range(p.A_p[j], p.A_p[j + 1]):
+                A[k] *= Et[p.A_i[k]] * Dt[j]
+            q[j] *= Dt[j]
+            qn = max(qn, abs(q[j]))
+        D, E = D * Dt, E * Et
+        ct = 1.0 / lim(max(csum / n, lim(qn)))
+        P, q, c = P * ct, q * ct, c * ct
+    return P, A, q, D, E, c
+
+
+@pytest.mark.parametrize("passes", [1, 10])
+def test_generated_p5f_ruiz_block_matches_numpy(passes):
+    from robobee3d_amd import asmqp, batchqp, qpstruct
+    st = batchqp.p5f_structure(10)
+    s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    ins, p = asmqp.ruiz_program(s)
+    rng = np.random.default_rng(passes)
+    f = lambda a: a.astype(np.float32)
+    for scale in (1.0, 1e-6, 3e5):           # the last two drive limit_scaling's branches
+        P = f(np.abs(rng.normal(size=p.nnzP)) * 10 * scale + 1e-3 * scale)
+        A = f(rng.normal(size=p.nnzA) * scale)
+        A[rng.random(p.nnzA) < 0.3] = 1.0
+        q = f(rng.normal(size=p.n) * scale)
+        lds = asmqp.simulate(ins, np.zeros(1, np.float32), np.zeros(1, np.float32), passes, (1.6, 1e-6, 0.01),
+                             regions=[(asmqp.S_AV, A), (asmqp.S_PV, P), (asmqp.S_QV, q)])
+        Pr, Ar, qr, Dr, Er, cr = _ruiz_numpy(p, P.astype(np.float64), A.astype(np.float64), q.astype(np.float64), passes)
+        for name, got, ref in (("A", lds[p.LW_A:p.LW_A + p.nnzA], Ar), ("P", lds[p.LW_P:p.LW_P + p.nnzP], Pr),
+                               ("q", lds[p.LW_Q:p.LW_Q + p.n], qr), ("D", lds[p.LW_D:p.LW_D + p.n], Dr),
+                               ("E", lds[p.LW_EV:p.LW_EV + p.m], Er)):
+            assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max(), (name, passes, scale)
+        assert abs(lds[p.LW_C] - cr) <= 5e-6 * cr
