@@ -945,3 +945,48 @@ def ruiz_program(s):
         e("ds_write_b32", base, v(t), off)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
     return e.ins, p
+
+
+# ---------------------------------------------------------------------------
+# Batched row loader: [row][B] arrays -> LDS words, one round trip
+# ---------------------------------------------------------------------------
+# hipcc fetches the ~900 warm-start / bound words of a p5f step one exposed global load at a time (load, wait, spill):
+# 0.45 ms of the tick for a lone wave. This block issues all loads of up to three arrays back to back into registers,
+# waits once, and leaves the words in LDS (float4-interleaved) where the C++ side picks them up at LDS latency.
+def loader_program(groups):
+    """groups: [(n_rows, first LDS word)] for the arrays at s[4:5], s[6:7], s[8:9]; v0 = 4*robot, v1 = lane LDS address,
+    s10 = 4*B"""
+    e = Emit()
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    items = []
+    for q, (nrows, w0) in enumerate(groups):
+        items += [((S_W, S_S, 8)[q], r, w0 + r) for r in range(nrows)]
+    cap = V_END - 6
+    for g in range(0, len(items), cap):
+        grp = items[g:g + cap]
+        last = None
+        for k, (base, row, word) in enumerate(grp):
+            if last is None or last[0] != base or last[1] + 1 != row:
+                e("s_mul_i32", "s%d" % S_P, "s%d" % S_STRIDE, row)
+                e("s_mul_hi_u32", "s%d" % (S_P + 1), "s%d" % S_STRIDE, row)
+                e("s_add_u32", "s%d" % S_P, "s%d" % S_P, "s%d" % base)
+                e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_P + 1), "s%d" % (base + 1))
+            else:
+                _adv(e, S_P)
+            last = (base, row)
+            e("global_load_dword", "v%d" % (6 + k), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+        e("s_waitcnt", "vmcnt(0)")
+        k = 0
+        while k < len(grp):
+            word = grp[k][2]
+            base, off = lds_addr(word)
+            if word % 4 == 0 and k + 3 < len(grp) and all(grp[k + z][2] == word + z for z in range(4)) and (6 + k) % 2 == 0:
+                e("ds_write_b128", base, "v[%d:%d]" % (6 + k, 6 + k + 3), off)
+                k += 4
+            else:
+                e("ds_write_b32", base, "v%d" % (6 + k), off)
+                k += 1
+        e("s_waitcnt", "lgkmcnt(0)")
+    return e.ins

@@ -69,12 +69,28 @@ def emit_structure(name, s, asm=None):
                  ["  qs[%d] = IN(a.q, %d);" % (j, j) for j in range(n)]
     if not asm:
         o.extend(load_lines)      # (the assembly variant's Ruiz block fetches Pv, Av, q itself)
-    for j in range(n):
-        E("  D[%d] = T(1.0); x[%d] = IN(a.x, %d);" % (j, j, j))
     E("  const T rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);")
-    for i in range(m):
-        E("  { const T e = IN(a.Eprev, %d); qp_classify(IN(a.l, %d) * e, IN(a.u, %d) * e, a.rho, rho_eq, rho[%d], rinv[%d]); "
-          "Ev[%d] = T(1.0); y[%d] = IN(a.y, %d); z[%d] = IN(a.z, %d); }" % (i, i, i, i, i, i, i, i, i, i))
+    if asm:
+        # the warm start and the bounds arrive through LDS: asmqp.loader_program fetches three [row][B] arrays in one round
+        # trip (hipcc would fetch the ~900 words one exposed load at a time: 0.45 ms of the tick)
+        E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
+        E("  auto uni = [](unsigned long long v_) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v_); };  // (the builtin returns int: no sign extension)")
+        E("  const unsigned voff = (unsigned)b * 4u, s_stride = __builtin_amdgcn_readfirstlane((unsigned)a.B * 4u);")
+        E("  BQP_%s_LOAD_XYZ(voff, ldsaddr, uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_stride);" % name.upper())
+        for j in range(n):
+            E("  D[%d] = T(1.0); x[%d] = LDSQ(%d);" % (j, j, j))
+        for i in range(m):
+            E("  Ev[%d] = T(1.0); y[%d] = LDSQ(%d); z[%d] = LDSQ(%d);" % (i, i, n + i, i, n + m + i))
+        E("  BQP_%s_LOAD_LUE(voff, ldsaddr, uni((unsigned long long)a.l), uni((unsigned long long)a.u), uni((unsigned long long)a.Eprev), s_stride);" % name.upper())
+        for i in range(m):
+            E("  { const T e = LDSQ(%d); qp_classify(LDSQ(%d) * e, LDSQ(%d) * e, a.rho, rho_eq, rho[%d], rinv[%d]); }"
+              % (2 * m + i, i, m + i, i, i))
+    else:
+        for j in range(n):
+            E("  D[%d] = T(1.0); x[%d] = IN(a.x, %d);" % (j, j, j))
+        for i in range(m):
+            E("  { const T e = IN(a.Eprev, %d); qp_classify(IN(a.l, %d) * e, IN(a.u, %d) * e, a.rho, rho_eq, rho[%d], rinv[%d]); "
+              "Ev[%d] = T(1.0); y[%d] = IN(a.y, %d); z[%d] = IN(a.z, %d); }" % (i, i, i, i, i, i, i, i, i, i))
     TIMING = asm is not None and os.environ.get("UMPC_QP_TIMING") == "1"   # diagnostic builds: phase intervals -> info rows
     mark = (lambda k: E("  tmark[%d] = __builtin_amdgcn_s_memrealtime();" % k)) if TIMING else (lambda k: None)
     if TIMING:
@@ -86,10 +102,7 @@ def emit_structure(name, s, asm=None):
         RP = asm.ruiz
         E("  // scaling.c:44-156 as generated assembly (asmqp.ruiz_program): the block fetches Pv, Av, q in batches, keeps the row")
         E("  // scalings in VGPRs, Dt / P / q in AGPRs, A and the accumulated D, E in LDS, and leaves everything in LDS")
-        E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
-        E("  auto uni = [](unsigned long long v_) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v_); };  // (the builtin returns int: no sign extension)")
         E("  if (a.scaling >= 1) {")
-        E("    const unsigned voff = (unsigned)b * 4u, s_stride = __builtin_amdgcn_readfirstlane((unsigned)a.B * 4u);")
         E("    const unsigned s_pass = __builtin_amdgcn_readfirstlane((unsigned)a.scaling);")
         E("    const unsigned long long avp = uni((unsigned long long)a.Av), pvp = uni((unsigned long long)a.Pv), qvp = uni((unsigned long long)a.q);")
         E("    BQP_%s_RUIZ_ASM(voff, ldsaddr, avp, pvp, qvp, s_stride, s_pass);" % name.upper())
@@ -105,7 +118,6 @@ def emit_structure(name, s, asm=None):
         E("  } else {")
         o.extend("  " + ln for ln in load_lines)
         E("  }")
-        E("#undef LDSQ")
     E("  for (int pass = 0; pass < (%s); ++pass) {" % ("0" if asm else "a.scaling"))
     for j in range(n):
         terms = "T(0.0)"
@@ -138,8 +150,14 @@ def emit_structure(name, s, asm=None):
     E("    c *= ct;")
     E("  }")
     E("  const T cinv = T(1.0) / c;")
-    for i in range(m):
-        E("  ls[%d] = IN(a.l, %d) * Ev[%d]; us[%d] = IN(a.u, %d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, i, i, i, i))
+    if asm:
+        E("  BQP_%s_LOAD_LUE(voff, ldsaddr, uni((unsigned long long)a.l), uni((unsigned long long)a.u), uni((unsigned long long)a.Eprev), s_stride);" % name.upper())
+        for i in range(m):
+            E("  ls[%d] = LDSQ(%d) * Ev[%d]; us[%d] = LDSQ(%d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, m + i, i, i, i))
+        E("#undef LDSQ")
+    else:
+        for i in range(m):
+            E("  ls[%d] = IN(a.l, %d) * Ev[%d]; us[%d] = IN(a.u, %d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, i, i, i, i))
     mark(1)
     # ---- factor
     for k in range(nk):
@@ -228,7 +246,7 @@ def emit_structure(name, s, asm=None):
             E("    sblk[%d + threadIdx.x] = %s;" % (q * 64, src[what] % i))
         mark(4)
         E("    {")
-        E("      const unsigned voff = (unsigned)b * 4u, lane4 = (unsigned)threadIdx.x * 4u, stride = (unsigned)a.B * 4u;")
+        E("      const unsigned lane4 = (unsigned)threadIdx.x * 4u, stride = (unsigned)a.B * 4u;")
         E("      // float constants come straight from the kernel arguments (SGPRs): a value computed with float arithmetic lives")
         E("      // in a VGPR and hipcc fails to copy it back (\"illegal VGPR to SGPR copy\"), so 1 - alpha and 1/rho_eq are the host's")
         E("      const unsigned s_alpha = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.alpha));")
@@ -400,6 +418,21 @@ def ruiz_macro(name, ins, rp):
     return "\n".join(out) + "\n"
 
 
+def loader_macro(name, tag, groups):
+    from . import asmqp
+    ins = asmqp.loader_program(groups)
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, asmqp.V_END)] + \
+           ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1)]
+    out = ["// Batched loader (asmqp.loader_program): rows %s of the arrays at s[4:5], s[6:7], s[8:9] -> LDS words, one round trip"
+           % ", ".join("%d -> %d.." % g for g in groups),
+           "#define BQP_%s_LOAD_%s(voff, ldsaddr, p0, p1, p2, stride) asm volatile( \\" % (name.upper(), tag)]
+    for t_ in ins:
+        out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(p0), "{s[6:7]}"(p1), "{s[8:9]}"(p2), "{s10}"(stride) \\')
+    out.append("  : " + ", ".join(clob) + ")")
+    return "\n".join(out) + "\n"
+
+
 def generate():
     """Returns {relative path under csrc/: source}: one translation unit per (structure, dtype) so that the build can
     compile them in parallel, plus the registry header umpc_bqp.hip includes."""
@@ -414,7 +447,9 @@ def generate():
             rins, plan.ruiz = asmqp.ruiz_program(s)
             asm_body = emit_structure(name, s, asm=plan)
             asm_hdr = "bqp_%s_asm.h" % name
-            files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + ruiz_macro(name, rins, plan.ruiz)
+            files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + ruiz_macro(name, rins, plan.ruiz) + \
+                loader_macro(name, "XYZ", [(s.n, 0), (s.m, s.n), (s.m, s.n + s.m)]) + \
+                loader_macro(name, "LUE", [(s.m, 0), (s.m, s.m), (s.m, 2 * s.m)])
         for tag, ctype in DTYPES:
             with_asm = asm_body is not None and tag == "f32"
             src = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
