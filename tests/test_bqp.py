@@ -621,6 +621,38 @@ def test_gpu_p5f_assembly_loop_agrees_with_the_table_kernel(margin):
 
 
 @pytest.mark.gpu
+def test_gpu_p5f_assembly_kernel_falls_back_when_a_dynamics_row_is_not_an_equality(margin):
+    """The assembly loop takes the 77 dynamics rows for equalities; the kernel checks it per wave and runs the C++ loop where
+    it does not hold. Robots 64..127 (one whole wave) and robot 150 (one lane of the third wave) get l < u on a dynamics
+    row: their waves must take the fallback, the other waves the assembly loop -- every robot agrees with the table
+    kernel either way (the Ruiz block and the batched loader run on both paths)."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    B = 256
+    mpc = PlanarP5fMPC(B, torch.float32)
+    assert mpc.qp.kernel_name == "p5f10+asm"
+    mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
+    mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
+    mpc.u[5, 64:128] += 0.25          # row 5 of the dynamics block: now an inequality for these robots
+    mpc.u[40, 150] += 0.5
+    res = []
+    for mode in ("lane", "tables"):
+        mpc.qp.reset()
+        mpc.qp.set_kernel(mode)
+        for ti in (2, 3):
+            mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti))
+            mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x)])
+    d = np.max(np.stack([(np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(0) for a, b in zip(*res)]), axis=0)   # per robot
+    fallback = np.zeros(B, bool)
+    fallback[64:192] = True           # waves 1 and 2
+    margin("robots on the assembly path, |d| / max(1, |ref|)", d[~fallback].max(), 3e-6)
+    margin("robots on the fallback path, |d| / max(1, |ref|)", d[fallback].max(), 3e-6)
+    assert np.all(np.isfinite(res[0][0]))
+
+
+@pytest.mark.gpu
 def test_gpu_wave_kernel_agrees_with_lane_kernels():
     """One wavefront per robot (LDS-resident, level-scheduled; the default) against the lane-per-robot table kernel on
     three structures: the same iterates to rounding (the factorisation and the Ruiz cost sums associate differently)."""
