@@ -553,12 +553,44 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds):
         byte = int(V[int(basereg[1:])]) + off
         return (byte // 1024) * 2 + (byte % 1024) // 8
 
+    # completion model (as asmqp.simulate): LDS operations and VMEM loads complete in issue order; a register that an
+    # outstanding load will write must not be read or written before an s_waitcnt has retired that load
+    pend = {"lgkmcnt": [], "vmcnt": []}
+
+    def regs_of(x):
+        if not isinstance(x, str):
+            return set()
+        x = x.lstrip("-").strip("|")
+        if x[:2] in ("v[", "a["):
+            lo_, hi_ = x[2:-1].split(":")
+            return {(x[0], r) for r in range(int(lo_), int(hi_) + 1)}
+        if x[0] in "va" and x[1:].isdigit():
+            return {(x[0], int(x[1:]))}
+        return set()
+
     pc = nexec = 0
     while pc < len(ins):
         t = ins[pc]
         m = t[0]
         nexec += 1
         assert nexec < 2000000, "runaway program"
+        if m == "s_waitcnt":
+            for part in t[1].split():
+                name, val = part[:-1].split("(")
+                del pend[name][:max(0, len(pend[name]) - int(val))]
+        elif m[0] == "v" or m.startswith("ds_") or m.startswith("global_"):
+            used = set().union(*[regs_of(x) for x in t[1:]])
+            for q_ in pend.values():
+                for dst in q_:
+                    assert not (dst & used), ("register used before its load was waited for", pc, t, sorted(dst & used))
+            if m.startswith("ds_read"):
+                pend["lgkmcnt"].append(regs_of(t[1]))
+            elif m.startswith("ds_write"):
+                pend["lgkmcnt"].append(set())
+            elif m.startswith("global_load"):
+                pend["vmcnt"].append(regs_of(t[1]))
+            elif m.startswith("global_store"):
+                pend["vmcnt"].append(set())
         if m in ("label", "s_waitcnt", "s_nop"):
             pass
         elif m == "v_mov_b32":

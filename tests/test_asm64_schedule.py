@@ -179,3 +179,12 @@ def test_fp64_ruiz_stream_assembles_and_fits():
         assert r.returncode == 0, r.stderr[:3000]
     finally:
         os.unlink(f.name)
+
+
+def test_fp64_completion_model_catches_a_missing_wait(oracle_built, prog):
+    """the interpreter's in-order completion model guards the s_waitcnt placement of the fp64 streams too"""
+    g, ins, s = prog
+    seq = golden("seq_iter50.npz")
+    stripped = [t for t in ins if t[0] != "s_waitcnt"]
+    with pytest.raises(AssertionError):
+        _case(oracle_built, g, stripped, s, seq, 0, 2)
