@@ -30,7 +30,6 @@ LQ_Q, LQ_LO, LQ_L, LQ_END = 0, 6, 11, 20
 DESPACE = int(os.environ.get("UMPC_X_DESPACE", "1"))
 S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO = asmgen.S_ALPHA, asmgen.S_OMA, asmgen.S_SIGMA, asmgen.S_RINV, asmgen.S_RHO
 S_MA, S_MB, S_ALL, S_CNT = 36, 38, 40, 14      # exec masks of lane 0 / lane 1 of every pair, all lanes; loop counter
-QP = {("A", "A"): None, ("B", "B"): None}
 
 
 def quad_perm(la, lb):
