@@ -75,8 +75,10 @@ class Fetch:
     with src = ('L', lds word) | ('A', first AGPR of the word) | ('V', first VGPR of the word); emit receives the first
     VGPR of every source word. LDS quads live in NSLOT ring slots, least recently used replaced (static analysis)."""
 
-    def __init__(self, e, ahead=14, la=2):
+    def __init__(self, e, ahead=None, la=2):
+        ahead = int(os.environ.get("UMPC_ASM64_AHEAD", "14")) if ahead is None else ahead
         self.e, self.ahead, self.la = e, ahead, la
+        self.merge = int(os.environ.get("UMPC_ASM64_MERGE", "1"))     # a wait also covers this many later reads in flight
 
     def run(self, ops):
         e = self.e
@@ -139,7 +141,7 @@ class Fetch:
                         issue(it)
                         next_inst += 1
                     if it["issued"] > waited:
-                        upto = min(nds - 1, it["issued"] + 1)
+                        upto = min(nds - 1, it["issued"] + self.merge)
                         e("s_waitcnt", "lgkmcnt(%d)" % min(15, nds - 1 - upto))
                         waited = upto if nds - 1 - upto <= 15 else it["issued"]
                     regs.append(V_RING + 4 * it["slot"] + 2 * (src[1] & 1))
