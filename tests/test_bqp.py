@@ -599,8 +599,8 @@ def test_gpu_p5f_assembly_loop_agrees_with_the_table_kernel(margin):
     a full-wave batch, a ragged one and one too small for the stream buffer (falls back to the C++ loop)."""
     import torch
     from robobee3d_amd.batchqp import PlanarP5fMPC
-    for B in (200, 64, 5):
-        mpc = PlanarP5fMPC(B, torch.float32)
+    for B, scaling in ((200, 10), (64, 10), (5, 10), (130, 3), (130, 0)):     # (other pass counts: the block's loop / no block)
+        mpc = PlanarP5fMPC(B, torch.float32, scaling=scaling)
         mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
         mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
         res = []
@@ -615,7 +615,7 @@ def test_gpu_p5f_assembly_loop_agrees_with_the_table_kernel(margin):
             res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x, mpc.qp.Eprev)]
                        + [mpc.qp.status.cpu().numpy().copy(), mpc.qp.info.cpu().numpy().copy()])
         worst = max(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) for a, b in zip(res[0][:5], res[1][:5]))
-        margin("B=%d iterates / solution, |d| / max(1, |ref|)" % B, worst, 3e-6 if B >= 64 else 0.0)
+        margin("B=%d, %d Ruiz passes: iterates / solution, |d| / max(1, |ref|)" % (B, scaling), worst, 3e-6 if B >= 64 else 0.0)
         assert np.count_nonzero(res[0][5] != res[1][5]) <= B // 8
         assert np.all(np.isfinite(res[0][0]))
 
