@@ -37,7 +37,7 @@ def builtin_structures():
 
 
 ASM_STRUCTURES = {"p5f10": list(range(77))}   # structure -> rows assumed to be equalities by the assembly loop (asmqp.py)
-ASM_STREAM_ROW = 1280                          # the stream buffer starts at this row of the workspace
+ASM_STREAM_ROW = 1024                          # the hand-off rows of an assembly specialisation stay below this row
 
 
 def emit_structure(name, s, asm=None):
@@ -240,7 +240,7 @@ def emit_structure(name, s, asm=None):
         for i, q in sorted(P.zpos.items()):
             E("    IN(a.W, %d) = z[%d];" % (P.R_Z + q, i))
         nst = P.n_stream + len(P.extra)
-        E("    T *const sblk = a.W + (size_t)%d * B + (size_t)wave * %d;   // wave-uniform (SGPR) base" % (ASM_STREAM_ROW, nst * 64))
+        E("    T *const sblk = a.S + (size_t)wave * %d;   // wave-uniform (SGPR) base" % (nst * 64))
         src = {"rinv": "rinv[%d]", "l": "ls[%d]", "u": "us[%d]", "rho": "rho[%d]", "q": "qs[%d]"}
         for q, (what, i) in enumerate(P.stream + P.extra):
             E("    sblk[%d + threadIdx.x] = %s;" % (q * 64, src[what] % i))

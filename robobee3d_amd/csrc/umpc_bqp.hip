@@ -803,6 +803,7 @@ __global__ void umpcn_extract_kernel(int Bn, int N, T dt, const T *__restrict__ 
 struct qp_batch {
   int B, dtype, n, m, nk, nnzP, nnzA, nnzL, nrows, fixed, use_tables, wave;   // wave: 1 = wave-per-robot kernel
   int no_asm;   // umpcQPSetKernel(h, 3): the lane specialisation without its assembly loop
+  size_t asm_tail;   // elements of the stream buffer behind the workspace rows (0: none)
   size_t wave_lds;
   bool wave_ok;
   umpcQPSettings st;
@@ -811,12 +812,12 @@ struct qp_batch {
 };
 
 // assembly specialisations (gen/bqp_*_asm.h, fp32) keep one iteration's read-only words in a [wave][item][lane] block
-// behind row 1280 of the workspace (codegen_qp.ASM_STREAM_ROW); 1024 items bound every built-in structure.
-// UMPC_QP_NO_ASM=1 disables them.
+// (1024 items bound every built-in structure) that umpcQPCreate allocates behind the workspace rows, and hand the
+// factor over through the first 1024 rows. UMPC_QP_NO_ASM=1 disables them.
+size_t asm_tail_elems(int B) { return (size_t)((B + 63) / 64) * 64 * 1024; }
 bool asm_room(const qp_batch *h) {
   static const bool no_asm = getenv("UMPC_QP_NO_ASM") != nullptr;
-  const size_t need = (size_t)((h->B + 63) / 64) * 64 * 1024, have = h->nrows > 1280 ? (size_t)(h->nrows - 1280) * h->B : 0;
-  return !no_asm && !h->no_asm && need <= have;
+  return !no_asm && !h->no_asm && h->asm_tail > 0 && h->nrows >= 1024;
 }
 bool asm_active(const qp_batch *h) {
   const bool tables = h->use_tables || h->st.check_termination > 0 || h->st.adaptive_rho_interval > 0;
@@ -841,6 +842,7 @@ int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, con
   a.adaptive_rho_interval = h->st.adaptive_rho_interval;
   {
     a.asm_ok = asm_room(h) ? 1 : 0;
+    a.S = h->asm_tail ? (T *)h->W + (size_t)h->nrows * (size_t)h->B : nullptr;
     a.oma = T(1.0) - a.alpha;
     a.rinv_eq = T(1. / (double)T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho));
   }
@@ -968,8 +970,9 @@ void *umpcQPCreate(const int32_t *blob, int nwords, int B, int dtype, const umpc
     for (int k = 0; k < kNumFixedKernels; ++k) if (kFixedKernels[k].hash == hash) h->fixed = k;
   }
   const size_t esz = dtype == UMPC_F32 ? 4 : 8;
+  h->asm_tail = (h->fixed >= 0 && kFixedKernels[h->fixed].asm_f32 && dtype == UMPC_F32) ? asm_tail_elems(B) : 0;
   if (hipMalloc((void **)&h->tab, (size_t)nwords * 4) != hipSuccess ||
-      hipMalloc(&h->W, (size_t)nrows * (size_t)B * esz) != hipSuccess) {
+      hipMalloc(&h->W, ((size_t)nrows * (size_t)B + h->asm_tail) * esz) != hipSuccess) {
     umpc_set_error("umpcQPCreate: hipMalloc failed");
     delete h;
     return nullptr;

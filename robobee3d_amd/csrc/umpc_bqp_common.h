@@ -36,7 +36,8 @@ struct QPArgs {
   int max_iter, scaling;
   int adaptive_rho_interval;  // 0: fixed rho; k > 0: adapt_rho every k iterations (table kernel)
   int check_termination;  // 0: exactly max_iter iterations; k > 0: exact termination test every k iterations (table kernel)
-  int asm_ok;  // the workspace has room for the stream buffer of an assembly specialisation (gen/bqp_*_asm.h)
+  int asm_ok;  // an assembly specialisation (gen/bqp_*_asm.h) may run: S is allocated
+  T *S;        // its stream buffer: [wave][item][lane], 1024 items per wave, behind the workspace rows
   T oma, rinv_eq;  // 1 - alpha and 1 / rho_eq as the kernels compute them, evaluated on the host (assembly operands)
 };
 
