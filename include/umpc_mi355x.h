@@ -188,8 +188,9 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
 /* Step-kernel choice. 0 (default): automatic. fp32: the all-assembly kernel (robobee3d_amd/asmstep.py: phase A, ADMM
  * loop, phase C and the plant as one generated gfx950 stream) whenever the call is inside its scope (no task
  * generator, batch-constant weights, no WL coupling, maxIter >= 1), else the C++ kernel with the assembly ADMM loop.
- * fp64: for batches of at most 256 wavefronts (B <= 16 384) the C++ kernel with L and 1/D in LDS and the ADMM phase as
- * generated fp64 assembly (robobee3d_amd/asmgen64.py; maxIter >= 1), else the all-C++ kernel.
+ * fp64: the C++ kernel with L and 1/D in LDS and the Ruiz passes and the ADMM phase as generated fp64 assembly
+ * (robobee3d_amd/asmgen64.py; one workgroup per CU at a time, maxIter >= 1, batches up to ~4.8e5 robots), else the all-C++
+ * kernel.
  * 1: always the C++ kernel -- fp32 around the assembly ADMM loop, fp64 with the C++ loop (ablation / cross-check). */
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode);
 

@@ -336,10 +336,14 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
   const char *env = getenv("UMPC_SKEW_US");
   const int skew_us = env ? atoi(env) : (K >= 64 && sizeof(T) == 4 && h->B >= 32768 ? 80 : 0);
   if constexpr (sizeof(T) == 8) {
-    // small fp64 batches (BASELINE configs[1]: B = 4096 = one wave per CU at most): L and 1/D in LDS, not in scratch
+    // fp64 (BASELINE configs[1]: B = 4096 = one wave per CU at most): L and 1/D in LDS, not in scratch
     static const bool no_ldsf = getenv("UMPC_NO_F64_LDS") != nullptr;
     static const bool no_asm64 = getenv("UMPC_NO_ASM64") != nullptr;
-    if (!no_ldsf && grid <= 256) {
+    // Any grid: a workgroup of this kernel owns its CU's whole LDS, so larger batches run 256 workgroups at a time; measured
+    // (tools/f64_big.sh) that is still 5-13x faster than four all-C++ waves per CU: 0.42 / 0.82 / 1.61 ms per step at
+    // B = 16 384 / 32 768 / 65 536 against 5.3 / 6.2 / 8.6. UMPC_F64_LDS_MAX_GRID caps it (diagnostics).
+    static const int ldsf_max_grid = [] { const char *e_ = getenv("UMPC_F64_LDS_MAX_GRID"); return e_ ? atoi(e_) : 0x7fffffff; }();
+    if (!no_ldsf && grid <= ldsf_max_grid) {
       // ... and the ADMM phase as generated fp64 assembly (needs >= 1 iteration and 31-bit row offsets)
       const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 8 < ((size_t)1 << 31);
       if (!no_asm64 && h->step_kernel == 0 && h->prm.maxIter >= 1 && fits)
