@@ -253,20 +253,30 @@ def body(e, s, first, capture):
     RHO3 = lambda k: V_C + 6 * N + 2 * k
     RINV3 = lambda k: V_C + 8 * N + 2 * k
     ptr = sp(S_P2)
-    e("s_waitcnt", "vmcnt(0)")     # q in W_x (and l in W_z of the dynamics rows unless first)
+    # q (and, unless first, l of the dynamics rows) are on their way into the W registers: loads issued in the order q_0..q_44,
+    # l_0..l_35 behind the previous iteration's updates (or by the prologue), no other VMEM operation since. Each rhs
+    # operation waits for ITS word only (loads return in order), so the tail of the loads hides behind the head of the rhs.
+    npre = nx if first else nx + neq
+    waited = [-1]
+
+    def wait_pre(pos):
+        if pos > waited[0]:
+            e("s_waitcnt", "vmcnt(%d)" % min(63, npre - 1 - pos))
+            waited[0] = pos
     ops = []
 
     def op(srcs, fn):
         ops.append(dict(srcs=srcs, emit=fn))
     # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178), q / l already in W
     for j in range(nx):
-        op([("L", LW_X + j)], lambda r, j=j: e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j))))
+        op([("L", LW_X + j)], lambda r, j=j: (wait_pre(j), e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j)))))
     for i in range(neq):
         if first:
             op([("L", LW_Y + i), ("A", A_Z + 2 * i)],
                lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])))
         else:
-            op([("L", LW_Y + i)], lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i))))
+            op([("L", LW_Y + i)], lambda r, i=i: (wait_pre(nx + i),
+                                                  e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i)))))
     for k in range(N):
         i = neq + k
         op([("L", LW_Y + i)], lambda r, i=i, k=k: e("v_fma_f64", vp(W(nx + i)), "-" + vp(RINV3(k)), vp(r[0]), vp(Z3(k))))
@@ -291,6 +301,8 @@ def body(e, s, first, capture):
         e("ds_write_b64", base, vp(reg), off + 8 * half)
         return 1
     quads = _words(LW_X, LW_X + nx)
+    if not first:
+        _row_ptr(e, S_P, S_WS, FAC_Q)      # the next iteration's q follows the update into each group of W_x registers
     for g in range(0, len(quads), NSLOT):
         grp = quads[g:g + NSLOT]
         where = _read_group(e, grp)
@@ -304,6 +316,11 @@ def body(e, s, first, capture):
                 e("v_mul_f64", vp(t), sO, vp(r))
                 e("v_fma_f64", vp(t if capture else r), sA, vp(W(j)), vp(t))
             nw += _write_quad(e, qd, ws, {w: (V_TT + 2 * ((w - LW_X) % N_TT) if capture else where[w]) for w in ws})
+        if not first:
+            for qd, ws in grp:
+                for w in ws:
+                    e("global_load_dwordx2", vp(W(w - LW_X)), "v0", sp(S_P))
+                    _adv(e, S_P)
     if first:
         # l of the dynamics rows (the new z there) -> the W_x registers the x update has just freed, one round trip for
         # all 36 rows; q follows after the row update
@@ -312,10 +329,10 @@ def body(e, s, first, capture):
             e("global_load_dwordx2", vp(W(i)), "v0", sp(S_P))
             _adv(e, S_P)
         e("s_waitcnt", "vmcnt(0)")
-    else:
-        preload_q(e, s)
     # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
     quads = _words(LW_Y, LW_Y + nc)
+    if not first:
+        _row_ptr(e, S_P, S_WS, FAC_LOEQ)   # ... and l into each group of W_z registers
     for g in range(0, len(quads), NSLOT):
         grp = quads[g:g + NSLOT]
         where = _read_group(e, grp)
@@ -362,9 +379,15 @@ def body(e, s, first, capture):
                 e("v_add_f64", vp(r), vp(r), vp(t2))
                 newreg[w] = r
             nw += _write_quad(e, qd, ws, newreg)
+        if not first:
+            for qd, ws in grp:
+                for w in ws:
+                    if w - LW_Y < neq:
+                        e("global_load_dwordx2", vp(W(nx + w - LW_Y)), "v0", sp(S_P))
+                        _adv(e, S_P)
     if first:
         preload_q(e, s)
-    preload_l(e, s, neq)
+        preload_l(e, s, neq)
 
 
 def epilogue(e, s):
@@ -407,11 +430,19 @@ def program(N=3, perm=None):
     """maxIter >= 1 (the caller takes the C++ loop otherwise)"""
     s = symbolic.analyse(N, perm)
     e = Emit()
+    timing = os.environ.get("UMPC_ASM64_TIMING") == "1"      # diagnostic builds: 100 MHz stamps -> spare LDS words 297..
+
+    def stamp(k):
+        if timing:
+            e("s_memrealtime", sp(36 + 2 * k))
+    stamp(0)
     prologue(e, s)
+    stamp(1)
     # the captures overwrite L in LDS, so only the LAST iteration captures: a single iteration is its own variant
     e("s_cmp_lt_i32", "s%d" % S_ITERS, 2)
     e("s_cbranch_scc1", "4f")
     body(e, s, first=True, capture=False)
+    stamp(2)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_ITERS, 2)
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
     e("s_cbranch_scc1", "8f")
@@ -421,12 +452,23 @@ def program(N=3, perm=None):
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
     e("label", "8")
+    stamp(3)
     body(e, s, first=False, capture=True)
     e("s_branch", "6f")
     e("label", "4")
     body(e, s, first=True, capture=True)
     e("label", "6")
+    stamp(4)
     epilogue(e, s)
+    if timing:
+        stamp(5)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for k in range(6):
+            e("v_mov_b32", "v%d" % V_TT, "s%d" % (36 + 2 * k))
+            e("v_mov_b32", "v%d" % (V_TT + 1), "s%d" % (37 + 2 * k))
+            base, off, half = lds_addr(LW_END + k)
+            e("ds_write_b64", base, vp(V_TT), off + 8 * half)
+        e("s_waitcnt", "lgkmcnt(0)")
     return e.ins, s
 
 
@@ -445,7 +487,8 @@ def fmt(t):
 def write(path=None, N=3, perm=None):
     path = path or os.path.join(HERE, "csrc", "umpc_admm_asm64.h")
     ins, s = program(N, perm)
-    used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1] + list(range(S_ALPHA, S_RHO + 2))
+    used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1] + list(range(S_ALPHA, S_RHO + 2)) + \
+             (list(range(36, 48)) if os.environ.get("UMPC_ASM64_TIMING") == "1" else [])
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
     lab7 = [k for k, t in enumerate(ins) if t == ("label", "7")][0]

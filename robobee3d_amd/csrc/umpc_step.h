@@ -1041,6 +1041,15 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   UMPC_TMARK(6);
 #pragma unroll
   for (int i = 0; i < 6; ++i) GLD(a.out, 3 + i) = T(tmark[i + 1] - tmark[i]);
+#ifdef UMPC_ASM64_TIMING   /* header generated with UMPC_ASM64_TIMING=1: the block's own stamps, LDS words 297..302 */
+  if constexpr (ASM64) {
+    long long st[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st[k] = __builtin_bit_cast(long long, LDSF_W(297 + k));
+    // out rows 0..2: block prologue, (first iteration .. loop), epilogue; rows 3.. keep the phase intervals
+    GLD(a.out, 0) = T(st[1] - st[0]); GLD(a.out, 1) = T(st[4] - st[1]); GLD(a.out, 2) = T(st[5] - st[4]);
+  }
+#endif
 #endif
 #undef UMPC_TMARK
 #undef GLD
