@@ -499,7 +499,7 @@ def fmt(t):
 # ---------------------------------------------------------------------------
 # CPU interpreter (one lane) and a numpy statement of the same iteration
 # ---------------------------------------------------------------------------
-def simulate(ins, W, S, iters, consts, regions=None):
+def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None):
     """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
     Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there)."""
     f32 = np.float32
@@ -517,6 +517,10 @@ def simulate(ins, W, S, iters, consts, regions=None):
     SG[S_S], SG[S_S + 1] = 1 << 30, 0
     SG[S_STRIDE], SG[S_ITERS] = STRIDE, iters
     # regions (the Ruiz block's inputs): [(SGPR pair, array)], row-major with the simulated stride, 1 << 32 apart
+    for k_, v_ in (sgpr or {}).items():
+        SG[k_] = v_
+    if lds0 is not None:
+        lds[:len(lds0)] = lds0
     regmap = {}
     for q, (sreg, arr) in enumerate(regions or []):
         SG[sreg], SG[sreg + 1] = 0, q + 1
@@ -608,11 +612,19 @@ def simulate(ins, W, S, iters, consts, regions=None):
         if m in ("label", "s_waitcnt", "s_nop"):
             pass
         elif m == "v_mov_b32":
-            V[int(t[1][1:])] = (t[2] if isinstance(t[2], int) else f32bits(t[2]) if isinstance(t[2], float) else V[int(t[2][1:])])
+            V[int(t[1][1:])] = (t[2] if isinstance(t[2], int) else f32bits(t[2]) if isinstance(t[2], float)
+                                else SG[int(t[2][1:])] if t[2][0] == "s" else V[int(t[2][1:])])
         elif m == "v_cmp_nlt_f32":
             SG["vcc"] = int(not (fval(t[2]) < fval(t[3])))
+        elif m == "v_cmp_lt_f32":
+            SG["vcc"] = int(fval(t[2]) < fval(t[3]))
+        elif m == "v_cndmask_b32_e64":
+            bits = lambda x: f32bits(x) if isinstance(x, float) else x if isinstance(x, int) else int(V[int(x[1:])])
+            V[int(t[1][1:])] = bits(t[3]) if SG["vcc"] else bits(t[2])
+        elif m == "v_cvt_f32_i32":
+            setf(t[1], float(sval(t[2])))
         elif m == "v_cndmask_b32":
-            src0 = f32bits(t[2]) if isinstance(t[2], float) else int(V[int(t[2][1:])])
+            src0 = f32bits(t[2]) if isinstance(t[2], float) else t[2] if isinstance(t[2], int) else int(V[int(t[2][1:])])
             V[int(t[1][1:])] = int(V[int(t[3][1:])]) if SG["vcc"] else src0
         elif m == "v_rsq_f32":
             setf(t[1], 1.0 / np.sqrt(np.float64(fval(t[2]))))
@@ -772,12 +784,47 @@ class RuizPlan:
         assert self.LW_END <= 640 and self.nnzA <= 2 * self.m
 
 
+class ResPlan:
+    """Layout of the RESIDUAL stream of a wave (items behind the loop's stream in the same block, [item][lane] floats): the
+    equilibrated data the residual block reads after the loop, written by the Ruiz block's epilogue (A, E, D, q, P, c) and
+    by the C++ side (the scaled bounds of the equality rows, = their z)."""
+
+    def __init__(self, s, eq_rows, rs0):
+        t = s.tables
+        n, m = s.n, s.m
+        self.s, self.n, self.m, self.rs0 = s, n, m, rs0
+        self.A_p, self.A_i, self.pidx = list(t["A_p"]), list(t["A_i"]), list(t["pidx"])
+        self.eq = set(int(i) for i in eq_rows)
+        idx = rs0
+        self.it_A = idx
+        idx += s.nnzA
+        self.it_rows = idx                  # consumption order from here on
+        self.it_ev, self.it_ls = {}, {}
+        for i in range(m):
+            self.it_ev[i] = idx
+            idx += 1
+            if i in self.eq:
+                self.it_ls[i] = idx
+                idx += 1
+        self.it_d, self.it_q, self.it_p = {}, {}, {}
+        for j in range(n):
+            self.it_d[j], self.it_q[j] = idx, idx + 1
+            idx += 2
+            if self.pidx[j] >= 0:
+                self.it_p[j] = idx
+                idx += 1
+        self.it_c = idx
+        self.end = idx + 1
+
+
 S_AV, S_PV, S_QV = 4, 6, 8          # s[4:5] Av rows, s[6:7] Pv rows, s[8:9] q rows (the block's inputs, [k][B] floats)
+S_RSB, V_RLANE = 24, 210           # Ruiz block with a residual stream: s[24:25] = the wave's stream block, v210 = 4*lane
 S_RMIN, S_RMAX = 20, 21            # 1e-4, 1e4 (float bits, set by the block)
 
 
-def ruiz_program(s):
-    """s11 = number of passes (>= 1). Inputs as above, v0 = 4*robot, v1 = lane LDS address, s10 = 4*B."""
+def ruiz_program(s, res=None):
+    """s11 = number of passes (>= 1). Inputs as above, v0 = 4*robot, v1 = lane LDS address, s10 = 4*B.
+    res: a ResPlan -> the epilogue also writes the equilibrated A, E, D, q, P and c to the wave's residual stream."""
     p = RuizPlan(s)
     n, m = p.n, p.m
     e = Emit()
@@ -943,6 +990,38 @@ def ruiz_program(s):
         e("v_accvgpr_read_b32", v(t), "a%d" % (p.A_P + k))
         base, off = lds_addr(p.LW_P + k)
         e("ds_write_b32", base, v(t), off)
+    if res is not None:
+        assert V_RLANE >= p.V_TT + p.NT
+        e("s_waitcnt", "lgkmcnt(0)")
+
+        def put(item, reg):
+            e("s_add_u32", "s%d" % S_P, "s%d" % S_RSB, (item // BLOCK) * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_RSB + 1), 0)
+            e("global_store_dword", "v%d" % V_RLANE, v(reg), "s[%d:%d]" % (S_P, S_P + 1), (item % BLOCK) * 256)
+        # LDS words (A, D, E) through the ring registers, a group of quads at a time
+        words = [(p.LW_A + k, res.it_A + k) for k in range(p.nnzA)] + [(p.LW_D + j, res.it_d[j]) for j in range(n)] + \
+                [(p.LW_EV + i, res.it_ev[i]) for i in range(m)]
+        item_of = dict(words)
+        quads = sorted(set(w >> 2 for w, _ in words))
+        for g in range(0, len(quads), NRING):
+            grp = quads[g:g + NRING]
+            for q, qd in enumerate(grp):
+                base, off = lds_addr(4 * qd)
+                e("ds_read_b128", "v[%d:%d]" % (p.V_RING + 4 * q, p.V_RING + 4 * q + 3), base, off)
+            e("s_waitcnt", "lgkmcnt(0)")
+            for q, qd in enumerate(grp):
+                for h in range(4):
+                    if 4 * qd + h in item_of:
+                        put(item_of[4 * qd + h], p.V_RING + 4 * q + h)
+        for j in range(n):
+            t_ = T(j % 8)
+            e("v_accvgpr_read_b32", v(t_), "a%d" % (p.A_Q + j))
+            put(res.it_q[j], t_)
+            if p.pidx[j] >= 0:
+                t2 = T(8 + j % 4)
+                e("v_accvgpr_read_b32", v(t2), "a%d" % (p.A_P + p.pidx[j]))
+                put(res.it_p[j], t2)
+        put(res.it_c, T(13))
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
     return e.ins, p
 
@@ -990,3 +1069,189 @@ def loader_program(groups):
                 k += 1
         e("s_waitcnt", "lgkmcnt(0)")
     return e.ins
+
+
+# ---------------------------------------------------------------------------
+# Residuals, termination test and the solution stores after the loop (auxil.c:243-307, osqp.c:524-573), fp32
+# ---------------------------------------------------------------------------
+# hipcc's version of this phase is ~0.45 ms of the p5f tick (arrays in scratch, one exposed access at a time). This block
+# reads x, y, z where the loop left them (LDS), the equilibrated A / E / D / q / P / c from the wave's residual stream
+# (ResPlan: A into AGPRs up front, the rest through the landing registers in consumption order), forms
+#     pri_res = |E^-1 (A x - z)|_inf,  dua_res = |D^-1 (q + P x + A' y)|_inf / c   and the norms of the relative tolerances,
+# stores x, y, z, D x, E y / c to the caller's rows, and decides ONLY the common case: every robot of the wave passes the
+# termination test at the strict tolerances -> status 1 and the info rows are written and LDS word RES_FLAG is 1. Otherwise
+# the flag is 0 and the C++ side redoes the phase for the wave (certificates, inaccurate statuses, cold start: unchanged).
+RES_FLAG = 639
+S_XO, S_YO, S_ZO, S_SX, S_SY, S_ST, S_IN = 24, 26, 28, 30, 32, 34, 36   # pointer pairs: x, y, z, sol_x, sol_y, status, info rows
+S_EPSA, S_EPSR, S_MAXIT = 38, 39, 40                                    # eps_abs, eps_rel (float bits), max_iter (int)
+
+
+class _ResRegs:
+    def __init__(self, m):
+        self.V_ACC = 6          # (even: the LDS ring behind it holds 4-register tuples)
+        self.V_RING = self.V_ACC + m
+        self.V_LAND = self.V_RING + 4 * NRING
+        self.V_AT = self.V_LAND + NLAND
+        self.V_TT = self.V_AT + N_AT
+        self.NT = 12
+        assert self.V_TT + self.NT <= V_END, self.V_TT + self.NT
+        self.n_land = 0
+
+
+def res_program(s, eq_rows, ap, res):
+    """ap: the loop's Plan (LDS words of x, y, z), res: the ResPlan. v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane,
+    s[6:7] = the wave's stream block, s10 = 4*B"""
+    n, m = s.n, s.m
+    R = _ResRegs(m)
+    R.n_land = res.it_c + 1 - res.it_rows          # the landing stream: items it_rows .. it_c
+    e = Emit()
+    v = lambda r: "v%d" % r
+    T = lambda q: R.V_TT + q
+    ACC = lambda i: v(R.V_ACC + i)
+    ab = lambda x: "|" + x + "|"
+    PRI, NZ, NAX, DUA, NQ, NATY, NPX, CINV, C = (T(q) for q in range(9))     # T(9..11): scratch
+
+    def recip(y, t, a_):
+        e("v_rcp_f32", v(y), v(t))
+        e("s_nop", 0)
+        e("v_fma_f32", v(a_), "-" + v(t), v(y), 1.0)
+        e("v_fma_f32", v(y), v(y), v(a_), v(y))
+
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    # A -> AGPRs (direct loads), c
+    for k in range(s.nnzA):
+        it = res.it_A + k
+        if k == 0 or it % BLOCK == 0:
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (it // BLOCK) * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        e("global_load_dword", "a%d" % k, "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (it % BLOCK) * 256)
+    e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (res.it_c // BLOCK) * BLOCK * 256)
+    e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+    e("global_load_dword", v(C), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (res.it_c % BLOCK) * 256)
+    e("s_waitcnt", "vmcnt(0)")
+    recip(CINV, C, T(9))
+    for r in (PRI, NZ, NAX, DUA, NQ, NATY, NPX):
+        e("v_mov_b32", v(r), 0)
+
+    class P_:               # what Sched needs
+        pass
+    pl = P_()
+    pl.V_RING, pl.V_LAND, pl.V_AT, pl.n_land = R.V_RING, R.V_LAND, R.V_AT, R.n_land
+    sc = Sched(e, pl, 0)
+    # the landing stream starts at item it_rows: pointer and block bookkeeping relative to it
+    e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, res.it_rows * 256)
+    e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+    SI = lambda item: ("S", item - res.it_rows)
+    ops = []
+
+    def op(srcs, fn):
+        ops.append(dict(srcs=srcs, emit=fn))
+    # store pointers: running copies of the caller's row pointers (x, y, z, sol_x, sol_y, info), advanced after each store
+    PTR = {"x": 42, "y": 44, "z": 46, "sx": 48, "sy": 50, "in": 52}
+    for name, src in (("x", S_XO), ("y", S_YO), ("z", S_ZO), ("sx", S_SX), ("sy", S_SY), ("in", S_IN)):
+        e("s_mov_b64", "s[%d:%d]" % (PTR[name], PTR[name] + 1), "s[%d:%d]" % (src, src + 1))
+
+    def store(which, reg):
+        b = PTR[which]
+        e("global_store_dword", "v0", v(reg), "s[%d:%d]" % (b, b + 1), 0)
+        e("s_add_u32", "s%d" % b, "s%d" % b, "s%d" % S_STRIDE)
+        e("s_addc_u32", "s%d" % (b + 1), "s%d" % (b + 1), 0)
+    # ---- pass 1: A x by columns into the row accumulators
+    touched = set()
+    for j in range(n):
+        for q in range(res.A_p[j], res.A_p[j + 1]):
+            i = res.A_i[q]
+
+            def f(g, i=i, first=i not in touched):
+                if first:
+                    e("v_mul_f32", ACC(i), v(g[0]), v(g[1]))
+                else:
+                    e("v_fmac_f32", ACC(i), v(g[0]), v(g[1]))
+            op([("A", q), ("L", ap.LW_X + j)], f)
+            touched.add(i)
+    assert len(touched) == m
+    # rows: residual entries, E y / c, stores of y, z
+    for i in range(m):
+        zsrc = SI(res.it_ls[i]) if i in res.eq else ("L", ap.LW_Z + ap.zpos[i])
+        srcs = [SI(res.it_ev[i]), ("L", ap.LW_Y + i), zsrc]
+        if i in res.eq:           # stream items must be named in consumption order
+            srcs = [SI(res.it_ev[i]), SI(res.it_ls[i]), ("L", ap.LW_Y + i)]
+
+        def f(g, i=i, eq=i in res.eq):
+            ev, z, y = (g[0], g[1], g[2]) if eq else (g[0], g[2], g[1])
+            recip(T(9), ev, T(10))                                   # 1 / E_i
+            e("v_sub_f32", v(T(10)), ACC(i), v(z))
+            e("v_mul_f32", v(T(10)), v(T(9)), v(T(10)))
+            e("v_max_f32", v(PRI), v(PRI), ab(v(T(10))))
+            e("v_mul_f32", v(T(10)), v(T(9)), v(z))
+            e("v_max_f32", v(NZ), v(NZ), ab(v(T(10))))
+            e("v_mul_f32", v(T(10)), v(T(9)), ACC(i))
+            e("v_max_f32", v(NAX), v(NAX), ab(v(T(10))))
+            e("v_mul_f32", v(T(11)), v(y), v(ev))
+            e("v_mul_f32", v(T(11)), v(T(11)), v(CINV))              # sol_y = (y E) / c
+            store("y", y)
+            store("z", z)
+            store("sy", T(11))
+        op(srcs, f)
+    op([], lambda g: e("v_max_f32", v(NZ), v(NZ), v(NAX)))            # prim_rel; NAX is a temporary from here on
+    # ---- pass 2: y into the accumulator registers, then columns: A' y, P x, q
+    for i in range(m):
+        op([("L", ap.LW_Y + i)], lambda g, i=i: e("v_mov_b32", ACC(i), v(g[0])))
+    for j in range(n):
+        cols = list(range(res.A_p[j], res.A_p[j + 1]))
+        for qn, q in enumerate(cols):
+            op([("A", q)], lambda g, q=q, qn=qn: e("v_mul_f32" if qn == 0 else "v_fmac_f32", v(T(9)), v(g[0]), ACC(res.A_i[q])))
+        if not cols:
+            op([], lambda g: e("v_mov_b32", v(T(9)), 0))
+        has_p = j in res.it_p
+        srcs = [SI(res.it_d[j]), SI(res.it_q[j])] + ([SI(res.it_p[j])] if has_p else []) + [("L", ap.LW_X + j)]
+
+        def f(g, has_p=has_p):
+            d, qv, x = g[0], g[1], g[-1]
+            if has_p:
+                e("v_mul_f32", v(T(10)), v(g[2]), v(x))              # px
+                e("v_add_f32", v(T(11)), v(qv), v(T(10)))
+                scratch = g[2]                                        # (P_j's landing register is dead now)
+            else:
+                e("v_mov_b32", v(T(11)), v(qv))
+                scratch = T(10)
+            e("v_add_f32", v(T(11)), v(T(11)), v(T(9)))               # (q + P x) + A' y     [T(9) = A' y]
+            e("v_mul_f32", v(NAX), v(x), v(d))                        # sol_x = x D
+            store("x", x)
+            store("sx", NAX)
+            recip(NAX, d, scratch)                                    # 1 / D_j
+            e("v_mul_f32", v(T(11)), v(NAX), v(T(11)))
+            e("v_max_f32", v(DUA), v(DUA), ab(v(T(11))))
+            e("v_mul_f32", v(T(11)), v(NAX), v(qv))
+            e("v_max_f32", v(NQ), v(NQ), ab(v(T(11))))
+            e("v_mul_f32", v(T(11)), v(NAX), v(T(9)))
+            e("v_max_f32", v(NATY), v(NATY), ab(v(T(11))))
+            if has_p:
+                e("v_mul_f32", v(T(11)), v(NAX), v(T(10)))
+                e("v_max_f32", v(NPX), v(NPX), ab(v(T(11))))
+        op(srcs, f)
+    sc.run(ops)
+    # ---- termination test at the strict tolerances (osqp.c:524-573), flag, status and info rows
+    e("v_mul_f32", v(DUA), v(CINV), v(DUA))
+    e("v_max_f32", v(NQ), v(NQ), v(NATY))
+    e("v_max_f32", v(NQ), v(NQ), v(NPX))
+    e("v_mul_f32", v(NQ), v(NQ), v(CINV))                              # dual_rel (prim_rel is in NZ)
+    e("v_mov_b32", v(T(9)), "s%d" % S_EPSA)
+    e("v_fma_f32", v(T(10)), "s%d" % S_EPSR, v(NZ), v(T(9)))
+    e("v_fma_f32", v(T(11)), "s%d" % S_EPSR, v(NQ), v(T(9)))
+    e("v_cmp_lt_f32", "vcc", v(PRI), v(T(10)))
+    e("v_cndmask_b32_e64", v(T(9)), 0, 1.0, "vcc")
+    e("v_cmp_lt_f32", "vcc", v(DUA), v(T(11)))
+    e("v_cndmask_b32", v(T(10)), 0, v(T(9)), "vcc")                    # 1.0 iff both tests pass
+    base, off = lds_addr(RES_FLAG)
+    e("ds_write_b32", base, v(T(10)), off)
+    e("v_mov_b32", v(T(9)), 1)
+    e("global_store_dword", "v0", v(T(9)), "s[%d:%d]" % (S_ST, S_ST + 1), 0)
+    e("v_cvt_f32_i32", v(NAX), "s%d" % S_MAXIT)
+    e("v_mov_b32", v(NATY), 0)
+    for reg in (PRI, DUA, C, NATY, NAX, NATY):                         # info rows: pri, dua, c, 0 (no zero pivot), max_iter, 0
+        store("in", reg)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    return e.ins, R

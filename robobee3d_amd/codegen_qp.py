@@ -38,6 +38,8 @@ def builtin_structures():
 
 ASM_STRUCTURES = {"p5f10": list(range(77))}   # structure -> rows assumed to be equalities by the assembly loop (asmqp.py)
 ASM_STREAM_ROW = 1024                          # the hand-off rows of an assembly specialisation stay below this row
+ASM_STREAM_ITEMS = 2048                        # items of a wave's stream block: the loop's stream, then the residual stream
+ASM_RES_ITEM0 = 600                            # first item of the residual stream (asmqp.ResPlan)
 
 
 def emit_structure(name, s, asm=None):
@@ -76,6 +78,9 @@ def emit_structure(name, s, asm=None):
         E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
         E("  auto uni = [](unsigned long long v_) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v_); };  // (the builtin returns int: no sign extension)")
         E("  const unsigned voff = (unsigned)b * 4u, s_stride = __builtin_amdgcn_readfirstlane((unsigned)a.B * 4u);")
+        E("  T *const sblk = a.S + (size_t)wave * %d;   // this wave's stream block ([item][lane]); wave-uniform (SGPR) base" % (ASM_STREAM_ITEMS * 64))
+        E("  const unsigned long long ssp = a.asm_ok ? uni((unsigned long long)sblk) : 0ull;")
+        E("  const unsigned lane4 = (unsigned)threadIdx.x * 4u;")
         E("  BQP_%s_LOAD_XYZ(voff, ldsaddr, uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_stride);" % name.upper())
         for j in range(n):
             E("  D[%d] = T(1.0); x[%d] = LDSQ(%d);" % (j, j, j))
@@ -102,10 +107,12 @@ def emit_structure(name, s, asm=None):
         RP = asm.ruiz
         E("  // scaling.c:44-156 as generated assembly (asmqp.ruiz_program): the block fetches Pv, Av, q in batches, keeps the row")
         E("  // scalings in VGPRs, Dt / P / q in AGPRs, A and the accumulated D, E in LDS, and leaves everything in LDS")
+        E("  bool rs_valid = false;   // the residual stream is written (by the Ruiz block; the residual block needs it)")
         E("  if (a.scaling >= 1) {")
         E("    const unsigned s_pass = __builtin_amdgcn_readfirstlane((unsigned)a.scaling);")
         E("    const unsigned long long avp = uni((unsigned long long)a.Av), pvp = uni((unsigned long long)a.Pv), qvp = uni((unsigned long long)a.q);")
-        E("    BQP_%s_RUIZ_ASM(voff, ldsaddr, avp, pvp, qvp, s_stride, s_pass);" % name.upper())
+        E("    if (a.asm_ok) { BQP_%s_RUIZ_RS_ASM(voff, ldsaddr, lane4, avp, pvp, qvp, ssp, s_stride, s_pass); rs_valid = true; }" % name.upper())
+        E("    else BQP_%s_RUIZ_ASM(voff, ldsaddr, avp, pvp, qvp, s_stride, s_pass);" % name.upper())
         for k in range(s.nnzA):
             E("    As[%d] = LDSQ(%d);" % (k, RP.LW_A + k))
         for k in range(s.nnzP):
@@ -155,6 +162,10 @@ def emit_structure(name, s, asm=None):
         for i in range(m):
             E("  ls[%d] = LDSQ(%d) * Ev[%d]; us[%d] = LDSQ(%d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, m + i, i, i, i))
         E("#undef LDSQ")
+        E("  if (a.asm_ok) {   // z of the equality rows (= their scaled bound) for the residual block")
+        for i in sorted(asm.res.it_ls):
+            E("    sblk[%d + threadIdx.x] = ls[%d];" % (asm.res.it_ls[i] * 64, i))
+        E("  }")
     else:
         for i in range(m):
             E("  ls[%d] = IN(a.l, %d) * Ev[%d]; us[%d] = IN(a.u, %d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, i, i, i, i))
@@ -223,6 +234,7 @@ def emit_structure(name, s, asm=None):
         for i in sorted(r["i"] for r in P.rows if r["eq"]):
             E("  eqok = eqok && (rho[%d] == rho_eq) && (ls[%d] == us[%d]);" % (i, i, i))
         E("  const int mid = a.max_iter - 2;")
+        E("  bool resdone = false;")
         E("  const bool use_asm = mid >= 1 && __all(eqok);")
         E("  if (a.max_iter >= 1) iterate();")
         mark(3)
@@ -240,13 +252,12 @@ def emit_structure(name, s, asm=None):
         for i, q in sorted(P.zpos.items()):
             E("    IN(a.W, %d) = z[%d];" % (P.R_Z + q, i))
         nst = P.n_stream + len(P.extra)
-        E("    T *const sblk = a.S + (size_t)wave * %d;   // wave-uniform (SGPR) base" % (nst * 64))
         src = {"rinv": "rinv[%d]", "l": "ls[%d]", "u": "us[%d]", "rho": "rho[%d]", "q": "qs[%d]"}
         for q, (what, i) in enumerate(P.stream + P.extra):
             E("    sblk[%d + threadIdx.x] = %s;" % (q * 64, src[what] % i))
         mark(4)
         E("    {")
-        E("      const unsigned lane4 = (unsigned)threadIdx.x * 4u, stride = (unsigned)a.B * 4u;")
+
         E("      // float constants come straight from the kernel arguments (SGPRs): a value computed with float arithmetic lives")
         E("      // in a VGPR and hipcc fails to copy it back (\"illegal VGPR to SGPR copy\"), so 1 - alpha and 1/rho_eq are the host's")
         E("      const unsigned s_alpha = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.alpha));")
@@ -254,13 +265,25 @@ def emit_structure(name, s, asm=None):
         E("      const unsigned s_sigma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.sigma));")
         E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
         E("      // every scalar operand is made provably wave-uniform (the values are; the compiler cannot always see it)")
-        E("      const unsigned long long wsp = uni((unsigned long long)a.W), ssp = uni((unsigned long long)sblk);")
-        E("      const unsigned s_stride = __builtin_amdgcn_readfirstlane(stride), s_mid = __builtin_amdgcn_readfirstlane((unsigned)mid);")
+        E("      const unsigned long long wsp = uni((unsigned long long)a.W);")
+        E("      const unsigned s_mid = __builtin_amdgcn_readfirstlane((unsigned)mid);")
         E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq);" % name.upper())
         E("    }")
         mark(5)
-        E("    // the loop left x, y, z of the inequality rows, x_prev and delta_y in LDS (float4-interleaved words)")
         E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
+        E("    // residuals, the termination test at the strict tolerances and the solution stores as generated assembly")
+        E("    // (asmqp.res_program); it settles the wave only if every robot is SOLVED -- otherwise the C++ phase below runs")
+        E("    if (rs_valid && a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
+        E("      const unsigned s_epsa = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.eps_abs));")
+        E("      const unsigned s_epsr = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.eps_rel));")
+        E("      const unsigned s_maxit = __builtin_amdgcn_readfirstlane((unsigned)a.max_iter);")
+        E("      BQP_%s_RES_ASM(voff, ldsaddr, lane4, ssp, s_stride, uni((unsigned long long)a.x), uni((unsigned long long)a.y), "
+          "uni((unsigned long long)a.z), uni((unsigned long long)a.sol_x), uni((unsigned long long)a.sol_y), "
+          "uni((unsigned long long)a.status), uni((unsigned long long)a.info), s_epsa, s_epsr, s_maxit);" % name.upper())
+        E("      resdone = __all(LDSQ(%d) == T(1.0));" % 639)
+        E("    }")
+        E("    if (!resdone) {")
+        E("    // the loop left x, y, z of the inequality rows, x_prev and delta_y in LDS (float4-interleaved words)")
         for j in range(n):
             E("    x[%d] = LDSQ(%d);" % (j, P.LW_X + j))
         for i in range(m):
@@ -274,6 +297,7 @@ def emit_structure(name, s, asm=None):
             E("    xp[%d] = LDSQ(%d);" % (j, P.LW_XP + j))
         for i in range(m):
             E("    dy[%d] = LDSQ(%d);" % (i, P.LW_DY + i))
+        E("    }")
         E("#undef LDSQ")
         E("  } else {")
         E("#pragma nounroll")
@@ -282,6 +306,8 @@ def emit_structure(name, s, asm=None):
         E("  }")
     mark(6)
     # ---- residuals
+    if asm:
+        E("  if (!resdone) {")
     E("  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);")
     for i in range(m):
         E("  { T acc = T(0.0);")
@@ -354,6 +380,8 @@ def emit_structure(name, s, asm=None):
           "IN(a.z, %d) = bad ? T(0.0) : z[%d];" % (i, i, i, i, i, i, i))
     E("  if (a.status) a.status[b] = status;")
     E("  if (a.info) { IN(a.info, 0) = pri_res; IN(a.info, 1) = dua_res; IN(a.info, 2) = c; IN(a.info, 3) = fail ? T(1) : T(0); IN(a.info, 4) = T(a.max_iter); IN(a.info, 5) = T(0); }")
+    if asm:
+        E("  }")
     if TIMING:
         E("  tmark[7] = __builtin_amdgcn_s_memrealtime();")
         E("  if (a.info) { IN(a.info, 0) = T(tmark[1] - tmark[0]); IN(a.info, 1) = T(tmark[2] - tmark[1]); IN(a.info, 2) = T(tmark[3] - tmark[2]); "
@@ -406,10 +434,38 @@ def asm_macro(name, ins, plan):
     return "\n".join(out) + "\n"
 
 
-def ruiz_macro(name, ins, rp):
+def res_macro(name, ins):
     from . import asmqp
-    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, asmqp.V_END)] + ['"a%d"' % i for i in range(256)] + \
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
+           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in [asmqp.S_SP, asmqp.S_SP + 1] + list(range(42, 54))]
+    out = ["// Residuals, strict termination test and solution stores after the loop (asmqp.res_program): %d instructions." % len(ins),
+           "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[6:7] = the wave's stream block, s10 = 4*B,",
+           "// s[24:25] .. s[36:37] = x, y, z, sol_x, sol_y, status, info rows, s38 / s39 = eps_abs / eps_rel (float bits), s40 = max_iter",
+           "#define BQP_%s_RES_ASM(voff, ldsaddr, lane4, sblk, stride, xo, yo, zo, sxo, syo, sto, ino, epsa, epsr, maxit) asm volatile( \\" % name.upper()]
+    for t_ in ins:
+        out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[6:7]}"(sblk), "{s10}"(stride), "{s[24:25]}"(xo), '
+               '"{s[26:27]}"(yo), "{s[28:29]}"(zo), "{s[30:31]}"(sxo), "{s[32:33]}"(syo), "{s[34:35]}"(sto), "{s[36:37]}"(ino), '
+               '"{s38}"(epsa), "{s39}"(epsr), "{s40}"(maxit) \\')
+    out.append("  : " + ", ".join(clob) + ")")
+    return "\n".join(out) + "\n"
+
+
+def ruiz_macro(name, ins, rp, rs=False):
+    from . import asmqp
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, asmqp.V_END) if not (rs and i == asmqp.V_RLANE)] + \
+           ['"a%d"' % i for i in range(256)] + \
            ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_RMIN, asmqp.S_RMAX)]
+    if rs:
+        lab7 = [k for k, t_ in enumerate(ins) if t_ == ("label", "7")][0]
+        out = ["// The same passes, and the equilibrated A, E, D, q, P, c written to the wave's residual stream (s[24:25], v%d = 4*lane)." % asmqp.V_RLANE,
+               "#define BQP_%s_RUIZ_RS_ASM(voff, ldsaddr, lane4, av, pv, qv, sblk, stride, passes) asm volatile( \\" % name.upper()]
+        for t_ in ins:
+            out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+        out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v%d}"(lane4), "{s[4:5]}"(av), "{s[6:7]}"(pv), "{s[8:9]}"(qv), '
+                   '"{s[24:25]}"(sblk), "{s10}"(stride), "{s11}"(passes) \\' % asmqp.V_RLANE)
+        out.append("  : " + ", ".join(clob) + ")")
+        return "\n".join(out) + "\n"
     lab7 = [k for k, t_ in enumerate(ins) if t_ == ("label", "7")][0]
     br = [k for k, t_ in enumerate(ins) if t_[0] == "s_cbranch_scc1"][0]
     out = ["// The Ruiz passes of the %s structure (asmqp.ruiz_program), fp32: %d instructions, %d per pass." % (name, len(ins), br - lab7),
@@ -448,10 +504,16 @@ def generate():
         if name in ASM_STRUCTURES:
             from . import asmqp
             ins, plan = asmqp.program(s, ASM_STRUCTURES[name])
+            assert plan.n_stream + len(plan.extra) <= ASM_RES_ITEM0
+            plan.res = asmqp.ResPlan(s, ASM_STRUCTURES[name], ASM_RES_ITEM0)
+            assert plan.res.end <= ASM_STREAM_ITEMS
             rins, plan.ruiz = asmqp.ruiz_program(s)
+            rsins, _ = asmqp.ruiz_program(s, plan.res)
+            resins, _ = asmqp.res_program(s, ASM_STRUCTURES[name], plan, plan.res)
             asm_body = emit_structure(name, s, asm=plan)
             asm_hdr = "bqp_%s_asm.h" % name
             files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + ruiz_macro(name, rins, plan.ruiz) + \
+                ruiz_macro(name, rsins, plan.ruiz, rs=True) + res_macro(name, resins) + \
                 loader_macro(name, "XYZ", [(s.n, 0), (s.m, s.n), (s.m, s.n + s.m)]) + \
                 loader_macro(name, "LUE", [(s.m, 0), (s.m, s.m), (s.m, 2 * s.m)])
         for tag, ctype in DTYPES:

@@ -812,9 +812,9 @@ struct qp_batch {
 };
 
 // assembly specialisations (gen/bqp_*_asm.h, fp32) keep one iteration's read-only words in a [wave][item][lane] block
-// (1024 items bound every built-in structure) that umpcQPCreate allocates behind the workspace rows, and hand the
+// (2048 items: the loop's stream, then the residual stream) that umpcQPCreate allocates behind the workspace rows, and hand the
 // factor over through the first 1024 rows. UMPC_QP_NO_ASM=1 disables them.
-size_t asm_tail_elems(int B) { return (size_t)((B + 63) / 64) * 64 * 1024; }
+size_t asm_tail_elems(int B) { return (size_t)((B + 63) / 64) * 64 * 2048; }   // codegen_qp.ASM_STREAM_ITEMS per wave
 bool asm_room(const qp_batch *h) {
   static const bool no_asm = getenv("UMPC_QP_NO_ASM") != nullptr;
   return !no_asm && !h->no_asm && h->asm_tail > 0 && h->nrows >= 1024;

@@ -165,3 +165,83 @@ def test_generated_p5f_ruiz_block_matches_numpy(passes):
                                ("E", lds[p.LW_EV:p.LW_EV + p.m], Er)):
             assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max(), (name, passes, scale)
         assert abs(lds[p.LW_C] - cr) <= 5e-6 * cr
+
+
+def _p5f():
+    from robobee3d_amd import asmqp, batchqp, codegen_qp, qpstruct
+    st = batchqp.p5f_structure(10)
+    s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    return asmqp, s, eq, asmqp.Plan(s, eq), asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
+
+
+def test_ruiz_block_writes_the_residual_stream():
+    """with a ResPlan the Ruiz block's epilogue also leaves the equilibrated A, E, D, q, P, c in the wave's residual stream"""
+    asmqp, s, eq, ap, res = _p5f()
+    ins, p = asmqp.ruiz_program(s, res)
+    rng = np.random.default_rng(5)
+    P = np.abs(rng.normal(size=p.nnzP)).astype(np.float32) + 0.1
+    A = rng.normal(size=p.nnzA).astype(np.float32)
+    q = rng.normal(size=p.n).astype(np.float32)
+    S = np.full(res.end, np.nan, np.float32)
+    lds = asmqp.simulate(ins, np.zeros(1, np.float32), S, 3, (1.6, 1e-6, 0.01),
+                         regions=[(asmqp.S_AV, A), (asmqp.S_PV, P), (asmqp.S_QV, q)], sgpr={asmqp.S_RSB: 1 << 30, asmqp.S_RSB + 1: 0})
+    assert np.array_equal(S[res.it_A:res.it_A + p.nnzA], lds[p.LW_A:p.LW_A + p.nnzA])
+    for i in range(p.m):
+        assert S[res.it_ev[i]] == lds[p.LW_EV + i]
+    for j in range(p.n):
+        assert S[res.it_d[j]] == lds[p.LW_D + j] and S[res.it_q[j]] == lds[p.LW_Q + j]
+        if j in res.it_p:
+            assert S[res.it_p[j]] == lds[p.LW_P + p.pidx[j]]
+    assert S[res.it_c] == lds[p.LW_C]
+    assert all(np.isnan(S[res.it_ls[i]]) for i in res.it_ls)       # (the C++ side writes these)
+
+
+@pytest.mark.parametrize("eps, expect", [(1e-3, 0.0), (1e3, 1.0)])
+def test_residual_block_matches_numpy(eps, expect):
+    """pri_res / dua_res, the strict termination flag, the info rows and the solution stores of asmqp.res_program against a
+    float64 statement of auxil.c:243-307 + osqp.c:524-573 on random data (the flag must follow the test, both ways)"""
+    asmqp, s, eq, ap, res = _p5f()
+    ins, R = asmqp.res_program(s, eq, ap, res)
+    rng = np.random.default_rng(0)
+    n, m = s.n, s.m
+    f32 = lambda a: a.astype(np.float32)
+    A, P, q = f32(rng.normal(size=s.nnzA)), f32(np.abs(rng.normal(size=s.nnzP))), f32(rng.normal(size=n))
+    D, Ev, c = f32(np.abs(rng.normal(size=n)) + 0.5), f32(np.abs(rng.normal(size=m)) + 0.5), np.float32(0.7)
+    x, y, z = f32(rng.normal(size=n)), f32(rng.normal(size=m)), f32(rng.normal(size=m))
+    Ax, Aty = np.zeros(m), np.zeros(n)
+    for j in range(n):
+        for k in range(res.A_p[j], res.A_p[j + 1]):
+            Ax[res.A_i[k]] += float(A[k]) * float(x[j])
+            Aty[j] += float(A[k]) * float(y[res.A_i[k]])
+    einv, dinv = 1 / Ev.astype(np.float64), 1 / D.astype(np.float64)
+    px = np.array([float(P[res.pidx[j]]) * float(x[j]) if res.pidx[j] >= 0 else 0.0 for j in range(n)])
+    pri, dua = np.abs(einv * (Ax - z)).max(), np.abs(dinv * (q + px + Aty)).max() / c
+    prel = max(np.abs(einv * z).max(), np.abs(einv * Ax).max())
+    drel = max(np.abs(dinv * q).max(), np.abs(dinv * Aty).max(), np.abs(dinv * px).max()) / c
+    assert float(pri < eps + eps * prel and dua < eps + eps * drel) == expect
+    S = np.zeros(res.end, np.float32)
+    S[res.it_A:res.it_A + s.nnzA] = A
+    for i in range(m):
+        S[res.it_ev[i]] = Ev[i]
+        if i in res.eq:
+            S[res.it_ls[i]] = z[i]
+    for j in range(n):
+        S[res.it_d[j]], S[res.it_q[j]] = D[j], q[j]
+        if j in res.it_p:
+            S[res.it_p[j]] = P[res.pidx[j]]
+    S[res.it_c] = c
+    lds0 = np.zeros(640, np.float32)
+    lds0[ap.LW_X:ap.LW_X + n], lds0[ap.LW_Y:ap.LW_Y + m] = x, y
+    for i, qq in ap.zpos.items():
+        lds0[ap.LW_Z + qq] = z[i]
+    xo, yo, zo, sx, sy = [np.full(k, np.nan, np.float32) for k in (n, m, m, n, m)]
+    stt, info = np.zeros(1, np.float32), np.zeros(6, np.float32)
+    sg = {asmqp.S_EPSA: asmqp.f32bits(eps), asmqp.S_EPSR: asmqp.f32bits(eps), asmqp.S_MAXIT: 50}
+    lds = asmqp.simulate(ins, np.zeros(1, np.float32), S, 1, (1.6, 1e-6, 0.01),
+                         regions=[(asmqp.S_XO, xo), (asmqp.S_YO, yo), (asmqp.S_ZO, zo), (asmqp.S_SX, sx), (asmqp.S_SY, sy),
+                                  (asmqp.S_ST, stt), (asmqp.S_IN, info)], sgpr=sg, lds0=lds0)
+    assert lds[asmqp.RES_FLAG] == expect
+    assert abs(info[0] - pri) <= 2e-6 * pri and abs(info[1] - dua) <= 2e-6 * dua and info[2] == c and info[3] == 0 and info[4] == 50
+    assert np.array_equal(xo, x) and np.array_equal(yo, y) and np.array_equal(zo, z)
+    assert np.abs(sx - x * D).max() <= 1e-6 * np.abs(x * D).max() and np.abs(sy - y * Ev / c).max() <= 1e-6 * np.abs(y * Ev / c).max()
