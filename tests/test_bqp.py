@@ -613,9 +613,20 @@ def test_gpu_p5f_assembly_loop_agrees_with_the_table_kernel(margin):
                 mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
             torch.cuda.synchronize()
             res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x, mpc.qp.Eprev)]
-                       + [mpc.qp.status.cpu().numpy().copy(), mpc.qp.info.cpu().numpy().copy()])
+                       + [mpc.qp.status.cpu().numpy().copy(), mpc.qp.info.cpu().numpy().astype(np.float64).copy(),
+                          mpc.qp.sol_y.cpu().numpy().astype(np.float64).copy()])
         worst = max(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) for a, b in zip(res[0][:5], res[1][:5]))
         margin("B=%d, %d Ruiz passes: iterates / solution, |d| / max(1, |ref|)" % (B, scaling), worst, 3e-6)
+        # what the residual block writes: the scaled multipliers, the residuals and the bookkeeping rows of info
+        margin("B=%d, %d Ruiz passes: sol_y, |d| / max(1, |ref|)" % (B, scaling),
+               np.max(np.abs(res[0][7] - res[1][7]) / np.maximum(1.0, np.abs(res[1][7]))), 1e-5)
+        ia, ib = res[0][6], res[1][6]
+        # (at convergence the residuals are differences of nearly equal numbers: two fp32 evaluations agree in magnitude only)
+        ratio = np.maximum(ia[:2], 1e-12) / np.maximum(ib[:2], 1e-12)
+        margin("B=%d, %d Ruiz passes: pri_res, dua_res, median ratio (max of r, 1/r)" % (B, scaling),
+               np.median(np.maximum(ratio, 1.0 / ratio)), 3.0)
+        margin("B=%d, %d Ruiz passes: pri_res, dua_res, |d|" % (B, scaling), np.max(np.abs(ia[:2] - ib[:2])), 1e-5)
+        assert np.array_equal(ia[3:], ib[3:]) and np.max(np.abs(ia[2] - ib[2]) / ib[2]) <= 1e-5
         assert np.count_nonzero(res[0][5] != res[1][5]) <= B // 8
         assert np.all(np.isfinite(res[0][0]))
 
