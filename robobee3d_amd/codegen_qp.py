@@ -236,7 +236,13 @@ def emit_structure(name, s, asm=None):
         E("  const int mid = a.max_iter - 2;")
         E("  bool resdone = false;")
         E("  const bool use_asm = mid >= 1 && __all(eqok);")
-        E("  if (a.max_iter >= 1) iterate();")
+        E("  // the first iteration needs C++ only where the warm-start z of an equality row differs from its bound (the loop")
+        E("  // takes z == l there); with constant bounds -- p5f -- it never does after the first call")
+        E("  bool z0ok = true;")
+        for i in sorted(r["i"] for r in P.rows if r["eq"]):
+            E("  z0ok = z0ok && (z[%d] == ls[%d]);" % (i, i))
+        E("  const bool asm_first = use_asm && __all(z0ok);")
+        E("  if (a.max_iter >= 1 && !asm_first) iterate();")
         mark(3)
         E("  if (use_asm) {")
         E("    // hand-off: negated L in the loop's storage order, 1/D, x, y, z of the inequality rows -> workspace rows;")
@@ -266,7 +272,7 @@ def emit_structure(name, s, asm=None):
         E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
         E("      // every scalar operand is made provably wave-uniform (the values are; the compiler cannot always see it)")
         E("      const unsigned long long wsp = uni((unsigned long long)a.W);")
-        E("      const unsigned s_mid = __builtin_amdgcn_readfirstlane((unsigned)mid);")
+        E("      const unsigned s_mid = __builtin_amdgcn_readfirstlane((unsigned)(asm_first ? mid + 1 : mid));")
         E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq);" % name.upper())
         E("    }")
         mark(5)
