@@ -126,8 +126,8 @@ class Sched:
     AGPR words two ops ahead, stream items through the landing registers. op = dict(srcs=[...], emit=fn(regs)),
     src = ('L', lds word) | ('A', agpr) | ('S', stream item) | ('V', vgpr). emit may call lds_write()."""
 
-    def __init__(self, e, plan, vm_outstanding):
-        self.e, self.p = e, plan
+    def __init__(self, e, plan, vm_outstanding, la=3):
+        self.e, self.p, self.la = e, plan, la    # la: ops of look-ahead for AGPR reads (0: right before use)
         self.nlds = 0                       # LDS instructions issued so far (reads and writes complete in order)
         self.nvm = vm_outstanding           # VMEM loads issued so far; the first `vm_outstanding` are the preloads
         self.vmpos = {}                     # stream item -> its load's issue index
@@ -195,7 +195,7 @@ class Sched:
             op = ops[i]
             if op.get("flush"):
                 continue
-            while next_acc < n and next_acc < i + 3:
+            while next_acc < n and next_acc < i + max(1, self.la):
                 for q, src in enumerate(ops[next_acc].get("srcs", [])):
                     if src[0] == "A":
                         t = p.V_AT + acc_rr % N_AT
@@ -406,11 +406,11 @@ def body(e, p, capture=False):
         preloads(e, p)
 
 
-def _row_ptr(e, sreg, row):
+def _row_ptr(e, sreg, row, base=S_W):
     e("s_mul_i32", "s%d" % sreg, "s%d" % S_STRIDE, row)
     e("s_mul_hi_u32", "s%d" % (sreg + 1), "s%d" % S_STRIDE, row)
-    e("s_add_u32", "s%d" % sreg, "s%d" % sreg, "s%d" % S_W)
-    e("s_addc_u32", "s%d" % (sreg + 1), "s%d" % (sreg + 1), "s%d" % (S_W + 1))
+    e("s_add_u32", "s%d" % sreg, "s%d" % sreg, "s%d" % base)
+    e("s_addc_u32", "s%d" % (sreg + 1), "s%d" % (sreg + 1), "s%d" % (base + 1))
 
 
 def _adv(e, sreg):
@@ -447,7 +447,11 @@ def prologue(e, p):
     for k in range(p.nk):
         e("global_load_dword", "a%d" % k, "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
         _adv(e, S_P)
-    # once-only stream items (l of the leaf equality rows) -> their registers
+    prologue_tail(e, p)
+
+
+def prologue_tail(e, p):
+    """once-only stream items (l of the leaf equality rows) -> their registers; the first iteration's preloads"""
     idx = p.n_stream
     for q, (_, i) in enumerate(p.extra):
         e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, ((idx + q) // BLOCK) * BLOCK * 256)
@@ -463,11 +467,91 @@ def epilogue(e, p):
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
 
-def program(s, eq_rows):
-    """s11 = number of non-capturing iterations (>= 0); one capturing iteration follows them"""
+S_FAST, S_XI, S_YI, S_ZI = 30, 24, 26, 28    # fast start: flag, the caller's x, y, z rows ([row][B] floats)
+FAC_MIN = 638                                # LDS word: min |d_k| of the factorisation (0 = a zero pivot)
+
+
+def prologue_fast(e, p, res):
+    """KKT fill + LDL' inside the block (factor_emit): the equilibrated A and P come from the wave's residual stream (written
+    by the Ruiz block), 1/rho of the inequality rows from the loop's stream, the warm start straight from the caller's rows.
+    -L lands in the loop's LDS words, 1/D in its AGPRs: no hand-off rows at all."""
+    s = p.s
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    cur = [None]
+
+    def sload(reg, idx):
+        if idx // BLOCK != cur[0]:
+            cur[0] = idx // BLOCK
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, cur[0] * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        e("global_load_dword", "v%d" % reg, "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
+    # A -> LDS words LW_X.. (the x, y, z words: the warm start arrives after the factorisation)
+    assert p.LW_X + s.nnzA <= 640
+    G = V_END - V_W
+    for g in range(0, s.nnzA, G):
+        ks = list(range(g, min(s.nnzA, g + G)))
+        for q, k in enumerate(ks):
+            sload(V_W + q, res.it_A + k)
+        e("s_waitcnt", "vmcnt(0)")
+        for q, k in enumerate(ks):
+            base, off = lds_addr(p.LW_X + k)
+            e("ds_write_b32", base, "v%d" % (V_W + q), off)
+        e("s_waitcnt", "lgkmcnt(0)")
+    # P, 1/rho of the inequality rows -> registers for the whole factorisation
+    v_p, v_rinv = V_W, V_W + s.nnzP
+    gen = sorted(p.zpos, key=lambda i: p.zpos[i])
+    pool0 = v_rinv + len(gen)
+    assert pool0 + 30 <= p.V_RING
+    for j in sorted(res.it_p):
+        sload(v_p + res.pidx[j], res.it_p[j])
+    for q, i in enumerate(gen):
+        assert p.stream[q] == ("rinv", i)
+        sload(v_rinv + q, q)
+    v_fmin = p.V_TT + N_TT - 1
+    e("v_mov_b32", "v%d" % v_fmin, 1.0)
+    e("s_waitcnt", "vmcnt(0)")
+    factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING)),
+                list(range(p.V_LAND, p.V_LAND + NLAND)), v_fmin)
+    base, off = lds_addr(FAC_MIN)
+    e("ds_write_b32", base, "v%d" % v_fmin, off)
+    e("s_waitcnt", "lgkmcnt(0)")
+    # the warm start: x, y, z of the inequality rows -> LDS
+    rows = [(S_XI, j, p.LW_X + j) for j in range(p.n)] + [(S_YI, i, p.LW_Y + i) for i in range(p.m)] + \
+           [(S_ZI, i, p.LW_Z + p.zpos[i]) for i in gen]
+    for g in range(0, len(rows), G):
+        grp = rows[g:g + G]
+        last = None
+        for q, (sb, row, word) in enumerate(grp):
+            if last is None or (sb, row) != (last[0], last[1] + 1):
+                _row_ptr(e, S_P, row, sb)
+            else:
+                _adv(e, S_P)
+            last = (sb, row)
+            e("global_load_dword", "v%d" % (V_W + q), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+        e("s_waitcnt", "vmcnt(0)")
+        for q, (sb, row, word) in enumerate(grp):
+            base, off = lds_addr(word)
+            e("ds_write_b32", base, "v%d" % (V_W + q), off)
+        e("s_waitcnt", "lgkmcnt(0)")
+    prologue_tail(e, p)
+
+
+def program(s, eq_rows, res=None):
+    """s11 = number of non-capturing iterations (>= 0); one capturing iteration follows them.
+    res: a ResPlan -> the block also holds the fast start (prologue_fast), taken when s30 != 0"""
     p = Plan(s, eq_rows)
     e = Emit()
+    if res is not None:
+        e("s_cmp_lg_u32", "s%d" % S_FAST, 0)
+        e("s_cbranch_scc1", "5f")
     prologue(e, p)
+    if res is not None:
+        e("s_branch", "6f")
+        e("label", "5")
+        prologue_fast(e, p, res)
+        e("label", "6")
     e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
     e("s_cbranch_scc1", "8f")
@@ -499,7 +583,7 @@ def fmt(t):
 # ---------------------------------------------------------------------------
 # CPU interpreter (one lane) and a numpy statement of the same iteration
 # ---------------------------------------------------------------------------
-def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None):
+def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_agpr=False):
     """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
     Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there)."""
     f32 = np.float32
@@ -656,6 +740,11 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None):
             a = sval(t[1])
             a = a - (1 << 32) if a & 0x80000000 else a
             scc = int(a > sval(t[2])) if m == "s_cmp_gt_i32" else int(a < sval(t[2]))
+        elif m == "s_cmp_lg_u32":
+            scc = int(sval(t[1]) != sval(t[2]))
+        elif m == "s_branch":
+            lab = t[1][:-1]
+            pc = min(c for c in labels[lab] if c > pc)
         elif m == "s_cbranch_scc1":
             if scc:
                 lab, d = t[1][:-1], t[1][-1]
@@ -708,6 +797,8 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None):
         else:
             raise ValueError("unknown instruction %r" % (t,))
         pc += 1
+    if ret_agpr:
+        return lds, np.array([bits2f(b) for b in A], np.float32)
     return lds
 
 
@@ -1255,3 +1346,79 @@ def res_program(s, eq_rows, ap, res):
         store("in", reg)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
     return e.ins, R
+
+
+# ---------------------------------------------------------------------------
+# KKT fill + LDL' (kkt.c:184-222, qdldl.c:86-247) of a build-time-known structure, fp32, into the loop's homes
+# ---------------------------------------------------------------------------
+def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, v_pin, v_fmax):
+    """Emits the up-looking factorisation recorded in s.factor_ops: -L goes to the loop's LDS words (p.lpos), 1/D to the
+    loop's AGPRs (a[k], permuted index k); v_fmax accumulates min |d_k| (0 = a zero pivot, qdldl.c:221-224).
+    lw_a: LDS word of A entry 0 (the equilibrated A, CSC order); v_p: first VGPR of P (nnzP); v_rinv: first VGPR of 1/rho of
+    the inequality rows in gen_pos order; equality rows use s_rinveq; v_pool: list of temporaries; v_pin: temporaries that
+    keep the L entries a later row's elimination multiplies again."""
+    n, nk = s.n, s.nk
+    t = s.tables
+    pidx = list(t["pidx"])
+    v = lambda r: "v%d" % r
+    reused = sorted({j for op_ in s.factor_ops for (_, upd, _) in op_["elim"] for (j, _) in upd})
+    assert len(reused) <= len(v_pin), (len(reused), len(v_pin))
+    pin = {j: v_pin[q] for q, j in enumerate(reused)}
+
+    class P_:
+        pass
+    pl = P_()
+    pl.V_RING, pl.V_LAND, pl.V_AT, pl.n_land = p.V_RING, p.V_LAND, p.V_AT, 0
+    sc = Sched(e, pl, 0, la=0)
+    ops = []
+    free = list(v_pool)
+    T_DK, T_LV, T_A = free.pop(), free.pop(), free.pop()
+
+    def op(srcs, fn):
+        ops.append(dict(srcs=srcs, emit=fn))
+    for op_ in s.factor_ops:
+        k = op_["k"]
+        yv = {}
+        for (bb, pk) in op_["init"]:
+            reg = free.pop()
+            yv[bb] = reg
+            op([("L", lw_a + s.K_src[pk][1])], lambda g, reg=reg: e("v_mov_b32", v(reg), v(g[0])))
+        orig = s.perm[k]
+        if orig < n:
+            if pidx[orig] >= 0:
+                op([], lambda g, r=v_p + pidx[orig]: e("v_add_f32", v(T_DK), "s%d" % s_sigma, v(r)))
+            else:
+                op([], lambda g: e("v_mov_b32", v(T_DK), "s%d" % s_sigma))
+        elif (orig - n) in gen_pos:
+            op([], lambda g, r=v_rinv + gen_pos[orig - n]: e("v_mul_f32", v(T_DK), -1.0, v(r)))
+        else:
+            op([], lambda g: e("v_mul_f32", v(T_DK), -1.0, "s%d" % s_rinveq))
+        for (cidx, upd, new) in op_["elim"]:
+            for (j, row) in upd:
+                if row in yv:
+                    op([], lambda g, row=row, j=j, c=cidx, yv=dict(yv): e("v_fmac_f32", v(yv[row]), v(pin[j]), v(yv[c])))
+                else:
+                    reg = free.pop()
+                    yv[row] = reg
+                    op([], lambda g, reg=reg, j=j, c=yv[cidx]: e("v_mul_f32", v(reg), v(pin[j]), v(c)))
+
+            def fe(g, yc=yv[cidx], new=new):
+                e("v_mul_f32", v(T_LV), "-" + v(yc), v(g[0]))              # -L = -(y_c / D_c)
+                sc.lds_write(p.LW_L + p.lpos[new], T_LV)
+                e("v_fmac_f32", v(T_DK), v(yc), v(T_LV))                   # d_k -= y_c L
+                if new in pin:
+                    e("v_mov_b32", v(pin[new]), v(T_LV))
+            op([("A", cidx)], fe)
+        for reg in yv.values():
+            free.append(reg)
+
+        def fin(g, k=k):
+            e("v_rcp_f32", v(T_LV), v(T_DK))
+            e("s_nop", 0)
+            e("v_fma_f32", v(T_A), "-" + v(T_DK), v(T_LV), 1.0)
+            e("v_fma_f32", v(T_LV), v(T_LV), v(T_A), v(T_LV))
+            e("v_accvgpr_write_b32", "a%d" % k, v(T_LV))
+            e("v_min_f32", v(v_fmax), v(v_fmax), "|" + v(T_DK) + "|")
+        op([], fin)
+    sc.run(ops)
+    e("s_waitcnt", "lgkmcnt(0)")

@@ -170,27 +170,52 @@ def emit_structure(name, s, asm=None):
         for i in range(m):
             E("  ls[%d] = IN(a.l, %d) * Ev[%d]; us[%d] = IN(a.u, %d) * Ev[%d]; IN(a.Eprev, %d) = Ev[%d];" % (i, i, i, i, i, i, i, i))
     mark(1)
+    FI = "  "
+    if asm:
+        P = asm
+        # the assembly loop takes the rows in ASM_STRUCTURES[name] for equalities: checked here, per wave
+        E("  static_assert(BQP_%s_ASM_STREAM_ITEMS <= 1024 && BQP_%s_ASM_ROWS <= %d, \"stream buffer / hand-off rows\");"
+          % (name.upper(), name.upper(), ASM_STREAM_ROW))
+        E("  bool eqok = a.asm_ok != 0;")
+        for i in sorted(r["i"] for r in P.rows if r["eq"]):
+            E("  eqok = eqok && (rho[%d] == rho_eq) && (ls[%d] == us[%d]);" % (i, i, i))
+        E("  const int mid = a.max_iter - 2;")
+        E("  bool resdone = false;")
+        E("  const bool use_asm = mid >= 1 && __all(eqok);")
+        E("  // the first iteration needs C++ only where the warm-start z of an equality row differs from its bound (the loop")
+        E("  // takes z == l there); with constant bounds -- p5f -- it never does after the first call")
+        E("  bool z0ok = true;")
+        for i in sorted(r["i"] for r in P.rows if r["eq"]):
+            E("  z0ok = z0ok && (z[%d] == ls[%d]);" % (i, i))
+        E("  const bool asm_first = use_asm && __all(z0ok);")
+        E("  // fast start: the block fills and factorises the KKT matrix itself (asmqp.prologue_fast) from the residual stream")
+        E("  const bool fast = asm_first && rs_valid;")
+        FI = "    "
     # ---- factor
-    for k in range(nk):
-        E("  yv[%d] = T(0.0);" % k)
     E("  int fail = 0;")
+    if asm:
+        E("  if (!fast) {")
+    for k in range(nk):
+        E(FI + "yv[%d] = T(0.0);" % k)
     for op in s.factor_ops:
         k = op["k"]
         for (bb, p) in op["init"]:
-            E("  yv[%d] = As[%d];" % (bb, s.K_src[p][1]))
+            E(FI + "yv[%d] = As[%d];" % (bb, s.K_src[p][1]))
         orig = s.perm[k]
         if orig < n:
             dk = "Ps[%d] + sigma" % pidx[orig] if pidx[orig] >= 0 else "sigma"
         else:
             dk = "-rinv[%d]" % (orig - n)
-        E("  { T dk = %s;" % dk)
+        E(FI + "{ T dk = %s;" % dk)
         for (cidx, upd, new) in op["elim"]:
-            E("    { const T yc = yv[%d];" % cidx)
+            E(FI + "  { const T yc = yv[%d];" % cidx)
             for (j, row) in upd:
-                E("      yv[%d] -= Lx[%d] * yc;" % (row, j))
-            E("      const T lv = yc * DI[%d]; Lx[%d] = lv; dk -= yc * lv; yv[%d] = T(0.0); }" % (cidx, new, cidx))
-        E("    if (dk == T(0.0)) fail = 1;")
-        E("    DI[%d] = T(1.0) / dk; }" % k)
+                E(FI + "    yv[%d] -= Lx[%d] * yc;" % (row, j))
+            E(FI + "    const T lv = yc * DI[%d]; Lx[%d] = lv; dk -= yc * lv; yv[%d] = T(0.0); }" % (cidx, new, cidx))
+        E(FI + "  if (dk == T(0.0)) fail = 1;")
+        E(FI + "  DI[%d] = T(1.0) / dk; }" % k)
+    if asm:
+        E("  }")
     mark(2)
     # ---- ADMM
     for j in range(n):
@@ -227,36 +252,23 @@ def emit_structure(name, s, asm=None):
         E("  auto iterate = [&]() __attribute__((always_inline)) {")
         o.extend(it_lines)
         E("  };")
-        # the assembly loop takes the rows in ASM_STRUCTURES[name] for equalities: checked here, per wave
-        E("  static_assert(BQP_%s_ASM_STREAM_ITEMS <= 1024 && BQP_%s_ASM_ROWS <= %d, \"stream buffer / hand-off rows\");"
-          % (name.upper(), name.upper(), ASM_STREAM_ROW))
-        E("  bool eqok = a.asm_ok != 0;")
-        for i in sorted(r["i"] for r in P.rows if r["eq"]):
-            E("  eqok = eqok && (rho[%d] == rho_eq) && (ls[%d] == us[%d]);" % (i, i, i))
-        E("  const int mid = a.max_iter - 2;")
-        E("  bool resdone = false;")
-        E("  const bool use_asm = mid >= 1 && __all(eqok);")
-        E("  // the first iteration needs C++ only where the warm-start z of an equality row differs from its bound (the loop")
-        E("  // takes z == l there); with constant bounds -- p5f -- it never does after the first call")
-        E("  bool z0ok = true;")
-        for i in sorted(r["i"] for r in P.rows if r["eq"]):
-            E("  z0ok = z0ok && (z[%d] == ls[%d]);" % (i, i))
-        E("  const bool asm_first = use_asm && __all(z0ok);")
         E("  if (a.max_iter >= 1 && !asm_first) iterate();")
         mark(3)
         E("  if (use_asm) {")
         E("    // hand-off: negated L in the loop's storage order, 1/D, x, y, z of the inequality rows -> workspace rows;")
         E("    // one iteration's read-only words -> this wave's stream block, in consumption order (asmqp.Plan.stream)")
+        E("    if (!fast) {")
         for j, pos in sorted(P.lpos.items()):
-            E("    IN(a.W, %d) = -Lx[%d];" % (P.R_L + pos, j))
+            E("      IN(a.W, %d) = -Lx[%d];" % (P.R_L + pos, j))
         for k in range(nk):
-            E("    IN(a.W, %d) = DI[%d];" % (P.R_DI + k, k))
+            E("      IN(a.W, %d) = DI[%d];" % (P.R_DI + k, k))
         for j in range(n):
-            E("    IN(a.W, %d) = x[%d];" % (P.R_X + j, j))
+            E("      IN(a.W, %d) = x[%d];" % (P.R_X + j, j))
         for i in range(m):
-            E("    IN(a.W, %d) = y[%d];" % (P.R_Y + i, i))
+            E("      IN(a.W, %d) = y[%d];" % (P.R_Y + i, i))
         for i, q in sorted(P.zpos.items()):
-            E("    IN(a.W, %d) = z[%d];" % (P.R_Z + q, i))
+            E("      IN(a.W, %d) = z[%d];" % (P.R_Z + q, i))
+        E("    }")
         nst = P.n_stream + len(P.extra)
         src = {"rinv": "rinv[%d]", "l": "ls[%d]", "u": "us[%d]", "rho": "rho[%d]", "q": "qs[%d]"}
         for q, (what, i) in enumerate(P.stream + P.extra):
@@ -273,10 +285,13 @@ def emit_structure(name, s, asm=None):
         E("      // every scalar operand is made provably wave-uniform (the values are; the compiler cannot always see it)")
         E("      const unsigned long long wsp = uni((unsigned long long)a.W);")
         E("      const unsigned s_mid = __builtin_amdgcn_readfirstlane((unsigned)(asm_first ? mid + 1 : mid));")
-        E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq);" % name.upper())
+        E("      const unsigned s_fast = __builtin_amdgcn_readfirstlane((unsigned)(fast ? 1 : 0));")
+        E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq, "
+          "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_fast);" % name.upper())
         E("    }")
         mark(5)
         E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
+        E("    if (fast) fail = (LDSQ(%d) == T(0.0)) ? 1 : 0;   // a zero pivot of the block's factorisation (qdldl.c:221-224)" % P.fac_min)
         E("    // residuals, the termination test at the strict tolerances and the solution stores as generated assembly")
         E("    // (asmqp.res_program); it settles the wave only if every robot is SOLVED -- otherwise the C++ phase below runs")
         E("    if (rs_valid && a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
@@ -430,12 +445,15 @@ def asm_macro(name, ins, plan):
            "constexpr int BQP_%s_ASM_STREAM_ITEMS = %d, BQP_%s_ASM_ROWS = %d;" % (name.upper(), plan.n_stream + len(plan.extra),
                                                                           name.upper(), plan.R_END),
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[4:5] = row workspace, s[6:7] = the wave's stream",
-           "// block, s10 = 4*B, s11 = iterations (>= 1), s20..s23 = alpha, 1 - alpha, sigma, 1/rho_eq (float bits)",
-           "#define BQP_%s_ASM(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq) asm volatile( \\" % name.upper()]
+           "// block, s10 = 4*B, s11 = iterations (>= 1), s20..s23 = alpha, 1 - alpha, sigma, 1/rho_eq (float bits);",
+           "// s30 != 0: fast start (asmqp.prologue_fast: the block factorises; no hand-off rows) with s[24:25], s[26:27], s[28:29] =",
+           "// the caller's x, y, z rows; min |d_k| of the factorisation -> LDS word %d" % asmqp.FAC_MIN,
+           "#define BQP_%s_ASM(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast) asm volatile( \\" % name.upper()]
     for t_ in ins:
         out.append('  "%s\\n" \\' % asmqp.fmt(t_))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(ws), "{s[6:7]}"(sblk), "{s10}"(stride), '
-               '"{s11}"(iters), "{s20}"(alpha), "{s21}"(oma), "{s22}"(sigma), "{s23}"(rinveq) \\')
+               '"{s11}"(iters), "{s20}"(alpha), "{s21}"(oma), "{s22}"(sigma), "{s23}"(rinveq), "{s[24:25]}"(xi), "{s[26:27]}"(yi), '
+               '"{s[28:29]}"(zi), "{s30}"(fast) \\')
     out.append("  : " + ", ".join(clob) + ")")
     return "\n".join(out) + "\n"
 
@@ -509,9 +527,10 @@ def generate():
         asm_body, asm_hdr = None, None
         if name in ASM_STRUCTURES:
             from . import asmqp
-            ins, plan = asmqp.program(s, ASM_STRUCTURES[name])
+            res = asmqp.ResPlan(s, ASM_STRUCTURES[name], ASM_RES_ITEM0)
+            ins, plan = asmqp.program(s, ASM_STRUCTURES[name], res)
             assert plan.n_stream + len(plan.extra) <= ASM_RES_ITEM0
-            plan.res = asmqp.ResPlan(s, ASM_STRUCTURES[name], ASM_RES_ITEM0)
+            plan.res, plan.fac_min = res, asmqp.FAC_MIN
             assert plan.res.end <= ASM_STREAM_ITEMS
             rins, plan.ruiz = asmqp.ruiz_program(s)
             rsins, _ = asmqp.ruiz_program(s, plan.res)

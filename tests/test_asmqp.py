@@ -11,7 +11,9 @@ def prog():
     from robobee3d_amd import asmqp, batchqp, codegen_qp, qpstruct
     st = batchqp.p5f_structure(10)
     s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
-    ins, p = asmqp.program(s, codegen_qp.ASM_STRUCTURES["p5f10"])
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    # (the block codegen_qp emits: both starts -- hand-off rows, s30 == 0, and the in-block factorisation, s30 != 0)
+    ins, p = asmqp.program(s, eq, asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0))
     return asmqp, ins, p
 
 
@@ -33,7 +35,7 @@ def _data(p, seed, eq):
     return d
 
 
-def _run(asmqp, ins, p, d, iters, eq):
+def _run(asmqp, ins, p, d, iters, eq, sigma=1e-6):
     n, m, nk = p.n, p.m, p.nk
     gen = [i for i in range(m) if i not in set(eq)]
     W = np.zeros(p.R_END, np.float32)
@@ -46,7 +48,7 @@ def _run(asmqp, ins, p, d, iters, eq):
     S = np.zeros(p.n_stream + len(p.extra), np.float32)
     for q, (what, i) in enumerate(p.stream + p.extra):
         S[q] = {"rinv": d["rinv"], "l": d["l"], "u": d["u"], "rho": d["rho"], "q": d["q"]}[what][i]
-    lds = asmqp.simulate(ins, W, S, iters, (1.6, 1e-6, float(np.float32(1.0 / 100.0))))
+    lds = asmqp.simulate(ins, W, S, iters, (1.6, sigma, float(np.float32(1.0 / 100.0))))
     return (lds[p.LW_X:p.LW_X + n], lds[p.LW_Y:p.LW_Y + m], lds[p.LW_Z:p.LW_Z + len(gen)], gen,
             lds[p.LW_XP:p.LW_XP + n], lds[p.LW_DY:p.LW_DY + m])
 
@@ -65,6 +67,70 @@ def test_generated_p5f_iterations_match_numpy(prog, iters):
         for got, ref in ((gx, xr), (gy, yr), (gz, zr[gen]), (gxp, xq)):
             assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (iters, seed)
         assert np.abs(gdy - (yr - yq)).max() <= 2e-5 * np.abs(yr).max(), (iters, seed)
+
+
+def _ldl_numpy(s, A, Pv, rinv, sigma):
+    """qdldl.c:86-247 on the KKT matrix of kkt.c:184-222, in the elimination order the generator recorded; float64"""
+    n, nk = s.n, s.nk
+    pidx = list(s.tables["pidx"])
+    Lx, DI, yv = np.zeros(s.nnzL), np.zeros(nk), np.zeros(nk)
+    for op in s.factor_ops:
+        k = op["k"]
+        for (bb, pk) in op["init"]:
+            yv[bb] = A[s.K_src[pk][1]]
+        orig = s.perm[k]
+        dk = ((Pv[pidx[orig]] if pidx[orig] >= 0 else 0.0) + sigma) if orig < n else -rinv[orig - n]
+        for (cidx, upd, new) in op["elim"]:
+            yc = yv[cidx]
+            for (j, row) in upd:
+                yv[row] -= Lx[j] * yc
+            lv = yc * DI[cidx]
+            Lx[new] = lv
+            dk -= yc * lv
+            yv[cidx] = 0.0
+        DI[k] = 1.0 / dk
+    return Lx, DI
+
+
+@pytest.mark.parametrize("iters", [0, 2])
+def test_fast_start_factorises_in_the_block(prog, iters):
+    """s30 != 0: A, P from the residual stream, 1/rho from the loop's stream, x, y, z from the caller's rows; the factor the
+    block computes must drive the same iterations as a float64 LDL' handed over through the rows"""
+    from robobee3d_amd import codegen_qp
+    asmqp, ins, p = prog
+    s = p.s
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    for seed in (0, 1):
+        rng = np.random.default_rng(10 + seed)
+        d = _data(p, seed, eq)
+        A = f(rng.normal(size=s.nnzA))
+        Pv = f(np.abs(rng.normal(size=s.nnzP)) + 0.5)
+        # (a well-conditioned KKT matrix, so that fp32 against float64 factors is a sharp comparison: no loose rows, large sigma)
+        sigma = float(np.float32(0.5))
+        d["rho"][[i for i in range(p.m) if i not in set(eq)]] = f(np.array([0.1]))[0]
+        d["rinv"] = f(1.0 / d["rho"])
+        d["L"], d["DI"] = _ldl_numpy(s, A, Pv, d["rinv"], sigma)
+        ref = _run(asmqp, ins, p, d, iters, eq, sigma)
+        gen = ref[3]
+        S = np.zeros(res.end, np.float32)
+        for q, (what, i) in enumerate(p.stream + p.extra):
+            S[q] = {"rinv": d["rinv"], "l": d["l"], "u": d["u"], "rho": d["rho"], "q": d["q"]}[what][i]
+        S[res.it_A:res.it_A + s.nnzA] = A
+        for j, it in res.it_p.items():
+            S[it] = Pv[res.pidx[j]]
+        arrs = [d[k].astype(np.float32) for k in ("x", "y", "z")]
+        lds = asmqp.simulate(ins, np.full(p.R_END, np.nan, np.float32), S, iters, (1.6, sigma, float(np.float32(0.01))),
+                             regions=[(asmqp.S_XI, arrs[0]), (asmqp.S_YI, arrs[1]), (asmqp.S_ZI, arrs[2])],
+                             sgpr={asmqp.S_FAST: 1})
+        got = (lds[p.LW_X:p.LW_X + p.n], lds[p.LW_Y:p.LW_Y + p.m], lds[p.LW_Z:p.LW_Z + len(gen)], gen,
+               lds[p.LW_XP:p.LW_XP + p.n], lds[p.LW_DY:p.LW_DY + p.m])
+        for k in (0, 1, 2, 4, 5):
+            assert np.isfinite(ref[k]).all()
+            assert np.abs(got[k] - ref[k]).max() <= 2e-4 * max(1.0, np.abs(ref[k]).max()), (seed, k)
+        dmin = np.abs(1.0 / d["DI"]).min()
+        assert abs(lds[asmqp.FAC_MIN] - min(1.0, dmin)) <= 1e-5 * min(1.0, dmin)
 
 
 def test_plan_fits_the_lane(prog):
