@@ -702,6 +702,10 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
             SG["vcc"] = int(not (fval(t[2]) < fval(t[3])))
         elif m == "v_cmp_lt_f32":
             SG["vcc"] = int(fval(t[2]) < fval(t[3]))
+        elif m == "v_cmp_gt_f32":
+            SG["vcc"] = int(fval(t[2]) > fval(t[3]))
+        elif m == "v_cmp_eq_f32":
+            SG["vcc"] = int(fval(t[2]) == fval(t[3]))
         elif m == "v_cndmask_b32_e64":
             bits = lambda x: f32bits(x) if isinstance(x, float) else x if isinstance(x, int) else int(V[int(x[1:])])
             V[int(t[1][1:])] = bits(t[3]) if SG["vcc"] else bits(t[2])
@@ -1175,6 +1179,7 @@ def loader_program(groups):
 RES_FLAG = 639
 S_XO, S_YO, S_ZO, S_SX, S_SY, S_ST, S_IN = 24, 26, 28, 30, 32, 34, 36   # pointer pairs: x, y, z, sol_x, sol_y, status, info rows
 S_EPSA, S_EPSR, S_MAXIT = 38, 39, 40                                    # eps_abs, eps_rel (float bits), max_iter (int)
+S_EP = 54                                                                # pointer pair: the caller's Eprev rows (E of this solve)
 
 
 class _ResRegs:
@@ -1240,8 +1245,8 @@ def res_program(s, eq_rows, ap, res):
     def op(srcs, fn):
         ops.append(dict(srcs=srcs, emit=fn))
     # store pointers: running copies of the caller's row pointers (x, y, z, sol_x, sol_y, info), advanced after each store
-    PTR = {"x": 42, "y": 44, "z": 46, "sx": 48, "sy": 50, "in": 52}
-    for name, src in (("x", S_XO), ("y", S_YO), ("z", S_ZO), ("sx", S_SX), ("sy", S_SY), ("in", S_IN)):
+    PTR = {"x": 42, "y": 44, "z": 46, "sx": 48, "sy": 50, "in": 52, "ep": 56}
+    for name, src in (("x", S_XO), ("y", S_YO), ("z", S_ZO), ("sx", S_SX), ("sy", S_SY), ("in", S_IN), ("ep", S_EP)):
         e("s_mov_b64", "s[%d:%d]" % (PTR[name], PTR[name] + 1), "s[%d:%d]" % (src, src + 1))
 
     def store(which, reg):
@@ -1285,6 +1290,7 @@ def res_program(s, eq_rows, ap, res):
             store("y", y)
             store("z", z)
             store("sy", T(11))
+            store("ep", ev)
         op(srcs, f)
     op([], lambda g: e("v_max_f32", v(NZ), v(NZ), v(NAX)))            # prim_rel; NAX is a temporary from here on
     # ---- pass 2: y into the accumulator registers, then columns: A' y, P x, q
@@ -1422,3 +1428,139 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
         op([], fin)
     sc.run(ops)
     e("s_waitcnt", "lgkmcnt(0)")
+
+
+# ---------------------------------------------------------------------------
+# Glue between the Ruiz block and the loop: rho classification, scaled bounds, the loop's stream
+# ---------------------------------------------------------------------------
+# After the Ruiz block (E in LDS words RuizPlan.LW_EV.., q in LW_Q..) this block does what the C++ side of
+# codegen_qp.emit_structure does between scaling and factorisation -- update_rho_vec on the bounds scaled by the previous E
+# (auxil.c:103-145), l E and u E (scaling.c:scale_data), the loop's read-only stream, z of the equality rows for the
+# residual block -- from batched row loads instead of one exposed load per word, and decides whether the wave may take the
+# all-assembly route: LDS word GLUE_FLAG = 1 iff every row of eq_rows is an equality (rho == rho_eq, l E == u E) whose
+# warm-start z equals its bound.
+GLUE_FLAG = 637
+S_LR, S_UR, S_ER, S_ZR = 4, 8, 24, 26         # pointer pairs: l, u, Eprev, z rows (s[6:7] = the wave's stream block)
+GV_RHO0, GV_RINV0, GV_RHOEQ, GV_RINVEQ = 5, 6, 7, 8      # inputs (VGPRs, wave-uniform floats)
+QP_RHO_MIN, QP_RHO_TOL, QP_INF_SCALED = 1e-6, 1e-4, 1e20 * 1e-4
+
+
+def _f32_strict_bounds():
+    """float thresholds that make the fp32 comparisons equal to umpc_bqp_common.h's comparisons in double:
+    (double)x > 1e16 <=> x > F with F the largest float <= 1e16; (double)d < 1e-4 <=> d < TOL with TOL the smallest
+    float >= 1e-4"""
+    f32 = np.float32
+    F = f32(QP_INF_SCALED)
+    if float(F) > QP_INF_SCALED:
+        F = np.nextafter(F, f32(0))
+    TOL = f32(QP_RHO_TOL)
+    if float(TOL) < QP_RHO_TOL:
+        TOL = np.nextafter(TOL, f32(1))
+    return float(F), float(TOL)
+
+
+def glue_program(s, eq_rows, p, res, rp):
+    """p: Plan (stream positions), res: ResPlan (z of the equality rows), rp: RuizPlan (where E and q are in LDS)"""
+    n, m = s.n, s.m
+    eq = set(int(i) for i in eq_rows)
+    pos = {}
+    for q, it in enumerate(p.stream + p.extra):
+        pos.setdefault(it, []).append(q)
+    e = Emit()
+    v = lambda r: "v%d" % r
+    V_RMIN, V_RIMIN, V_F, V_NF, V_TOL, V_FLAG = 9, 10, 11, 12, 13, 14
+    R = 44
+    V_L, V_U, V_E, V_Z = 16, 16 + R, 16 + 2 * R, 16 + 3 * R
+
+    class P_:
+        pass
+    pl = P_()
+    pl.V_RING = 16 + 4 * R
+    pl.V_LAND = pl.V_AT = pl.V_RING + 4 * NRING
+    pl.n_land = 0
+    V_T = pl.V_AT + N_AT
+    NSET = (V_END - V_T) // 8
+    assert NSET >= 2
+    F, TOL = _f32_strict_bounds()
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    for reg, val in ((V_RMIN, np.float32(QP_RHO_MIN)), (V_RIMIN, np.float32(1.0 / QP_RHO_MIN)), (V_F, F), (V_NF, -F), (V_TOL, TOL)):
+        e("v_mov_b32", v(reg), f32bits(float(val)))
+    e("v_mov_b32", v(V_FLAG), 1.0)
+    cur = [None]
+
+    def put(item, reg):
+        if item // BLOCK != cur[0]:
+            cur[0] = item // BLOCK
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, cur[0] * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        e("global_store_dword", "v%d" % V_LANE, v(reg), "s[%d:%d]" % (S_SP, S_SP + 1), (item % BLOCK) * 256)
+
+    def check(a_, b_):
+        e("v_cmp_eq_f32", "vcc", v(a_), v(b_))
+        e("v_cndmask_b32", v(V_FLAG), 0, v(V_FLAG), "vcc")
+    nrow = 0
+    for c0 in range(0, m, R):
+        rows = list(range(c0, min(m, c0 + R)))
+        for base_s, v0_, sel in ((S_LR, V_L, rows), (S_UR, V_U, rows), (S_ER, V_E, rows), (S_ZR, V_Z, [i for i in rows if i in eq])):
+            last = None
+            for i in sel:
+                if last is None or i != last + 1:
+                    _row_ptr(e, S_P, i, base_s)
+                else:
+                    _adv(e, S_P)
+                last = i
+                e("global_load_dword", v(v0_ + i - c0), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+        e("s_waitcnt", "vmcnt(0)")
+        sc = Sched(e, pl, 0)
+        ops = []
+        for i in rows:
+            def f(g, i=i, k=nrow):
+                T = lambda q: V_T + 8 * (k % NSET) + q
+                l_, u_, e_, z_ = V_L + i - c0, V_U + i - c0, V_E + i - c0, V_Z + i - c0
+                le, ue, d, t, rho, rinv, ls, us = (T(q) for q in range(8))
+                e("v_mul_f32", v(le), v(l_), v(e_))
+                e("v_mul_f32", v(ue), v(u_), v(e_))
+                e("v_sub_f32", v(d), v(ue), v(le))
+                e("v_mov_b32", v(rho), v(GV_RHO0))
+                e("v_mov_b32", v(rinv), v(GV_RINV0))
+                e("v_cmp_gt_f32", "vcc", v(V_TOL), v(d))                        # u - l < RHO_TOL: an equality row
+                e("v_cndmask_b32", v(rho), v(rho), v(GV_RHOEQ), "vcc")
+                e("v_cndmask_b32", v(rinv), v(rinv), v(GV_RINVEQ), "vcc")
+                e("v_cmp_lt_f32", "vcc", v(V_F), v(ue))                         # both bounds infinite: a loose row
+                e("v_cndmask_b32", v(t), 0, v(le), "vcc")
+                e("v_cmp_gt_f32", "vcc", v(V_NF), v(t))
+                e("v_cndmask_b32", v(rho), v(rho), v(V_RMIN), "vcc")
+                e("v_cndmask_b32", v(rinv), v(rinv), v(V_RIMIN), "vcc")
+                e("v_mul_f32", v(ls), v(l_), v(g[0]))
+                e("v_mul_f32", v(us), v(u_), v(g[0]))
+                if i in eq:
+                    check(rho, GV_RHOEQ)
+                    check(ls, us)
+                    check(z_, ls)
+                    for q in pos[("l", i)]:
+                        put(q, ls)
+                    put(res.it_ls[i], ls)
+                else:
+                    for what, reg in (("rinv", rinv), ("l", ls), ("u", us), ("rho", rho)):
+                        for q in pos[(what, i)]:
+                            put(q, reg)
+            ops.append(dict(srcs=[("L", rp.LW_EV + i)], emit=f))
+            nrow += 1
+        sc.run(ops)
+        e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")        # the landing registers are loaded again by the next chunk
+    sc = Sched(e, pl, 0)
+    ops = []
+    for j in range(n):
+        def fq(g, j=j):
+            for q in pos[("q", j)]:
+                put(q, g[0])
+        ops.append(dict(srcs=[("L", rp.LW_Q + j)], emit=fq))
+    sc.run(ops)
+    base, off = lds_addr(GLUE_FLAG)
+    e("ds_write_b32", base, v(V_FLAG), off)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    written = sorted(q for lst in pos.values() for q in lst)
+    assert written == list(range(p.n_stream + len(p.extra)))
+    return e.ins

@@ -72,6 +72,10 @@ def emit_structure(name, s, asm=None):
     if not asm:
         o.extend(load_lines)      # (the assembly variant's Ruiz block fetches Pv, Av, q itself)
     E("  const T rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);")
+    TIMING = asm is not None and os.environ.get("UMPC_QP_TIMING") == "1"   # diagnostic builds: phase intervals -> info rows
+    mark = (lambda k: E("  tmark[%d] = __builtin_amdgcn_s_memrealtime();" % k)) if TIMING else (lambda k: None)
+    if TIMING:
+        E("  long long tmark[8];")
     if asm:
         # the warm start and the bounds arrive through LDS: asmqp.loader_program fetches three [row][B] arrays in one round
         # trip (hipcc would fetch the ~900 words one exposed load at a time: 0.45 ms of the tick)
@@ -81,6 +85,8 @@ def emit_structure(name, s, asm=None):
         E("  T *const sblk = a.S + (size_t)wave * %d;   // this wave's stream block ([item][lane]); wave-uniform (SGPR) base" % (ASM_STREAM_ITEMS * 64))
         E("  const unsigned long long ssp = a.asm_ok ? uni((unsigned long long)sblk) : 0ull;")
         E("  const unsigned lane4 = (unsigned)threadIdx.x * 4u;")
+        emit_fast_route(E, name, s, asm, TIMING, mark)
+        E("  if (mode == 0) {   // the general route: C++ glue around the assembly blocks, or all C++")
         E("  BQP_%s_LOAD_XYZ(voff, ldsaddr, uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_stride);" % name.upper())
         for j in range(n):
             E("  D[%d] = T(1.0); x[%d] = LDSQ(%d);" % (j, j, j))
@@ -96,13 +102,9 @@ def emit_structure(name, s, asm=None):
         for i in range(m):
             E("  { const T e = IN(a.Eprev, %d); qp_classify(IN(a.l, %d) * e, IN(a.u, %d) * e, a.rho, rho_eq, rho[%d], rinv[%d]); "
               "Ev[%d] = T(1.0); y[%d] = IN(a.y, %d); z[%d] = IN(a.z, %d); }" % (i, i, i, i, i, i, i, i, i, i))
-    TIMING = asm is not None and os.environ.get("UMPC_QP_TIMING") == "1"   # diagnostic builds: phase intervals -> info rows
-    mark = (lambda k: E("  tmark[%d] = __builtin_amdgcn_s_memrealtime();" % k)) if TIMING else (lambda k: None)
-    if TIMING:
-        E("  long long tmark[8];")
     mark(0)
     # ---- Ruiz
-    E("  T c = T(1.0);")
+    E("  c = T(1.0);" if asm else "  T c = T(1.0);")
     if asm:
         RP = asm.ruiz
         E("  // scaling.c:44-156 as generated assembly (asmqp.ruiz_program): the block fetches Pv, Av, q in batches, keeps the row")
@@ -156,7 +158,7 @@ def emit_structure(name, s, asm=None):
         E("    qs[%d] *= ct;" % j)
     E("    c *= ct;")
     E("  }")
-    E("  const T cinv = T(1.0) / c;")
+    E("  cinv = T(1.0) / c;" if asm else "  const T cinv = T(1.0) / c;")
     if asm:
         E("  BQP_%s_LOAD_LUE(voff, ldsaddr, uni((unsigned long long)a.l), uni((unsigned long long)a.u), uni((unsigned long long)a.Eprev), s_stride);" % name.upper())
         for i in range(m):
@@ -180,7 +182,6 @@ def emit_structure(name, s, asm=None):
         for i in sorted(r["i"] for r in P.rows if r["eq"]):
             E("  eqok = eqok && (rho[%d] == rho_eq) && (ls[%d] == us[%d]);" % (i, i, i))
         E("  const int mid = a.max_iter - 2;")
-        E("  bool resdone = false;")
         E("  const bool use_asm = mid >= 1 && __all(eqok);")
         E("  // the first iteration needs C++ only where the warm-start z of an equality row differs from its bound (the loop")
         E("  // takes z == l there); with constant bounds -- p5f -- it never does after the first call")
@@ -189,10 +190,10 @@ def emit_structure(name, s, asm=None):
             E("  z0ok = z0ok && (z[%d] == ls[%d]);" % (i, i))
         E("  const bool asm_first = use_asm && __all(z0ok);")
         E("  // fast start: the block fills and factorises the KKT matrix itself (asmqp.prologue_fast) from the residual stream")
-        E("  const bool fast = asm_first && rs_valid;")
+        E("  constexpr bool fast = false;   // (the route above is the one that takes it)")
         FI = "    "
     # ---- factor
-    E("  int fail = 0;")
+    E("  fail = 0;" if asm else "  int fail = 0;")
     if asm:
         E("  if (!fast) {")
     for k in range(nk):
@@ -300,7 +301,7 @@ def emit_structure(name, s, asm=None):
         E("      const unsigned s_maxit = __builtin_amdgcn_readfirstlane((unsigned)a.max_iter);")
         E("      BQP_%s_RES_ASM(voff, ldsaddr, lane4, ssp, s_stride, uni((unsigned long long)a.x), uni((unsigned long long)a.y), "
           "uni((unsigned long long)a.z), uni((unsigned long long)a.sol_x), uni((unsigned long long)a.sol_y), "
-          "uni((unsigned long long)a.status), uni((unsigned long long)a.info), s_epsa, s_epsr, s_maxit);" % name.upper())
+          "uni((unsigned long long)a.status), uni((unsigned long long)a.info), s_epsa, s_epsr, s_maxit, uni((unsigned long long)a.Eprev));" % name.upper())
         E("      resdone = __all(LDSQ(%d) == T(1.0));" % 639)
         E("    }")
         E("    if (!resdone) {")
@@ -328,6 +329,8 @@ def emit_structure(name, s, asm=None):
     mark(6)
     # ---- residuals
     if asm:
+        E("  }   // general route")
+        emit_fast_route_reload(E, name, s, asm)
         E("  if (!resdone) {")
     E("  T pri_res = T(0.0), nz = T(0.0), nAx = T(0.0);")
     for i in range(m):
@@ -429,6 +432,105 @@ def emit_structure(name, s, asm=None):
 DTYPES = (("f32", "float"), ("f64", "double"))
 
 
+def emit_fast_route(E, name, s, P, TIMING, mark):
+    """The all-assembly route of the fp32 assembly variant: Ruiz block, glue block (asmqp.glue_program), the loop with its fast
+    start (the block factorises), the residual block. Taken when the glue block finds every row of ASM_STRUCTURES[name] an
+    equality whose warm-start z equals its bound; otherwise nothing the caller can see has been touched and the general
+    route below runs. Sets mode: 0 not taken, 1 taken but the residual block did not settle the wave, 2 done."""
+    from . import asmqp
+    U = name.upper()
+    E("  int mode = 0, fail = 0;")
+    E("  T c = T(1.0), cinv = T(1.0);")
+    E("  bool resdone = false;")
+    E("  if (a.asm_ok && a.scaling >= 1) {")
+    mark(0)
+    E("    const unsigned s_pass = __builtin_amdgcn_readfirstlane((unsigned)a.scaling);")
+    E("    BQP_%s_RUIZ_RS_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.Av), uni((unsigned long long)a.Pv), "
+      "uni((unsigned long long)a.q), ssp, s_stride, s_pass);" % U)
+    E("    BQP_%s_GLUE_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.l), ssp, uni((unsigned long long)a.u), s_stride, "
+      "uni((unsigned long long)a.Eprev), uni((unsigned long long)a.z), a.rho, T(1. / (double)a.rho), rho_eq, T(1. / (double)rho_eq));" % U)
+    mark(1)
+    if TIMING:
+        E("    tmark[2] = tmark[3] = tmark[4] = tmark[1];")
+    E("    if (__all(LDSQ(%d) == T(1.0))) {" % asmqp.GLUE_FLAG)
+    E("      const unsigned s_alpha = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.alpha));")
+    E("      const unsigned s_oma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.oma));")
+    E("      const unsigned s_sigma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.sigma));")
+    E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
+    E("      const unsigned s_iters = __builtin_amdgcn_readfirstlane((unsigned)(a.max_iter - 1));")
+    E("      BQP_%s_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
+      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u);" % U)
+    mark(5)
+    E("      fail = (LDSQ(%d) == T(0.0)) ? 1 : 0;   // a zero pivot of the block's factorisation (qdldl.c:221-224)" % asmqp.FAC_MIN)
+    E("      if (a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
+    E("        const unsigned s_epsa = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.eps_abs));")
+    E("        const unsigned s_epsr = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.eps_rel));")
+    E("        const unsigned s_maxit = __builtin_amdgcn_readfirstlane((unsigned)a.max_iter);")
+    E("        BQP_%s_RES_ASM(voff, ldsaddr, lane4, ssp, s_stride, uni((unsigned long long)a.x), uni((unsigned long long)a.y), "
+      "uni((unsigned long long)a.z), uni((unsigned long long)a.sol_x), uni((unsigned long long)a.sol_y), "
+      "uni((unsigned long long)a.status), uni((unsigned long long)a.info), s_epsa, s_epsr, s_maxit, uni((unsigned long long)a.Eprev));" % U)
+    E("        resdone = __all(LDSQ(%d) == T(1.0));" % asmqp.RES_FLAG)
+    E("      }")
+    E("      mode = resdone ? 2 : 1;")
+    E("    }")
+    E("  }")
+
+
+def emit_fast_route_reload(E, name, s, P):
+    """mode 1 (rare: a robot of the wave is not SOLVED at the strict tolerances, or the caller wants no solution rows): the C++
+    residual phase needs the equilibrated data and the iterates in registers; they are in the wave's streams and in LDS"""
+    n, m = s.n, s.m
+    res = P.res
+    pos = {}
+    for q, it in enumerate(P.stream + P.extra):
+        pos.setdefault(it, q)
+    E("  if (mode == 1) {")
+    E("#define SB(item) sblk[(item) * 64 + threadIdx.x]")
+    for k in range(s.nnzA):
+        E("    As[%d] = SB(%d);" % (k, res.it_A + k))
+    for j in range(n):
+        E("    D[%d] = SB(%d); qs[%d] = SB(%d);" % (j, res.it_d[j], j, res.it_q[j]))
+        if j in res.it_p:
+            E("    Ps[%d] = SB(%d);" % (res.pidx[j], res.it_p[j]))
+    for i in range(m):
+        E("    Ev[%d] = SB(%d); IN(a.Eprev, %d) = Ev[%d];" % (i, res.it_ev[i], i, i))
+        if i in res.eq:
+            E("    ls[%d] = us[%d] = SB(%d);" % (i, i, res.it_ls[i]))
+        else:
+            E("    ls[%d] = SB(%d); us[%d] = SB(%d);" % (i, pos[("l", i)], i, pos[("u", i)]))
+    E("    c = SB(%d); cinv = T(1.0) / c;" % res.it_c)
+    E("#undef SB")
+    E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
+    for j in range(n):
+        E("    x[%d] = LDSQ(%d); xp[%d] = LDSQ(%d);" % (j, P.LW_X + j, j, P.LW_XP + j))
+    for i in range(m):
+        E("    y[%d] = LDSQ(%d); dy[%d] = LDSQ(%d);" % (i, P.LW_Y + i, i, P.LW_DY + i))
+    for r in P.rows:
+        if r["eq"]:
+            E("    z[%d] = ls[%d];" % (r["i"], r["i"]))
+        else:
+            E("    z[%d] = LDSQ(%d);" % (r["i"], P.LW_Z + P.zpos[r["i"]]))
+    E("#undef LDSQ")
+    E("  }")
+
+
+def glue_macro(name, ins):
+    from . import asmqp
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(9, asmqp.V_END))] + \
+           ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1, asmqp.S_SP, asmqp.S_SP + 1)]
+    out = ["// Glue between the Ruiz block and the loop (asmqp.glue_program): rho classification, scaled bounds, the loop's stream,",
+           "// LDS word %d = 1 iff the wave may take the all-assembly route. %d instructions." % (asmqp.GLUE_FLAG, len(ins)),
+           "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[4:5] / s[8:9] / s[24:25] / s[26:27] = l, u, Eprev, z rows,",
+           "// s[6:7] = the wave's stream block, s10 = 4*B, v5..v8 = rho, 1/rho, rho_eq, 1/rho_eq (floats)",
+           "#define BQP_%s_GLUE_ASM(voff, ldsaddr, lane4, lp, sblk, up, stride, ep, zp, rho0, rinv0, rhoeq, rinveq) asm volatile( \\" % name.upper()]
+    for t_ in ins:
+        out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(lp), "{s[6:7]}"(sblk), "{s[8:9]}"(up), "{s10}"(stride), '
+               '"{s[24:25]}"(ep), "{s[26:27]}"(zp), "{v5}"(rho0), "{v6}"(rinv0), "{v7}"(rhoeq), "{v8}"(rinveq) \\')
+    out.append("  : " + ", ".join(clob) + ")")
+    return "\n".join(out) + "\n"
+
+
 def asm_macro(name, ins, plan):
     """csrc/gen/bqp_<name>_asm.h: the instruction stream of asmqp.program as one asm volatile statement"""
     from . import asmqp
@@ -461,16 +563,17 @@ def asm_macro(name, ins, plan):
 def res_macro(name, ins):
     from . import asmqp
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
-           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in [asmqp.S_SP, asmqp.S_SP + 1] + list(range(42, 54))]
+           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in [asmqp.S_SP, asmqp.S_SP + 1] + list(range(42, 54)) + [56, 57]]
     out = ["// Residuals, strict termination test and solution stores after the loop (asmqp.res_program): %d instructions." % len(ins),
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[6:7] = the wave's stream block, s10 = 4*B,",
-           "// s[24:25] .. s[36:37] = x, y, z, sol_x, sol_y, status, info rows, s38 / s39 = eps_abs / eps_rel (float bits), s40 = max_iter",
-           "#define BQP_%s_RES_ASM(voff, ldsaddr, lane4, sblk, stride, xo, yo, zo, sxo, syo, sto, ino, epsa, epsr, maxit) asm volatile( \\" % name.upper()]
+           "// s[24:25] .. s[36:37] = x, y, z, sol_x, sol_y, status, info rows, s38 / s39 = eps_abs / eps_rel (float bits), s40 = max_iter,",
+           "// s[54:55] = Eprev rows (E of this solve is stored there)",
+           "#define BQP_%s_RES_ASM(voff, ldsaddr, lane4, sblk, stride, xo, yo, zo, sxo, syo, sto, ino, epsa, epsr, maxit, epo) asm volatile( \\" % name.upper()]
     for t_ in ins:
         out.append('  "%s\\n" \\' % asmqp.fmt(t_))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[6:7]}"(sblk), "{s10}"(stride), "{s[24:25]}"(xo), '
                '"{s[26:27]}"(yo), "{s[28:29]}"(zo), "{s[30:31]}"(sxo), "{s[32:33]}"(syo), "{s[34:35]}"(sto), "{s[36:37]}"(ino), '
-               '"{s38}"(epsa), "{s39}"(epsr), "{s40}"(maxit) \\')
+               '"{s38}"(epsa), "{s39}"(epsr), "{s40}"(maxit), "{s[54:55]}"(epo) \\')
     out.append("  : " + ", ".join(clob) + ")")
     return "\n".join(out) + "\n"
 
@@ -535,10 +638,11 @@ def generate():
             rins, plan.ruiz = asmqp.ruiz_program(s)
             rsins, _ = asmqp.ruiz_program(s, plan.res)
             resins, _ = asmqp.res_program(s, ASM_STRUCTURES[name], plan, plan.res)
+            glins = asmqp.glue_program(s, ASM_STRUCTURES[name], plan, plan.res, plan.ruiz)
             asm_body = emit_structure(name, s, asm=plan)
             asm_hdr = "bqp_%s_asm.h" % name
             files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + ruiz_macro(name, rins, plan.ruiz) + \
-                ruiz_macro(name, rsins, plan.ruiz, rs=True) + res_macro(name, resins) + \
+                ruiz_macro(name, rsins, plan.ruiz, rs=True) + res_macro(name, resins) + glue_macro(name, glins) + \
                 loader_macro(name, "XYZ", [(s.n, 0), (s.m, s.n), (s.m, s.n + s.m)]) + \
                 loader_macro(name, "LUE", [(s.m, 0), (s.m, s.m), (s.m, 2 * s.m)])
         for tag, ctype in DTYPES:

@@ -169,7 +169,10 @@ def test_p5f_stream_assembles(prog):
     mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
     if not os.path.exists(mc):
         pytest.skip("llvm-mc not available")
+    from robobee3d_amd import codegen_qp
     asmqp, ins, p = prog
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    ins = ins + asmqp.glue_program(p.s, eq, p, asmqp.ResPlan(p.s, eq, codegen_qp.ASM_RES_ITEM0), asmqp.RuizPlan(p.s))
     with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
         f.write("\n".join(asmqp.fmt(t) for t in ins) + "\n")
     try:
@@ -302,12 +305,78 @@ def test_residual_block_matches_numpy(eps, expect):
     for i, qq in ap.zpos.items():
         lds0[ap.LW_Z + qq] = z[i]
     xo, yo, zo, sx, sy = [np.full(k, np.nan, np.float32) for k in (n, m, m, n, m)]
-    stt, info = np.zeros(1, np.float32), np.zeros(6, np.float32)
+    stt, info, epo = np.zeros(1, np.float32), np.zeros(6, np.float32), np.full(m, np.nan, np.float32)
     sg = {asmqp.S_EPSA: asmqp.f32bits(eps), asmqp.S_EPSR: asmqp.f32bits(eps), asmqp.S_MAXIT: 50}
     lds = asmqp.simulate(ins, np.zeros(1, np.float32), S, 1, (1.6, 1e-6, 0.01),
                          regions=[(asmqp.S_XO, xo), (asmqp.S_YO, yo), (asmqp.S_ZO, zo), (asmqp.S_SX, sx), (asmqp.S_SY, sy),
-                                  (asmqp.S_ST, stt), (asmqp.S_IN, info)], sgpr=sg, lds0=lds0)
-    assert lds[asmqp.RES_FLAG] == expect
+                                  (asmqp.S_ST, stt), (asmqp.S_IN, info), (asmqp.S_EP, epo)], sgpr=sg, lds0=lds0)
+    assert lds[asmqp.RES_FLAG] == expect and np.array_equal(epo, Ev)       # (E of this solve -> the caller's Eprev rows)
     assert abs(info[0] - pri) <= 2e-6 * pri and abs(info[1] - dua) <= 2e-6 * dua and info[2] == c and info[3] == 0 and info[4] == 50
     assert np.array_equal(xo, x) and np.array_equal(yo, y) and np.array_equal(zo, z)
     assert np.abs(sx - x * D).max() <= 1e-6 * np.abs(x * D).max() and np.abs(sy - y * Ev / c).max() <= 1e-6 * np.abs(y * Ev / c).max()
+
+
+def _glue_expected(p, res, eq, l, u, ep, ev, q, rho0):
+    """the C++ glue of codegen_qp.emit_structure in numpy float32 (update_rho_vec auxil.c:103-145 with the comparisons in
+    double; l E, u E)"""
+    f32 = np.float32
+    rho_eq = f32(1e3 * float(rho0))
+    le, ue = l * ep, u * ep
+    rho = np.where((le.astype(np.float64) < -1e16) & (ue.astype(np.float64) > 1e16), f32(1e-6),
+                   np.where((ue - le).astype(np.float64) < 1e-4, rho_eq, f32(rho0))).astype(f32)
+    rinv = np.where(rho == f32(1e-6), f32(1.0 / 1e-6), np.where(rho == rho_eq, f32(1.0 / float(rho_eq)), f32(1.0 / float(rho0)))).astype(f32)
+    ls, us = l * ev, u * ev
+    S = np.zeros(res.end, f32)
+    src = {"rinv": rinv, "l": ls, "u": us, "rho": rho, "q": q}
+    for k, (what, i) in enumerate(p.stream + p.extra):
+        S[k] = src[what][i]
+    for i, it in res.it_ls.items():
+        S[it] = ls[i]
+    return S, rho, ls, us
+
+
+def test_glue_block_classifies_and_writes_the_stream(prog):
+    from robobee3d_amd import codegen_qp
+    asmqp, _, p = prog
+    s = p.s
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
+    rp = asmqp.RuizPlan(s)
+    ins = asmqp.glue_program(s, eq, p, res, rp)
+    f32 = np.float32
+    rng = np.random.default_rng(5)
+    rho0 = f32(0.1)
+    consts = {asmqp.GV_RHO0: rho0, asmqp.GV_RINV0: f32(1.0 / float(rho0)), asmqp.GV_RHOEQ: f32(1e3 * float(rho0)),
+              asmqp.GV_RINVEQ: f32(1.0 / float(f32(1e3 * float(rho0))))}
+    pre = [("v_mov_b32", "v%d" % r, asmqp.f32bits(float(val))) for r, val in consts.items()]
+    for case in ("ok", "cold", "noteq"):
+        m, n = p.m, p.n
+        l = rng.normal(size=m).astype(f32)
+        u = (l + np.abs(rng.normal(size=m)).astype(f32) + f32(0.1)).astype(f32)
+        loose = [i for i in range(m) if i not in set(eq)][::7]
+        l[loose], u[loose] = f32(-1e20), f32(1e20)
+        half = [i for i in range(m) if i not in set(eq)][3::7]
+        u[half] = f32(1e20)                              # one-sided rows are ordinary inequality rows
+        u[eq] = l[eq]
+        ep = (np.abs(rng.normal(size=m)) + 0.5).astype(f32)
+        ev = (np.abs(rng.normal(size=m)) + 0.5).astype(f32)
+        q = rng.normal(size=n).astype(f32)
+        if case == "noteq":
+            u[eq[5]] = l[eq[5]] + f32(1.0)
+        z = rng.normal(size=m).astype(f32)
+        z[eq] = (l * ev)[eq]
+        if case == "cold":
+            z[eq[11]] += f32(0.5)
+        Sx, rho, ls, us = _glue_expected(p, res, eq, l, u, ep, ev, q, rho0)
+        lds0 = np.zeros(640, f32)
+        lds0[rp.LW_EV:rp.LW_EV + m] = ev
+        lds0[rp.LW_Q:rp.LW_Q + n] = q
+        S = np.full(res.end, np.nan, f32)
+        lds = asmqp.simulate(pre + ins, np.zeros(1, f32), S, 0, (1.6, 1e-6, 0.01), lds0=lds0,
+                             regions=[(asmqp.S_LR, l), (asmqp.S_UR, u), (asmqp.S_ER, ep), (asmqp.S_ZR, z)])
+        nst = p.n_stream + len(p.extra)
+        assert np.array_equal(S[:nst], Sx[:nst]), case
+        its = sorted(res.it_ls.values())
+        assert np.array_equal(S[its], Sx[its]), case
+        assert lds[asmqp.GLUE_FLAG] == (1.0 if case == "ok" else 0.0), case
+        assert (rho == f32(1e-6)).sum() == len(loose) and (rho == f32(100.0)).sum() == len(eq) - (case == "noteq")
