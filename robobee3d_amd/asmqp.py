@@ -42,15 +42,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 S_W, S_S, S_STRIDE, S_ITERS = 4, 6, 10, 11          # s[4:5] row workspace, s[6:7] this wave's stream block, 4*B, iterations
 S_P, S_CNT, S_SP = 12, 14, 16                       # row pointer, loop counter, stream pointer
 S_ALPHA, S_OMA, S_SIGMA, S_RINVEQ = 20, 21, 22, 23  # floats (inputs)
+S_RHO0, S_RINV0, S_RHOEQ = 31, 34, 35               # rho, 1/rho, rho_eq (float bits, inputs): the classes update_rho_vec assigns
+RHO_MIN_F32 = 1e-6                                  # (auxil.c:103-145; the third class, both bounds infinite, is a constant)
 V_B1, V_B2, V_LANE, V_W = 2, 3, 4, 5     # inputs: v0 = 4*robot, v1 = lane LDS address (16*lane), v4 = 4*lane
 NRING, NLAND, N_AT, N_TT = 6, 36, 4, 8
 V_END = 246
 BLOCK = 16                                          # stream items per pointer bump (16 x 256 B = the offset field's reach)
+LW_FLAGS = 637                                      # LDS words 637..639: GLUE_FLAG, FAC_MIN, RES_FLAG (between the blocks)
 
 
 def lds_addr(word):
     byte = (word >> 2) * 1024
     return "v%d" % (1, V_B1, V_B2)[byte >> 16], (byte & 0xFFFF) + 4 * (word & 3)
+
+
+# generation-time switches (experiments; the defaults are what ships): where the bounds of the leaf equality rows live
+# ('V': registers, 'A': the AGPRs behind 1/D then LDS), 1/rho of some inequality rows resident in the free LDS words,
+# rho selected instead of streamed
+KNOB = dict(leafeq=os.environ.get("UMPC_QP_LEAFEQ", "V"), rinv_lds=os.environ.get("UMPC_QP_RINV_LDS", "1") == "1",
+            rho_select=os.environ.get("UMPC_QP_RHO_SELECT", "0") == "1")
 
 
 class Plan:
@@ -79,11 +89,18 @@ class Plan:
         for r in self.rows:
             if r["leaf"]:
                 assert r["r"] in self.wreg, "a leaf row must hang off a non-leaf unknown"
-        self.V_LEQ = V_W + len(self.nonleaf)
+        # (generation-time experiment UMPC_QP_RHO_SELECT=1: rho of a row selected from the three class constants by comparing
+        # its streamed 1/rho instead of streaming it -- 20 % fewer stream items, 4 more VALU per row: slower, the loop is
+        # bound by instruction issue; off by default)
+        self.V_RHO0 = V_W + len(self.nonleaf)
+        self.V_RHOEQ, self.V_RHOMIN = self.V_RHO0 + 1, self.V_RHO0 + 2
         self.leafeq = [r["i"] for r in self.rows if r["leaf"] and r["eq"]]
-        self.V_RING = self.V_LEQ + len(self.leafeq)
+        self.V_LEQ = self.V_RHO0 + (3 if KNOB["rho_select"] else 0)
+        self.V_RING = self.V_LEQ + (len(self.leafeq) if KNOB["leafeq"] == "V" else 0)
         self.V_LAND = self.V_RING + 4 * NRING
-        self.V_AT = self.V_LAND + NLAND
+        self.NLAND = V_END - N_TT - N_AT - self.V_LAND        # every register left over lands stream items
+        assert self.NLAND >= 16
+        self.V_AT = self.V_LAND + self.NLAND
         self.V_TT = self.V_AT + N_AT
         assert self.V_TT + N_TT <= V_END, (self.V_TT + N_TT, V_END)
         # L storage: leaf entries in row order, then the solve entries in forward order (walked backwards by the
@@ -99,15 +116,30 @@ class Plan:
         self.zpos = {i: q for q, i in enumerate(gen)}
         self.LW_END = self.LW_Z + len(gen)
         assert self.LW_END <= 640
-        # stream items of one iteration, in consumption order
-        self.stream = [("rinv", i) for i in gen]
+        # Words that are constant over the iterations and find a home on chip are loaded ONCE (prologue) instead of streamed
+        # every iteration: the scaled bounds of the leaf equality rows -> the AGPRs behind 1/D, then LDS; 1/rho of as many
+        # inequality rows as LDS words are left (each is read twice per iteration: rhs and row update).
+        self.once = {}                                         # item -> ('A', agpr) | ('L', lds word)
+        free_a = list(range(nk, 256))
+        free_l = list(range(self.LW_END, LW_FLAGS))
+        for q, i in enumerate(self.leafeq):
+            if KNOB["leafeq"] == "V":
+                self.once[("l", i)] = ("V", self.V_LEQ + q)
+            else:
+                self.once[("l", i)] = ("A", free_a.pop(0)) if free_a else ("L", free_l.pop(0))
         for i in gen:
-            self.stream += [("l", i), ("u", i), ("rinv", i), ("rho", i)]
+            if free_l and KNOB["rinv_lds"]:
+                self.once[("rinv", i)] = ("L", free_l.pop(0))
+        # stream items of one iteration, in consumption order (rho is not streamed: see V_RHO0)
+        self.stream = [("rinv", i) for i in gen if ("rinv", i) not in self.once]
+        for i in gen:
+            self.stream += [("l", i), ("u", i)] + ([("rinv", i)] if ("rinv", i) not in self.once else []) + \
+                           ([("rho", i)] if not KNOB["rho_select"] else [])
         self.n_land = len(self.stream)
         self.stream += [("q", j) for j in range(n)]
         self.stream += [("l", r["i"]) for r in self.rows if r["eq"] and not r["leaf"]]
         self.n_stream = len(self.stream)
-        self.extra = [("l", i) for i in self.leafeq]          # loaded once (prologue), after the per-iteration items
+        self.extra = list(self.once)                           # loaded once (prologue), after the per-iteration items
         # row-major hand-off rows (floats, [row][B])
         self.R_L, self.R_DI = 0, len(L_i)
         self.R_X = self.R_DI + nk
@@ -121,6 +153,12 @@ class Plan:
         assert self.LW_DY + m <= self.LW_X and self.LW_XP + n <= self.n_leaf + m
 
 
+# distance (instructions) after which an LDS / stream access is taken to have completed when a wait is placed: the wait
+# then covers it too and the later wait for it is not emitted (0: every wait covers exactly what its op needs)
+MERGE_LDS = int(os.environ.get("UMPC_QP_MERGE_LDS", "16"))
+MERGE_VM = int(os.environ.get("UMPC_QP_MERGE_VM", "150"))
+
+
 class Sched:
     """Emits a list of ops with their operand fetches: LDS quads through a ring (prefetched `ahead` ops before first use),
     AGPR words two ops ahead, stream items through the landing registers. op = dict(srcs=[...], emit=fn(regs)),
@@ -132,10 +170,13 @@ class Sched:
         self.nvm = vm_outstanding           # VMEM loads issued so far; the first `vm_outstanding` are the preloads
         self.vmpos = {}                     # stream item -> its load's issue index
         self.s_issued = 0                   # landing items issued
+        self.nland = getattr(plan, "NLAND", NLAND)
         self.sp_block = 0
+        self.lds_at, self.vm_at = {}, {}    # issue position -> instruction index (for merging waits, see MERGE_*)
 
     def lds_write(self, word, reg):
         base, off = lds_addr(word)
+        self.lds_at[self.nlds] = len(self.e.ins)
         self.e("ds_write_b32", base, "v%d" % reg, off)
         self.nlds += 1
 
@@ -145,9 +186,10 @@ class Sched:
             e("s_add_u32", "s%d" % S_SP, "s%d" % S_SP, BLOCK * 256)
             e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_SP + 1), 0)
             self.sp_block += 1
-        e("global_load_dword", "v%d" % (p.V_LAND + idx % NLAND), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1),
+        e("global_load_dword", "v%d" % (p.V_LAND + idx % self.nland), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1),
           (idx % BLOCK) * 256)
         self.vmpos[idx] = self.nvm
+        self.vm_at[self.nvm] = len(e.ins)
         self.nvm += 1
 
     def run(self, ops):
@@ -188,6 +230,7 @@ class Sched:
         def issue(it):
             base, off = lds_addr(4 * it["quad"])
             r = p.V_RING + 4 * it["slot"]
+            self.lds_at[self.nlds] = len(e.ins)
             e("ds_read_b128", "v[%d:%d]" % (r, r + 3), base, off)
             it["issued"] = self.nlds
             self.nlds += 1
@@ -206,7 +249,7 @@ class Sched:
             # stream: keep the landing registers full ahead of the consumer
             nxt = next((f for f in first_item[i:] if f is not None), None)
             if nxt is not None:
-                while self.s_issued < p.n_land and self.s_issued < nxt + NLAND - 4:
+                while self.s_issued < p.n_land and self.s_issued < nxt + self.nland - 4:
                     self.issue_stream(self.s_issued)
                     self.s_issued += 1
             while next_inst < len(insts):
@@ -232,9 +275,14 @@ class Sched:
                     if idx > waited_vm:
                         # one wait also covers the other items of this op
                         last = max(s_[1] for s_ in op["srcs"] if s_[0] == "S")
+                        # (a wait costs an issue slot of the lone wave: retire with it every later load that was issued
+                        # so long ago that it has arrived anyway)
+                        now = len(e.ins)
+                        while MERGE_VM and last + 1 in self.vmpos and self.vm_at[self.vmpos[last + 1]] <= now - MERGE_VM:
+                            last += 1
                         e("s_waitcnt", "vmcnt(%d)" % min(63, self.nvm - 1 - self.vmpos[last]))
                         waited_vm = last
-                    regs.append(p.V_LAND + idx % NLAND)
+                    regs.append(p.V_LAND + idx % self.nland)
                 else:
                     it = insts[inst_of[(i, q)]]
                     if it["issued"] is None:
@@ -242,8 +290,11 @@ class Sched:
                         issue(it)
                         next_inst += 1
                     if it["issued"] > waited_lds:
-                        e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nlds - 1 - it["issued"]))
-                        waited_lds = it["issued"]
+                        J, now = it["issued"], len(e.ins)
+                        while MERGE_LDS and J + 1 < self.nlds and self.lds_at[J + 1] <= now - MERGE_LDS:
+                            J += 1
+                        e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nlds - 1 - J))
+                        waited_lds = J
                     regs.append(p.V_RING + 4 * it["slot"] + (src[1] & 3))
             op["emit"](regs)
 
@@ -296,8 +347,15 @@ def body(e, p, capture=False):
             e("v_fma_f32", W(k), sS, v(r[0]), "-" + W(k))
         op([("L", p.LW_X + j)], f)
     # ---- P2/P3: rhs of the rows; leaf rows push theirs into their variable's unknown
-    land = 0
-    leafeq_reg = {i: p.V_LEQ + q for q, i in enumerate(p.leafeq)}
+    land = [0]
+
+    def src_of(item):
+        """a constant word: its on-chip home (Plan.once) or the next landing item"""
+        if item in p.once:
+            return p.once[item]
+        assert p.stream[land[0]] == item, (item, land[0])
+        land[0] += 1
+        return ("S", land[0] - 1)
     for r in p.rows:
         i, k = r["i"], r["k"]
         if r["eq"] and not r["leaf"]:
@@ -306,18 +364,16 @@ def body(e, p, capture=False):
                 e("v_fma_f32", W(k), "-" + v(g[0]), sRe, W(k))
             op([("L", p.LW_Y + i)], f)
         elif r["eq"]:
-            op([("L", p.LW_Y + i), ("L", p.lpos[r["j"]])],
-               lambda g, r=r, i=i: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(leafeq_reg[i])),
+            op([("L", p.LW_Y + i), ("L", p.lpos[r["j"]]), src_of(("l", i))],
+               lambda g, r=r, i=i: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
                                     e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0)))))
         elif not r["leaf"]:
-            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("S", land)],
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), src_of(("rinv", i))],
                lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[2]), v(g[0]), v(g[1])))
-            land += 1
         else:
-            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("S", land), ("L", p.lpos[r["j"]])],
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), src_of(("rinv", i)), ("L", p.lpos[r["j"]])],
                lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[2]), v(g[0]), v(g[1])),
                                e("v_fmac_f32", W(r["r"]), v(g[3]), v(T(0)))))
-            land += 1
     # ---- solves over the non-leaf unknowns (qdldl.c:250-293)
     for (r_, c, j) in p.solve_entries:
         op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
@@ -341,14 +397,14 @@ def body(e, p, capture=False):
         if r["eq"]:
             if r["leaf"]:
                 def f(g, r=r, i=i, yw=yw):
-                    e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(leafeq_reg[i]))
+                    e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[3]))
                     e("v_mul_f32", v(T(0)), v(T(0)), v(g[2]))
                     e("v_fmac_f32", v(T(0)), v(g[1]), W(r["r"]))          # nu
                     e("v_sub_f32", v(T(1)), v(T(0)), v(g[0]))
                     store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
                     e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
                     sc.lds_write(yw, T(1))
-                op([("L", yw), ("L", p.lpos[r["j"]]), ("A", k)], f)
+                op([("L", yw), ("L", p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
             else:
                 def f(g, k=k, yw=yw, i=i):
                     e("v_sub_f32", v(T(1)), W(k), v(g[0]))
@@ -358,18 +414,30 @@ def body(e, p, capture=False):
                 op([("L", yw)], f)
             continue
         zw = p.LW_Z + p.zpos[i]
-        srcs = [("L", yw), ("L", zw), ("S", land), ("S", land + 1), ("S", land + 2), ("S", land + 3)]
-        land += 4
+        srcs = [("L", yw), ("L", zw), src_of(("l", i)), src_of(("u", i)), src_of(("rinv", i))]
+        nfix = 5
+        if not KNOB["rho_select"]:
+            srcs.append(src_of(("rho", i)))
+            nfix = 6
         if r["leaf"]:
             srcs += [("L", p.lpos[r["j"]]), ("A", k)]
 
-        def f(g, r=r, k=k, yw=yw, zw=zw):
-            y, z, lo, up, rinv, rho = (v(x) for x in g[:6])
+        def f(g, r=r, k=k, yw=yw, zw=zw, nfix=nfix):
+            y, z, lo, up, rinv = (v(x) for x in g[:5])
             t3, nu, t2, tt, t4, d = (v(T(q)) for q in range(6))
+            if KNOB["rho_select"]:
+                rho = v(T(6))
+                # rho of the row: the class constant whose 1/rho this is (auxil.c:103-145 assigns one of three)
+                e("v_cmp_eq_f32", "vcc", "s%d" % S_RINV0, rinv)
+                e("v_cndmask_b32", rho, v(p.V_RHOMIN), v(p.V_RHO0), "vcc")
+                e("v_cmp_eq_f32", "vcc", sRe, rinv)
+                e("v_cndmask_b32", rho, rho, v(p.V_RHOEQ), "vcc")
+            else:
+                rho = v(g[5])
             e("v_fma_f32", t3, "-" + rinv, y, z)                          # z - y/rho (the rhs again)
             if r["leaf"]:
-                e("v_mul_f32", nu, t3, v(g[7]))
-                e("v_fmac_f32", nu, v(g[6]), W(r["r"]))
+                e("v_mul_f32", nu, t3, v(g[nfix + 1]))
+                e("v_fmac_f32", nu, v(g[nfix]), W(r["r"]))
             else:
                 nu = W(k)
             e("v_fma_f32", t3, rinv, nu, t3)                              # z~
@@ -388,7 +456,7 @@ def body(e, p, capture=False):
             sc.lds_write(zw, T(4))
             sc.lds_write(yw, T(5))
         op(srcs, f)
-    assert land == p.n_land
+    assert land[0] == p.n_land
     # ---- x <- alpha x~ + (1 - alpha) x
     for j in range(n):
         k = p.pinv[j]
@@ -453,11 +521,27 @@ def prologue(e, p):
 def prologue_tail(e, p):
     """once-only stream items (l of the leaf equality rows) -> their registers; the first iteration's preloads"""
     idx = p.n_stream
-    for q, (_, i) in enumerate(p.extra):
-        e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, ((idx + q) // BLOCK) * BLOCK * 256)
-        e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
-        e("global_load_dword", "v%d" % (p.V_LEQ + q), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), ((idx + q) % BLOCK) * 256)
+    assert len(p.extra) <= len(p.nonleaf)
+    blk = None
+    for q, item in enumerate(p.extra):
+        if (idx + q) // BLOCK != blk:
+            blk = (idx + q) // BLOCK
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, blk * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        kind, where = p.once[item]
+        dst = "a%d" % where if kind == "A" else "v%d" % where if kind == "V" else "v%d" % (V_W + q)   # (W: landing zone)
+        e("global_load_dword", dst, "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), ((idx + q) % BLOCK) * 256)
     e("s_waitcnt", "vmcnt(0)")
+    for q, item in enumerate(p.extra):
+        kind, where = p.once[item]
+        if kind == "L":
+            base, off = lds_addr(where)
+            e("ds_write_b32", base, "v%d" % (V_W + q), off)
+    e("s_waitcnt", "lgkmcnt(0)")
+    if KNOB["rho_select"]:
+        e("v_mov_b32", "v%d" % p.V_RHO0, "s%d" % S_RHO0)
+        e("v_mov_b32", "v%d" % p.V_RHOEQ, "s%d" % S_RHOEQ)
+        e("v_mov_b32", "v%d" % p.V_RHOMIN, f32bits(float(np.float32(RHO_MIN_F32))))
     preloads(e, p)
 
 
@@ -506,14 +590,14 @@ def prologue_fast(e, p, res):
     assert pool0 + 30 <= p.V_RING
     for j in sorted(res.it_p):
         sload(v_p + res.pidx[j], res.it_p[j])
+    items = p.stream + p.extra
     for q, i in enumerate(gen):
-        assert p.stream[q] == ("rinv", i)
-        sload(v_rinv + q, q)
+        sload(v_rinv + q, items.index(("rinv", i)))
     v_fmin = p.V_TT + N_TT - 1
     e("v_mov_b32", "v%d" % v_fmin, 1.0)
     e("s_waitcnt", "vmcnt(0)")
     factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING)),
-                list(range(p.V_LAND, p.V_LAND + NLAND)), v_fmin)
+                list(range(p.V_LAND, p.V_LAND + p.NLAND)), v_fmin)
     base, off = lds_addr(FAC_MIN)
     e("ds_write_b32", base, "v%d" % v_fmin, off)
     e("s_waitcnt", "lgkmcnt(0)")
@@ -609,9 +693,11 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
     for q, (sreg, arr) in enumerate(regions or []):
         SG[sreg], SG[sreg + 1] = 0, q + 1
         regmap[q + 1] = arr
-    alpha, sigma, rinv_eq = consts
-    for reg, val in ((S_ALPHA, f32(alpha)), (S_OMA, f32(f32(1.0) - f32(alpha))), (S_SIGMA, f32(sigma)), (S_RINVEQ, f32(rinv_eq))):
-        SG[reg] = f32bits(float(val))
+    alpha, sigma, rinv_eq = consts[:3]
+    rho0 = f32(consts[3] if len(consts) > 3 else 0.1)
+    for reg, val in ((S_ALPHA, f32(alpha)), (S_OMA, f32(f32(1.0) - f32(alpha))), (S_SIGMA, f32(sigma)), (S_RINVEQ, f32(rinv_eq)),
+                     (S_RHO0, rho0), (S_RINV0, f32(1.0 / float(rho0))), (S_RHOEQ, f32(1e3 * float(rho0)))):
+        SG.setdefault(reg, f32bits(float(val)))
 
     def sval(x):
         if isinstance(x, int):
@@ -1544,7 +1630,7 @@ def glue_program(s, eq_rows, p, res, rp):
                     put(res.it_ls[i], ls)
                 else:
                     for what, reg in (("rinv", rinv), ("l", ls), ("u", us), ("rho", rho)):
-                        for q in pos[(what, i)]:
+                        for q in pos.get((what, i), []):
                             put(q, reg)
             ops.append(dict(srcs=[("L", rp.LW_EV + i)], emit=f))
             nrow += 1

@@ -288,7 +288,7 @@ def emit_structure(name, s, asm=None):
         E("      const unsigned s_mid = __builtin_amdgcn_readfirstlane((unsigned)(asm_first ? mid + 1 : mid));")
         E("      const unsigned s_fast = __builtin_amdgcn_readfirstlane((unsigned)(fast ? 1 : 0));")
         E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq, "
-          "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_fast);" % name.upper())
+          "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_fast%s);" % (name.upper(), RHO_ARGS))
         E("    }")
         mark(5)
         E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
@@ -432,6 +432,12 @@ def emit_structure(name, s, asm=None):
 DTYPES = (("f32", "float"), ("f64", "double"))
 
 
+# the three rho classes of update_rho_vec as scalar operands of the loop block (kernel arguments: host-evaluated floats)
+RHO_ARGS = (", __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rho)), "
+            "__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv0)), "
+            "__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rho_eq))")
+
+
 def emit_fast_route(E, name, s, P, TIMING, mark):
     """The all-assembly route of the fp32 assembly variant: Ruiz block, glue block (asmqp.glue_program), the loop with its fast
     start (the block factorises), the residual block. Taken when the glue block finds every row of ASM_STRUCTURES[name] an
@@ -459,7 +465,7 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
     E("      const unsigned s_iters = __builtin_amdgcn_readfirstlane((unsigned)(a.max_iter - 1));")
     E("      BQP_%s_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
-      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u);" % U)
+      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s);" % (U, RHO_ARGS))
     mark(5)
     E("      fail = (LDSQ(%d) == T(0.0)) ? 1 : 0;   // a zero pivot of the block's factorisation (qdldl.c:221-224)" % asmqp.FAC_MIN)
     E("      if (a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
@@ -549,13 +555,14 @@ def asm_macro(name, ins, plan):
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[4:5] = row workspace, s[6:7] = the wave's stream",
            "// block, s10 = 4*B, s11 = iterations (>= 1), s20..s23 = alpha, 1 - alpha, sigma, 1/rho_eq (float bits);",
            "// s30 != 0: fast start (asmqp.prologue_fast: the block factorises; no hand-off rows) with s[24:25], s[26:27], s[28:29] =",
-           "// the caller's x, y, z rows; min |d_k| of the factorisation -> LDS word %d" % asmqp.FAC_MIN,
-           "#define BQP_%s_ASM(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast) asm volatile( \\" % name.upper()]
+           "// the caller's x, y, z rows; min |d_k| of the factorisation -> LDS word %d;" % asmqp.FAC_MIN,
+           "// s31 / s34 / s35 = rho, 1/rho, rho_eq (float bits): rho of a row is selected from its streamed 1/rho",
+           "#define BQP_%s_ASM(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast, rho0, rinv0, rhoeq) asm volatile( \\" % name.upper()]
     for t_ in ins:
         out.append('  "%s\\n" \\' % asmqp.fmt(t_))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(ws), "{s[6:7]}"(sblk), "{s10}"(stride), '
                '"{s11}"(iters), "{s20}"(alpha), "{s21}"(oma), "{s22}"(sigma), "{s23}"(rinveq), "{s[24:25]}"(xi), "{s[26:27]}"(yi), '
-               '"{s[28:29]}"(zi), "{s30}"(fast) \\')
+               '"{s[28:29]}"(zi), "{s30}"(fast), "{s31}"(rho0), "{s34}"(rinv0), "{s35}"(rhoeq) \\')
     out.append("  : " + ", ".join(clob) + ")")
     return "\n".join(out) + "\n"
 

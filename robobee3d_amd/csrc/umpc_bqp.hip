@@ -845,6 +845,8 @@ int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, con
     a.S = h->asm_tail ? (T *)h->W + (size_t)h->nrows * (size_t)h->B : nullptr;
     a.oma = T(1.0) - a.alpha;
     a.rinv_eq = T(1. / (double)T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho));
+    a.rinv0 = T(1. / (double)a.rho);
+    a.rho_eq = T(QP_RHO_EQ_OVER_RHO_INEQ * (double)a.rho);
   }
   // early termination / adaptive rho live in the table kernel
   const bool tables = h->use_tables || h->st.check_termination > 0 || h->st.adaptive_rho_interval > 0;

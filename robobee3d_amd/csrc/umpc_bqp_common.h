@@ -39,6 +39,7 @@ struct QPArgs {
   int asm_ok;  // an assembly specialisation (gen/bqp_*_asm.h) may run: S is allocated
   T *S;        // its stream buffer: [wave][item][lane], 1024 items per wave, behind the workspace rows
   T oma, rinv_eq;  // 1 - alpha and 1 / rho_eq as the kernels compute them, evaluated on the host (assembly operands)
+  T rinv0, rho_eq;  // 1 / rho and rho_eq likewise
 };
 
 template <typename T> __device__ __forceinline__ T qabs(T v) { return v < T(0) ? -v : v; }
