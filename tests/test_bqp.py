@@ -632,6 +632,52 @@ def test_gpu_p5f_assembly_loop_agrees_with_the_table_kernel(margin):
 
 
 @pytest.mark.gpu
+def test_gpu_p5f_all_assembly_route_hands_unsolved_waves_to_the_cpp_residual_phase(margin):
+    """A warm-started tick takes the all-assembly route (Ruiz, glue, LDL' + loop, residual block). When a robot of the wave
+    is not SOLVED at the strict tolerances the residual block does not settle the wave: the C++ residual phase (approximate
+    tolerances, certificates, status, solution rows) reloads the equilibrated data from the wave's streams and the iterates
+    from LDS. Forced here with few iterations after a large change of the linearisation; robots 0..63 keep the old
+    linearisation and stay solved where they can. Against the table kernel, incl. status and the info rows."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    B = 200
+    mpc = PlanarP5fMPC(B, torch.float32)
+    mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
+    mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
+    for iters in (3, 7):
+        res = []
+        for mode in ("lane", "tables"):
+            mpc.qp.reset()
+            mpc.qp.set_kernel(mode)
+            for ti in (2, 3):
+                mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti))
+                mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u, max_iter=50)
+            mpc.linearise(-15.0)
+            q = mpc.q.clone()
+            q[:, 64:] *= 3.0                      # (same bounds: z of the equality rows still equals them)
+            mpc.qp.solve(mpc.Pv, mpc.Av, q, mpc.l, mpc.u, max_iter=iters)
+            torch.cuda.synchronize()
+            res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.Eprev)]
+                       + [mpc.qp.status.cpu().numpy().copy(), mpc.qp.info.cpu().numpy().astype(np.float64).copy(),
+                          mpc.qp.sol_x.cpu().numpy().astype(np.float64).copy(), mpc.qp.sol_y.cpu().numpy().astype(np.float64).copy()])
+        st_a, st_b = res[0][4], res[1][4]
+        assert np.count_nonzero(st_b != 1) >= B // 2, "the case must leave robots unsolved"
+        worst = max(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) for a, b in zip(res[0][:4], res[1][:4]))
+        margin("%d iterations: iterates, |d| / max(1, |ref|)" % iters, worst, 1e-5)
+        margin("%d iterations: robots whose status differs" % iters, float(np.count_nonzero(st_a != st_b)), 2.0)
+        ia, ib = res[0][5], res[1][5]
+        margin("%d iterations: pri_res, dua_res, relative" % iters,
+               np.max(np.abs(ia[:2] - ib[:2]) / np.maximum(1e-6, np.abs(ib[:2]))), 1e-4)
+        assert np.array_equal(ia[3:], ib[3:])
+        same = st_a == st_b
+        for a, b in zip(res[0][6:], res[1][6:]):      # solution rows (NaN for robots flagged infeasible)
+            assert np.array_equal(np.isnan(a[:, same]), np.isnan(b[:, same]))
+            ok = same & ~np.isnan(b).any(0)
+            assert np.max(np.abs(a[:, ok] - b[:, ok]) / np.maximum(1.0, np.abs(b[:, ok]))) <= 1e-5
+    mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u, max_iter=50)       # (leave the default iteration count behind)
+
+
+@pytest.mark.gpu
 def test_gpu_p5f_assembly_kernel_falls_back_when_a_dynamics_row_is_not_an_equality(margin):
     """The assembly loop takes the 77 dynamics rows for equalities; the kernel checks it per wave and runs the C++ loop where
     it does not hold. Robots 64..127 (one whole wave) and robot 150 (one lane of the third wave) get l < u on a dynamics
