@@ -173,6 +173,19 @@ class Sched:
         self.nland = getattr(plan, "NLAND", NLAND)
         self.sp_block = 0
         self.lds_at, self.vm_at = {}, {}    # issue position -> instruction index (for merging waits, see MERGE_*)
+        self.vm_done = -1                   # VMEM loads up to this issue index are known to have arrived
+
+    def vm_wait(self, pos):
+        """the VMEM load with issue index `pos` must have arrived (loads arrive in order): emits a wait unless an earlier one
+        already implies it; retires with it the later loads that are old enough to have arrived anyway (MERGE_VM)"""
+        if pos <= self.vm_done:
+            return
+        now = len(self.e.ins)
+        while MERGE_VM and pos + 1 < self.nvm and self.vm_at.get(pos + 1, -10 ** 9) <= now - MERGE_VM:
+            pos += 1
+        c = min(63, self.nvm - 1 - pos)
+        self.e("s_waitcnt", "vmcnt(%d)" % c)
+        self.vm_done = self.nvm - 1 - c
 
     def lds_write(self, word, reg):
         base, off = lds_addr(word)
@@ -273,14 +286,9 @@ class Sched:
                     idx = src[1]
                     assert idx in self.vmpos, idx
                     if idx > waited_vm:
-                        # one wait also covers the other items of this op
+                        # one wait also covers the other items of this op (a wait costs an issue slot of the lone wave)
                         last = max(s_[1] for s_ in op["srcs"] if s_[0] == "S")
-                        # (a wait costs an issue slot of the lone wave: retire with it every later load that was issued
-                        # so long ago that it has arrived anyway)
-                        now = len(e.ins)
-                        while MERGE_VM and last + 1 in self.vmpos and self.vm_at[self.vmpos[last + 1]] <= now - MERGE_VM:
-                            last += 1
-                        e("s_waitcnt", "vmcnt(%d)" % min(63, self.nvm - 1 - self.vmpos[last]))
+                        self.vm_wait(self.vmpos[last])
                         waited_vm = last
                     regs.append(p.V_LAND + idx % self.nland)
                 else:
@@ -331,13 +339,9 @@ def body(e, p, capture=False):
     pre_pos = {}                         # W register preloaded -> index of its load among the preloads
     for q, (what, idx) in enumerate(p.stream[p.n_land:]):
         pre_pos[p.wreg[p.pinv[idx] if what == "q" else p.pinv[n + idx]]] = q
-    waited = [-1]
 
     def wait_pre(reg):
-        q = pre_pos[reg]
-        if q > waited[0]:
-            e("s_waitcnt", "vmcnt(%d)" % min(63, sc.nvm - 1 - q))
-            waited[0] = q
+        sc.vm_wait(pre_pos[reg])
     # ---- P1: W_x = sigma x - q (q preloaded)
     for j in range(n):
         k = p.pinv[j]
