@@ -189,13 +189,9 @@ def emit_structure(name, s, asm=None):
         for i in sorted(r["i"] for r in P.rows if r["eq"]):
             E("  z0ok = z0ok && (z[%d] == ls[%d]);" % (i, i))
         E("  const bool asm_first = use_asm && __all(z0ok);")
-        E("  // fast start: the block fills and factorises the KKT matrix itself (asmqp.prologue_fast) from the residual stream")
-        E("  constexpr bool fast = false;   // (the route above is the one that takes it)")
-        FI = "    "
-    # ---- factor
+    # ---- factor (the general route hands L and 1/D to the loop through the workspace rows; the loop block's own
+    # factorisation, asmqp.prologue_fast, belongs to the all-assembly route)
     E("  fail = 0;" if asm else "  int fail = 0;")
-    if asm:
-        E("  if (!fast) {")
     for k in range(nk):
         E(FI + "yv[%d] = T(0.0);" % k)
     for op in s.factor_ops:
@@ -215,8 +211,6 @@ def emit_structure(name, s, asm=None):
             E(FI + "    const T lv = yc * DI[%d]; Lx[%d] = lv; dk -= yc * lv; yv[%d] = T(0.0); }" % (cidx, new, cidx))
         E(FI + "  if (dk == T(0.0)) fail = 1;")
         E(FI + "  DI[%d] = T(1.0) / dk; }" % k)
-    if asm:
-        E("  }")
     mark(2)
     # ---- ADMM
     for j in range(n):
@@ -258,18 +252,16 @@ def emit_structure(name, s, asm=None):
         E("  if (use_asm) {")
         E("    // hand-off: negated L in the loop's storage order, 1/D, x, y, z of the inequality rows -> workspace rows;")
         E("    // one iteration's read-only words -> this wave's stream block, in consumption order (asmqp.Plan.stream)")
-        E("    if (!fast) {")
         for j, pos in sorted(P.lpos.items()):
-            E("      IN(a.W, %d) = -Lx[%d];" % (P.R_L + pos, j))
+            E("    IN(a.W, %d) = -Lx[%d];" % (P.R_L + pos, j))
         for k in range(nk):
-            E("      IN(a.W, %d) = DI[%d];" % (P.R_DI + k, k))
+            E("    IN(a.W, %d) = DI[%d];" % (P.R_DI + k, k))
         for j in range(n):
-            E("      IN(a.W, %d) = x[%d];" % (P.R_X + j, j))
+            E("    IN(a.W, %d) = x[%d];" % (P.R_X + j, j))
         for i in range(m):
-            E("      IN(a.W, %d) = y[%d];" % (P.R_Y + i, i))
+            E("    IN(a.W, %d) = y[%d];" % (P.R_Y + i, i))
         for i, q in sorted(P.zpos.items()):
-            E("      IN(a.W, %d) = z[%d];" % (P.R_Z + q, i))
-        E("    }")
+            E("    IN(a.W, %d) = z[%d];" % (P.R_Z + q, i))
         nst = P.n_stream + len(P.extra)
         src = {"rinv": "rinv[%d]", "l": "ls[%d]", "u": "us[%d]", "rho": "rho[%d]", "q": "qs[%d]"}
         for q, (what, i) in enumerate(P.stream + P.extra):
@@ -286,13 +278,11 @@ def emit_structure(name, s, asm=None):
         E("      // every scalar operand is made provably wave-uniform (the values are; the compiler cannot always see it)")
         E("      const unsigned long long wsp = uni((unsigned long long)a.W);")
         E("      const unsigned s_mid = __builtin_amdgcn_readfirstlane((unsigned)(asm_first ? mid + 1 : mid));")
-        E("      const unsigned s_fast = __builtin_amdgcn_readfirstlane((unsigned)(fast ? 1 : 0));")
         E("      BQP_%s_ASM(voff, ldsaddr, lane4, wsp, ssp, s_stride, s_mid, s_alpha, s_oma, s_sigma, s_rinveq, "
-          "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_fast%s);" % (name.upper(), RHO_ARGS))
+          "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 0u%s);" % (name.upper(), RHO_ARGS))
         E("    }")
         mark(5)
         E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
-        E("    if (fast) fail = (LDSQ(%d) == T(0.0)) ? 1 : 0;   // a zero pivot of the block's factorisation (qdldl.c:221-224)" % P.fac_min)
         E("    // residuals, the termination test at the strict tolerances and the solution stores as generated assembly")
         E("    // (asmqp.res_program); it settles the wave only if every robot is SOLVED -- otherwise the C++ phase below runs")
         E("    if (rs_valid && a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
@@ -640,7 +630,7 @@ def generate():
             res = asmqp.ResPlan(s, ASM_STRUCTURES[name], ASM_RES_ITEM0)
             ins, plan = asmqp.program(s, ASM_STRUCTURES[name], res)
             assert plan.n_stream + len(plan.extra) <= ASM_RES_ITEM0
-            plan.res, plan.fac_min = res, asmqp.FAC_MIN
+            plan.res = res
             assert plan.res.end <= ASM_STREAM_ITEMS
             rins, plan.ruiz = asmqp.ruiz_program(s)
             rsins, _ = asmqp.ruiz_program(s, plan.res)
