@@ -1032,12 +1032,10 @@ def ruiz_program(s, res=None):
         e("v_cndmask_b32", v(t), 1.0, v(t2), "vcc")
 
     def rsqrt(y, t, a_):
+        # v_rsq_f32 alone (1 ulp), as the uprightmpc2 step (asmstep.py) takes it: D and E only precondition, a last-bit
+        # difference to the divide + sqrt of the C++ statement moves the unscaled solution at round-off level
         e("v_rsq_f32", v(y), v(t))
         e("s_nop", 0)
-        e("v_mul_f32", v(a_), v(t), v(y))
-        e("v_fma_f32", v(a_), "-" + v(a_), v(y), 1.0)
-        e("v_mul_f32", v(t), 0.5, v(y))
-        e("v_fma_f32", v(y), v(t), v(a_), v(y))
 
     def recip(y, t, a_):
         e("v_rcp_f32", v(y), v(t))
