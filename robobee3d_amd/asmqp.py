@@ -1105,9 +1105,8 @@ def ruiz_program(s, res=None):
     for i in range(m):
         def fe(g, i=i):
             limit(p.V_ET + i, T(1))
-            rsqrt(T(1), p.V_ET + i, T(2))
-            e("v_mov_b32", ET(i), v(T(1)))
-        op([], fe)
+            e("v_rsq_f32", ET(i), ET(i))        # in place; the next VALU instruction (the next row's compare, or the
+        op([], fe)                               # csum initialisation) does not read it: no trans-use wait state needed
     # ---- apply; csum in T(4), qn in T(5), dt of the column in T(7)
     op([], lambda g: (e("v_mov_b32", v(T(4)), 0), e("v_mov_b32", v(T(5)), 0)))
     for j in range(n):
@@ -1365,7 +1364,8 @@ def res_program(s, eq_rows, ap, res):
 
         def f(g, i=i, eq=i in res.eq):
             ev, z, y = (g[0], g[1], g[2]) if eq else (g[0], g[2], g[1])
-            recip(T(9), ev, T(10))                                   # 1 / E_i
+            e("v_rcp_f32", v(T(9)), v(ev))                            # 1 / E_i (1 ulp: it only unscales norms that are
+            e("s_nop", 0)                                             # compared with tolerances)
             e("v_sub_f32", v(T(10)), ACC(i), v(z))
             e("v_mul_f32", v(T(10)), v(T(9)), v(T(10)))
             e("v_max_f32", v(PRI), v(PRI), ab(v(T(10))))
@@ -1406,7 +1406,8 @@ def res_program(s, eq_rows, ap, res):
             e("v_mul_f32", v(NAX), v(x), v(d))                        # sol_x = x D
             store("x", x)
             store("sx", NAX)
-            recip(NAX, d, scratch)                                    # 1 / D_j
+            e("v_rcp_f32", v(NAX), v(d))                              # 1 / D_j (likewise)
+            e("s_nop", 0)
             e("v_mul_f32", v(T(11)), v(NAX), v(T(11)))
             e("v_max_f32", v(DUA), v(DUA), ab(v(T(11))))
             e("v_mul_f32", v(T(11)), v(NAX), v(qv))
