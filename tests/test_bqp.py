@@ -678,6 +678,38 @@ def test_gpu_p5f_all_assembly_route_hands_unsolved_waves_to_the_cpp_residual_pha
 
 
 @pytest.mark.gpu
+def test_gpu_p5f_all_assembly_route_with_null_output_rows():
+    """umpcQPSolve allows NULL for sol_x, sol_y, status and info (include/umpc_mi355x.h). The residual block of the
+    all-assembly route writes all of them, so a call without them must leave it out and finish in the C++ residual phase:
+    same iterates and E as the call with outputs, bit for bit up to the route's own rounding (none: same blocks)."""
+    import ctypes as C
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC, _ptr
+    B = 130
+    mpc = PlanarP5fMPC(B, torch.float32)
+    mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
+    qp = mpc.qp
+    assert qp.kernel_name == "p5f10+asm"
+    res = []
+    for with_outputs in (True, False):
+        qp.reset()
+        for ti in (2, 3, 4):
+            mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti))
+            if with_outputs or ti < 4:
+                qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
+            else:
+                null = C.c_void_p(None)
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                rc = qp.L.umpcQPSolve(qp.h, _ptr(mpc.Pv), _ptr(mpc.Av), _ptr(mpc.q), _ptr(mpc.l), _ptr(mpc.u), _ptr(qp.x),
+                                      _ptr(qp.y), _ptr(qp.z), _ptr(qp.Eprev), null, null, null, null, stream)
+                assert rc == 0
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy().copy() for t in (qp.x, qp.y, qp.z, qp.Eprev)])
+    for a, b in zip(*res):
+        assert np.all(np.isfinite(a)) and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_gpu_p5f_assembly_kernel_falls_back_when_a_dynamics_row_is_not_an_equality(margin):
     """The assembly loop takes the 77 dynamics rows for equalities; the kernel checks it per wave and runs the C++ loop where
     it does not hold. Robots 64..127 (one whole wave) and robot 150 (one lane of the third wave) get l < u on a dynamics
