@@ -225,6 +225,16 @@ def main_p5f(args):
     alg = (2 * (s.n + 2 * s.m) + 15) * esz
     if rank == 0:
         kern_ms = e0.elapsed_time(e1) / args.steps
+        # HBM bytes: the committed rocprofv3 --pmc passes of this kernel (per robot-tick, scaled to this batch), when this run
+        # is the profiled kernel configuration
+        traffic, traffic_src = None, None
+        j = profile_json("pmc_config4_p5f")
+        if j is not None and args.dtype == "f32" and args.max_iter == 50 and mpc.qp.kernel_name.endswith("+asm"):
+            per = j["per_unit_bytes"]
+            traffic = (per["read_corrected"] + per["written"]) * B
+            traffic_src = "%s: %.0f B read + %.0f B written per robot-tick (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at B = %d, " \
+                          "gfx950 correction applied; the loop re-reads its read-only stream every iteration) x %d robots" \
+                          % (j["_file"], per["read_corrected"], per["written"], j["batch"], B)
         print(json.dumps({
             "metric": "closed-loop MPC steps/sec (QP+dyn)", "value": world * B * args.steps / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -234,7 +244,8 @@ def main_p5f(args):
                        "robots_per_gpu": B, "global_batch": world * B, "horizon": 10,
                        "parallelism": "robots sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": alg * B / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": alg * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": {"tables": "bqp_solve_kernel", "wave": "bqp_wave_kernel"}.get(
                              mpc.qp.kernel_name, "bqp_fixed_%s_asm_kernel" % mpc.qp.kernel_name[:-4] if mpc.qp.kernel_name.endswith("+asm")
                              else "bqp_fixed_%s_kernel" % mpc.qp.kernel_name),
@@ -375,6 +386,13 @@ def main():
             traffic = (per["read_corrected"] + per["written"]) * B * spl
             traffic_src = "%s: %.0f B read + %.0f B written per robot-step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
                           "gfx950 correction applied) x %d robots x %d steps" % (j["_file"], per["read_corrected"], per["written"], B, spl)
+        j = profile_json("pmc_config2_f64")      # the fp64 assembly-loop kernel (config 2) has its own counter passes
+        if (traffic is None and j is not None and args.dtype == "f64" and args.plant == "euler" and args.max_iter == 50
+                and args.nsub == 25 and not args.monte_carlo):
+            per = j["per_unit_bytes"]
+            traffic = (per["read_corrected"] + per["written"]) * B * spl
+            traffic_src = "%s: %.0f B read + %.0f B written per robot-step (rocprofv3 --pmc passes at B = %d, gfx950 correction " \
+                          "applied) x %d robots x %d steps" % (j["_file"], per["read_corrected"], per["written"], j["batch"], B, spl)
         j = profile_json("sq_counters")
         if same_kernel(j):
             valu_per_wave_step = j["per_wave_step"]["valu_instructions"]
