@@ -157,6 +157,9 @@ class Plan:
 # then covers it too and the later wait for it is not emitted (0: every wait covers exactly what its op needs)
 MERGE_LDS = int(os.environ.get("UMPC_QP_MERGE_LDS", "16"))
 MERGE_VM = int(os.environ.get("UMPC_QP_MERGE_VM", "150"))
+# generation-time experiment: the first NT_ITEMS landing items of an iteration are loaded with the non-temporal hint, so that
+# the rest of the stream (re-read every iteration) can stay in the XCD's L2 instead of the whole of it cycling through
+NT_ITEMS = int(os.environ.get("UMPC_QP_NT", "0"))
 
 
 class Sched:
@@ -200,7 +203,7 @@ class Sched:
             e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_SP + 1), 0)
             self.sp_block += 1
         e("global_load_dword", "v%d" % (p.V_LAND + idx % self.nland), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1),
-          (idx % BLOCK) * 256)
+          (idx % BLOCK) * 256, *(["nt"] if idx < NT_ITEMS else []))
         self.vmpos[idx] = self.nvm
         self.vm_at[self.nvm] = len(e.ins)
         self.nvm += 1
@@ -662,7 +665,7 @@ def fmt(t):
     if m.startswith("ds_"):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
     if m.startswith("global_"):
-        return "%s %s, %s, %s offset:%s" % (m, a[0], a[1], a[2], a[3])
+        return "%s %s, %s, %s offset:%s%s" % (m, a[0], a[1], a[2], a[3], " nt" if len(a) > 4 and a[4] == "nt" else "")
     if m == "s_waitcnt":
         return "s_waitcnt " + " ".join(a)
     return "%s %s" % (m, ", ".join(a))
