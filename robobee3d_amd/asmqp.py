@@ -160,6 +160,7 @@ MERGE_VM = int(os.environ.get("UMPC_QP_MERGE_VM", "150"))
 # generation-time experiment: the first NT_ITEMS landing items of an iteration are loaded with the non-temporal hint, so that
 # the rest of the stream (re-read every iteration) can stay in the XCD's L2 instead of the whole of it cycling through
 NT_ITEMS = int(os.environ.get("UMPC_QP_NT", "0"))
+RING_AHEAD = int(os.environ.get("UMPC_QP_RING_AHEAD", "20"))   # ops of look-ahead for the LDS ring reads
 
 
 class Sched:
@@ -271,7 +272,7 @@ class Sched:
             while next_inst < len(insts):
                 it = insts[next_inst]
                 prev = insts[it["prev"]] if it["prev"] is not None else None
-                if it["first"] <= i + 10 and (prev is None or prev["last"] < i):
+                if it["first"] <= i + RING_AHEAD and (prev is None or prev["last"] < i):
                     # (never fetched across a flush: the words may be rewritten before it)
                     if any(ops[z].get("flush") for z in range(i, it["first"])):
                         break
