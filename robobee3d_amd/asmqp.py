@@ -1535,6 +1535,7 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
 GLUE_FLAG = 637
 S_LR, S_UR, S_ER, S_ZR = 4, 8, 24, 26         # pointer pairs: l, u, Eprev, z rows (s[6:7] = the wave's stream block)
 GV_RHO0, GV_RINV0, GV_RHOEQ, GV_RINVEQ = 5, 6, 7, 8      # inputs (VGPRs, wave-uniform floats)
+GLUE_PTRS = (S_SP, 36, 38, 40)                           # SGPR pairs of the block pointers for the stream stores
 QP_RHO_MIN, QP_RHO_TOL, QP_INF_SCALED = 1e-6, 1e-4, 1e20 * 1e-4
 
 
@@ -1581,14 +1582,24 @@ def glue_program(s, eq_rows, p, res, rp):
     for reg, val in ((V_RMIN, np.float32(QP_RHO_MIN)), (V_RIMIN, np.float32(1.0 / QP_RHO_MIN)), (V_F, F), (V_NF, -F), (V_TOL, TOL)):
         e("v_mov_b32", v(reg), f32bits(float(val)))
     e("v_mov_b32", v(V_FLAG), 1.0)
-    cur = [None]
+    # a row's items go to three regions of the stream (1/rho list, per-row items, the residual stream): four block
+    # pointers are kept, least recently used replaced
+    ptrs = [[sreg, None, 0] for sreg in GLUE_PTRS]          # [SGPR pair, block, last use]
+    tick = [0]
 
     def put(item, reg):
-        if item // BLOCK != cur[0]:
-            cur[0] = item // BLOCK
-            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, cur[0] * BLOCK * 256)
-            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
-        e("global_store_dword", "v%d" % V_LANE, v(reg), "s[%d:%d]" % (S_SP, S_SP + 1), (item % BLOCK) * 256)
+        blk = item // BLOCK
+        tick[0] += 1
+        hit = [q for q in ptrs if q[1] == blk]
+        if hit:
+            q = hit[0]
+        else:
+            q = min(ptrs, key=lambda z: z[2])
+            q[1] = blk
+            e("s_add_u32", "s%d" % q[0], "s%d" % S_S, blk * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (q[0] + 1), "s%d" % (S_S + 1), 0)
+        q[2] = tick[0]
+        e("global_store_dword", "v%d" % V_LANE, v(reg), "s[%d:%d]" % (q[0], q[0] + 1), (item % BLOCK) * 256)
 
     def check(a_, b_):
         e("v_cmp_eq_f32", "vcc", v(a_), v(b_))

@@ -513,7 +513,7 @@ def emit_fast_route_reload(E, name, s, P):
 def glue_macro(name, ins):
     from . import asmqp
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(9, asmqp.V_END))] + \
-           ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1, asmqp.S_SP, asmqp.S_SP + 1)]
+           ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1)] + ['"s%d"' % (q + h) for q in asmqp.GLUE_PTRS for h in (0, 1)]
     out = ["// Glue between the Ruiz block and the loop (asmqp.glue_program): rho classification, scaled bounds, the loop's stream,",
            "// LDS word %d = 1 iff the wave may take the all-assembly route. %d instructions." % (asmqp.GLUE_FLAG, len(ins)),
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[4:5] / s[8:9] / s[24:25] / s[26:27] = l, u, Eprev, z rows,",
