@@ -1180,9 +1180,13 @@ def ruiz_program(s, res=None):
         assert V_RLANE >= p.V_TT + p.NT
         e("s_waitcnt", "lgkmcnt(0)")
 
+        rs_blk = [None]
+
         def put(item, reg):
-            e("s_add_u32", "s%d" % S_P, "s%d" % S_RSB, (item // BLOCK) * BLOCK * 256)
-            e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_RSB + 1), 0)
+            if item // BLOCK != rs_blk[0]:           # (consecutive items share the block pointer)
+                rs_blk[0] = item // BLOCK
+                e("s_add_u32", "s%d" % S_P, "s%d" % S_RSB, rs_blk[0] * BLOCK * 256)
+                e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_RSB + 1), 0)
             e("global_store_dword", "v%d" % V_RLANE, v(reg), "s[%d:%d]" % (S_P, S_P + 1), (item % BLOCK) * 256)
         # LDS words (A, D, E) through the ring registers, a group of quads at a time
         words = [(p.LW_A + k, res.it_A + k) for k in range(p.nnzA)] + [(p.LW_D + j, res.it_d[j]) for j in range(n)] + \
