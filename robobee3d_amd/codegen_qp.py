@@ -86,6 +86,10 @@ def emit_structure(name, s, asm=None):
         E("  const unsigned long long ssp = a.asm_ok ? uni((unsigned long long)sblk) : 0ull;")
         E("  const unsigned lane4 = (unsigned)threadIdx.x * 4u;")
         emit_fast_route(E, name, s, asm, TIMING, mark)
+        if not TIMING:
+            # (leave here: hipcc computes and spills ~700 row addresses of the routes below in their common dominator, which
+            # would otherwise be this point -- 1 000 scratch stores per tick that a settled wave never reads)
+            E("  if (mode == 2) return;")
         E("  if (mode == 0) {   // the general route: C++ glue around the assembly blocks, or all C++")
         E("  BQP_%s_LOAD_XYZ(voff, ldsaddr, uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), s_stride);" % name.upper())
         for j in range(n):
