@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 def profile_json(name):
     """A committed rocprofv3 summary under profiles/ (PMC counters cannot be read live from inside the process)."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(path):
             try:
@@ -107,6 +107,20 @@ def reference_anchor():
         return {"error": repr(ex)[:200]}
 
 
+def valu_issue(valu_per_wave_step, B, spl, kern_ms, src):
+    """Vector-instruction issue rate of the step kernel against BOTH peaks: the hardware's (MI355X_MICROARCH.md constants
+    table: a wave64 VALU op occupies a SIMD-32 for 2 cycles, reached with >= 2 waves per SIMD) and the lone-wave rate
+    (one wave per SIMD issues a VALU op every 4 cycles; this kernel's 512-register waves run one per SIMD by design)."""
+    ach = valu_per_wave_step * (B / 64) * spl / (kern_ms * 1e-3) / 1e9
+    p2, p4 = 1024 * 2.4 / 2, 1024 * 2.4 / 4
+    return {"valu_instr_per_wave_step": valu_per_wave_step, "achieved": ach, "unit": "G wave-instr/s",
+            "peak": p2, "frac": ach / p2, "peak_simd32": p2, "frac_simd32": ach / p2,
+            "peak_lone_wave": p4, "frac_lone_wave": ach / p4, "source": src,
+            "note": "VALU instructions only (SQ_INSTS_VALU per wave-step, profile-derived). peak / frac = the SIMD-32 issue "
+                    "peak, 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 op; *_lone_wave = 1024 SIMDs x 2.4 GHz / 4, the rate "
+                    "ONE wave per SIMD can issue at (the kernel's occupancy: 512 registers + 40 KiB LDS per wave)"}
+
+
 class DryRunMPC:
     """--dry-run stand-in for BatchUprightMPC on CPU: no kernel, statistics = the global robot index, so the
     launcher / rendezvous / gather path of bench.py can run under gloo in the CPU test-suite."""
@@ -175,6 +189,111 @@ def cpu_baseline(args, plant_mode):
             "sample": "%d robots x %d steps of the same workload (oracle/umpc_oracle.c, fp32, OpenMP over robots)"
                       % (Bs, Ks),
             "single_thread_value": n1 * Ks / dt1, "fp64_single_thread_value": n1 * Ks / dt2}
+
+
+def _timed(launch, steps, warmup, dev, spl=None):
+    """W untimed steps, then EXACTLY K timed ones: barrier-less one-GPU form of the main protocol (synchronise, wall clock
+    and HIP events on the launch stream around the K steps, synchronise). launch(k) enqueues k steps. Returns
+    (seconds, mean milliseconds per launch from the events, launches)."""
+    import torch
+    spl = steps if not spl else spl
+    w = warmup
+    while w > 0:
+        launch(min(spl, w))
+        w -= min(spl, w)
+    torch.cuda.synchronize(dev)
+    n = steps // spl
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    t0 = time.perf_counter()
+    for k in range(n):
+        evs[k][0].record()
+        launch(spl)
+        evs[k][1].record()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return dt, float(np.mean([a.elapsed_time(b) for a, b in evs])), n
+
+
+def side_configs(dev, steps, warmup):
+    """The other single-GPU configurations of BASELINE.json, driver-timed by the SAME command as the headline (after its
+    timed region): config 2 (configs[1]: fp64, B = 4096, the reference's Euler + expm plant), config 4 (configs[3]:
+    planar p5f, N = 10, B = 16384) and one GPU's shard of config 5 (configs[4]: B = 2^17, per-robot inertia + thrust
+    gain). Same protocol: W untimed steps, K timed steps, inputs resident, value = robots x K / wall time; the
+    roofline record prices the dominant kernel's ALGORITHMIC bytes against 8 TB/s from the HIP-event duration, with
+    the committed counter traffic of that kernel (per unit, labelled) beside it."""
+    import torch
+    from robobee3d_amd.batch import (BatchUprightMPC, hover_initial_conditions_device, monte_carlo_draws_device)
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    out = {}
+
+    def roof(alg_per_unit, units, kern_ms, prof, key):
+        ach = alg_per_unit * units / (kern_ms * 1e-3) / 1e9
+        tr = src = None
+        if prof is not None:
+            per = prof[key]
+            tr = (per["read_corrected"] + per["written"]) * units
+            src = "%s: %.0f B read + %.0f B written per unit (rocprofv3 --pmc passes, gfx950 correction applied), x %d units" \
+                  % (prof["_file"], per["read_corrected"], per["written"], units)
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": tr, "traffic_source": src, "alg_bytes_per_launch": alg_per_unit * units}
+
+    # ---- config 2: uprightmpc2 hover, B = 4096 random tilts, fp64 (seed 20201117, SURVEY 8d) ----
+    B = 4096
+    m = BatchUprightMPC(B, torch.float64, device=dev, plant_mode=0)
+    st, ref, _ = hover_initial_conditions_device(B, 20201117, torch.float64, device=dev)
+    m.set_state(st, ref)
+    dt, kms, n = _timed(m.rollout, steps, warmup, dev)
+    out["config2_fp64_B4096"] = {
+        "workload": "BASELINE configs[1]: uprightmpc2 hover, batch=4096 random initial tilts, fp64, Euler+expm plant, closed loop",
+        "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "dtype": "f64", "robots": B, "kernel": m.kernel_name, "kernel_ms": kms, "steps_per_launch": steps,
+        "roofline": roof(2 * ALG_BYTES_PER_STEP_FP32, B * steps, kms, profile_json("pmc_config2_f64"), "per_unit_bytes"),
+        "check": {"nonfinite_state_values": int((~torch.isfinite(m.state)).sum().item()),
+                  "status_solved_frac": float((m.status > 0).float().mean().item())}}
+    del m
+    # ---- config 4: planar p5f, N = 10, B = 16384, fp32 (seed 20201119) ----
+    B = 16384
+    mp = PlanarP5fMPC(B, torch.float32, device=dev)
+    pert = np.random.default_rng(20201119).uniform(-0.1, 0.1, (2, B))
+    mp.y[0] = torch.as_tensor(pert[0]).to(mp.y)
+    mp.y[3] = torch.as_tensor(pert[1]).to(mp.y)
+    tick = [2]
+
+    def p5f_launch(k):
+        for _ in range(k):
+            mp.tick(0.002 * tick[0]); tick[0] += 1
+    dt, kms, n = _timed(p5f_launch, steps, warmup, dev)
+    sq = mp.qp.s
+    alg = (2 * (sq.n + 2 * sq.m) + 15) * 4
+    kn = mp.qp.kernel_name
+    out["config4_p5f_B16384"] = {
+        "workload": "BASELINE configs[3]: planar/mpc_osqp_p5f stroke-plane MPC, N=10 (n=87, m=164), 50 ADMM it, 10 Ruiz, "
+                    "LDL' refactor per tick + Euler plant tick",
+        "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "dtype": "f32", "robots": B,
+        "kernel": "bqp_fixed_%s_asm_kernel" % kn[:-4] if kn.endswith("+asm") else kn,
+        "kernel_ms": kms / steps, "kernel_ms_note": "HIP events around the %d ticks (gather, getLin, QP, plant kernels of a tick) / ticks" % steps,
+        "roofline": roof(alg, B, kms / steps, profile_json("pmc_config4_p5f") if kn.endswith("+asm") else None, "per_unit_bytes"),
+        "check": {"nonfinite_state_values": int((~torch.isfinite(mp.y)).sum().item()),
+                  "status_solved_frac": float((mp.qp.status > 0).float().mean().item())}}
+    del mp
+    # ---- config 5, one GPU's shard: B = 2^17, per-robot inertia and thrust gain, fp32, RK4 (seed 20201120) ----
+    B = 131072
+    m = BatchUprightMPC(B, torch.float32, device=dev, plant_mode=1)
+    st, ref, _ = hover_initial_conditions_device(B, 20201118, torch.float32, device=dev)
+    m.set_state(st, ref)
+    m.Ib, m.gain = monte_carlo_draws_device(B, 20201120, torch.float32, device=dev)
+    dt, kms, n = _timed(m.rollout, steps, warmup, dev)
+    out["config5_shard_B131072"] = {
+        "workload": "BASELINE configs[4], one GPU's shard: Monte-Carlo mass/inertia sweep, 2^17 robots (of 2^20 over 8 GPUs), "
+                    "per-robot Ib (controller + plant) and thrust gain +-20 %, fp32, RK4 plant",
+        "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "dtype": "f32", "robots": B, "kernel": m.kernel_name, "kernel_ms": kms, "steps_per_launch": steps,
+        "roofline": roof(ALG_BYTES_PER_STEP_FP32 + 16, B * steps, kms, None, None),
+        "check": {"nonfinite_state_values": int((~torch.isfinite(m.state)).sum().item()),
+                  "status_solved_frac": float((m.status > 0).float().mean().item())}}
+    del m
+    return out
 
 
 def main_p5f(args):
@@ -278,6 +397,11 @@ def main():
     ap.add_argument("--monte-carlo", action="store_true",
                     help="BASELINE configs[4]: per-robot inertia (controller + plant) and plant thrust gain, +-20 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the driver-timed side configurations (BASELINE configs[1], [3], [4]'s shard) that a default "
+                         "one-GPU run of the headline workload appends under \"configs\"")
+    ap.add_argument("--side-steps", type=int, default=20)
+    ap.add_argument("--side-warmup", type=int, default=5)
     ap.add_argument("--cpu-robots", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=100)
     ap.add_argument("--dry-run", action="store_true",
@@ -315,17 +439,22 @@ def main():
 
     # synthetic inputs, resident in HBM before the timed region
     lo, _hi = shard.robot_range(B, rank)   # weak scaling: B robots per GPU, RNG keyed by the global index
-    st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=lo)
     if args.dry_run:
+        st, ref = hover_initial_conditions(B, 20201118, ndt, index_offset=lo)
         mpc = DryRunMPC(B, torch.as_tensor(st), rank)
     else:
+        # inputs are generated ON the device from the counter hash: no host-side pass over the batch per rank
+        from robobee3d_amd.batch import hover_initial_conditions_device, monte_carlo_draws_device
         mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode, maxIter=args.max_iter, nsub=args.nsub)
+        st, ref, _ = hover_initial_conditions_device(B, 20201118, tdt, index_offset=lo, device=dev)
         mpc.set_state(st, ref)
     if args.monte_carlo:  # Ib = Ib0 (1 + d), d ~ U(-0.2, 0.2)^3, thrust gain 1 + U(-0.2, 0.2)
-        from robobee3d_amd.batch import monte_carlo_draws
-        Ib, gain = monte_carlo_draws(B, 20201120, ndt, index_offset=lo)   # keyed by the GLOBAL robot index
-        mpc.Ib = torch.as_tensor(Ib).to(dev)
-        mpc.gain = torch.as_tensor(gain).to(dev)
+        if args.dry_run:
+            from robobee3d_amd.batch import monte_carlo_draws
+            Ib, gain = monte_carlo_draws(B, 20201120, ndt, index_offset=lo)   # keyed by the GLOBAL robot index
+            mpc.Ib, mpc.gain = torch.as_tensor(Ib), torch.as_tensor(gain)
+        else:
+            mpc.Ib, mpc.gain = monte_carlo_draws_device(B, 20201120, tdt, index_offset=lo, device=dev)
 
     def barrier():
         if dist.is_initialized():
@@ -358,6 +487,7 @@ def main():
     local = time.perf_counter() - t0          # this rank's K steps, start barrier -> local completion
     barrier()
     elapsed = shard.max_over_ranks(local, device=dev)
+    per_rank_s = shard.gather_scalars(local, device=dev)      # every rank's own K steps (the line reports the maximum)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if cuda else local / nlaunch * 1e3
 
     # end-of-run trajectory statistics: the only exchange of the path (RCCL all_gather over xGMI,
@@ -401,6 +531,7 @@ def main():
             "metric": "closed-loop MPC steps/sec (QP+dyn)", "value": value, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step_per_rank": [t / args.steps * 1e3 for t in per_rank_s],
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: closed-loop uprightmpc2 (N=3, 50 ADMM it, 10 Ruiz, LDL' "
                                    "refactor per step) + 25 plant substeps, random-tilt hover, seed 20201118",
@@ -409,7 +540,7 @@ def main():
                        "parallelism": "robots sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": _lib.lib().umpcKernelName(0 if args.dtype == "f32" else 1, plant_mode).decode(),
+                         "kernel": mpc.kernel_name if not args.dry_run else None,   # what the handle's last launch dispatched
                          "kernel_ms": kern_ms, "steps_per_launch": spl, "alg_bytes_per_launch": bps * B * spl,
                          # SURVEY 8d asks for all three rooflines; the one that binds is vector issue
                          "flops": {"achieved": 1.1e5 * B * spl / (kern_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
@@ -417,13 +548,7 @@ def main():
                          "lds": {"achieved": (args.max_iter * 78 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
                                  "unit": "GB/s", "peak": 256 * 128 * 2.4,
                                  "note": "78 ds_read_b128 per ADMM iteration per lane + hand-off; peak 128 B/clk/CU"},
-                         "valu_issue": {"valu_instr_per_wave_step": valu_per_wave_step,
-                                        "achieved": valu_per_wave_step * (B / 64) * spl / (kern_ms * 1e-3) / 1e9,
-                                        "peak": 1024 * 2.4 / 4, "unit": "G wave-instr/s",
-                                        "frac": valu_per_wave_step * (B / 64) * spl / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 4),
-                                        "source": valu_src,
-                                        "note": "VALU instructions only (SQ_INSTS_VALU per wave-step, profile-derived); peak = "
-                                                "1024 SIMDs x one wave64 VALU op per 4 cycles at 2.4 GHz"} if valu_per_wave_step else None,
+                         "valu_issue": valu_issue(valu_per_wave_step, B, spl, kern_ms, valu_src) if valu_per_wave_step else None,
                          "note": "path is VALU-issue bound, not HBM bound (DESIGN.md): ~1.1e5 flop per 1208 B"},
             "check": {"nonfinite_state_values": nbad,
                       "mean_pos_err_mm2": float(metric[0].mean().item()),
@@ -433,6 +558,12 @@ def main():
             line["dry_run"] = True
             line["value"] = line["ms_per_step"] = None     # no kernel ran: nothing was measured
             line["roofline"] = None
+        default_headline = (args.dtype == "f32" and B == 65536 and args.max_iter == 50 and args.nsub == 25
+                            and args.plant == "rk4" and not args.monte_carlo)
+        if world == 1 and not args.dry_run and not args.no_side_configs and default_headline:
+            del mpc
+            torch.cuda.empty_cache()
+            line["configs"] = side_configs(dev, args.side_steps, args.side_warmup)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             line["cpu_baseline"] = cpu_baseline(args, plant_mode)
         if dist.is_initialized():

@@ -86,8 +86,12 @@ void umpcS(float uquad_y1[/* 3 */], float accdes_y2[/* 6 */], const float p0_u1[
 /* OSQP status of the most recent umpcUpdate on `up` (the reference leaves it
  * in its global workspace.info->status_val; constants.h:18-30). */
 int umpcLastStatus(const UprightMPC_t *up);
-/* Releases the device-side state attached to `up` (optional). */
+/* Releases the device-side state attached to `up` (optional: umpcInit on a POD that already carries a live
+ * controller releases the previous one first, so re-initialising in a gain sweep or at a Simulink / MCU restart does
+ * not accumulate device memory or streams). */
 void umpcRelease(UprightMPC_t *up);
+/* Number of drop-in controllers currently holding device state (diagnostics / tests). */
+int umpcLiveControllers(void);
 
 /* ------------------------------------------------------------------ */
 /* Part 2: batched controllers                                         */
@@ -201,8 +205,11 @@ const int *umpcAxIdx(void);    /* 48 entries, uprightmpc2.c:65-113 */
 const int *umpcKKTPerm(void);  /* 84 entries, the build's own elimination order */
 int umpcNnzL(void);
 const char *umpcLastError(void);
-/* name and duration of the kernels, for bench.py */
+/* name of the kernel a DEFAULT rollout of this dtype dispatches (environment overrides included), and of the kernel
+ * the handle's last umpcBatchRollout / umpcBatchUpdate actually dispatched ("" before the first launch): bench.py and
+ * the tests attribute timings and profiles through the second one */
 const char *umpcKernelName(int dtype, int plant_mode);
+const char *umpcBatchKernelName(const umpc_batch_t *h);
 
 /* The reactive baseline of the reference's gain sweeps: reactiveController (template/template_controllers.py:
  * 282-296) inside controlTest(useMPC=False) (template/uprightmpc2.py:121-151): `nsteps` plant substeps of dtsim,

@@ -463,8 +463,9 @@ static int update_rho_vec(struct umpc_oracle *o, const real *ls, const real *us)
 static int osqp_update_bounds_(struct umpc_oracle *o) {
   /* osqp.c:801-808: a crossed pair rejects the whole update (data untouched; umpcUpdate ignores the return,
    * uprightmpc2.c:247). Canonical mode states the HIP kernel's semantics instead: bounds are
-   * applied as assembled -- only reachable with Tmax < 0, where the QP is infeasible and the certificate of
-   * auxil.c:362-424 fires (OSQP_NAN outputs + cold start, auxil.c:539-564). */
+   * applied as assembled -- only reachable with Tmax < 0, where the crossed thrust rows classify as equalities
+   * (u - l < RHO_TOL, auxil.c:118) and project onto u (proj.c:4-14): the thrust is driven to Tmax. The reference
+   * itself keeps solving its code-generated placeholder bounds (tests/golden/bounds_reject.npz). */
   if (!o->canonical)
     for (int i = 0; i < NC; ++i)
       if (o->l_new[i] > o->u_new[i]) return 1;

@@ -20,12 +20,12 @@ STATE_ROWS, CTRL_ROWS, REF_ROWS, OUT_ROWS, STAT_ROWS = 18, 127, 9, 9, 2
 NX, NC, NADATA = 45, 39, 48
 
 # every symbol include/umpc_mi355x.h declares
-EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease",
+EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease", "umpcLiveControllers",
            "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchSetStepKernel", "umpcBatchReactive", "umpcBatchTaskReference",
-           "umpcLastError", "umpcKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
+           "umpcLastError", "umpcKernelName", "umpcBatchKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
            "umpcP5fStep", "umpcNAssemble", "umpcNExtract"]
 
@@ -93,8 +93,18 @@ def _check_resources(remarks):
         m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\d+)", line)
         if m and cur is not None:
             cur[m.group(1).split(" ")[0]] = int(m.group(2))
-    with open(os.path.join(OBJ_DIR, "resources.json"), "w") as f:
+    _validate_resources(res)
+    # persisted next to the object: a later build that REUSES the object validates this record again
+    with open(RESOURCES_JSON, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
+    return res
+
+
+RESOURCES_JSON = os.path.join(OBJ_DIR, "resources.json")
+
+
+def _validate_resources(res):
+    import json
     if not os.path.exists(RESOURCE_LIMITS):
         return res
     limits = json.load(open(RESOURCE_LIMITS))
@@ -105,6 +115,8 @@ def _check_resources(remarks):
         for k in hits:
             r = res[k]
             for key, op in (("VGPRs", "=="), ("AGPRs", "=="), ("LDS", "=="), ("ScratchSize", "<=")):
+                if key in lim and key not in r:     # a remark the compiler no longer prints is a failed check, not a KeyError
+                    raise RuntimeError("resource check: %s missing for %s (hipcc remark format changed?)" % (key, k))
                 if key in lim and not (r[key] == lim[key] if op == "==" else r[key] <= lim[key]):
                     raise RuntimeError("resource check failed for %s: %s = %d, recorded %s %d (csrc/resource_limits.json)"
                                        % (k, key, r[key], op, lim[key]))
@@ -137,7 +149,16 @@ def build(force=False, verbose=False):
             extra = ["-Rpass-analysis=kernel-resource-usage"] if src == SRC else []
             todo.append(["hipcc"] + HIPCC_FLAGS + extra + ["-c", "-o", obj, src])
             relink = True
-    for stale in set(os.listdir(OBJ_DIR)) - {os.path.basename(o) for o in objs}:
+    step_obj = os.path.join(OBJ_DIR, os.path.basename(SRC) + ".o")
+    if not any(c[-1] == SRC for c in todo):
+        # the step-kernel object is reused: its recorded resource usage must still pass (and must exist)
+        import json
+        try:
+            _validate_resources(json.load(open(RESOURCES_JSON)))
+        except Exception:
+            todo.insert(0, ["hipcc"] + HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", step_obj, SRC])
+            relink = True
+    for stale in set(os.listdir(OBJ_DIR)) - {os.path.basename(o) for o in objs} - {os.path.basename(RESOURCES_JSON)}:
         os.remove(os.path.join(OBJ_DIR, stale))
     # one hipcc per translation unit, at most one per host CPU at a time
     running, width = [], max(1, min(len(todo), os.cpu_count() or 1))
@@ -156,8 +177,8 @@ def build(force=False, verbose=False):
         if cmd[-1] == SRC:
             try:
                 _check_resources((err or b"").decode())
-            except RuntimeError:
-                os.remove(cmd[-2])     # the object must not survive a failed check
+            except Exception:
+                os.remove(cmd[-2])     # the object must not survive a failed check (it would be reused unchecked)
                 raise
     if relink or any(os.path.getmtime(SO_PATH) < os.path.getmtime(o) for o in objs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs
@@ -191,6 +212,8 @@ def lib():
         L.umpcBatchAssemble.argtypes = [C.c_void_p] + [C.c_void_p] * 10
         L.umpcLastError.restype = C.c_char_p
         L.umpcKernelName.restype = C.c_char_p
+        L.umpcBatchKernelName.restype = C.c_char_p
+        L.umpcBatchKernelName.argtypes = [C.c_void_p]
         L.umpcAxIdx.restype = C.POINTER(C.c_int * NADATA)
         L.umpcKKTPerm.restype = C.POINTER(C.c_int * (NX + NC))
         L.umpcBatchSetTask.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double]

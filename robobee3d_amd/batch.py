@@ -71,6 +71,55 @@ def monte_carlo_draws(B, seed, dtype=np.float32, spread=0.2, index_offset=0):
     return Ib.astype(dtype), gain.astype(dtype)
 
 
+def _u01_device(seed, idx, salt):
+    """_u01 on the device: the same counter hash in int64 two's-complement arithmetic (wrap-around multiplies, logical
+    right shifts spelled as arithmetic shift + mask), bit-identical to the numpy uint64 version."""
+    def c(v):        # 64-bit constant as a signed int
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >> 63 else v
+
+    def lsr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    v = idx + c(int(seed) * 0x9E3779B97F4A7C15) + int(salt)
+    v = v ^ lsr(v, 30)
+    v = v * c(0xBF58476D1CE4E5B9)
+    v = v ^ lsr(v, 27)
+    v = v * c(0x94D049BB133111EB)
+    v = v ^ lsr(v, 31)
+    return lsr(v, 11).to(torch.float64) / float(1 << 53)
+
+
+def monte_carlo_draws_device(B, seed, dtype=torch.float32, spread=0.2, index_offset=0, device="cuda"):
+    """monte_carlo_draws generated ON the device (an 8-rank config-5 start is then 8 tiny kernels, not 8
+    host-side numpy passes over 2^17 x 4 draws + 8 uploads): same hash, same fp64 arithmetic, bit-identical values.
+    Returns Ib [3, B], gain [B] as device tensors."""
+    idx = torch.arange(index_offset, index_offset + B, dtype=torch.int64, device=device)
+    Ib0 = (3333.0, 3333.0, 1000.0)   # template/genqp.py:22
+    Ib = torch.stack([Ib0[i] * (1 + (2 * _u01_device(seed, idx, 11 + i) - 1) * spread) for i in range(3)])
+    gain = 1 + (2 * _u01_device(seed, idx, 14) - 1) * spread
+    return Ib.to(dtype).contiguous(), gain.to(dtype).contiguous()
+
+
+def hover_initial_conditions_device(B, seed, dtype=torch.float32, tilt=0.5, index_offset=0, device="cuda"):
+    """hover_initial_conditions generated ON the device: identical tilt angles (same hash, bit for bit); the rotation
+    entries come from the device's fp64 sin / cos, which may differ from numpy's in the last fp64 bit before the cast."""
+    idx = torch.arange(index_offset, index_offset + B, dtype=torch.int64, device=device)
+    a = (2 * _u01_device(seed, idx, 1) - 1) * tilt
+    b = (2 * _u01_device(seed, idx, 2) - 1) * tilt
+    ca, sa, cb, sb = torch.cos(a), torch.sin(a), torch.cos(b), torch.sin(b)
+    z = torch.zeros_like(a)
+    state = torch.zeros((18, B), dtype=torch.float64, device=device)
+    # R = Rx(a) Ry(b), column-major rows 3..11: entry r + 3 c
+    cols = ((cb, sa * sb, -ca * sb), (z, ca, sa), (sb, -sa * cb, ca * cb))
+    for cidx, col in enumerate(cols):
+        for r in range(3):
+            state[3 + r + 3 * cidx] = col[r]
+    state[12] = 0.1
+    ref = torch.zeros((9, B), dtype=torch.float64, device=device)
+    ref[8] = 1.0
+    return state.to(dtype).contiguous(), ref.to(dtype).contiguous(), (a, b)
+
+
 class BatchUprightMPC:
     """B independent uprightmpc2 controllers (+ plants), one GPU lane each."""
 
@@ -179,6 +228,11 @@ class BatchUprightMPC:
             self._check(self.L.umpcBatchSetWL(self.h, C.byref(wl.wl), md, _ptr(wl.u), _ptr(wl.w0)))
 
     @property
+    def kernel_name(self):
+        """The kernel the last rollout() / update() of this handle dispatched (umpcBatchKernelName)."""
+        return self.L.umpcBatchKernelName(self.h).decode()
+
+    @property
     def time_ms(self):
         return float(self.L.umpcBatchTime(self.h))
 
@@ -209,12 +263,15 @@ class BatchUprightMPC:
             self._check(self.L.umpcBatchTaskReference(self.h, float(t_ms), _ptr(self.ref), _ptr(out), self._stream()))
         return out
 
-    def control_test_log(self, tend, robots=(0,), use_mpc=True, gains=None):
+    def control_test_log(self, tend, robots=(0,), use_mpc=True, gains=None, fire=None):
         """The log of controlTest (template/uprightmpc2.py:113,150-159) for the selected robots, in the reference's
         layout -- a dict {'t' [Nt], 'y' [Nt, 12] = (p, Rb[:, 2], dq), 'u' [Nt, 3], 'pdes' [Nt, 3], 'accdes' [Nt, 6]}
         per robot that viewControlTestLog / logMetric (:14-84, :161-175) take as is -- plus 'metric'. The loop runs
-        from the current state at the fixed fire schedule (every nsub substeps), one launch per substep: this is
-        the logging path, not the throughput path. Returns {robot: log}."""
+        from the current state, one launch per substep: this is the logging path, not the throughput path.
+        fire: None = the fixed schedule (an MPC step every nsub substeps, the first at substep 0), or the substep
+        indices at which the MPC fires -- the reference fires when `tt[ti] - thlPrev > hlInterval` (:136), which in
+        floating point gives gaps of 25 / 26 substeps starting at substep 26; before the first fire the command is
+        zero (:118) and between fires it is held. Returns {robot: log}."""
         nsub, dts = int(self.prm.nsub), float(self.prm.dtsim)
         Nt = int(np.ceil(tend / dts - 1e-9))
         idx = torch.as_tensor(list(robots), device=self.device)
@@ -222,16 +279,16 @@ class BatchUprightMPC:
         t_start = self.time_ms
         acc_now = torch.zeros((6, len(robots)), dtype=self.dtype, device=self.device)
         tl = float(self.prm.taulim)
+        fire_at = None if fire is None else {int(i) for i in np.asarray(fire).ravel()}
+        u = torch.zeros((3, self.B), dtype=self.dtype, device=self.device)      # uquad = np.zeros(3), :118
         for ti in range(Nt):
             t = t_start + ti * dts
-            fire = ti % nsub == 0
+            fire = (ti % nsub == 0) if fire_at is None else (ti in fire_at)
             if use_mpc and fire:
                 self._check(self.L.umpcBatchSetTask(self.h, self._task_id(), self._task_params(), t))
                 self.update()
                 u = self.out[0:3].clone()
                 acc_now = self.out[3:9][:, idx].clone()
-            elif not use_mpc:
-                u = None
             pd = self.task_reference(t)[0:3][:, idx]
             if use_mpc:
                 u[1:3].clamp_(-tl, tl)

@@ -670,7 +670,10 @@ def generate():
                    % (fnv1a(s.blob), name, name, name, 1 if name in ASM_STRUCTURES else 0))
     hdr = ["// GENERATED by robobee3d_amd/codegen_qp.py -- do not edit.",
            "// Registry of the build-time specialisations (csrc/gen/bqp_*.hip), keyed by the FNV-1a hash of the table blob.",
-           "#pragma once", '#include "umpc_bqp_common.h"', ""] + decl + [
+           "#pragma once", '#include "umpc_bqp_common.h"', "",
+           "// items of one wave's stream block ([item][lane]; loop stream, then the residual stream): the allocation in",
+           "// umpcQPCreate and the sblk indexing of the generated kernels both use THIS constant",
+           "constexpr int BQP_ASM_STREAM_ITEMS_PER_WAVE = %d;" % ASM_STREAM_ITEMS, ""] + decl + [
            "struct FixedKernel { uint64_t hash; const char *name; void (*f32)(const umpcqp::QPArgs<float> &, hipStream_t); "
            "void (*f64)(const umpcqp::QPArgs<double> &, hipStream_t); int asm_f32; };",
            "static const FixedKernel kFixedKernels[] = {"] + reg + ["};",

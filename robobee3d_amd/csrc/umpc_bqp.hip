@@ -122,6 +122,13 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
     const T e = WR(R_E, i);
     WR(R_LS, i) = IN(a.l, i) * e;
     WR(R_US, i) = IN(a.u, i) * e;
+    // constr_type of the row (-1 loose, 0 inequality, 1 equality; auxil.c:103-145: decided on the bounds scaled by the
+    // PREVIOUS E, like rho above) parked in the per-pass scaling row, which is dead after the passes: the adaptive-rho
+    // update below drives rho_vec from the TYPE, as set_rho_vec / osqp_update_rho do, not from float comparisons of rho
+    const T ep = IN(a.Eprev, i), lsp = IN(a.l, i) * ep, usp = IN(a.u, i) * ep;
+    WR(R_ET, i) = (((double)lsp < -QP_INFTY * QP_MIN_SCALING) && ((double)usp > QP_INFTY * QP_MIN_SCALING)) ? T(-1.0)
+                  : ((double)(usp - lsp) < QP_RHO_TOL)                                                      ? T(1.0)
+                                                                                                             : T(0.0);
     IN(a.Eprev, i) = e;
   }
 
@@ -321,15 +328,14 @@ __global__ void __launch_bounds__(64) bqp_solve_kernel(const QPArgs<T> a) {
         T rho_new = rho_cur * qsqrt(pr / (du + T(1e-10)));
         rho_new = qmin(qmax(rho_new, T(QP_RHO_MIN)), T(1e6));
         if (rho_new > rho_cur * T(5.0) || rho_new < rho_cur / T(5.0)) {
-          // the constraint type of a row is read back from its current rho: rho_cur = inequality, RHO_MIN = loose
-          // (kept), anything else = equality (set_rho_vec, auxil.c:84-101)
-          const T rho_prev = rho_cur;
+          // by the stored constraint type (set_rho_vec, auxil.c:84-101): loose rows keep RHO_MIN, equality rows get
+          // 1e3 rho, inequality rows rho -- also after rho has been clamped to RHO_MIN
           rho_cur = rho_new;
           const T req = T(QP_RHO_EQ_OVER_RHO_INEQ) * rho_cur;
           for (int i = 0; i < m; ++i) {
-            const T r0 = WR(R_RHO, i);
-            if (r0 == T(QP_RHO_MIN) && rho_prev != T(QP_RHO_MIN)) continue;
-            const T r = r0 == rho_prev ? rho_cur : req;
+            const T ct = WR(R_ET, i);
+            if (ct < T(0.0)) continue;
+            const T r = ct > T(0.0) ? req : rho_cur;
             WR(R_RHO, i) = r; WR(R_RINV, i) = T(1.0) / r;
           }
           factor();
@@ -814,7 +820,7 @@ struct qp_batch {
 // assembly specialisations (gen/bqp_*_asm.h, fp32) keep one iteration's read-only words in a [wave][item][lane] block
 // (2048 items: the loop's stream, then the residual stream) that umpcQPCreate allocates behind the workspace rows, and hand the
 // factor over through the first 1024 rows. UMPC_QP_NO_ASM=1 disables them.
-size_t asm_tail_elems(int B) { return (size_t)((B + 63) / 64) * 64 * 2048; }   // codegen_qp.ASM_STREAM_ITEMS per wave
+size_t asm_tail_elems(int B) { return (size_t)((B + 63) / 64) * 64 * BQP_ASM_STREAM_ITEMS_PER_WAVE; }   // umpc_bqp_registry.h (codegen_qp.ASM_STREAM_ITEMS)
 bool asm_room(const qp_batch *h) {
   static const bool no_asm = getenv("UMPC_QP_NO_ASM") != nullptr;
   return !no_asm && !h->no_asm && h->asm_tail > 0 && h->nrows >= 1024;

@@ -37,7 +37,8 @@ struct QPArgs {
   int adaptive_rho_interval;  // 0: fixed rho; k > 0: adapt_rho every k iterations (table kernel)
   int check_termination;  // 0: exactly max_iter iterations; k > 0: exact termination test every k iterations (table kernel)
   int asm_ok;  // an assembly specialisation (gen/bqp_*_asm.h) may run: S is allocated
-  T *S;        // its stream buffer: [wave][item][lane], 1024 items per wave, behind the workspace rows
+  T *S;        // its stream buffer: [wave][item][lane], BQP_ASM_STREAM_ITEMS_PER_WAVE (umpc_bqp_registry.h) items per wave: the
+               // loop's stream first, the residual stream behind it; allocated behind the workspace rows
   T oma, rinv_eq;  // 1 - alpha and 1 / rho_eq as the kernels compute them, evaluated on the host (assembly operands)
   T rinv0, rho_eq;  // 1 / rho and rho_eq likewise
 };

@@ -285,6 +285,7 @@ struct umpc_batch {
   int step_kernel = 0;            // 0 = automatic (all-assembly fast path when it applies), 1 = always the C++ / loop-assembly kernel
   umpc::WLDev *wl = nullptr;      // device copy of the WL parameters (umpcBatchSetWL), null = no coupling
   void *wlu = nullptr, *wlw = nullptr;
+  const char *last_kernel = "";   // the kernel the last umpcBatchRollout / umpcBatchUpdate dispatched (umpcBatchKernelName)
 };
 
 template <typename T>
@@ -327,6 +328,7 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
       p.h = (float)q.dtsim; p.hh = 0.5f * p.h; p.h6 = p.h / 6.0f; p.taulim = (float)q.taulim; p.gpl = 9.81e-3f;
       p.idt = one / p.dt; p.nwpr = -p.wpr; p.nwpf = -p.wpf; p.nws = -p.ws_; p.nwvr = -p.wvr; p.nwvf = -p.wvf;
       hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, p, h->B);
+      h->last_kernel = "umpc_rollout_asm_kernel";
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
     }
@@ -346,18 +348,22 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
     if (!no_ldsf && grid <= ldsf_max_grid) {
       // ... and the ADMM phase as generated fp64 assembly (needs >= 1 iteration and 31-bit row offsets)
       const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 8 < ((size_t)1 << 31);
-      if (!no_asm64 && h->step_kernel == 0 && h->prm.maxIter >= 1 && fits)
+      if (!no_asm64 && h->step_kernel == 0 && h->prm.maxIter >= 1 && fits) {
         hipLaunchKernelGGL((umpc_rollout_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
                            (const T *)actualT0, 0);
-      else
+        h->last_kernel = "umpc_rollout_kernel<double, LDSF, ASM64>";
+      } else {
         hipLaunchKernelGGL((umpc_rollout_kernel<T, true, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
                            (const T *)actualT0, 0);
+        h->last_kernel = "umpc_rollout_kernel<double, LDSF>";
+      }
       hipError_t e2 = hipGetLastError();
       return e2 == hipSuccess ? 0 : fail(e2, "umpcBatchRollout");
     }
   }
   hipLaunchKernelGGL((umpc_rollout_kernel<T, false, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
                      (const T *)actualT0, skew_us * 100);
+  h->last_kernel = sizeof(T) == 4 ? "umpc_rollout_kernel<float>" : "umpc_rollout_kernel<double>";
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
 }
@@ -386,11 +392,16 @@ const int *umpcAxIdx(void) { return umpcgen::kAxIdx; }
 const int *umpcKKTPerm(void) { return umpcgen::kPerm; }
 int umpcNnzL(void) { return umpcgen::NNZL; }
 const char *umpcKernelName(int dtype, int plant_mode) {
-  // the kernel a default fp32 rollout dispatches to (launch_rollout)
-  if (dtype == UMPC_F64) return "umpc_rollout_kernel<double>";
+  // the kernel a DEFAULT rollout of this dtype dispatches to (launch_rollout); what a particular handle actually
+  // dispatched -- options such as maxIter = 0, step_kernel = 1 or the environment overrides change it -- is
+  // umpcBatchKernelName(h)
   (void)plant_mode;
+  if (dtype == UMPC_F64)
+    return getenv("UMPC_NO_F64_LDS") ? "umpc_rollout_kernel<double>"
+           : getenv("UMPC_NO_ASM64") ? "umpc_rollout_kernel<double, LDSF>" : "umpc_rollout_kernel<double, LDSF, ASM64>";
   return !getenv("UMPC_NO_ASM_STEP") ? "umpc_rollout_asm_kernel" : "umpc_rollout_kernel<float>";
 }
+const char *umpcBatchKernelName(const umpc_batch_t *h) { return h ? h->last_kernel : ""; }
 
 void umpcBatchDefaultParams(umpc_batch_params_t *p) {
   // createMPC, template/template_controllers.py:260-263,279; controlTest, template/uprightmpc2.py:87
@@ -600,6 +611,10 @@ void release_locked(uint32_t id) {
 void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, float wds, float wpr, float wpf,
               float wvr, float wvf, float wthrust, float wmom, const float Ib[3], int maxIter) {
   std::lock_guard<std::mutex> lk(g_mu);
+  // Re-initialising a POD that already carries a live controller (the reference allows it: a gain sweep, a Simulink
+  // or MCU start / stop) releases the previous controller first -- its batch handle, ctrl record, pinned buffer and
+  // stream -- instead of orphaning them. An uninitialised POD matching both the magic and a live id is not a concern.
+  release_locked(pod_id(up));
   // host-visible part of uprightmpc2.c:19-118
   memset(up, 0, sizeof(*up));
   up->dt = dt; up->g = g; up->Tmax = TtoWmax * g;
@@ -691,6 +706,10 @@ int umpcLastStatus(const UprightMPC_t *up) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_single.find(pod_id(up));
   return it == g_single.end() ? umpc::ST_UNSOLVED : it->second.status;
+}
+int umpcLiveControllers(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return (int)g_single.size();
 }
 void umpcRelease(UprightMPC_t *up) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -49,6 +49,16 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_scalars(value, device="cpu"):
+    """One float per rank -> the list over ranks, in rank order (every rank gets it)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if not dist.is_initialized():
+        return [float(t.item())]
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def gather_stats(stats):
     """stats [rows, B_local] on every rank -> [rows, sum B_local] in global robot order (all ranks)."""
     if not dist.is_initialized():

@@ -70,10 +70,10 @@ def structure():
     print("structure.npz: nnzA=%d nnzKKT=%d nnzL=%d" % (len(d["A_i"]), len(d["K_i"]), len(d["L_i"])))
 
 
-def sequence(seed, n, maxIter, fname, full_every=1, inputs=None):
+def sequence(seed, n, maxIter, fname, full_every=1, inputs=None, **ctor):
     """One controller from the pristine workspace through n calls (F1/F2)."""
     rng = np.random.default_rng(seed)
-    r = refbind.RefUMPC(maxIter=maxIter)
+    r = refbind.RefUMPC(maxIter=maxIter, **ctor)
     rec = {k: [] for k in ("p0 R0 dq0 pdes dpdes sdes actualT0 pre_x pre_y pre_z pre_T0 pre_E3 "
                            "l u q Px Ax c D E rho_vec constr_type Lx Dinv x y z sol_x sol_y uquad accdes "
                            "status pri_res dua_res T0 ret").split()}
@@ -119,6 +119,13 @@ def nan_branch():
         p0, R0, dq0, pdes, dpdes, sdes, aT0 = ins[k + 1]
         ins[k + 1] = (p0, R0, dq0, pdes, dpdes, sdes, 0.0098)   # T0 <- actualT0 (uprightmpc2.c:215-216)
     sequence(0, len(ins), 50, "nan_branch.npz", inputs=ins)
+
+
+def bounds_reject():
+    """osqp_update_bounds' reject path (template/uprightmpc2/osqp.c:801-808): TtoWmax < 0 crosses the thrust rows'
+    bounds (l = -T0 > u = Tmax - T0), every bounds update returns 1 without touching the workspace, and umpcUpdate
+    (which drops that return value, uprightmpc2.c:246) keeps solving with the code-generated placeholder bounds."""
+    sequence(20201117, 12, 50, "bounds_reject.npz", TtoWmax=-2.0)
 
 
 def import_reference_python():
@@ -462,6 +469,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "nan":
         nan_branch()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "reject":
+        bounds_reject()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wl":
         wl_step()
         sys.exit(0)
@@ -488,4 +498,5 @@ if __name__ == "__main__":
     v1_qp(mods)
     planar_p5f()
     nan_branch()
+    bounds_reject()
     mpc_wl_loop(mods)

@@ -23,13 +23,7 @@ def test_symbolic_structure_matches_reference(oracle_built, structure):
     assert len(structure["L_i"]) == 213 and len(structure["K_i"]) == 195
 
 
-@pytest.mark.parametrize("fname", ["seq_iter50.npz", "seq_iter1.npz", "seq_iter2.npz", "seq_iter10.npz", "nan_branch.npz"])
-def test_fp32_oracle_is_bit_identical_to_reference(oracle_built, structure, fname):
-    """Same ADMM iterate after the same number of iterations from the same warm
-    start, BIT FOR BIT, over a 256-call sequence starting at the pristine
-    workspace (covers the first-call constraint-type flip, F2)."""
-    seq = golden(fname)
-    o = oracle_built.Oracle(np.float32, perm=structure["perm"], maxIter=int(seq["maxIter"]))
+def _assert_bitwise(o, seq, structure):
     for k in range(len(seq["p0"])):
         assert np.array_equal(o.get("x"), seq["pre_x"][k])
         uq, ac = _replay(o, seq, k)
@@ -43,6 +37,30 @@ def test_fp32_oracle_is_bit_identical_to_reference(oracle_built, structure, fnam
         assert int(o.get("status_val")[0]) == int(seq["status"][k])
         assert o.ret == int(seq["ret"][k])
     assert np.array_equal(o.get("L_i"), structure["L_i"])
+
+
+@pytest.mark.parametrize("fname", ["seq_iter50.npz", "seq_iter1.npz", "seq_iter2.npz", "seq_iter10.npz", "nan_branch.npz"])
+def test_fp32_oracle_is_bit_identical_to_reference(oracle_built, structure, fname):
+    """Same ADMM iterate after the same number of iterations from the same warm
+    start, BIT FOR BIT, over a 256-call sequence starting at the pristine
+    workspace (covers the first-call constraint-type flip, F2)."""
+    seq = golden(fname)
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"], maxIter=int(seq["maxIter"]))
+    _assert_bitwise(o, seq, structure)
+
+
+def test_bounds_reject_path_is_bit_identical_to_reference(oracle_built, structure):
+    """osqp_update_bounds' reject path (template/uprightmpc2/osqp.c:801-808), reachable only with TtoWmax < 0: the
+    thrust rows' bounds cross, EVERY bounds update returns 1 without touching the workspace and umpcUpdate (which drops
+    that return value, uprightmpc2.c:246) keeps solving with the code-generated placeholder bounds l = 0, u = 1e30
+    (workspace.c:476-557) -- all 39 rows inequalities at rho = 0.1, return value 0. tests/golden/bounds_reject.npz
+    records 12 such calls of the compiled reference; the oracle's faithful mode reproduces them bit for bit
+    (the product documents a difference here: DESIGN.md 3.6, tests/test_r3_parity_evidence.py)."""
+    seq = golden("bounds_reject.npz")
+    assert np.all(seq["l"][:, 36:] > seq["u"][:, 36:]) and not seq["constr_type"].any() and not seq["ret"].any()
+    assert np.all(seq["rho_vec"] == np.float32(0.1))
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"], maxIter=int(seq["maxIter"]), TtoWmax=-2.0)
+    _assert_bitwise(o, seq, structure)
 
 
 def test_canonical_mode_tracks_faithful_mode(oracle_built, structure):

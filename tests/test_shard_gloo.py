@@ -61,6 +61,10 @@ def test_bench_self_launches_n_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["dry_run"] is True and j["steps"] == 4 and j["warmup"] == 3
     assert j["config"]["global_batch"] == 192 and j["scaling"] == "weak" and j["value"] is None
+    # every rank's own time for the K steps (the line's ms_per_step is their maximum) and the process group's facts
+    assert len(j["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in j["ms_per_step_per_rank"])
+    assert j["ms_per_step_per_rank"][1] > j["ms_per_step_per_rank"][0]      # the dry-run ranks sleep 1 + rank ms per launch
+    assert j["collectives"] == {"backend": "gloo", "world_size": 2, "gathered_robots": 192}
 
 
 def test_bench_launcher_propagates_failure():
@@ -76,3 +80,18 @@ def test_monte_carlo_draws_are_partition_invariant():
     np.testing.assert_array_equal(gain[150:250], gain2)
     assert np.all(np.abs(Ib / np.array([[3333.0], [3333.0], [1000.0]]) - 1) <= 0.2) and np.all(np.abs(gain - 1) <= 0.2)
     assert Ib.std(axis=1).min() > 50 and abs(gain.mean() - 1) < 0.02
+
+
+def test_device_draws_equal_the_host_draws():
+    """batch.monte_carlo_draws_device / hover_initial_conditions_device (what bench.py uses on the GPU: the draws are
+    generated on the device) run the same counter hash in int64 arithmetic: bit-identical to the numpy
+    versions (here on the CPU device; tests/test_r3_parity_evidence.py repeats it on the MI355X)."""
+    import torch
+    from robobee3d_amd import batch
+    Ib, g = batch.monte_carlo_draws(5000, 20201120, np.float32, index_offset=(1 << 20) - 2500)
+    Ibd, gd = batch.monte_carlo_draws_device(5000, 20201120, torch.float32, index_offset=(1 << 20) - 2500, device="cpu")
+    assert np.array_equal(Ib, Ibd.numpy()) and np.array_equal(g, gd.numpy())
+    st, ref = batch.hover_initial_conditions(3000, 20201118, np.float64, index_offset=77)
+    std, refd, (a, b) = batch.hover_initial_conditions_device(3000, 20201118, torch.float64, index_offset=77, device="cpu")
+    assert np.allclose(st, std.numpy(), rtol=0, atol=1e-15) and np.array_equal(ref, refd.numpy())
+    assert np.abs(a.numpy()).max() <= 0.5 and np.abs(b.numpy()).max() <= 0.5
