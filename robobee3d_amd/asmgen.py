@@ -392,9 +392,12 @@ def despace(ops, window=int(os.environ.get("UMPC_ASM_WINDOW", "12"))):
     return out
 
 
-def body(e, s, first, capture, plan, lv=False, delta_in_w=False):
+def body(e, s, first, capture, plan, lv=False, delta_in_w=False, qzero=frozenset(), lzero=frozenset()):
     """delta_in_w (asmstep.py, the all-assembly step kernel): a capturing iteration leaves delta_x = x - x_prev in
-    the x part of W and delta_y in the z part of W (registers) instead of writing x_prev / delta_y to the workspace."""
+    the x part of W and delta_y in the z part of W (registers) instead of writing x_prev / delta_y to the workspace.
+    qzero / lzero: x indices whose q and dynamics rows whose l (= u) are STRUCTURALLY zero for this QP (asmstep.Struct:
+    q is non-zero only on the y and dp entries, l on rows 0..5, 18..26 and 32): their right-hand side is sigma x /
+    -y / rho without the AGPR read (8.6 cycles each for a lone wave) -- 35 of an iteration's 214 reads."""
     nx, nc, nk = s.nx, s.nc, s.nk
     neq = 2 * s.N * symbolic.NY
     xs, zs, xinv, zinv = slot_maps(s)
@@ -440,18 +443,42 @@ def body(e, s, first, capture, plan, lv=False, delta_in_w=False):
     # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178), two slots per instruction
     for p_ in range(0, nx - 1, 2):
         j0, j1 = xinv[p_], xinv[p_ + 1]
-        op(("A2", A_Q + j0, A_Q + j1),
-           lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_W + p_, [_sb(S_SIGMA), _vp(V_X + p_), _vp(t)], [0, 0, 1]),
-           w=(V_W + p_, V_W + p_ + 1), r=(V_X + p_, V_X + p_ + 1))
+        rw = dict(w=(V_W + p_, V_W + p_ + 1), r=(V_X + p_, V_X + p_ + 1))
+        if j0 in qzero and j1 in qzero:
+            op(None, lambda t, p_=p_: pk(e, "v_pk_mul_f32", V_W + p_, [_sb(S_SIGMA), _vp(V_X + p_)]), **rw)
+        elif j0 in qzero or j1 in qzero:
+            jn, h = (j1, 1) if j0 in qzero else (j0, 0)
+
+            def mixed(t, p_=p_, h=h):
+                pk(e, "v_pk_mul_f32", V_W + p_, [_sb(S_SIGMA), _vp(V_X + p_)])
+                e("v_sub_f32", v(V_W + p_ + h), v(V_W + p_ + h), v(t))
+            op(("A", A_Q + jn), mixed, **rw)
+        else:
+            op(("A2", A_Q + j0, A_Q + j1),
+               lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_W + p_, [_sb(S_SIGMA), _vp(V_X + p_), _vp(t)], [0, 0, 1]), **rw)
     if nx % 2:
         jl = xinv[nx - 1]
-        op(("A", A_Q + jl), lambda t, jl=jl: e("v_fma_f32", v(WX(jl)), sS, X(jl), "-" + v(t)), w=(WX(jl),), r=(XR(jl),))
+        if jl in qzero:
+            op(None, lambda t, jl=jl: e("v_mul_f32", v(WX(jl)), sS, X(jl)), w=(WX(jl),), r=(XR(jl),))
+        else:
+            op(("A", A_Q + jl), lambda t, jl=jl: e("v_fma_f32", v(WX(jl)), sS, X(jl), "-" + v(t)), w=(WX(jl),), r=(XR(jl),))
     assert all(zinv[p_] < neq for p_ in range(neq)) and neq % 2 == 0
     for p_ in range(0, neq, 2):
         if lv:   # z of the dynamics rows is l (== u): read it from its AGPR home
-            op(("A2", A_LO + zinv[p_], A_LO + zinv[p_ + 1]),
-               lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(t)], [1, 0, 0]),
-               w=(V_WZ + p_, V_WZ + p_ + 1), r=(V_Y + p_, V_Y + p_ + 1))
+            i0, i1 = zinv[p_], zinv[p_ + 1]
+            rw = dict(w=(V_WZ + p_, V_WZ + p_ + 1), r=(V_Y + p_, V_Y + p_ + 1))
+            if i0 in lzero and i1 in lzero:
+                op(None, lambda t, p_=p_: pk(e, "v_pk_mul_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_)], [1, 0]), **rw)
+            elif i0 in lzero or i1 in lzero:
+                inz, h = (i1, 1) if i0 in lzero else (i0, 0)
+
+                def mixed_z(t, p_=p_, h=h):
+                    pk(e, "v_pk_mul_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_)], [1, 0])
+                    e("v_add_f32", v(V_WZ + p_ + h), v(V_WZ + p_ + h), v(t))
+                op(("A", A_LO + inz), mixed_z, **rw)
+            else:
+                op(("A2", A_LO + i0, A_LO + i1),
+                   lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(t)], [1, 0, 0]), **rw)
         else:
             op(None, lambda t, p_=p_: pk(e, "v_pk_fma_f32", V_WZ + p_, [_sb(S_RINV), _vp(V_Y + p_), _vp(V_Z + p_)], [1, 0, 0]),
                w=(V_WZ + p_, V_WZ + p_ + 1), r=(V_Y + p_, V_Y + p_ + 1, V_Z + p_, V_Z + p_ + 1))

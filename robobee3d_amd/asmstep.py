@@ -74,6 +74,8 @@ OPT_XV = os.environ.get("UMPC_ASM_XV", "1") == "1"
 # Measured SLOWER on the MI355X (same box, K = 500: 0.1261 vs 0.1239 ms per step): five VALU -> SGPR -> s_cbranch_vccz
 # round trips per Ruiz pass cost more than the 150 instructions they skip. Off.
 OPT_LIMIT_FAST = os.environ.get("UMPC_ASM_LIMIT_FAST", "0") == "1"
+# ZSKIP: the right-hand side of entries whose q / l is structurally zero is formed without the AGPR read (asmgen.body)
+OPT_ZSKIP = os.environ.get("UMPC_ASM_ZSKIP", "1") == "1"
 
 
 class Pool:
@@ -250,6 +252,11 @@ class Struct:
             for i in range(3):
                 self.qslot[s.N * NYv + k_ * NYv + i] = base + 3 * k_ + i
         self.nq = base + 3 * s.N
+        # structural zeros of the right-hand side data (uprightmpc2.c:126-207): q outside the y / dp entries; the raw
+        # bounds of the dynamics rows outside rows 0..5 (-y1), 18..23, 24..26 and 32 (the constant dt g)
+        self.qzero = frozenset(j for j in range(nx) if j not in self.qslot)
+        lnz = set(range(6)) | set(range(3 * 6, 3 * 6 + 6)) | set(range(4 * 6, 4 * 6 + 3)) | {5 * 6 + 2}
+        self.lzero = frozenset(i for i in range(self.neq) if i not in lnz) if s.N == 3 else frozenset()
 
     def weight_of(self, j):
         """name of the objective weight of column j (umpcInit layout, uprightmpc2.c:27-36)"""
@@ -892,7 +899,8 @@ class StepGen:
             e("v_mov_b32", v(pad), 0)
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
         plan = st.plan
-        asmgen.body(e, s, first=True, capture=True, plan=plan, delta_in_w=True)
+        zk = dict(qzero=st.qzero, lzero=st.lzero) if OPT_ZSKIP else {}
+        asmgen.body(e, s, first=True, capture=True, plan=plan, delta_in_w=True, **zk)
         for p_ in range(NVZ):      # the z registers of the dynamics rows take the L entries parked in a0..a35
             e("v_accvgpr_read_b32", v(V_Z + p_), "a%d" % (A_L + p_))
         lab7, lab8, lab6 = self.label(), self.label(), self.label()
@@ -900,14 +908,14 @@ class StepGen:
         e("s_cmp_lt_i32", sg(S_CNT), 1)
         e("s_cbranch_scc1", lab8 + "f")
         e("label", lab7)
-        asmgen.body(e, s, first=False, capture=False, plan=plan, lv=True)
+        asmgen.body(e, s, first=False, capture=False, plan=plan, lv=True, **zk)
         e("s_sub_i32", sg(S_CNT), sg(S_CNT), 1)
         e("s_cmp_gt_i32", sg(S_CNT), 0)
         e("s_cbranch_scc1", lab7 + "b")
         e("label", lab8)
         e("s_cmp_lt_i32", sg(S_ITERS), 2)
         e("s_cbranch_scc1", lab6 + "f")
-        asmgen.body(e, s, first=False, capture=True, plan=plan, lv=True, delta_in_w=True)
+        asmgen.body(e, s, first=False, capture=True, plan=plan, lv=True, delta_in_w=True, **zk)
         e("label", lab6)
         # x, y, thrust-row z, delta_x (x part of W), delta_y (z part of W) stay where they are; z == l on the dynamics rows
         for i in range(st.neq):

@@ -68,10 +68,20 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a,
 
 // The all-assembly fp32 fast path (asmstep.py -> umpc_step_asm.h): the whole K-step loop of one wavefront is ONE
 // generated instruction stream; C++ only hands over the lane's offsets and the parameter block (kernarg).
-__global__ __launch_bounds__(kBlock) void umpc_rollout_asm_kernel(const umpcasm::StepParams prm, int B) {
+__global__ __launch_bounds__(kBlock) void umpc_rollout_asm_kernel(const umpcasm::StepParams prm, int B, int skew_ticks,
+                                                                  int skew_groups) {
   __shared__ float4 lds[(umpcasm::STEP_LDS_BYTES_PER_LANE / 16) * kBlock];
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= B) return;
+  // All 1024 resident waves run the same phases; started together they hit HBM at the same instants (phase A's loads,
+  // phase C's loads and stores) and idle the ALUs meanwhile, until they have drifted apart. Starting them in
+  // `skew_groups` groups `skew_ticks` (100 MHz) apart desynchronises them from the first step on; the last group ends
+  // (groups - 1) x skew later, which is why the skew is a fraction of ONE memory phase, not of a step.
+  if (skew_ticks > 0) {
+    const unsigned g = (blockIdx.x / 8u) % (unsigned)skew_groups;  // blocks b and b+8 share an XCD: spread groups inside each
+    const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (long long)g * skew_ticks) __builtin_amdgcn_s_sleep(8);
+  }
   const unsigned ldsaddr = (unsigned)(size_t)(&lds[threadIdx.x]);
   const unsigned voff = (unsigned)b * 4u;
   // the parameter block is read where it lies, in the kernarg segment (first argument, offset 0): taking &prm would
@@ -327,7 +337,12 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
       p.Ibi0 = one / p.Ib0; p.Ibi1 = one / p.Ib1; p.Ibi2 = one / p.Ib2;
       p.h = (float)q.dtsim; p.hh = 0.5f * p.h; p.h6 = p.h / 6.0f; p.taulim = (float)q.taulim; p.gpl = 9.81e-3f;
       p.idt = one / p.dt; p.nwpr = -p.wpr; p.nwpf = -p.wpf; p.nws = -p.ws_; p.nwvr = -p.wvr; p.nwvf = -p.wvf;
-      hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, p, h->B);
+      // wave-group start skew (see the kernel): UMPC_ASM_SKEW_US / UMPC_ASM_SKEW_GROUPS override the measured default
+      static const int skew_us10 = [] { const char *e_ = getenv("UMPC_ASM_SKEW_US"); return e_ ? (int)(atof(e_) * 10) : 0; }();
+      static const int skew_groups = [] { const char *e_ = getenv("UMPC_ASM_SKEW_GROUPS"); return e_ ? atoi(e_) : 4; }();
+      const int skew_ticks = (h->B >= 32768 && K >= 2) ? skew_us10 * 10 : 0;
+      hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, p, h->B, skew_ticks,
+                         skew_groups < 1 ? 1 : skew_groups);
       h->last_kernel = "umpc_rollout_asm_kernel";
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : fail(e, "umpcBatchRollout");
