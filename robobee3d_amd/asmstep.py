@@ -37,25 +37,34 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ----------------------------------------------------------------------------------------------------------
 # Parameter block (kernarg-resident struct umpcasm::StepParams, 4-byte words; the kernel s_loads it once)
 # ----------------------------------------------------------------------------------------------------------
-PTRS = ["state", "ctrl", "ref", "ws", "out", "stats", "status", "info", "Ib", "gain", "aT0"]
+PTRS = ["state", "ctrl", "ref", "ws", "out", "stats", "status", "info", "Ib", "gain", "aT0",
+        # SURVEY 8(f) options: per-step task table (8 floats per step, see phase_a), per-robot weights [8][B], the
+        # wrench-linearisation parameters (struct umpc::WLDev, 150 floats) with its state rows u4 [4][B] and w0 [6][B]
+        "taskf", "weights", "wl", "wlu", "wlw"]
+NPTR_RES = 11             # the first 11 pointers live in s40..s61 for the whole kernel
 INTS = ["stride", "K", "maxIter", "nsub", "plant"]
 FLOATS = ["dt", "dtg", "Tmax", "wpr", "wpf", "ws_", "wvr", "wvf", "wds", "wthrust", "wmom",
           "iwpr", "iwpf", "iws", "iwvr", "iwvf", "iwds", "iwthrust", "iwmom",
-          "Ib0", "Ib1", "Ib2", "Ibi0", "Ibi1", "Ibi2", "h", "hh", "h6", "taulim", "gpl", "idt", "nwpr", "nwpf", "nws",
-          "nwvr", "nwvf"]
-# SGPR homes. s[4:5] = parameter block (input). asmgen's loop owns s14 (S_CNT) and s20..s29 (alpha, 1-alpha, sigma,
-# 1/rho_eq, rho_eq as even pairs); s11 = S_ITERS.
+          "Ib0", "Ib1", "Ib2", "Ibi0", "Ibi1", "Ibi2", "h", "hh", "h6", "taulim", "gpl", "idt", "mbg"]
+WNAMES = ["wpr", "wpf", "ws_", "wvr", "wvf", "wds", "wthrust", "wmom"]
+WROW = {"ws_": 0, "wds": 1, "wpr": 2, "wpf": 3, "wvr": 4, "wvf": 5, "wthrust": 6, "wmom": 7}     # rows of the weights table
+A_W, A_IW = 230, 238      # AGPR parking of the step's weights and their reciprocals (the loop owns a0..a229)
+# SGPR homes. s[4:5] = parameter block (input; kept in s[2:3]). asmgen's loop owns s14 (S_CNT) and s20..s29 (alpha,
+# 1-alpha, sigma, 1/rho_eq, rho_eq as even pairs); s11 = S_ITERS.
 S_PARAM = 4
-S_PTR = {n: 40 + 2 * k for k, n in enumerate(PTRS)}                  # s40..s61
+S_PBLK = 2                                                           # s[2:3]: the parameter block, for the late s_loads
+S_PTR = {n: 40 + 2 * k for k, n in enumerate(PTRS[:NPTR_RES])}       # s40..s61
+S_PTR["taskf"], S_PTR["weights"] = 0, 96                             # s[0:1], s[96:97]
+S_PTR["wl"], S_PTR["wlu"], S_PTR["wlw"] = 30, 32, 34                 # loaded where the WL step starts (masks are dead there)
 S_INT = {"stride": 10, "K": 13, "maxIter": S_ITERS, "nsub": 5, "plant": 39}
-S_F = {n: 64 + k for k, n in enumerate(FLOATS)}                      # s64..s99
-assert max(S_F.values()) <= 101
+S_F = {n: 64 + k for k, n in enumerate(FLOATS)}                      # s64..s95
+assert max(S_F.values()) <= 95
 S_STEP, S_SUB, S_RUIZ = 12, 15, 15          # loop counters: closed-loop step; plant substep / Ruiz pass (never nested)
 S_MBAD, S_MP0 = 62, 14                      # phase C masks: s[62:63]; s[14:15] (ADMM / Ruiz counters are dead there)
 S_M0, S_M1, S_M2, S_M3 = 30, 32, 34, 36     # lane masks (pairs)
 S_C = {"minscal": 16, "maxscal": 17, "c45": 18, "eps10": 19, "eps": 38, "rho": 6, "rinv": 7, "rmin": 8,
        "rmininv": 9, "infty_ms": 100, "rhotol": 101}   # scalar constants set by the prologue
-S_TMP = 4     # s[4:5] is free once the prologue has read the parameter block
+S_TMP = 4     # s4 is free once the prologue has read the parameter block (s5 = nsub)
 OFF = {}
 _o = 0
 for _n in PTRS:
@@ -151,6 +160,10 @@ class Pool:
 
 def v(n):
     return "v%d" % n
+
+
+def SF_(n):
+    return "s%d" % S_F[n]
 
 
 def sg(n):
@@ -303,6 +316,16 @@ class StepGen:
             e("s_mul_i32", sg(S_TMP), sg(S_INT["stride"]), first_row)
             e("v_add_u32", v(voff), sg(S_TMP), "v0")
 
+    def load_taskf(self):
+        """s[S_M0 .. S_M0+7] = the 8 floats of this step's task-table entry (32 B per step; an x8 load needs a 4-aligned
+        destination, the masks start at s30: three loads)"""
+        e = self.e
+        e("s_lshl_b32", sg(S_TMP), sg(S_STEP), 5)
+        e("s_load_dwordx2", sp(S_M0), sp(S_PTR["taskf"]), sg(S_TMP), "offset:0")
+        e("s_load_dwordx4", "s[%d:%d]" % (S_M0 + 2, S_M0 + 5), sp(S_PTR["taskf"]), sg(S_TMP), "offset:8")
+        e("s_load_dwordx2", sp(S_M0 + 6), sp(S_PTR["taskf"]), sg(S_TMP), "offset:24")
+        e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+
     def adv(self, voff):
         self.e("v_add_u32", v(voff), sg(S_INT["stride"]), v(voff))
 
@@ -334,15 +357,18 @@ class StepGen:
     def prologue(self):
         e = self.e
         P = sp(S_PARAM)
+        e("s_mov_b64", sp(S_PBLK), P)
+        P = sp(S_PBLK)
         e("s_load_dwordx16", "s[40:55]", P, OFF["state"])
         e("s_load_dwordx4", "s[56:59]", P, OFF["state"] + 64)
         e("s_load_dwordx2", "s[60:61]", P, OFF["state"] + 80)
+        e("s_load_dwordx2", sp(S_PTR["taskf"]), P, OFF["taskf"])
+        e("s_load_dwordx2", sp(S_PTR["weights"]), P, OFF["weights"])
         e("s_load_dwordx16", "s[64:79]", P, OFF[FLOATS[0]])
         e("s_load_dwordx16", "s[80:95]", P, OFF[FLOATS[0]] + 64)
-        e("s_load_dwordx4", "s[96:99]", P, OFF[FLOATS[0]] + 128)
-        for n in sorted(INTS, key=lambda n_: S_INT[n_] in (S_PARAM, S_PARAM + 1)):   # the load into s5 goes last: s[4:5] is the base
+        for n in INTS:
             e("s_load_dword", sg(S_INT[n]), P, OFF[n])
-        assert len(FLOATS) == 36
+        assert len(FLOATS) == 32
         import numpy as np
         f32 = np.float32
         for reg, val in ((S_ALPHA, 1.6), (S_OMA, float(f32(1.0) - f32(1.6))), (S_SIGMA, 1e-6), (S_RINV, 0.01), (S_RHO, 100.0)):
@@ -370,6 +396,49 @@ class StepGen:
         self.load_rows("state", 0, ST, voff)
         self.load_rows("ref", 0, RF, voff)
         self.load_rows("ctrl", nx + 2 * nc, [T0] + EP, voff)
+        # per-robot objective weights (gain sweeps, uprightmpc2.py:272-303) or the batch constants; their reciprocals
+        # (D is recovered as sqrt(P_scaled / (P_raw c))) -- both parked in AGPRs across Ruiz and the loop
+        WV = {n: pool.get() for n in WNAMES}
+        IWV = {n: pool.get() for n in WNAMES}
+        self.WV = WV
+        lab_w, lab_w2 = self.label(), self.label()
+        e("s_cmp_eq_u64", sp(S_PTR["weights"]), 0)
+        e("s_cbranch_scc1", lab_w + "f")
+        self.rows_ptr(voff, 0)
+        by_row = sorted(WNAMES, key=lambda n: WROW[n])
+        for k, n in enumerate(by_row):
+            e("global_load_dword", v(WV[n]), v(voff), sp(S_PTR["weights"]))
+            if k + 1 < len(by_row):
+                self.adv(voff)
+        e("s_waitcnt", "vmcnt(0)")
+        t = pool.get()
+        for n in WNAMES:
+            self.rcp_nr(IWV[n], WV[n], t)
+        pool.free(t)
+        e("s_branch", lab_w2 + "f")
+        e("label", lab_w)
+        for n in WNAMES:
+            e("v_mov_b32", v(WV[n]), SF(n))
+            e("v_mov_b32", v(IWV[n]), SF("i" + n.rstrip("_")))
+        e("label", lab_w2)
+        for k, n in enumerate(WNAMES):
+            e("v_accvgpr_write_b32", "a%d" % (A_W + k), v(WV[n]))
+            e("v_accvgpr_write_b32", "a%d" % (A_IW + k), v(IWV[n]))
+        pool.free(*IWV.values(), *WV.values())
+        # task generator (template/flight_tasks.py:6-49): the time-dependent part of (pdes, dpdes, sdes) is the same for
+        # every robot, so the host side evaluates it once per step into a table of 8 floats per step -- (dp[3], dpdes[3],
+        # sdes_x, sdes_z); sdes_y is 0 in every task -- read here with ONE scalar load; rows 0..2 of ref are initialPos
+        lab_tk = self.label()
+        e("s_cmp_eq_u64", sp(S_PTR["taskf"]), 0)
+        e("s_cbranch_scc1", lab_tk + "f")
+        self.load_taskf()
+        for i in range(3):
+            e("v_add_f32", v(RF[i]), sg(S_M0 + i), v(RF[i]))
+            e("v_mov_b32", v(RF[3 + i]), sg(S_M0 + 3 + i))
+        e("v_mov_b32", v(RF[6]), sg(S_M0 + 6))
+        e("v_mov_b32", v(RF[7]), 0)
+        e("v_mov_b32", v(RF[8]), sg(S_M0 + 7))
+        e("label", lab_tk)
         ibi0, ibi1 = pool.get(), pool.get()
         lab_ib, lab_ib2 = self.label(), self.label()
         e("s_cmp_eq_u64", sp(S_PTR["Ib"]), 0)
@@ -499,18 +568,21 @@ class StepGen:
         RQ = lambda j: VQ + st.qslot[j]
         self.RP, self.RA, self.RQ = RP, RA, RQ
         for j in range(nx):
-            e("v_mov_b32", v(RP(j)), SF(st.weight_of(j)))
+            e("v_accvgpr_read_b32", v(RP(j)), "a%d" % (A_W + WNAMES.index(st.weight_of(j))))
         e("v_mov_b32", v(VP + nx), 0)
         ydes = RF[0:3] + RF[6:9]
         dpdes = RF[3:6]
+        WV = {n: pool.get() for n in ("wpr", "wpf", "ws_", "wvr", "wvf")}      # the weights q is built from
+        for n, r in WV.items():
+            e("v_accvgpr_read_b32", v(r), "a%d" % (A_W + WNAMES.index(n)))
         for j in st.qnz:
             if j < N * NYv:
                 k, i = divmod(j, NYv)
-                wname = ("nwpf" if k == N - 1 else "nwpr") if i < 3 else "nws"
-                e("v_mul_f32", v(RQ(j)), SF(wname), v(ydes[i]))                 # (-w) * ydes
+                wname = ("wpf" if k == N - 1 else "wpr") if i < 3 else "ws_"
+                e("v_mul_f32", v(RQ(j)), "-" + v(WV[wname]), v(ydes[i]))                 # (-w) * ydes
             else:
                 k, i = divmod(j - N * NYv, NYv)
-                e("v_mul_f32", v(RQ(j)), SF("nwvf" if k == N - 1 else "nwvr"), v(dpdes[i]))
+                e("v_mul_f32", v(RQ(j)), "-" + v(WV["wvf" if k == N - 1 else "wvr"]), v(dpdes[i]))
         if st.nq % 2:
             e("v_mov_b32", v(VQ + st.nq), 0)
         for p, tag in enumerate(s.A_tag):
@@ -529,6 +601,7 @@ class StepGen:
         pool.free(dtT0, *s0dt, *Bdt, t)
         pool.free(*ST)
         pool.free(*RF)
+        pool.free(*WV.values())
         pool.free_range(LS, 20)
         self.ruiz()
         self.recover_and_bounds()
@@ -718,16 +791,17 @@ class StepGen:
         cinv, t, d, r = pool.get(), pool.get(), pool.get(), pool.get()
         self.rcp_nr(cinv, cs, t)
         voff = pool.get()
-        self.rows_ptr(voff, asmgen.WS_DS)
+        self.rows_ptr(voff, 0)     # the kernel's `ws` pointer is the workspace row WS_DS (host side): rows D 0.., E 45.., c 84
         rows_of_col = {}
         for i in range(nc):
             rows_of_col.setdefault(st.unit[i][1], []).append(i)
-        iw = {"wpr": "iwpr", "wpf": "iwpf", "ws_": "iws", "wvr": "iwvr", "wvf": "iwvf", "wds": "iwds",
-              "wthrust": "iwthrust", "wmom": "iwmom"}
+        IWV = {n: pool.get() for n in WNAMES}
+        for k, n in enumerate(WNAMES):
+            e("v_accvgpr_read_b32", v(IWV[n]), "a%d" % (A_IW + k))
         for j in range(nx):
             # D_j = sqrt((P_jj / c) / P_raw,jj)   
             e("v_mul_f32", v(d), v(RP(j)), v(cinv))
-            e("v_mul_f32", v(d), SF(iw[st.weight_of(j)]), v(d))
+            e("v_mul_f32", v(d), v(IWV[st.weight_of(j)]), v(d))
             e("v_sqrt_f32", v(d), v(d))
             e("s_nop", 0)
             e("global_store_dword", v(voff), v(d), sp(S_PTR["ws"]))
@@ -743,7 +817,7 @@ class StepGen:
             self.adv(voff)
         e("global_store_dword", v(voff), v(cs), sp(S_PTR["ws"]))
         self.store_rows("ctrl", nx + 2 * nc + 1, [RE(neq + k) for k in range(N)], voff)     # Eprev of the next step
-        pool.free(cinv, d, r, voff, cs)
+        pool.free(cinv, d, r, voff, cs, *IWV.values())
         # scaled bounds from the LDS stash
         LS = pool.getn(20)
         for qd in range(5):
@@ -948,8 +1022,8 @@ class StepGen:
         DS, dblocks = slot_blocks(nx)
         DR = lambda j: DS(st.xs[j])
         cr, T0 = g_(), g_()
-        self.load_rows("ws", asmgen.WS_DS, [DR(j) for j in range(nx)], voff)
-        self.load_rows("ws", asmgen.WS_C, [cr], voff)
+        self.load_rows("ws", 0, [DR(j) for j in range(nx)], voff)
+        self.load_rows("ws", asmgen.WS_C - asmgen.WS_DS, [cr], voff)
         self.load_rows("ctrl", nx + 2 * nc, [T0], voff)
         e("v_mov_b32", v(DS(nx)), 0)
         # 2. the controller record goes back now (a cold start, if any, rewrites it below): x, y, z
@@ -982,10 +1056,22 @@ class StepGen:
         ER = lambda i: ES(st.zs[i])
         ST = [g_() for _ in range(18)]
         RF = [g_() for _ in range(9)]
-        self.load_rows("ws", asmgen.WS_ES, [ER(i) for i in range(nc)], voff)
+        self.load_rows("ws", asmgen.WS_ES - asmgen.WS_DS, [ER(i) for i in range(nc)], voff)
         self.load_rows("state", 0, ST, voff)
         self.load_rows("ref", 0, RF, voff)
         e("v_mov_b32", v(ES(nc)), 1.0)
+        # the step's reference again (phase A's task-table entry)
+        lab_tk = self.label()
+        e("s_cmp_eq_u64", sp(S_PTR["taskf"]), 0)
+        e("s_cbranch_scc1", lab_tk + "f")
+        self.load_taskf()
+        for i in range(3):
+            e("v_add_f32", v(RF[i]), sg(S_M0 + i), v(RF[i]))
+            e("v_mov_b32", v(RF[3 + i]), sg(S_M0 + 3 + i))
+        e("v_mov_b32", v(RF[6]), sg(S_M0 + 6))
+        e("v_mov_b32", v(RF[7]), 0)
+        e("v_mov_b32", v(RF[8]), sg(S_M0 + 7))
+        e("label", lab_tk)
         cinv, t = g_(), g_()
         self.rcp_nr(cinv, cr, t)
         pool.free(cr)
@@ -1012,6 +1098,7 @@ class StepGen:
             pk(e, "v_pk_mul_f32", V_Y + k, [P2(ES(k)), P2(V_Y + k)])
         for k in range(0, nc + 1, 2):
             pk(e, "v_pk_mul_f32", V_Y + k, [P2(V_Y + k), PB(cinv)])
+        pool.free(cinv)
         zu3 = [g_() for _ in range(N)]
         for k in range(N):
             e("v_rcp_f32", v(zu3[k]), v(ER(neq + k)))
@@ -1102,6 +1189,23 @@ class StepGen:
                     e("v_fmac_f32", v(dst), c, x)
 
         # 7. update_info in unscaled variables (auxil.c:243-307): pri_res = |A xu - zu|_inf, dua_res = |q + P xu + A' yu|_inf
+        # the step's objective weights, parked in AGPRs by phase A: the registers are nearly all taken here, so the
+        # weights come through a 2-register LRU cache (columns visit them in runs: ~30 reads per step)
+        wc_regs, wc_names = [g_() for _ in range(2)], [None, None]
+
+        class _W:
+            def __getitem__(self_, name):
+                if name in wc_names:
+                    k = wc_names.index(name)
+                else:
+                    k = 0
+                    e("v_accvgpr_read_b32", v(wc_regs[k]), "a%d" % (A_W + WNAMES.index(name)))
+                    e("s_nop", 0)
+                    wc_names[k] = name
+                wc_regs.append(wc_regs.pop(k))          # most recently used last
+                wc_names.append(wc_names.pop(k))
+                return wc_regs[-1]
+        WV = _W()
         pri, nAx, nz, dua, nq, nAty, nPx, nan = [g_() for _ in range(8)]
         for r in (pri, nAx, nz, dua, nq, nAty, nPx, nan):
             e("v_mov_b32", v(r), 0)
@@ -1130,15 +1234,15 @@ class StepGen:
         def qraw(dst, j):
             if j < N * NYv:
                 k, i = divmod(j, NYv)
-                wname = ("nwpf" if k == N - 1 else "nwpr") if i < 3 else "nws"
-                e("v_mul_f32", v(dst), SF(wname), v(ydes[i]))
+                wname = ("wpf" if k == N - 1 else "wpr") if i < 3 else "ws_"
+                e("v_mul_f32", v(dst), "-" + v(WV[wname]), v(ydes[i]))
             else:
                 k, i = divmod(j - N * NYv, NYv)
-                e("v_mul_f32", v(dst), SF("nwvf" if k == N - 1 else "nwvr"), v(dpdes[i]))
+                e("v_mul_f32", v(dst), "-" + v(WV["wvf" if k == N - 1 else "wvr"]), v(dpdes[i]))
         a3, a4 = g_(), g_()
         for j in range(nx):
             dot(a1, range(s.A_p[j], s.A_p[j + 1]), YR, lambda p: s.A_i[p])
-            e("v_mul_f32", v(a2), SF(st.weight_of(j)), v(XR(j)))
+            e("v_mul_f32", v(a2), v(WV[st.weight_of(j)]), v(XR(j)))
             if j in st.qslot:
                 qraw(a3, j)
                 e("v_add_f32", v(a4), v(a3), v(a2))
@@ -1169,7 +1273,7 @@ class StepGen:
             if j in st.qslot:
                 qraw(a3, j)
                 e("v_fmac_f32", v(qdx), v(a3), v(DXR(j)))
-            e("v_mul_f32", v(a2), SF(st.weight_of(j)), v(DXR(j)))
+            e("v_mul_f32", v(a2), v(WV[st.weight_of(j)]), v(DXR(j)))
             e("v_max_f32", v(nP), v(nP), "|%s|" % v(a2))
         # |A' dyE|_inf and |A dxu|_inf only when some robot passes the cheap parts of a certificate (never, in practice)
         infv = g_()
@@ -1197,7 +1301,7 @@ class StepGen:
             dot(a1, st.rows[i], DXR, lambda p: st.col_of[p])
             e("v_max_f32", v(nAdx), v(nAdx), "|%s|" % v(a1))
         e("label", lab_d)
-        pool.free(dtT0, *s0dt, *Bdt, lT, uT, *[LR[i] for i in LR], *zu3)
+        pool.free(dtT0, *s0dt, *Bdt, lT, uT, *[LR[i] for i in LR], *zu3, *wc_regs)
         # 9. check_termination, exact then approximate (osqp.c:524-573, auxil.c:684-789)
         relp, reld, stv = g_(), g_(), g_()
         e("v_max_f32", v(relp), v(nz), v(nAx))
@@ -1287,7 +1391,6 @@ class StepGen:
         for i in range(6):
             e("v_mul_f32", v(OUT[3 + i]), SF("idt"), v(OUT[3 + i]))
         self.store_rows("out", 0, OUT, voff)
-        self.store_rows("ctrl", nx + 2 * nc, [OUT[0]], voff)
         lab_s, lab_i, lab_c = self.label(), self.label(), self.label()
         e("s_cmp_eq_u64", sp(S_PTR["status"]), 0)
         e("s_cbranch_scc1", lab_s + "f")
@@ -1307,14 +1410,140 @@ class StepGen:
             self.adv(voff)
         e("label", lab_c)
         e("s_mov_b64", "exec", sp(S_M1))
-        pool.free(pri, dua, stv, a1, a2, t, cinv, T0, *RF)
+        pool.free(pri, dua, stv, a1, a2, t, T0, *RF)
         # free the loop's arrays
         pool.free_range(V_W, V_X - V_W, kill=False)
         pool.free_range(V_X, V_Y - V_X, kill=False)
         pool.free_range(V_Y, V_Z - V_Y, kill=False)
+        # thrust accumulator of the next step: T0 + u0, or the WL step's actualT0 (uprightmpc2.c:215-216, 256-257)
+        T0n = g_()
+        e("v_mov_b32", v(T0n), v(OUT[0]))
+        self.wl_step(OUT, R0, T0n, voff)
+        self.store_rows("ctrl", nx + 2 * nc, [T0n], voff)
+        pool.free(T0n)
         self.plant(ST, OUT, voff)
         pool.free(*OUT, *ST, voff)
         assert len(pool.free_) == VEND - VFIRST, "phase C leaked registers: %s" % sorted(set(range(VFIRST, VEND)) - pool.free_)
+
+    # ---- MPC -> WL -> actualT0 (robobee_test_controllers.py:162-171, funapprox.c:118-165) ---------------
+    def wl_step(self, OUT, R0, T0n, voff):
+        """h0 = (Rb' (0, 0, mb g), 0), pdotdes = M0 accdes, (u4, w0) = wlConUpdate(h0, pdotdes); the NEXT controller
+        step assembles with actualT0 = w0[2] / M0[2,2] when that is >= 0 (uprightmpc2.c:215-216). Operation order of
+        umpc::wl_step (csrc/umpc_step.h; no fused multiply-adds there). The parameters are batch constants (struct
+        umpc::WLDev in global memory): every lane loads the same word."""
+        e, pool = self.e, self.pool
+        g_ = pool.get
+        lab_end = self.label()
+        P = sp(S_PBLK)
+        e("s_load_dwordx2", sp(S_PTR["wl"]), P, OFF["wl"])
+        e("s_load_dwordx2", sp(S_PTR["wlu"]), P, OFF["wlu"])
+        e("s_load_dwordx2", sp(S_PTR["wlw"]), P, OFF["wlw"])
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_cmp_eq_u64", sp(S_PTR["wl"]), 0)
+        e("s_cbranch_scc1", lab_end + "f")
+        # WLDev word offsets
+        O_UMIN, O_UMAX, O_DUMAX, O_QW, O_A0, O_A1, O_A2, O_MD = 0, 4, 8, 12, 18, 24, 48, 144
+        a1, a2, t = g_(), g_(), g_()
+        zero = g_()
+        e("v_mov_b32", v(zero), 0)
+
+        def prm(dst, word):
+            e("global_load_dword", v(dst), v(zero), sp(S_PTR["wl"]), "offset:%d" % (4 * word))
+        u0 = [g_() for _ in range(4)]
+        self.load_rows("wlu", 0, u0, voff)
+        Md = [g_() for _ in range(6)]
+        for i in range(6):
+            prm(Md[i], O_MD + i)
+        e("s_waitcnt", "vmcnt(0)")
+        h0 = [g_() for _ in range(3)]
+        pd = [g_() for _ in range(6)]
+        for c in range(3):
+            e("v_mul_f32", v(h0[c]), SF_("mbg"), v(R0[2 + 3 * c]))
+        for i in range(6):
+            e("v_mul_f32", v(pd[i]), v(Md[i]), v(OUT[3 + i]))
+        w0 = [g_() for _ in range(6)]
+        a0v = [g_() for _ in range(6)]
+        A1 = [[g_() for _ in range(4)] for _ in range(6)]
+        PA = [g_() for _ in range(21)]          # a0, a1[4], A2[16] of one output
+        vout = [g_() for _ in range(4)]
+        dot, quad = g_(), g_()
+        for i in range(6):
+            prm(PA[0], O_A0 + i)
+            for l in range(4):
+                prm(PA[1 + l], O_A1 + 4 * i + l)
+            for k in range(16):
+                prm(PA[5 + k], O_A2 + 16 * i + k)
+            e("s_waitcnt", "vmcnt(0)")
+            # dot = sum_l u0[l] a1[l]  (accumulated from 0 like the reference's matMult)
+            e("v_mul_f32", v(dot), v(u0[0]), v(PA[1]))
+            for l in range(1, 4):
+                e("v_mul_f32", v(t), v(u0[l]), v(PA[1 + l]))
+                e("v_add_f32", v(dot), v(dot), v(t))
+            for r in range(4):
+                e("v_mul_f32", v(vout[r]), v(PA[5 + r]), v(u0[0]))
+                for l in range(1, 4):
+                    e("v_mul_f32", v(t), v(PA[5 + r + 4 * l]), v(u0[l]))
+                    e("v_add_f32", v(vout[r]), v(vout[r]), v(t))
+            e("v_mul_f32", v(quad), v(u0[0]), v(vout[0]))
+            for l in range(1, 4):
+                e("v_mul_f32", v(t), v(u0[l]), v(vout[l]))
+                e("v_add_f32", v(quad), v(quad), v(t))
+            e("v_add_f32", v(a1), v(PA[0]), v(dot))
+            e("v_mul_f32", v(a2), 0.5, v(quad))
+            e("v_add_f32", v(w0[i]), v(a1), v(a2))
+            if i < 3:
+                e("v_sub_f32", v(a0v[i]), v(w0[i]), v(h0[i]))
+            else:
+                e("v_mov_b32", v(a0v[i]), v(w0[i]))                 # h0[3..5] = 0
+            e("v_sub_f32", v(a0v[i]), v(a0v[i]), v(pd[i]))
+            for j in range(4):
+                e("v_add_f32", v(A1[i][j]), v(PA[1 + j]), v(vout[j]))
+        # one clipped gradient step (funapprox.c:139-164)
+        lim = [g_() for _ in range(12)]                             # umin[4] umax[4] dumax[4]
+        qw = [g_() for _ in range(6)]
+        for k in range(12):
+            prm(lim[k], O_UMIN + k)
+        for i in range(6):
+            prm(qw[i], O_QW + i)
+        e("s_waitcnt", "vmcnt(0)")
+        for i in range(6):
+            e("v_mul_f32", v(a0v[i]), v(qw[i]), v(a0v[i]))          # Qw[i] * a0v[i]
+        Lb, Ub, acc = g_(), g_(), g_()
+        for j in range(4):
+            e("v_mul_f32", v(acc), v(A1[0][j]), v(a0v[0]))
+            for i in range(1, 6):
+                e("v_mul_f32", v(t), v(A1[i][j]), v(a0v[i]))
+                e("v_add_f32", v(acc), v(acc), v(t))
+            e("v_mul_f32", v(acc), -1000.0, v(acc))
+            e("v_mul_f32", v(Lb), -1.0, v(lim[8 + j]))
+            e("v_mov_b32", v(Ub), v(lim[8 + j]))
+            # if (u0 < umin) Lb = 0; else if (u0 > umax) Ub = 0
+            e("v_cmp_lt_f32_e64", sp(S_M3), v(u0[j]), v(lim[j]))
+            e("v_cmp_gt_f32", "vcc", v(u0[j]), v(lim[4 + j]))
+            e("s_andn2_b64", "vcc", "vcc", sp(S_M3))
+            e("v_cndmask_b32_e64", v(Lb), v(Lb), 0, sp(S_M3))
+            e("v_cndmask_b32", v(Ub), v(Ub), v(zero), "vcc")
+            # if (d < Lb) d = Lb; else if (d > Ub) d = Ub
+            e("v_cmp_lt_f32_e64", sp(S_M3), v(acc), v(Lb))
+            e("v_cmp_gt_f32", "vcc", v(acc), v(Ub))
+            e("s_andn2_b64", "vcc", "vcc", sp(S_M3))
+            e("v_cndmask_b32", v(acc), v(acc), v(Ub), "vcc")
+            e("v_cndmask_b32_e64", v(acc), v(acc), v(Lb), sp(S_M3))
+            e("v_add_f32", v(u0[j]), v(u0[j]), v(acc))
+        self.store_rows("wlu", 0, u0, voff)
+        lab_w = self.label()
+        e("s_cmp_eq_u64", sp(S_PTR["wlw"]), 0)
+        e("s_cbranch_scc1", lab_w + "f")
+        self.store_rows("wlw", 0, w0, voff)
+        e("label", lab_w)
+        # actualT0 of the next step: w0[2] / M0[2,2], taken when >= 0
+        self.rcp_nr(a1, Md[2], t)
+        e("v_mul_f32", v(a1), v(w0[2]), v(a1))
+        e("v_cmp_le_f32", "vcc", 0, v(a1))
+        e("v_cndmask_b32", v(T0n), v(T0n), v(a1), "vcc")
+        pool.free(zero, *u0, *Md, *h0, *pd, *w0, *a0v, *[r for row in A1 for r in row], *PA, *vout, dot, quad, *lim, *qw,
+                  Lb, Ub, acc, a1, a2, t)
+        e("label", lab_end)
 
     # ---- plant: nsub RK4 substeps of template/genqp.py:24-30 (build-defined integrator), statistics -----------------
     def plant(self, ST, OUT, voff):
@@ -1577,7 +1806,10 @@ def fmt(t):
     if m in ("ds_read_b128", "ds_write_b128", "ds_write_b32", "ds_read_b32"):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], t[3])
     if m.startswith("s_load_"):
-        return "%s %s, %s, 0x%x" % (m, a[0], a[1], t[3])
+        return "%s %s, %s, %s%s" % (m, a[0], a[1], ("0x%x" % t[3]) if isinstance(t[3], int) else t[3],
+                                    (" " + t[4]) if len(t) > 4 else "")
+    if m.startswith("global_") and isinstance(t[-1], str) and t[-1].startswith("offset:"):
+        return "%s %s %s" % (m, ", ".join(a[:-1]), t[-1])
     if m == "s_waitcnt":
         return "s_waitcnt " + " ".join(a)
     return "%s %s%s" % (m, ", ".join(a), mods)
@@ -1731,12 +1963,17 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
             return asf(V[lo + sel])
         return asf(u32(S.get(lo + sel, 0)))
 
+    FLAT = ("taskf", "wl")      # plain word arrays (not [row][B]): the byte offset / 4 indexes them
+
     def mem(addr):
         aid = addr >> 40
         if aid == 99:
             return None, (addr & ((1 << 40) - 1))
         name = names[aid - 1]
-        row, rem = divmod(addr & ((1 << 40) - 1), STRIDE)
+        if name in FLAT:
+            row, rem = divmod(addr & ((1 << 40) - 1), 4)
+        else:
+            row, rem = divmod(addr & ((1 << 40) - 1), STRIDE)
         assert rem == 0 and arrays[name] is not None and 0 <= row < len(arrays[name]), (name, row, rem)
         return arrays[name], row
 
@@ -1766,10 +2003,14 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
                 pass
             elif m.startswith("s_load_dword"):
                 n = {"s_load_dword": 1, "s_load_dwordx2": 2, "s_load_dwordx4": 4, "s_load_dwordx8": 8, "s_load_dwordx16": 16}[m]
-                _, off = mem(s64(t[2]))
+                imm = int(t[4].split(":")[1]) if len(t) > 4 else 0
+                arr, off = mem(s64(t[2]) + (t[3] if isinstance(t[3], int) else s32(t[3])) + imm)
                 lo = sreg(t[1])
                 for k in range(n):
-                    S[lo + k] = struct.unpack_from("<I", blob, off + t[3] + 4 * k)[0]
+                    if arr is None:
+                        S[lo + k] = struct.unpack_from("<I", blob, off + 4 * k)[0]
+                    else:
+                        S[lo + k] = int(bits(arr[off + k]))
             elif m == "s_mov_b32":
                 S[sreg(t[1])] = s32(t[2])
             elif m == "s_mov_b64":
@@ -1778,6 +2019,8 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
                     set64(t[1], 1)
             elif m == "s_mul_i32":
                 S[sreg(t[1])] = (s32(t[2]) * s32(t[3])) & 0xFFFFFFFF
+            elif m == "s_lshl_b32":
+                S[sreg(t[1])] = (s32(t[2]) << (s32(t[3]) & 31)) & 0xFFFFFFFF
             elif m in ("s_add_i32", "s_sub_i32"):
                 a, b = s32(t[2]), s32(t[3])
                 S[sreg(t[1])] = (a + b if m == "s_add_i32" else a - b) & 0xFFFFFFFF
@@ -1809,7 +2052,8 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
             elif not exec_ and m[0] in "vgd":
                 pass                                      # the lane is masked off
             elif m == "global_load_dword":
-                arr, row = mem(s64(t[3]) + int(V[int(t[2][1:])]))
+                imm = int(t[4].split(":")[1]) if len(t) > 4 and isinstance(t[4], str) and t[4].startswith("offset:") else 0
+                arr, row = mem(s64(t[3]) + int(V[int(t[2][1:])]) + imm)
                 val = np.array([arr[row]]).view(u32)[0] if arr.dtype != np.float32 else bits(arr[row])
                 if t[1][0] == "a":
                     A[int(t[1][1:])] = val
@@ -1920,7 +2164,7 @@ if __name__ == "__main__":
 
 
 def host_floats(dt=5.0, g=9.81e-3, TtoWmax=2.0, ws=1e1, wds=1e3, wpr=1.0, wpf=5.0, wvr=1e3, wvf=2e3, wthrust=1e-1, wmom=1e-2,
-                Ib=(3333.0, 3333.0, 1000.0), dtsim=0.2, taulim=100.0):
+                Ib=(3333.0, 3333.0, 1000.0), dtsim=0.2, taulim=100.0, mb=100.0):
     """The float members of StepParams exactly as umpc_mi355x.hip fills them (fp32 arithmetic on the host)."""
     import numpy as np
     f = np.float32
@@ -1929,11 +2173,10 @@ def host_floats(dt=5.0, g=9.81e-3, TtoWmax=2.0, ws=1e1, wds=1e3, wpr=1.0, wpf=5.
     d = dict(dt=f(dt), dtg=f(f(dt) * f(g)), Tmax=f(f(TtoWmax) * f(g)), **w)
     for k, val in w.items():
         d["i" + k.rstrip("_")] = f(one / val)
-    for k in ("wpr", "wpf", "ws_", "wvr", "wvf"):
-        d["n" + k.rstrip("_")] = f(-w[k])
     for i in range(3):
         d["Ib%d" % i] = f(Ib[i])
         d["Ibi%d" % i] = f(one / f(Ib[i]))
-    d.update(h=f(dtsim), hh=f(f(0.5) * f(dtsim)), h6=f(f(dtsim) / f(6.0)), taulim=f(taulim), gpl=f(9.81e-3), idt=f(one / f(dt)))
+    d.update(h=f(dtsim), hh=f(f(0.5) * f(dtsim)), h6=f(f(dtsim) / f(6.0)), taulim=f(taulim), gpl=f(9.81e-3), idt=f(one / f(dt)),
+             mbg=f(f(mb) * f(g)))
     assert set(d) == set(FLOATS), set(FLOATS) ^ set(d)
     return {k: float(val) for k, val in d.items()}

@@ -259,6 +259,20 @@ __global__ void umpc_taskref_kernel(DevParams<T> prm, int B_, T t, const T *ref,
   for (int i = 0; i < 9; ++i) out[(size_t)i * B + b] = r[i];
 }
 
+// Task table of the all-assembly step kernel: the time-dependent part of (pdes, dpdes, sdes) is the same for every
+// robot (template/flight_tasks.py:6-49 add it to initialPos), so it is evaluated ONCE per closed-loop step of the
+// launch -- 8 floats per step: dp[3], dpdes[3], sdes_x, sdes_z (sdes_y is 0 in every task) -- with the same
+// task_reference() and the same fire time the C++ kernel uses per robot.
+__global__ void umpc_taskf_kernel(DevParams<float> prm, int K, float t0, float *tab) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float tnow = t0 + float(k) * (float(prm.nsub) * prm.dtsim);
+  umpc::task_reference(prm.task, prm.task_p, tnow, r);
+  float *o = tab + 8 * (size_t)k;
+  o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[4]; o[5] = r[5]; o[6] = r[6]; o[7] = r[8];
+}
+
 template <typename T>
 __global__ void umpc_init_ctrl_kernel(int B_, T *ctrl) {
   const size_t B = (size_t)B_;
@@ -295,7 +309,10 @@ struct umpc_batch {
   int step_kernel = 0;            // 0 = automatic (all-assembly fast path when it applies), 1 = always the C++ / loop-assembly kernel
   umpc::WLDev *wl = nullptr;      // device copy of the WL parameters (umpcBatchSetWL), null = no coupling
   void *wlu = nullptr, *wlw = nullptr;
+  float wl_md2 = 0.f;             // M0[2,2] of the WL coupling (host copy, for the kernel's mb g)
   const char *last_kernel = "";   // the kernel the last umpcBatchRollout / umpcBatchUpdate dispatched (umpcBatchKernelName)
+  float *taskf = nullptr;         // task table of the all-assembly kernel: 8 floats per step of a launch
+  int taskf_cap = 0;              // ... steps it holds
 };
 
 template <typename T>
@@ -320,11 +337,30 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
     // all-assembly fast path: fp32, no task generator, batch-constant weights, no WL coupling, >= 1 iteration, row
     // offsets within 31 bits (either plant); UMPC_NO_ASM_STEP=1 forces the C++ / assembly-loop kernel
     static const bool no_asm = getenv("UMPC_NO_ASM_STEP") != nullptr;
-    const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 4 < ((size_t)1 << 31);
-    if (!no_asm && h->step_kernel == 0 && fits && K >= 1 && h->task == 0 && !h->weights && !h->wl && h->prm.maxIter >= 1) {
+    // (32-bit lane offsets inside one array: the largest is ctrl, 127 rows; the kernel's workspace pointer is the row it
+    // parks D, E, c in, so the 559-row workspace does not count)
+    const bool fits = (size_t)UMPC_CTRL_ROWS * (size_t)h->B * 4 < ((size_t)1 << 31);
+    if (!no_asm && h->step_kernel == 0 && fits && K >= 1 && h->prm.maxIter >= 1) {
       umpcasm::StepParams p;
-      p.state = state; p.ctrl = ctrl; p.ref = ref; p.ws = h->ws; p.out = out; p.stats = stats; p.status = status;
+      p.state = state; p.ctrl = ctrl; p.ref = ref; p.out = out; p.stats = stats; p.status = status;
+      p.ws = (char *)h->ws + (size_t)umpcasm::WS_DS * (size_t)h->B * 4;
       p.info = info; p.Ib = Ib; p.gain = gain; p.aT0 = actualT0;
+      // SURVEY 8(f) options of the same stream: task generator (a table of K entries written by a K-thread kernel ahead
+      // of the launch, same stream), per-robot weights, the fused WL step
+      p.taskf = nullptr;
+      if (h->task != 0) {
+        if (K > h->taskf_cap) {
+          if (h->taskf) (void)hipFree(h->taskf);      // (synchronises: an earlier launch may still read the old table)
+          h->taskf = nullptr; h->taskf_cap = 0;
+          const int cap = K < 1024 ? 1024 : K;
+          const hipError_t em = hipMalloc((void **)&h->taskf, (size_t)cap * 8 * sizeof(float));
+          if (em != hipSuccess) return fail(em, "umpcBatchRollout: task table");
+          h->taskf_cap = cap;
+        }
+        hipLaunchKernelGGL(umpc_taskf_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, a.prm, K, a.t0, h->taskf);
+        p.taskf = h->taskf;
+      }
+      p.weights = h->weights; p.wl = h->wl; p.wlu = h->wlu; p.wlw = h->wlw;
       p.stride = h->B * 4; p.K = K; p.maxIter = h->prm.maxIter; p.nsub = nsub; p.plant = h->prm.plant_mode;
       const umpc_batch_params_t &q = h->prm;
       const float one = 1.0f;
@@ -336,7 +372,9 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
       p.Ib0 = (float)q.Ib[0]; p.Ib1 = (float)q.Ib[1]; p.Ib2 = (float)q.Ib[2];
       p.Ibi0 = one / p.Ib0; p.Ibi1 = one / p.Ib1; p.Ibi2 = one / p.Ib2;
       p.h = (float)q.dtsim; p.hh = 0.5f * p.h; p.h6 = p.h / 6.0f; p.taulim = (float)q.taulim; p.gpl = 9.81e-3f;
-      p.idt = one / p.dt; p.nwpr = -p.wpr; p.nwpf = -p.wpf; p.nws = -p.ws_; p.nwvr = -p.wvr; p.nwvf = -p.wvf;
+      p.idt = one / p.dt;
+      // h0 = Rb' (0, 0, mb g) of the WL coupling: M0[2] is float in WLDev (umpcBatchSetWL), the product as the C++ kernel forms it
+      p.mbg = h->wl ? h->wl_md2 * (float)q.g : 0.0f;
       // wave-group start skew (see the kernel): UMPC_ASM_SKEW_US / UMPC_ASM_SKEW_GROUPS override the measured default
       static const int skew_us10 = [] { const char *e_ = getenv("UMPC_ASM_SKEW_US"); return e_ ? (int)(atof(e_) * 10) : 0; }();
       static const int skew_groups = [] { const char *e_ = getenv("UMPC_ASM_SKEW_GROUPS"); return e_ ? atoi(e_) : 4; }();
@@ -457,6 +495,7 @@ void umpcBatchDestroy(umpc_batch_t *h) {
   if (!h) return;
   if (h->ws) (void)hipFree(h->ws);
   if (h->wl) (void)hipFree(h->wl);
+  if (h->taskf) (void)hipFree(h->taskf);
   delete h;
 }
 int umpcBatchSetTask(umpc_batch_t *h, int task, const double params[4], double t_ms) {
@@ -840,6 +879,7 @@ int umpcBatchSetWL(umpc_batch_t *h, const WLCon_t *wl, const double Mdiag[6], vo
   if (!Mdiag || !u4 || !(Mdiag[2] > 0)) { g_err = "umpcBatchSetWL: bad argument"; return -1; }
   WLDev d = make_wl(wl);
   for (int i = 0; i < 6; ++i) d.Md[i] = (float)Mdiag[i];
+  h->wl_md2 = d.Md[2];
   hipError_t e = hipSuccess;
   if (!h->wl) e = hipMalloc((void **)&h->wl, sizeof(WLDev));
   if (e == hipSuccess) e = hipMemcpy(h->wl, &d, sizeof(WLDev), hipMemcpyHostToDevice);

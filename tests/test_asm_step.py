@@ -19,12 +19,16 @@ def program():
     return g, g.program()
 
 
-def _arrays(st, ref, b, Ib=None, gain=None, aT0=None):
+def _arrays(st, ref, b, Ib=None, gain=None, aT0=None, weights=None, taskf=None, wl=None, wlu=None, wlw=None):
     a = dict(state=st[:, b].astype(np.float32), ctrl=np.zeros(127, np.float32), ref=ref[:, b].astype(np.float32),
              ws=np.zeros(asmgen.WS_ROWS, np.float32), out=np.zeros(9, np.float32), stats=np.zeros(2, np.float32),
              status=np.zeros(1, np.int32), info=np.zeros(2, np.float32),
              Ib=None if Ib is None else Ib[:, b].astype(np.float32), gain=None if gain is None else gain[b:b + 1].astype(np.float32),
-             aT0=None if aT0 is None else aT0[b:b + 1].astype(np.float32))
+             aT0=None if aT0 is None else aT0[b:b + 1].astype(np.float32),
+             weights=None if weights is None else weights[:, b].astype(np.float32),
+             taskf=None if taskf is None else np.ascontiguousarray(taskf, np.float32).ravel(),
+             wl=None if wl is None else np.ascontiguousarray(wl, np.float32),
+             wlu=None if wlu is None else wlu[:, b].astype(np.float32), wlw=None if wlw is None else wlw[:, b].astype(np.float32))
     a["ctrl"][124:] = 1
     return a
 
@@ -146,3 +150,122 @@ def test_reference_euler_expm_plant_mode(program, oracle_built):
         R = a["state"][3:12].reshape(3, 3)
         assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5
         np.testing.assert_allclose(a["stats"], stats_o[:, 0], rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) options of the all-assembly stream: per-robot weights, task table, fused WL step
+# ----------------------------------------------------------------------------------------------------------------
+def _check_band(a, s64, out_o, b, k_state=(1e-4, 3e-5)):
+    assert np.abs(a["state"][0:3] - s64[0:3, b]).max() < k_state[0] and np.abs(a["state"][3:] - s64[3:, b]).max() < k_state[1]
+    assert abs(a["out"][0] - out_o[0, b]) < 3e-5
+    assert np.all(np.abs(a["out"][1:3] - out_o[1:3, b]) <= np.maximum(2e-2, 1e-3 * np.abs(out_o[1:3, b])))
+    assert np.abs(a["out"][3:] - out_o[3:, b]).max() < 3e-5
+
+
+def test_per_robot_weights(program, oracle_built):
+    """A (wpr, wvr) gain sweep (template/uprightmpc2.py:272-303): the weights table is read per robot, 1 / w by
+    v_rcp + Newton, both parked in AGPRs across the Ruiz passes and the loop."""
+    g, ins = program
+    B, K = 3, 2
+    st, ref = hover_initial_conditions(B, 3, np.float32)
+    W = np.tile(np.array([1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2])[:, None], (1, B))
+    W[2] = [0.02, 1.0, 7.0]          # wpr
+    W[4] = [30.0, 1e3, 8e3]          # wvr
+    s64 = st.astype(np.float64)
+    c64 = np.zeros((127, B)); c64[124:] = 1
+    out_o, stats_o, status_o = oracle_built.batch_rollout(s64, c64, ref.astype(np.float64), K, dtype=np.float64,
+                                                          perm=g.s.perm, plant_mode=1, weights=W)
+    for b in range(B):
+        a = _arrays(st, ref, b, weights=W)
+        asmstep.simulate(ins, a, dict(K=K, maxIter=50, nsub=25, plant=1), asmstep.host_floats())
+        _check_band(a, s64, out_o, b)
+        np.testing.assert_allclose(a["stats"], stats_o[:, b], rtol=1e-4)
+    # the table with the batch constants == no table (same weights; reciprocal by Newton vs the host's division)
+    a0, a1 = _arrays(st, ref, 0), _arrays(st, ref, 0, weights=np.tile(np.array([1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2])[:, None], (1, B)))
+    for a in (a0, a1):
+        asmstep.simulate(ins, a, dict(K=1, maxIter=50, nsub=25, plant=1), asmstep.host_floats())
+    assert np.abs(a0["state"] - a1["state"]).max() < 2e-6 and np.abs(a0["out"] - a1["out"]).max() < 2e-3
+
+
+def _task_table(oracle_built, task, tp, t0, K, nsub=25, dtsim=0.2):
+    """What the host side hands the kernel: per step (dp[3], dpdes[3], sdes_x, sdes_z) of the task at the fire time,
+    evaluated with initialPos = 0 in float32 (umpc_taskf_kernel)."""
+    f = np.float32
+    tab = np.zeros((K, 8), f)
+    for k in range(K):
+        t = f(t0) + f(k) * (f(nsub) * f(dtsim))
+        r = oracle_built.task_reference(task, tp, float(t), np.zeros(3), np.float32)
+        assert r[7] == 0
+        tab[k] = [r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[8]]
+    return tab
+
+
+@pytest.mark.parametrize("task,tp", [(1, (80.0, 1.0, 0.15, 1.0)), (3, (100.0, 200.0)), (4, (500.0, 100.0, 450.0, 0.2))],
+                         ids=["helix", "flip", "perch"])
+def test_task_table(program, oracle_built, task, tp):
+    """template/flight_tasks.py generators: the time-dependent part of the reference is one scalar load per step; rows
+    0..2 of ref are the robot's initialPos."""
+    g, ins = program
+    B, K, t0 = 2, 3, 110.0
+    st, ref = hover_initial_conditions(B, 11, np.float32, tilt=0.2)
+    rng = np.random.default_rng(5)
+    ref[:] = 0
+    ref[0:3] = rng.normal(size=(3, B))
+    st[0:3] = ref[0:3]
+    s64 = st.astype(np.float64)
+    c64 = np.zeros((127, B)); c64[124:] = 1
+    out_o, _, _ = oracle_built.batch_rollout(s64, c64, ref.astype(np.float64), K, dtype=np.float64, perm=g.s.perm,
+                                             plant_mode=1, task=task, task_p=tp, t0=t0)
+    tab = _task_table(oracle_built, task, tp, t0, K)
+    for b in range(B):
+        a = _arrays(st, ref, b, taskf=tab)
+        asmstep.simulate(ins, a, dict(K=K, maxIter=50, nsub=25, plant=1), asmstep.host_floats())
+        _check_band(a, s64, out_o, b, k_state=(3e-4, 1e-4))
+
+
+def _wldev_words(args, Mdiag):
+    """struct umpc::WLDev (csrc/umpc_step.h) as the host builds it from wlConInit's WLCon_t (funapprox.c:35-51,102-116)"""
+    u0, umin, umax, dumax, Qw, rate, popts = args
+    f = np.float32
+    w = np.zeros(150, f)
+    w[0:4], w[4:8] = f(umin), f(umax)
+    w[8:12] = f(dumax) / f(rate)
+    w[12:18] = f(Qw)
+    for i in range(6):
+        p = f(popts)[15 * i:15 * i + 15]
+        w[18 + i] = p[0]
+        w[24 + 4 * i:28 + 4 * i] = p[1:5]
+        A2 = np.zeros(16, f)
+        kk = 0
+        for r in range(4):
+            for c in range(r, 4):
+                A2[r + 4 * c] = A2[c + 4 * r] = p[5 + kk]
+                kk += 1
+        w[48 + 16 * i:64 + 16 * i] = A2
+    w[144:150] = f(Mdiag)
+    return w
+
+
+def test_fused_wl_step(program, oracle_built):
+    """MPC -> WL -> actualT0 (template/robobee_test_controllers.py:162-171) fused behind every controller step, against
+    the oracle's coupled rollout: state, WL input state u4, wrench w0 and the fed-back thrust."""
+    from conftest import golden
+    from test_wl_step import _args, _loop_inputs
+    g, ins = program
+    gl = golden("mpc_wl_loop.npz")
+    K = 4
+    Md = (100.0, 100.0, 100.0, 3333.0, 3333.0, 1000.0)
+    st, ref, ctrl, u4 = _loop_inputs(gl, np.float64, 1)
+    wlo = oracle_built.WLOracle(*_args(gl), dtype=np.float64)
+    w64 = np.zeros((6, 1))
+    s64, c64, u64 = st.copy(), ctrl.copy(), u4.copy()
+    out_o, _, _ = oracle_built.batch_rollout(s64, c64, ref.copy(), K, dtype=np.float64, perm=g.s.perm, plant_mode=1,
+                                             wl=wlo, wl_u=u64, wl_w=w64)
+    a = _arrays(st.astype(np.float32), ref.astype(np.float32), 0, wl=_wldev_words(_args(gl), Md),
+                wlu=u4.astype(np.float32), wlw=np.zeros((6, 1), np.float32))
+    asmstep.simulate(ins, a, dict(K=K, maxIter=50, nsub=25, plant=1), asmstep.host_floats())
+    _check_band(a, s64, out_o, 0, k_state=(2e-4, 5e-5))
+    np.testing.assert_allclose(a["wlw"], w64[:, 0], rtol=1e-4, atol=5e-4)
+    assert np.all(np.abs(a["wlu"] - u64[:, 0]) <= 2e-2 * np.array([5.0, 0.01, 0.01, 0.01]) + 1e-6)       # 2 % of the rate limits
+    np.testing.assert_allclose(a["ctrl"][123], c64[123, 0], rtol=1e-4)          # accumulator := actualT0 = w0[2] / M0[2,2]
+    assert abs(a["ctrl"][123] - a["out"][0]) > 1e-6                                # ... which is not T0 + u0

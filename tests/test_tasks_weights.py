@@ -5,7 +5,7 @@ flight_tasks.py. GPU: closed loops with tasks / weight tables match the oracle."
 import numpy as np
 import pytest
 
-from conftest import golden
+from conftest import golden, record_margin
 
 # (task id, parameter tuple in the C ABI's order, golden key); defaults of flight_tasks.py
 CASES = [
@@ -58,6 +58,7 @@ def test_closed_loop_with_task_matches_oracle(oracle_built, case):
     m32.set_state(st.astype(np.float32), ref.astype(np.float32))
     m32.set_task(names[task], t_ms=t0, **dict(zip(kwn, tp)))
     m32.rollout(K)
+    assert m32.kernel_name == "umpc_rollout_asm_kernel"      # the task generators are an option of the all-assembly stream
     s32 = m32.state.cpu().numpy().astype(np.float64)
     # straightAcc commands a 2 m/s velocity step: moments saturate at the clip and positions reach 40 mm,
     # so the fp32 band is relative there
@@ -105,6 +106,23 @@ def test_gain_sweep_per_robot_weights_match_oracle(oracle_built):
     m3.set_weights(np.tile(np.array([1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2])[:, None], (1, B)))
     m3.rollout(K)
     np.testing.assert_array_equal(m2.state.cpu().numpy(), m3.state.cpu().numpy())
+    # fp32: the sweep runs on the all-assembly kernel (per-robot weights are an option of that stream); closed-loop fp32
+    # band against the fp64 oracle, self-calibrated like the task test (extreme gains amplify round-off)
+    m32 = BatchUprightMPC(B, torch.float32)
+    m32.set_state(st.astype(np.float32), ref.astype(np.float32))
+    m32.set_weights(W.astype(np.float32))
+    m32.rollout(K)
+    assert m32.kernel_name == "umpc_rollout_asm_kernel"
+    s32 = m32.state.cpu().numpy().astype(np.float64)
+    s_o32 = st.astype(np.float32)
+    c32 = np.zeros((127, B), np.float32); c32[124:] = 1
+    oracle_built.batch_rollout(s_o32, c32, ref.astype(np.float32), K, dtype=np.float32, perm=perm, weights=W.astype(np.float32))
+    band_p = max(2e-3, 4 * np.abs(s_o32[0:3].astype(np.float64) - s_o[0:3]).max())
+    band_r = max(3e-4, 4 * np.abs(s_o32[3:].astype(np.float64) - s_o[3:]).max())
+    record_margin("gain sweep 10x10 fp32 (assembly kernel) K=6", "|dp| mm vs fp64 oracle", np.abs(s32[0:3] - s_o[0:3]).max(), band_p)
+    record_margin("gain sweep 10x10 fp32 (assembly kernel) K=6", "|dR|,|ddq| vs fp64 oracle", np.abs(s32[3:] - s_o[3:]).max(), band_r)
+    assert np.abs(s32[0:3] - s_o[0:3]).max() <= band_p and np.abs(s32[3:] - s_o[3:]).max() <= band_r
+    np.testing.assert_allclose(m32.stats.cpu().numpy(), stats_o, rtol=2e-3)
 
 
 def test_save_viewlog_writes_the_reference_format(tmp_path):

@@ -160,6 +160,7 @@ def test_fused_mpc_wl_loop_on_gpu(oracle_built):
     wl.u.copy_(torch.as_tensor(g["pre_u4"].T.copy()))
     mpc.set_wl(wl)
     mpc.rollout(1)
+    assert mpc.kernel_name == "umpc_rollout_asm_kernel"      # the WL coupling is an option of the all-assembly stream
     out = mpc.out.cpu().numpy().astype(np.float64)
     d_t = np.abs(out[0] - g["uquad"][:, 0]).max()
     d_m = (np.abs(out[1:3] - g["uquad"][:, 1:].T) / np.maximum(2e-2, 1e-3 * np.abs(g["uquad"][:, 1:].T))).max()
@@ -187,6 +188,7 @@ def test_fused_mpc_wl_loop_on_gpu(oracle_built):
         m.set_state(s0, r0)
         m.set_wl(w)
         m.rollout(K)
+        assert dtype == torch.float64 or m.kernel_name == "umpc_rollout_asm_kernel"
         s = m.state.cpu().numpy().astype(np.float64)
         dp, ds = np.abs(s[0:3] - st64[0:3]).max(), np.abs(s[3:] - st64[3:]).max()
         du = np.abs(w.u.cpu().numpy() - u64).max()
