@@ -293,6 +293,26 @@ def side_configs(dev, steps, warmup):
         "check": {"nonfinite_state_values": int((~torch.isfinite(m.state)).sum().item()),
                   "status_solved_frac": float((m.status > 0).float().mean().item())}}
     del m
+    # ---- the reference's 10 x 10 (wpr, wvr) gain-tuning grid (template/uprightmpc2.py:272-303) as ONE batch
+    # of the headline size: per-robot objective weights, same kernel as the headline ----
+    B = 65536
+    m = BatchUprightMPC(B, torch.float32, device=dev, plant_mode=1)
+    st, ref, _ = hover_initial_conditions_device(B, 20201118, torch.float32, device=dev)
+    m.set_state(st, ref)
+    g1, g2 = np.meshgrid(np.logspace(-2, 1, 10), np.logspace(1, 4, 10))
+    W = np.tile(np.array([1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2])[:, None], (1, B))
+    W[2], W[4] = np.resize(g1.ravel(), B), np.resize(g2.ravel(), B)
+    m.set_weights(W)
+    dt, kms, n = _timed(m.rollout, steps, warmup, dev)
+    out["f3_gain_sweep_B65536"] = {
+        "workload": "SURVEY 8(f-3): 10x10 (wpr, wvr) gain grid of gainTuningSims tiled over 65536 robots, per-robot objective "
+                    "weights, closed loop, fp32, RK4 plant",
+        "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "dtype": "f32", "robots": B, "kernel": m.kernel_name, "kernel_ms": kms, "steps_per_launch": steps,
+        "roofline": roof(ALG_BYTES_PER_STEP_FP32 + 32, B * steps, kms, None, None),
+        "check": {"nonfinite_state_values": int((~torch.isfinite(m.state)).sum().item()),
+                  "status_solved_frac": float((m.status > 0).float().mean().item())}}
+    del m
     return out
 
 
