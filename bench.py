@@ -193,25 +193,35 @@ def cpu_baseline(args, plant_mode):
 
 def _timed(launch, steps, warmup, dev, spl=None):
     """W untimed steps, then EXACTLY K timed ones: barrier-less one-GPU form of the main protocol (synchronise, wall clock
-    and HIP events on the launch stream around the K steps, synchronise). launch(k) enqueues k steps. Returns
-    (seconds, mean milliseconds per launch from the events, launches)."""
+    and HIP events on the launch stream around the K steps, synchronise). launch(k) enqueues k steps. Like the headline,
+    a pass shorter than the chip's clock ramp (< 25 ms) is repeated behind >= 30 ms of the same work and the first pass
+    is kept as the cold-clock figure. Returns (seconds, mean milliseconds per launch from the events, launches,
+    cold-pass seconds or None)."""
     import torch
     spl = steps if not spl else spl
-    w = warmup
-    while w > 0:
-        launch(min(spl, w))
-        w -= min(spl, w)
-    torch.cuda.synchronize(dev)
     n = steps // spl
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-    t0 = time.perf_counter()
-    for k in range(n):
-        evs[k][0].record()
-        launch(spl)
-        evs[k][1].record()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    return dt, float(np.mean([a.elapsed_time(b) for a, b in evs])), n
+
+    def one_pass():
+        w = warmup
+        while w > 0:
+            launch(min(spl, w))
+            w -= min(spl, w)
+        torch.cuda.synchronize(dev)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        t0 = time.perf_counter()
+        for k in range(n):
+            evs[k][0].record()
+            launch(spl)
+            evs[k][1].record()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    dt, kms = one_pass()
+    cold = None
+    if dt * (1 + warmup / max(1, steps)) < 25e-3:
+        cold = dt
+        launch(int(np.ceil(30e-3 / (dt / steps))))
+        dt, kms = one_pass()
+    return dt, kms, n, cold
 
 
 def side_configs(dev, steps, warmup):
@@ -242,10 +252,11 @@ def side_configs(dev, steps, warmup):
     m = BatchUprightMPC(B, torch.float64, device=dev, plant_mode=0)
     st, ref, _ = hover_initial_conditions_device(B, 20201117, torch.float64, device=dev)
     m.set_state(st, ref)
-    dt, kms, n = _timed(m.rollout, steps, warmup, dev)
+    dt, kms, n, cold = _timed(m.rollout, steps, warmup, dev)
     out["config2_fp64_B4096"] = {
         "workload": "BASELINE configs[1]: uprightmpc2 hover, batch=4096 random initial tilts, fp64, Euler+expm plant, closed loop",
         "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "cold_clocks_ms_per_step": None if cold is None else cold / steps * 1e3,
         "dtype": "f64", "robots": B, "kernel": m.kernel_name, "kernel_ms": kms, "steps_per_launch": steps,
         "roofline": roof(2 * ALG_BYTES_PER_STEP_FP32, B * steps, kms, profile_json("pmc_config2_f64"), "per_unit_bytes"),
         "check": {"nonfinite_state_values": int((~torch.isfinite(m.state)).sum().item()),
@@ -262,7 +273,7 @@ def side_configs(dev, steps, warmup):
     def p5f_launch(k):
         for _ in range(k):
             mp.tick(0.002 * tick[0]); tick[0] += 1
-    dt, kms, n = _timed(p5f_launch, steps, warmup, dev)
+    dt, kms, n, cold = _timed(p5f_launch, steps, warmup, dev)
     sq = mp.qp.s
     alg = (2 * (sq.n + 2 * sq.m) + 15) * 4
     kn = mp.qp.kernel_name
@@ -270,6 +281,7 @@ def side_configs(dev, steps, warmup):
         "workload": "BASELINE configs[3]: planar/mpc_osqp_p5f stroke-plane MPC, N=10 (n=87, m=164), 50 ADMM it, 10 Ruiz, "
                     "LDL' refactor per tick + Euler plant tick",
         "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "cold_clocks_ms_per_step": None if cold is None else cold / steps * 1e3,
         "dtype": "f32", "robots": B,
         "kernel": "bqp_fixed_%s_asm_kernel" % kn[:-4] if kn.endswith("+asm") else kn,
         "kernel_ms": kms / steps, "kernel_ms_note": "HIP events around the %d ticks (gather, getLin, QP, plant kernels of a tick) / ticks" % steps,
@@ -283,11 +295,12 @@ def side_configs(dev, steps, warmup):
     st, ref, _ = hover_initial_conditions_device(B, 20201118, torch.float32, device=dev)
     m.set_state(st, ref)
     m.Ib, m.gain = monte_carlo_draws_device(B, 20201120, torch.float32, device=dev)
-    dt, kms, n = _timed(m.rollout, steps, warmup, dev)
+    dt, kms, n, cold = _timed(m.rollout, steps, warmup, dev)
     out["config5_shard_B131072"] = {
         "workload": "BASELINE configs[4], one GPU's shard: Monte-Carlo mass/inertia sweep, 2^17 robots (of 2^20 over 8 GPUs), "
                     "per-robot Ib (controller + plant) and thrust gain +-20 %, fp32, RK4 plant",
         "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "cold_clocks_ms_per_step": None if cold is None else cold / steps * 1e3,
         "dtype": "f32", "robots": B, "kernel": m.kernel_name, "kernel_ms": kms, "steps_per_launch": steps,
         "roofline": roof(ALG_BYTES_PER_STEP_FP32 + 16, B * steps, kms, None, None),
         "check": {"nonfinite_state_values": int((~torch.isfinite(m.state)).sum().item()),
@@ -303,11 +316,12 @@ def side_configs(dev, steps, warmup):
     W = np.tile(np.array([1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2])[:, None], (1, B))
     W[2], W[4] = np.resize(g1.ravel(), B), np.resize(g2.ravel(), B)
     m.set_weights(W)
-    dt, kms, n = _timed(m.rollout, steps, warmup, dev)
+    dt, kms, n, cold = _timed(m.rollout, steps, warmup, dev)
     out["f3_gain_sweep_B65536"] = {
         "workload": "SURVEY 8(f-3): 10x10 (wpr, wvr) gain grid of gainTuningSims tiled over 65536 robots, per-robot objective "
                     "weights, closed loop, fp32, RK4 plant",
         "value": B * steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "cold_clocks_ms_per_step": None if cold is None else cold / steps * 1e3,
         "dtype": "f32", "robots": B, "kernel": m.kernel_name, "kernel_ms": kms, "steps_per_launch": steps,
         "roofline": roof(ALG_BYTES_PER_STEP_FP32 + 32, B * steps, kms, None, None),
         "check": {"nonfinite_state_values": int((~torch.isfinite(m.state)).sum().item()),
@@ -417,6 +431,8 @@ def main():
     ap.add_argument("--monte-carlo", action="store_true",
                     help="BASELINE configs[4]: per-robot inertia (controller + plant) and plant thrust gain, +-20 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-precondition", action="store_true",
+                    help="report the first W + K pass even when it is shorter than the chip's clock ramp (see `cold_clocks`)")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the driver-timed side configurations (BASELINE configs[1], [3], [4]'s shard) that a default "
                          "one-GPU run of the headline workload appends under \"configs\"")
@@ -487,32 +503,57 @@ def main():
     # EXACTLY `warmup` untimed steps, as multi-step launches like the timed ones (full launches of spl steps, then
     # the remainder as one shorter launch): the code object, the workspace pages and the clocks are warm and no
     # warm-up step runs in a shape the timed region does not use
-    w = args.warmup
-    while w > 0:
-        mpc.rollout(min(spl, w))
-        w -= min(spl, w)
-    barrier()
     nlaunch = args.steps // spl
     cuda = dev.type == "cuda"
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)] if cuda else []
-    t0 = time.perf_counter()
-    for k in range(nlaunch):
+
+    def protocol():
+        """W untimed steps, then EXACTLY K timed steps bracketed by barrier + synchronize on both sides; returns this
+        rank's seconds, the maximum over ranks, every rank's seconds and the mean HIP-event milliseconds per launch."""
+        w = args.warmup
+        while w > 0:
+            mpc.rollout(min(spl, w))
+            w -= min(spl, w)
+        barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)] if cuda else []
+        t0 = time.perf_counter()
+        for k in range(nlaunch):
+            if cuda:
+                evs[k][0].record()      # on the stream the kernel is launched on (torch's current stream)
+            mpc.rollout(spl)        # ONE launch = spl closed-loop steps of all B robots
+            if cuda:
+                evs[k][1].record()
         if cuda:
-            evs[k][0].record()      # on the stream the kernel is launched on (torch's current stream)
-        mpc.rollout(spl)        # ONE launch = spl closed-loop steps of all B robots
-        if cuda:
-            evs[k][1].record()
-    if cuda:
-        torch.cuda.synchronize(dev)
-    local = time.perf_counter() - t0          # this rank's K steps, start barrier -> local completion
-    barrier()
-    elapsed = shard.max_over_ranks(local, device=dev)
-    per_rank_s = shard.gather_scalars(local, device=dev)      # every rank's own K steps (the line reports the maximum)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if cuda else local / nlaunch * 1e3
+            torch.cuda.synchronize(dev)
+        local = time.perf_counter() - t0          # this rank's K steps, start barrier -> local completion
+        barrier()
+        return (local, shard.max_over_ranks(local, device=dev), shard.gather_scalars(local, device=dev),
+                float(np.mean([a.elapsed_time(b) for a, b in evs])) if cuda else local / nlaunch * 1e3)
+
+    local, elapsed, per_rank_s, kern_ms = protocol()
+    nsteps_done = args.warmup + args.steps
+    cold, precond = None, None
+    # The chip needs ~25 ms of sustained load to reach its loaded clock (measured: profiles/r03_clock_ramp.txt -- behind a
+    # long launch a 20-step launch runs at the 500-step rate, after idle it is 15-20 % slower and consecutive launches
+    # ramp for ~22 ms). W + K steps of 0.12 ms are far shorter than that ramp, so a run this short measures the ramp, not
+    # the kernel. When the whole protocol took < 25 ms it is therefore run a SECOND time behind >= 30 ms of the same
+    # step kernel on the same batch: `value` is the second pass (same W, same K, same barriers), the first pass is kept
+    # as `cold_clocks`. --no-precondition reports the first pass as `value`.
+    if not args.no_precondition and not args.dry_run and elapsed * (1 + args.warmup / max(1, args.steps)) < 25e-3:
+        cold = {"value": world * B * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kern_ms,
+                "ms_per_step_per_rank": [t / args.steps * 1e3 for t in per_rank_s],
+                "what": "the same W + K protocol as the first GPU work of the process (clocks ramping)"}
+        P = int(np.ceil(30e-3 / (elapsed / args.steps)))
+        t0 = time.perf_counter()
+        mpc.rollout(P)
+        barrier()
+        precond = {"steps": P, "ms": (time.perf_counter() - t0) * 1e3,
+                   "what": "untimed launch of the same kernel on the same batch so that the timed region runs at the loaded clock"}
+        local, elapsed, per_rank_s, kern_ms = protocol()
+        nsteps_done = 2 * (args.warmup + args.steps) + P
 
     # end-of-run trajectory statistics: the only exchange of the path (RCCL all_gather over xGMI,
     # outside the timed region; 2 floats per robot)
-    metric = shard.gather_stats(mpc.metrics(args.warmup + args.steps))
+    metric = shard.gather_stats(mpc.metrics(nsteps_done))
     status = mpc.status
     nbad = int((~torch.isfinite(mpc.state)).sum().item())
     if args.dry_run and rank == 0:
@@ -552,6 +593,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "ms_per_step_per_rank": [t / args.steps * 1e3 for t in per_rank_s],
+            "cold_clocks": cold, "preconditioning": precond,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: closed-loop uprightmpc2 (N=3, 50 ADMM it, 10 Ruiz, LDL' "
                                    "refactor per step) + 25 plant substeps, random-tilt hover, seed 20201118",
