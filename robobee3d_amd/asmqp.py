@@ -675,9 +675,33 @@ def fmt(t):
 # ---------------------------------------------------------------------------
 # CPU interpreter (one lane) and a numpy statement of the same iteration
 # ---------------------------------------------------------------------------
-def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_agpr=False):
+class AddressFault(Exception):
+    """A simulated global access outside every array handed to the interpreter (on the GPU: a memory access fault)."""
+
+
+# Simulated device addresses: like real ones, the low word of a base has bit 31 set, so a 32-bit half that is
+# sign-extended somewhere on its way into an SGPR pair (the bug fixed in 37f012f: `readfirstlane` returns int) lands
+# 4 GiB below the array and is caught by the bounds check of every access.
+SIM_BASE_W, SIM_BASE_S, SIM_BASE_REGION = 0x00007F4A90000000, 0x00007F4BA0000000, 0x00007F5080000000
+
+
+def uni_scalar_operand(v, sign_extend_bug=False):
+    """How the C++ side of the generated kernels makes a 64-bit scalar operand provably wave-uniform (codegen_qp.emit_structure,
+    `uni`): two readfirstlane halves. The builtin returns int; before 37f012f the halves were widened as SIGNED ints, which
+    fills the upper word with ones whenever bit 31 of the low half is set (sign_extend_bug=True restates that)."""
+    lo, hi = v & 0xFFFFFFFF, (v >> 32) & 0xFFFFFFFF
+    if sign_extend_bug:
+        sx = lambda w: w | (0xFFFFFFFF00000000 if w & 0x80000000 else 0)
+        return ((sx(hi) << 32) | sx(lo)) & 0xFFFFFFFFFFFFFFFF
+    return (hi << 32) | lo
+
+
+def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_agpr=False, base_xform=None):
     """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
-    Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there)."""
+    Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there).
+    Addresses are formed as the ISA does for global_* with an SGPR base: SGPR pair (64 bits) + zero-extended 32-bit VGPR
+    offset + immediate; every access must fall on an element of an array handed in (AddressFault otherwise). base_xform
+    models what the C++ glue does to a base pointer before it reaches the SGPR pair (uni_scalar_operand)."""
     f32 = np.float32
     V = np.zeros(256, np.uint32)
     A = np.zeros(256, np.uint32)
@@ -689,18 +713,29 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
         if t[0] == "label":
             labels.setdefault(t[1], []).append(k)
     STRIDE = 4096
-    SG[S_W], SG[S_W + 1] = 1 << 20, 0
-    SG[S_S], SG[S_S + 1] = 1 << 30, 0
+    base_xform = base_xform or (lambda a: a)
+    space = [(SIM_BASE_W, STRIDE, W), (SIM_BASE_S, 256, S)]          # (true base, bytes between elements, array)
+
+    def setbase(sreg, base):
+        val = base_xform(base)
+        SG[sreg], SG[sreg + 1] = val & 0xFFFFFFFF, (val >> 32) & 0xFFFFFFFF
+    setbase(S_W, SIM_BASE_W)
+    setbase(S_S, SIM_BASE_S)
     SG[S_STRIDE], SG[S_ITERS] = STRIDE, iters
-    # regions (the Ruiz block's inputs): [(SGPR pair, array)], row-major with the simulated stride, 1 << 32 apart
+    # regions (the Ruiz block's inputs): [(SGPR pair, array)], row-major with the simulated stride, 8 GiB apart
     for k_, v_ in (sgpr or {}).items():
-        SG[k_] = v_
+        if v_ == "S":
+            setbase(k_, SIM_BASE_S)
+        elif v_ == "W":
+            setbase(k_, SIM_BASE_W)
+        else:
+            SG[k_] = v_
     if lds0 is not None:
         lds[:len(lds0)] = lds0
-    regmap = {}
     for q, (sreg, arr) in enumerate(regions or []):
-        SG[sreg], SG[sreg + 1] = 0, q + 1
-        regmap[q + 1] = arr
+        base = SIM_BASE_REGION + (q << 33)
+        space.append((base, STRIDE, arr))
+        setbase(sreg, base)
     alpha, sigma, rinv_eq = consts[:3]
     rho0 = f32(consts[3] if len(consts) > 3 else 0.1)
     for reg, val in ((S_ALPHA, f32(alpha)), (S_OMA, f32(f32(1.0) - f32(alpha))), (S_SIGMA, f32(sigma)), (S_RINVEQ, f32(rinv_eq)),
@@ -734,13 +769,12 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
         V[int(x[1:])] = f32bits(float(f32(val)))
 
     def gaddr(t):
-        """(array, index) of a global access v_off, s[base], imm"""
-        addr = sval(t[3]) + t[4]
-        if addr >> 32:
-            return regmap[addr >> 32], (addr & 0xFFFFFFFF) // STRIDE
-        if addr >= (1 << 30):
-            return S, (addr - (1 << 30)) // 256
-        return W, (addr - (1 << 20)) // STRIDE
+        """(array, index) of a global access (mnemonic, data, v_off, s[base:base+1], imm): base + zext(v_off) + imm"""
+        addr = (sval(t[3]) + int(V[int(t[2][1:])]) + t[4]) & 0xFFFFFFFFFFFFFFFF
+        for base, stride, arr in space:
+            if base <= addr < base + len(arr) * stride and (addr - base) % stride == 0:
+                return arr, (addr - base) // stride
+        raise AddressFault("%r touches 0x%016x, outside every array of the call" % (ins[pc], addr))
 
     def ldsword(basereg, off):
         byte = int(V[int(basereg[1:])]) + off

@@ -1852,7 +1852,7 @@ def write(path=None, N=3, perm=None):
 # ----------------------------------------------------------------------------------------------------------
 # CPU interpreter of the emitted stream (one lane), for tests/test_asm_step.py
 # ----------------------------------------------------------------------------------------------------------
-def simulate(ins, arrays, ints, floats, max_exec=3000000):
+def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
     """arrays: name -> float32 / int32 numpy vector indexed by ROW (one robot), or None for a null pointer; ints /
     floats: the StepParams scalars (ints without `stride`). Runs the whole kernel; arrays are updated in place.
     Returns the executed instruction count (pseudo-instructions excluded)."""
@@ -1867,17 +1867,20 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
     V[:] = POISON
     A[:] = POISON
     names = list(PTRS)
-    base_of = {n: (k + 1) << 40 for k, n in enumerate(names)}
+    # simulated device addresses with bit 31 of the low word set (like real ones): a half that gets sign-extended on its
+    # way into an address lands outside every array and is caught below
+    base_of = {n: 0x00007F0080000000 + (k << 36) for k, n in enumerate(names)}
+    ptr_xform = ptr_xform or (lambda a: a)
     blob = bytearray(PARAM_BYTES)
     for n in PTRS:
-        struct.pack_into("<Q", blob, OFF[n], base_of[n] if arrays.get(n) is not None else 0)
+        struct.pack_into("<Q", blob, OFF[n], ptr_xform(base_of[n]) if arrays.get(n) is not None else 0)
     allints = dict(ints)
     allints["stride"] = STRIDE
     for n in INTS:
         struct.pack_into("<i", blob, OFF[n], int(allints[n]))
     for n in FLOATS:
         struct.pack_into("<f", blob, OFF[n], float(floats[n]))
-    PBASE = 99 << 40
+    PBASE = 0x00007E0080000000
     S[S_PARAM], S[S_PARAM + 1] = PBASE & 0xFFFFFFFF, PBASE >> 32
     V[0], V[1] = 0, 0
     exec_ = 1
@@ -1966,16 +1969,21 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000):
     FLAT = ("taskf", "wl")      # plain word arrays (not [row][B]): the byte offset / 4 indexes them
 
     def mem(addr):
-        aid = addr >> 40
-        if aid == 99:
-            return None, (addr & ((1 << 40) - 1))
-        name = names[aid - 1]
-        if name in FLAT:
-            row, rem = divmod(addr & ((1 << 40) - 1), 4)
-        else:
-            row, rem = divmod(addr & ((1 << 40) - 1), STRIDE)
-        assert rem == 0 and arrays[name] is not None and 0 <= row < len(arrays[name]), (name, row, rem)
-        return arrays[name], row
+        """array and element of a byte address: SGPR base (64 bits) + zero-extended VGPR offset + immediate, as the ISA forms
+        it; anything that is not an element of an array handed in is a fault (asmqp.AddressFault)"""
+        addr &= 0xFFFFFFFFFFFFFFFF
+        if PBASE <= addr < PBASE + PARAM_BYTES:
+            return None, addr - PBASE
+        for name in names:
+            arr = arrays.get(name)
+            if arr is None:
+                continue
+            stride = 4 if name in FLAT else STRIDE
+            off = addr - base_of[name]
+            if 0 <= off < len(arr) * stride and off % stride == 0:
+                return arr, off // stride
+        from .asmqp import AddressFault
+        raise AddressFault("%r touches 0x%016x, outside every array of the call" % (ins[pc], addr))
 
     def setmask(dst, cond):
         if dst == "vcc":

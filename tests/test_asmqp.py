@@ -254,7 +254,7 @@ def test_ruiz_block_writes_the_residual_stream():
     q = rng.normal(size=p.n).astype(np.float32)
     S = np.full(res.end, np.nan, np.float32)
     lds = asmqp.simulate(ins, np.zeros(1, np.float32), S, 3, (1.6, 1e-6, 0.01),
-                         regions=[(asmqp.S_AV, A), (asmqp.S_PV, P), (asmqp.S_QV, q)], sgpr={asmqp.S_RSB: 1 << 30, asmqp.S_RSB + 1: 0})
+                         regions=[(asmqp.S_AV, A), (asmqp.S_PV, P), (asmqp.S_QV, q)], sgpr={asmqp.S_RSB: "S"})
     assert np.array_equal(S[res.it_A:res.it_A + p.nnzA], lds[p.LW_A:p.LW_A + p.nnzA])
     for i in range(p.m):
         assert S[res.it_ev[i]] == lds[p.LW_EV + i]
@@ -380,3 +380,62 @@ def test_glue_block_classifies_and_writes_the_stream(prog):
         assert np.array_equal(S[its], Sx[its]), case
         assert lds[asmqp.GLUE_FLAG] == (1.0 if case == "ok" else 0.0), case
         assert (rho == f32(1e-6)).sum() == len(loose) and (rho == f32(100.0)).sum() == len(eq) - (case == "noteq")
+
+
+def test_interpreter_faults_on_a_sign_extended_base_pointer():
+    """The GPU memory fault of round 2 (a uniform scalar operand widened as a SIGNED int on its way into a 64-bit base
+    pointer, fixed in 37f012f) is now caught on the CPU: the interpreters form addresses as the ISA does -- SGPR pair +
+    zero-extended VGPR offset + immediate, on simulated device addresses whose low word has bit 31 set, like real ones --
+    and every access must land on an element of an array handed in. The pre-37f012f operand faults; today's passes."""
+    asmqp, s, eq, ap, res = _p5f()
+    ins, p = asmqp.ruiz_program(s, res)
+    rng = np.random.default_rng(5)
+    P = np.abs(rng.normal(size=p.nnzP)).astype(np.float32) + 0.1
+    A = rng.normal(size=p.nnzA).astype(np.float32)
+    q = rng.normal(size=p.n).astype(np.float32)
+
+    def run(xform):
+        S = np.full(res.end, np.nan, np.float32)
+        return asmqp.simulate(ins, np.zeros(1, np.float32), S, 3, (1.6, 1e-6, 0.01), base_xform=xform,
+                              regions=[(asmqp.S_AV, A), (asmqp.S_PV, P), (asmqp.S_QV, q)], sgpr={asmqp.S_RSB: "S"})
+    run(asmqp.uni_scalar_operand)                                              # the shipped glue: fine
+    assert asmqp.uni_scalar_operand(asmqp.SIM_BASE_S) == asmqp.SIM_BASE_S
+    assert asmqp.uni_scalar_operand(asmqp.SIM_BASE_S, sign_extend_bug=True) != asmqp.SIM_BASE_S
+    with pytest.raises(asmqp.AddressFault):
+        run(lambda a: asmqp.uni_scalar_operand(a, sign_extend_bug=True))       # the pre-37f012f operand
+    # an access one row past an array is a fault too (not a silent read of a neighbour)
+    with pytest.raises(asmqp.AddressFault):
+        asmqp.simulate(ins, np.zeros(1, np.float32), np.full(res.end, np.nan, np.float32), 3, (1.6, 1e-6, 0.01),
+                       regions=[(asmqp.S_AV, A[:-1]), (asmqp.S_PV, P), (asmqp.S_QV, q)], sgpr={asmqp.S_RSB: "S"})
+
+
+def test_step_interpreter_faults_on_a_bad_pointer():
+    """asmstep.simulate applies the same address model to the all-assembly step kernel: a parameter-block pointer whose
+    low half was sign-extended, or an array one row short, faults instead of reading something else."""
+    from robobee3d_amd import asmgen, asmstep
+    from robobee3d_amd.batch import hover_initial_conditions
+    ins = asmstep.StepGen().program()
+    st, ref = hover_initial_conditions(1, 1, np.float32)
+
+    def arrays(nctrl=127):
+        a = dict(state=st[:, 0].copy(), ctrl=np.zeros(nctrl, np.float32), ref=ref[:, 0].copy(),
+                 ws=np.zeros(asmgen.WS_ROWS, np.float32), out=np.zeros(9, np.float32), stats=np.zeros(2, np.float32),
+                 status=np.zeros(1, np.int32), info=np.zeros(2, np.float32))
+        a["ctrl"][124:] = 1
+        return a
+    prm = dict(K=1, maxIter=2, nsub=1, plant=1)
+    asmstep.simulate(ins, arrays(), prm, asmstep.host_floats())
+    with pytest.raises(asmqp_fault()):
+        asmstep.simulate(ins, arrays(), prm, asmstep.host_floats(), ptr_xform=lambda a: _sx(a))
+    with pytest.raises(asmqp_fault()):
+        asmstep.simulate(ins, arrays(nctrl=126), prm, asmstep.host_floats())
+
+
+def asmqp_fault():
+    from robobee3d_amd import asmqp
+    return asmqp.AddressFault
+
+
+def _sx(a):
+    from robobee3d_amd import asmqp
+    return asmqp.uni_scalar_operand(a, sign_extend_bug=True)
