@@ -40,9 +40,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PTRS = ["state", "ctrl", "ref", "ws", "out", "stats", "status", "info", "Ib", "gain", "aT0",
         # SURVEY 8(f) options: per-step task table (8 floats per step, see phase_a), per-robot weights [8][B], the
         # wrench-linearisation parameters (struct umpc::WLDev, 150 floats) with its state rows u4 [4][B] and w0 [6][B]
-        "taskf", "weights", "wl", "wlu", "wlw"]
+        "taskf", "weights", "wl", "wlu", "wlw",
+        # B = 1 drop-in: a host-visible word the stream writes `seq` to, system scope, after its last store (null: nothing)
+        "done"]
 NPTR_RES = 11             # the first 11 pointers live in s40..s61 for the whole kernel
-INTS = ["stride", "K", "maxIter", "nsub", "plant"]
+INTS = ["stride", "K", "maxIter", "nsub", "plant", "seq"]
 FLOATS = ["dt", "dtg", "Tmax", "wpr", "wpf", "ws_", "wvr", "wvf", "wds", "wthrust", "wmom",
           "iwpr", "iwpf", "iws", "iwvr", "iwvf", "iwds", "iwthrust", "iwmom",
           "Ib0", "Ib1", "Ib2", "Ibi0", "Ibi1", "Ibi2", "h", "hh", "h6", "taulim", "gpl", "idt", "mbg"]
@@ -56,7 +58,7 @@ S_PBLK = 2                                                           # s[2:3]: t
 S_PTR = {n: 40 + 2 * k for k, n in enumerate(PTRS[:NPTR_RES])}       # s40..s61
 S_PTR["taskf"], S_PTR["weights"] = 0, 96                             # s[0:1], s[96:97]
 S_PTR["wl"], S_PTR["wlu"], S_PTR["wlw"] = 30, 32, 34                 # loaded where the WL step starts (masks are dead there)
-S_INT = {"stride": 10, "K": 13, "maxIter": S_ITERS, "nsub": 5, "plant": 39}
+S_INT = {"stride": 10, "K": 13, "maxIter": S_ITERS, "nsub": 5, "plant": 39}       # (seq is read at the very end)
 S_F = {n: 64 + k for k, n in enumerate(FLOATS)}                      # s64..s95
 assert max(S_F.values()) <= 95
 S_STEP, S_SUB, S_RUIZ = 12, 15, 15          # loop counters: closed-loop step; plant substep / Ruiz pass (never nested)
@@ -366,7 +368,7 @@ class StepGen:
         e("s_load_dwordx2", sp(S_PTR["weights"]), P, OFF["weights"])
         e("s_load_dwordx16", "s[64:79]", P, OFF[FLOATS[0]])
         e("s_load_dwordx16", "s[80:95]", P, OFF[FLOATS[0]] + 64)
-        for n in INTS:
+        for n in S_INT:
             e("s_load_dword", sg(S_INT[n]), P, OFF[n])
         assert len(FLOATS) == 32
         import numpy as np
@@ -1779,6 +1781,23 @@ class StepGen:
         e("s_cmp_lt_i32", sg(S_STEP), sg(S_INT["K"]))
         e("s_cbranch_scc1", top + "b")
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+        # completion word for a host that polls instead of synchronising the stream (the B = 1 drop-in): every store of
+        # the wave has been acknowledged (vmcnt 0); write back L2 at system scope, then the flag itself at system scope
+        lab = self.label()
+        e("s_load_dwordx2", sp(S_M0), sp(S_PBLK), OFF["done"])
+        e("s_load_dword", sg(S_M1), sp(S_PBLK), OFF["seq"])
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_cmp_eq_u64", sp(S_M0), 0)
+        e("s_cbranch_scc1", lab + "f")
+        e("buffer_wbl2", "sc0 sc1")
+        e("s_waitcnt", "vmcnt(0)")
+        a, b = self.pool.get(), self.pool.get()
+        e("v_mov_b32", v(a), 0)
+        e("v_mov_b32", v(b), sg(S_M1))
+        e("global_store_dword", v(a), v(b), sp(S_M0), "sc0 sc1")
+        e("s_waitcnt", "vmcnt(0)")
+        self.pool.free(a, b)
+        e("label", lab)
         return e.ins
 
 
@@ -1808,8 +1827,10 @@ def fmt(t):
     if m.startswith("s_load_"):
         return "%s %s, %s, %s%s" % (m, a[0], a[1], ("0x%x" % t[3]) if isinstance(t[3], int) else t[3],
                                     (" " + t[4]) if len(t) > 4 else "")
-    if m.startswith("global_") and isinstance(t[-1], str) and t[-1].startswith("offset:"):
+    if m.startswith("global_") and isinstance(t[-1], str) and (t[-1].startswith("offset:") or t[-1].startswith("sc0")):
         return "%s %s %s" % (m, ", ".join(a[:-1]), t[-1])
+    if m == "buffer_wbl2":
+        return "buffer_wbl2 %s" % t[1]
     if m == "s_waitcnt":
         return "s_waitcnt " + " ".join(a)
     return "%s %s%s" % (m, ", ".join(a), mods)
@@ -1876,6 +1897,7 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
         struct.pack_into("<Q", blob, OFF[n], ptr_xform(base_of[n]) if arrays.get(n) is not None else 0)
     allints = dict(ints)
     allints["stride"] = STRIDE
+    allints.setdefault("seq", 0)
     for n in INTS:
         struct.pack_into("<i", blob, OFF[n], int(allints[n]))
     for n in FLOATS:
@@ -2007,7 +2029,7 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
                 continue
             nexec += 1
             assert nexec < max_exec, "runaway program"
-            if m in ("s_waitcnt", "s_nop"):
+            if m in ("s_waitcnt", "s_nop", "buffer_wbl2"):
                 pass
             elif m.startswith("s_load_dword"):
                 n = {"s_load_dword": 1, "s_load_dwordx2": 2, "s_load_dwordx4": 4, "s_load_dwordx8": 8, "s_load_dwordx16": 16}[m]

@@ -92,6 +92,24 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_asm_kernel(const umpcasm:
 }
 
 template <typename T>
+__device__ __forceinline__ void assemble_rows(const DevParams<T> &prm, int B_, int b, const T *state, const T *ctrl,
+                                              const T *refA, const T *IbA, const T *actualT0, T *l, T *u, T *q, T *Px, T *Ax);
+
+// B = 1 drop-in (umpcUpdate): the caller-visible debug fields of UprightMPC_t (l, u, q, Px_data, Ax_data: what vectors() /
+// matrices() of the reference's pybind class read, py/uprightmpc2py.cpp:46-51) are the raw assembly of this call. They do not
+// depend on the step, so this one-lane kernel runs on a SECOND stream beside the step kernel; both write into the pinned,
+// mapped host buffer and end with a system-scope release of a completion word that the host polls (no stream
+// synchronisation on the critical path). `t0dbg` is the thrust accumulator this call assembles with (host-known: the POD's
+// T0 or actualT0), so this kernel never reads the controller record the step kernel is updating.
+__global__ void umpc_dropin_debug_kernel(DevParams<float> dprm, const float *state, const float *ref, const float *t0dbg,
+                                         float *l, float *u, float *q, float *Px, float *Ax, unsigned *done1, unsigned seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  assemble_rows<float>(dprm, 1, 0, state, nullptr, ref, nullptr, t0dbg, l, u, q, Px, Ax);
+  __threadfence_system();
+  __hip_atomic_store(done1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T>
 __global__ __launch_bounds__(kBlock) void umpc_plant_kernel(DevParams<T> prm, int B_, int nsub, T *state,
                                                             const T *u, const T *IbA, const T *gainA) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
@@ -124,6 +142,12 @@ __global__ __launch_bounds__(kBlock) void umpc_assemble_kernel(DevParams<T> prm,
                                                                const T *actualT0, T *l, T *u, T *q, T *Px, T *Ax) {
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= B_) return;
+  assemble_rows(prm, B_, b, state, ctrl, refA, IbA, actualT0, l, u, q, Px, Ax);
+}
+
+template <typename T>
+__device__ __forceinline__ void assemble_rows(const DevParams<T> &prm, int B_, int b, const T *state, const T *ctrl,
+                                              const T *refA, const T *IbA, const T *actualT0, T *l, T *u, T *q, T *Px, T *Ax) {
   const size_t B = (size_t)B_;
   T p[3], R[9], dq[6], ref[9], Ibi[3];
 #pragma unroll
@@ -136,8 +160,9 @@ __global__ __launch_bounds__(kBlock) void umpc_assemble_kernel(DevParams<T> prm,
   for (int i = 0; i < 9; ++i) ref[i] = refA[(size_t)i * B + b];
 #pragma unroll
   for (int i = 0; i < 3; ++i) Ibi[i] = T(1) / (IbA ? IbA[(size_t)i * B + b] : prm.Ib[i]);
-  T T0 = ctrl[(size_t)(NX + 2 * NC) * B + b];
-  if (actualT0 && actualT0[b] >= T(0)) T0 = actualT0[b];  // uprightmpc2.c:215-216
+  // ctrl == null (the drop-in's debug assembly): actualT0 IS the accumulator this call assembles with
+  T T0 = ctrl ? ctrl[(size_t)(NX + 2 * NC) * B + b] : T(0);
+  if (actualT0 && (!ctrl || actualT0[b] >= T(0))) T0 = actualT0[b];  // uprightmpc2.c:215-216
   umpc::RawQP<T> qp;
   const umpc::Weights<T> wt = {prm.ws, prm.wds, prm.wpr, prm.wpf, prm.wvr, prm.wvf, prm.wthrust, prm.wmom};
   umpc::assemble(prm, wt, Ibi, T0, p, R, dq, ref, qp);
@@ -315,6 +340,34 @@ struct umpc_batch {
   int taskf_cap = 0;              // ... steps it holds
 };
 
+// Parameter block of the all-assembly step kernel (umpcasm::StepParams, read by the stream with scalar loads)
+static umpcasm::StepParams make_step_params(umpc_batch_t *h, int K, int nsub, void *state, void *ctrl, const void *ref,
+                                            const void *actualT0, const void *Ib, const void *gain, void *out, void *stats,
+                                            int32_t *status, void *info) {
+  umpcasm::StepParams p;
+  p.state = state; p.ctrl = ctrl; p.ref = ref; p.out = out; p.stats = stats; p.status = status;
+  // (the kernel's workspace pointer is the row it parks D, E, c in: 32-bit lane offsets stay inside one array)
+  p.ws = (char *)h->ws + (size_t)umpcasm::WS_DS * (size_t)h->B * 4;
+  p.info = info; p.Ib = Ib; p.gain = gain; p.aT0 = actualT0;
+  p.taskf = nullptr; p.weights = h->weights; p.wl = h->wl; p.wlu = h->wlu; p.wlw = h->wlw;
+  p.done = nullptr; p.seq = 0;
+  p.stride = h->B * 4; p.K = K; p.maxIter = h->prm.maxIter; p.nsub = nsub; p.plant = h->prm.plant_mode;
+  const umpc_batch_params_t &q = h->prm;
+  const float one = 1.0f;
+  p.dt = (float)q.dt; p.dtg = (float)q.dt * (float)q.g; p.Tmax = (float)q.TtoWmax * (float)q.g;
+  p.wpr = (float)q.wpr; p.wpf = (float)q.wpf; p.ws_ = (float)q.ws; p.wvr = (float)q.wvr; p.wvf = (float)q.wvf;
+  p.wds = (float)q.wds; p.wthrust = (float)q.wthrust; p.wmom = (float)q.wmom;
+  p.iwpr = one / p.wpr; p.iwpf = one / p.wpf; p.iws = one / p.ws_; p.iwvr = one / p.wvr; p.iwvf = one / p.wvf;
+  p.iwds = one / p.wds; p.iwthrust = one / p.wthrust; p.iwmom = one / p.wmom;
+  p.Ib0 = (float)q.Ib[0]; p.Ib1 = (float)q.Ib[1]; p.Ib2 = (float)q.Ib[2];
+  p.Ibi0 = one / p.Ib0; p.Ibi1 = one / p.Ib1; p.Ibi2 = one / p.Ib2;
+  p.h = (float)q.dtsim; p.hh = 0.5f * p.h; p.h6 = p.h / 6.0f; p.taulim = (float)q.taulim; p.gpl = 9.81e-3f;
+  p.idt = one / p.dt;
+  // h0 = Rb' (0, 0, mb g) of the WL coupling: M0[2] is float in WLDev (umpcBatchSetWL), the product as the C++ kernel forms it
+  p.mbg = h->wl ? h->wl_md2 * (float)q.g : 0.0f;
+  return p;
+}
+
 template <typename T>
 static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *ctrl, const void *ref,
                           const void *actualT0, const void *Ib, const void *gain, void *out, void *stats,
@@ -341,13 +394,9 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
     // parks D, E, c in, so the 559-row workspace does not count)
     const bool fits = (size_t)UMPC_CTRL_ROWS * (size_t)h->B * 4 < ((size_t)1 << 31);
     if (!no_asm && h->step_kernel == 0 && fits && K >= 1 && h->prm.maxIter >= 1) {
-      umpcasm::StepParams p;
-      p.state = state; p.ctrl = ctrl; p.ref = ref; p.out = out; p.stats = stats; p.status = status;
-      p.ws = (char *)h->ws + (size_t)umpcasm::WS_DS * (size_t)h->B * 4;
-      p.info = info; p.Ib = Ib; p.gain = gain; p.aT0 = actualT0;
+      umpcasm::StepParams p = make_step_params(h, K, nsub, state, ctrl, ref, actualT0, Ib, gain, out, stats, status, info);
       // SURVEY 8(f) options of the same stream: task generator (a table of K entries written by a K-thread kernel ahead
       // of the launch, same stream), per-robot weights, the fused WL step
-      p.taskf = nullptr;
       if (h->task != 0) {
         if (K > h->taskf_cap) {
           if (h->taskf) (void)hipFree(h->taskf);      // (synchronises: an earlier launch may still read the old table)
@@ -360,21 +409,6 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
         hipLaunchKernelGGL(umpc_taskf_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, a.prm, K, a.t0, h->taskf);
         p.taskf = h->taskf;
       }
-      p.weights = h->weights; p.wl = h->wl; p.wlu = h->wlu; p.wlw = h->wlw;
-      p.stride = h->B * 4; p.K = K; p.maxIter = h->prm.maxIter; p.nsub = nsub; p.plant = h->prm.plant_mode;
-      const umpc_batch_params_t &q = h->prm;
-      const float one = 1.0f;
-      p.dt = (float)q.dt; p.dtg = (float)q.dt * (float)q.g; p.Tmax = (float)q.TtoWmax * (float)q.g;
-      p.wpr = (float)q.wpr; p.wpf = (float)q.wpf; p.ws_ = (float)q.ws; p.wvr = (float)q.wvr; p.wvf = (float)q.wvf;
-      p.wds = (float)q.wds; p.wthrust = (float)q.wthrust; p.wmom = (float)q.wmom;
-      p.iwpr = one / p.wpr; p.iwpf = one / p.wpf; p.iws = one / p.ws_; p.iwvr = one / p.wvr; p.iwvf = one / p.wvf;
-      p.iwds = one / p.wds; p.iwthrust = one / p.wthrust; p.iwmom = one / p.wmom;
-      p.Ib0 = (float)q.Ib[0]; p.Ib1 = (float)q.Ib[1]; p.Ib2 = (float)q.Ib[2];
-      p.Ibi0 = one / p.Ib0; p.Ibi1 = one / p.Ib1; p.Ibi2 = one / p.Ib2;
-      p.h = (float)q.dtsim; p.hh = 0.5f * p.h; p.h6 = p.h / 6.0f; p.taulim = (float)q.taulim; p.gpl = 9.81e-3f;
-      p.idt = one / p.dt;
-      // h0 = Rb' (0, 0, mb g) of the WL coupling: M0[2] is float in WLDev (umpcBatchSetWL), the product as the C++ kernel forms it
-      p.mbg = h->wl ? h->wl_md2 * (float)q.g : 0.0f;
       // wave-group start skew (see the kernel): UMPC_ASM_SKEW_US / UMPC_ASM_SKEW_GROUPS override the measured default
       static const int skew_us10 = [] { const char *e_ = getenv("UMPC_ASM_SKEW_US"); return e_ ? (int)(atof(e_) * 10) : 0; }();
       static const int skew_groups = [] { const char *e_ = getenv("UMPC_ASM_SKEW_GROUPS"); return e_ ? atoi(e_) : 4; }();
@@ -633,8 +667,9 @@ struct Single {
   float *ctrl = nullptr;   // device: the 127-word controller record
   float *host = nullptr;   // pinned + mapped: inputs | outputs (layout below)
   float *hdev = nullptr;   // device alias of `host`
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;      // step kernel | debug-field kernel
   int status = umpc::ST_UNSOLVED;
+  unsigned seq = 0;        // call counter: the kernels write it to the completion words of the mapped buffer
 };
 std::mutex g_mu;
 std::map<uint32_t, Single> g_single;
@@ -642,7 +677,8 @@ uint32_t g_next_id = 1;
 constexpr uint32_t kMagic = 0x554d5043u;  // "UMPC"
 constexpr int O_STATE = 0, O_REF = 18, O_AT0 = O_REF + 9, O_OUT = O_AT0 + 1, O_INFO = O_OUT + 9, O_L = O_INFO + 2,
               O_U = O_L + 39, O_Q = O_U + 39, O_PX = O_Q + 45, O_AX = O_PX + 45, O_STATUS = O_AX + 48,
-              O_TOTAL = O_STATUS + 1;
+              O_T0DBG = O_STATUS + 1, O_DONE0 = O_T0DBG + 1 + 14 /* own cache line */, O_DONE1 = O_DONE0 + 16,
+              O_TOTAL = O_DONE1 + 16;
 
 uint32_t pod_id(const UprightMPC_t *up) {
   uint32_t w[2];
@@ -654,6 +690,7 @@ void release_locked(uint32_t id) {
   if (it == g_single.end()) return;
   Single &s = it->second;
   if (s.stream) (void)hipStreamSynchronize(s.stream);
+  if (s.stream2) { (void)hipStreamSynchronize(s.stream2); (void)hipStreamDestroy(s.stream2); }
   if (s.h) umpcBatchDestroy(s.h);
   if (s.ctrl) (void)hipFree(s.ctrl);
   if (s.host) (void)hipHostFree(s.host);
@@ -694,15 +731,17 @@ void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, floa
   s.h = umpcBatchCreate(&p, 1, UMPC_F32);
   if (!s.h) { fprintf(stderr, "umpcInit: %s\n", g_err.c_str()); return; }
   if (hipMalloc((void **)&s.ctrl, UMPC_CTRL_ROWS * sizeof(float)) != hipSuccess ||
-      hipHostMalloc((void **)&s.host, O_TOTAL * sizeof(float), hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc((void **)&s.host, O_TOTAL * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void **)&s.hdev, s.host, 0) != hipSuccess ||
-      hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) != hipSuccess) {
     fprintf(stderr, "umpcInit: device / pinned allocation failed\n");
     if (s.ctrl) (void)hipFree(s.ctrl);
     if (s.host) (void)hipHostFree(s.host);
     umpcBatchDestroy(s.h);
     return;
   }
+  memset(s.host, 0, O_TOTAL * sizeof(float));
   umpcBatchInitCtrl(s.h, s.ctrl, s.stream);
   (void)hipStreamSynchronize(s.stream);
   const uint32_t id = g_next_id++, w[2] = {kMagic, id};
@@ -726,15 +765,50 @@ int umpcUpdate(UprightMPC_t *up, float uquad[3], float accdes[6], const float p0
   // The POD's T0 is the accumulator of record (uprightmpc2.c:215-216, 256-257): a host that edits up->T0
   // between calls is honoured, and actualT0 >= 0 overrides it for this call.
   hb[O_AT0] = actualT0 >= 0 ? actualT0 : up->T0;
+  hb[O_T0DBG] = hb[O_AT0];
   float *d = s.hdev;
-  int rc = assemble_launch(s.h, d + O_STATE, s.ctrl, d + O_REF, nullptr, d + O_AT0, d + O_L, d + O_U, d + O_Q,
-                           d + O_PX, d + O_AX, s.stream);
-  if (!rc)
-    rc = umpcBatchUpdate(s.h, d + O_STATE, s.ctrl, d + O_REF, d + O_AT0, nullptr, d + O_OUT,
-                         (int32_t *)(d + O_STATUS), d + O_INFO, s.stream);
-  if (rc) return 1;
-  const hipError_t e = hipStreamSynchronize(s.stream);
-  if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
+  // UMPC_DROPIN_TWO_LAUNCHES=1: the round-2 form (assembly kernel + step kernel + stream synchronisation), for A/B timing
+  static const bool two_launches = getenv("UMPC_DROPIN_TWO_LAUNCHES") != nullptr || getenv("UMPC_NO_ASM_STEP") != nullptr;
+  if (two_launches || s.h->prm.maxIter < 1) {
+    int rc = assemble_launch(s.h, d + O_STATE, s.ctrl, d + O_REF, nullptr, d + O_AT0, d + O_L, d + O_U, d + O_Q,
+                             d + O_PX, d + O_AX, s.stream);
+    if (!rc)
+      rc = umpcBatchUpdate(s.h, d + O_STATE, s.ctrl, d + O_REF, d + O_AT0, nullptr, d + O_OUT,
+                           (int32_t *)(d + O_STATUS), d + O_INFO, s.stream);
+    if (rc) return 1;
+    const hipError_t e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
+  } else {
+    // the step kernel (B = 1, all assembly) and the debug-field kernel on two streams, completion by polling the two words
+    // they release at system scope: no stream synchronisation on the critical path
+    const unsigned seq = ++s.seq ? s.seq : ++s.seq;       // never 0 (the words start at 0)
+    umpcasm::StepParams p = make_step_params(s.h, 1, 0, d + O_STATE, s.ctrl, d + O_REF, d + O_AT0, nullptr, nullptr, d + O_OUT,
+                                             nullptr, (int32_t *)(d + O_STATUS), d + O_INFO);
+    p.done = d + O_DONE0; p.seq = (int)seq;
+    hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1, 0, 1);
+    hipLaunchKernelGGL(umpc_dropin_debug_kernel, dim3(1), dim3(64), 0, s.stream2, make_dev<float>(s.h->prm),
+                       (const float *)(d + O_STATE), (const float *)(d + O_REF), (const float *)(d + O_T0DBG), d + O_L, d + O_U,
+                       d + O_Q, d + O_PX, d + O_AX, (unsigned *)(d + O_DONE1), seq);
+    s.h->last_kernel = "umpc_rollout_asm_kernel";
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
+    volatile unsigned *f0 = (volatile unsigned *)(hb + O_DONE0), *f1 = (volatile unsigned *)(hb + O_DONE1);
+    // a healthy call completes in ~0.15 ms; after ~50 ms of polling fall back to the stream (which also reports a fault)
+    bool done = false;
+    for (long spin = 0; spin < 20000000L; ++spin) {
+      if (*f0 == seq && *f1 == seq) { done = true; break; }
+      __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (!done) {
+      e = hipStreamSynchronize(s.stream);
+      const hipError_t e2 = hipStreamSynchronize(s.stream2);
+      if (e != hipSuccess || e2 != hipSuccess || *f0 != seq || *f1 != seq) {
+        fail(e != hipSuccess ? e : e2, "umpcUpdate: kernel did not complete");
+        return 1;
+      }
+    }
+  }
   memcpy(uquad, hb + O_OUT, 12); memcpy(accdes, hb + O_OUT + 3, 24);
   memcpy(up->l, hb + O_L, 39 * 4); memcpy(up->u, hb + O_U, 39 * 4);
   memcpy(up->q, hb + O_Q, 45 * 4); memcpy(up->Px_data, hb + O_PX, 45 * 4);
