@@ -48,7 +48,15 @@ V_B1, V_B2, V_LANE, V_W = 2, 3, 4, 5     # inputs: v0 = 4*robot, v1 = lane LDS a
 NRING, NLAND, N_AT, N_TT = 6, 36, 4, 8
 V_END = 246
 BLOCK = 16                                          # stream items per pointer bump (16 x 256 B = the offset field's reach)
-LW_FLAGS = 637                                      # LDS words 637..639: GLUE_FLAG, FAC_MIN, RES_FLAG (between the blocks)
+LW_FLAGS = 636                                      # LDS words 636..639: LOOSE_FLAG, GLUE_FLAG, FAC_MIN, RES_FLAG (between the blocks)
+# The LOOSE variant of the loop (program(..., loose=True)): every inequality row of the wave is in the third class of
+# update_rho_vec (auxil.c:103-145: both scaled bounds beyond +-1e30 * 1e-4, rho = RHO_MIN) -- the reference's planar p5f
+# problem has xmin = umin = -inf, xmax = umax = +inf (planar/mpc_osqp_p5f.py:94-97), so ALL 87 of its inequality rows are.
+# Their rho and 1/rho are then two constants and the projection onto [l, u] never clips a finite value: the variant takes
+# them from SGPRs, drops v_max / v_min and streams NOTHING per inequality row (the general loop streams l, u, 1/rho, rho:
+# 4-5 loads per row and iteration). Same operations on the same values: bit-identical results. The glue block decides
+# per wave (LDS word LOOSE_FLAG).
+S_RIMIN, S_RHOMIN = 36, 37                            # 1 / RHO_MIN, RHO_MIN as float bits (set by the loose program itself)
 
 
 def lds_addr(word):
@@ -326,8 +334,9 @@ def preloads(e, p):
         idx += 1
 
 
-def body(e, p, capture=False):
-    """capture: the LAST iteration -- x_prev and delta_y go to rows R_XP / R_DY (auxil.c:362-512 consumes them)"""
+def body(e, p, capture=False, loose=False):
+    """capture: the LAST iteration -- x_prev and delta_y go to rows R_XP / R_DY (auxil.c:362-512 consumes them)
+    loose: every inequality row is a loose row (see S_RIMIN above)"""
     n, m = p.n, p.m
     v = lambda r: "v%d" % r
     sA, sO, sS, sRe = ("s%d" % r for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINVEQ))
@@ -375,6 +384,13 @@ def body(e, p, capture=False):
             op([("L", p.LW_Y + i), ("L", p.lpos[r["j"]]), src_of(("l", i))],
                lambda g, r=r, i=i: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
                                     e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0)))))
+        elif loose and not r["leaf"]:
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i])],
+               lambda g, k=k: e("v_fma_f32", W(k), "-s%d" % S_RIMIN, v(g[0]), v(g[1])))
+        elif loose:
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])],
+               lambda g, r=r: (e("v_fma_f32", v(T(0)), "-s%d" % S_RIMIN, v(g[0]), v(g[1])),
+                               e("v_fmac_f32", W(r["r"]), v(g[2]), v(T(0)))))
         elif not r["leaf"]:
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), src_of(("rinv", i))],
                lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[2]), v(g[0]), v(g[1])))
@@ -422,18 +438,28 @@ def body(e, p, capture=False):
                 op([("L", yw)], f)
             continue
         zw = p.LW_Z + p.zpos[i]
-        srcs = [("L", yw), ("L", zw), src_of(("l", i)), src_of(("u", i)), src_of(("rinv", i))]
-        nfix = 5
-        if not KNOB["rho_select"]:
-            srcs.append(src_of(("rho", i)))
-            nfix = 6
+        if loose:
+            srcs, nfix = [("L", yw), ("L", zw)], 2
+        else:
+            srcs = [("L", yw), ("L", zw), src_of(("l", i)), src_of(("u", i)), src_of(("rinv", i))]
+            nfix = 5
+            if not KNOB["rho_select"]:
+                srcs.append(src_of(("rho", i)))
+                nfix = 6
         if r["leaf"]:
             srcs += [("L", p.lpos[r["j"]]), ("A", k)]
 
         def f(g, r=r, k=k, yw=yw, zw=zw, nfix=nfix):
-            y, z, lo, up, rinv = (v(x) for x in g[:5])
+            if loose:
+                y, z = v(g[0]), v(g[1])
+                lo = up = None
+                rinv = "s%d" % S_RIMIN
+            else:
+                y, z, lo, up, rinv = (v(x) for x in g[:5])
             t3, nu, t2, tt, t4, d = (v(T(q)) for q in range(6))
-            if KNOB["rho_select"]:
+            if loose:
+                rho = "s%d" % S_RHOMIN
+            elif KNOB["rho_select"]:
                 rho = v(T(6))
                 # rho of the row: the class constant whose 1/rho this is (auxil.c:103-145 assigns one of three)
                 e("v_cmp_eq_f32", "vcc", "s%d" % S_RINV0, rinv)
@@ -452,8 +478,9 @@ def body(e, p, capture=False):
             e("v_mul_f32", t2, sO, z)
             e("v_fma_f32", tt, sA, t3, t2)                                # alpha z~ + (1 - alpha) z
             e("v_fma_f32", t4, rinv, y, tt)
-            e("v_max_f32", t4, t4, lo)
-            e("v_min_f32", t4, t4, up)                                    # z_new
+            if not loose:                                                 # (infinite bounds never clip a finite value)
+                e("v_max_f32", t4, t4, lo)
+                e("v_min_f32", t4, t4, up)                                # z_new
             e("v_sub_f32", d, tt, t4)
             if capture:
                 e("v_mul_f32", d, rho, d)                                 # delta_y
@@ -464,7 +491,7 @@ def body(e, p, capture=False):
             sc.lds_write(zw, T(4))
             sc.lds_write(yw, T(5))
         op(srcs, f)
-    assert land[0] == p.n_land
+    assert land[0] == (0 if loose else p.n_land)
     # ---- x <- alpha x~ + (1 - alpha) x
     for j in range(n):
         k = p.pinv[j]
@@ -526,12 +553,15 @@ def prologue(e, p):
     prologue_tail(e, p)
 
 
-def prologue_tail(e, p):
+def prologue_tail(e, p, loose=False):
     """once-only stream items (l of the leaf equality rows) -> their registers; the first iteration's preloads"""
     idx = p.n_stream
     assert len(p.extra) <= len(p.nonleaf)
     blk = None
+    skip = (lambda item: loose and item[0] == "rinv")          # (the loose loop takes 1/rho of those rows from an SGPR)
     for q, item in enumerate(p.extra):
+        if skip(item):
+            continue
         if (idx + q) // BLOCK != blk:
             blk = (idx + q) // BLOCK
             e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, blk * BLOCK * 256)
@@ -542,7 +572,7 @@ def prologue_tail(e, p):
     e("s_waitcnt", "vmcnt(0)")
     for q, item in enumerate(p.extra):
         kind, where = p.once[item]
-        if kind == "L":
+        if kind == "L" and not skip(item):
             base, off = lds_addr(where)
             e("ds_write_b32", base, "v%d" % (V_W + q), off)
     e("s_waitcnt", "lgkmcnt(0)")
@@ -563,7 +593,7 @@ S_FAST, S_XI, S_YI, S_ZI = 30, 24, 26, 28    # fast start: flag, the caller's x,
 FAC_MIN = 638                                # LDS word: min |d_k| of the factorisation (0 = a zero pivot)
 
 
-def prologue_fast(e, p, res):
+def prologue_fast(e, p, res, loose=False):
     """KKT fill + LDL' inside the block (factor_emit): the equilibrated A and P come from the wave's residual stream (written
     by the Ruiz block), 1/rho of the inequality rows from the loop's stream, the warm start straight from the caller's rows.
     -L lands in the loop's LDS words, 1/D in its AGPRs: no hand-off rows at all."""
@@ -600,7 +630,10 @@ def prologue_fast(e, p, res):
         sload(v_p + res.pidx[j], res.it_p[j])
     items = p.stream + p.extra
     for q, i in enumerate(gen):
-        sload(v_rinv + q, items.index(("rinv", i)))
+        if loose:
+            e("v_mov_b32", "v%d" % (v_rinv + q), "s%d" % S_RIMIN)
+        else:
+            sload(v_rinv + q, items.index(("rinv", i)))
     v_fmin = p.V_TT + N_TT - 1
     e("v_mov_b32", "v%d" % v_fmin, 1.0)
     e("s_waitcnt", "vmcnt(0)")
@@ -627,33 +660,40 @@ def prologue_fast(e, p, res):
             base, off = lds_addr(word)
             e("ds_write_b32", base, "v%d" % (V_W + q), off)
         e("s_waitcnt", "lgkmcnt(0)")
-    prologue_tail(e, p)
+    prologue_tail(e, p, loose)
 
 
-def program(s, eq_rows, res=None):
+def program(s, eq_rows, res=None, loose=False):
     """s11 = number of non-capturing iterations (>= 0); one capturing iteration follows them.
     res: a ResPlan -> the block also holds the fast start (prologue_fast), taken when s30 != 0"""
     p = Plan(s, eq_rows)
     e = Emit()
-    if res is not None:
-        e("s_cmp_lg_u32", "s%d" % S_FAST, 0)
-        e("s_cbranch_scc1", "5f")
-    prologue(e, p)
-    if res is not None:
-        e("s_branch", "6f")
-        e("label", "5")
-        prologue_fast(e, p, res)
-        e("label", "6")
+    if loose:
+        # the loose variant exists for the all-assembly route only: always the fast start (the caller passes s30 != 0)
+        assert res is not None
+        e("s_mov_b32", "s%d" % S_RIMIN, f32bits(float(np.float32(1.0 / QP_RHO_MIN))))
+        e("s_mov_b32", "s%d" % S_RHOMIN, f32bits(float(np.float32(QP_RHO_MIN))))
+        prologue_fast(e, p, res, loose=True)
+    else:
+        if res is not None:
+            e("s_cmp_lg_u32", "s%d" % S_FAST, 0)
+            e("s_cbranch_scc1", "5f")
+        prologue(e, p)
+        if res is not None:
+            e("s_branch", "6f")
+            e("label", "5")
+            prologue_fast(e, p, res)
+            e("label", "6")
     e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
     e("s_cbranch_scc1", "8f")
     e("label", "7")
-    body(e, p)
+    body(e, p, loose=loose)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
     e("label", "8")
-    body(e, p, capture=True)
+    body(e, p, capture=True, loose=loose)
     epilogue(e, p)
     return e.ins, p
 
@@ -1571,6 +1611,7 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
 # all-assembly route: LDS word GLUE_FLAG = 1 iff every row of eq_rows is an equality (rho == rho_eq, l E == u E) whose
 # warm-start z equals its bound.
 GLUE_FLAG = 637
+LOOSE_FLAG = 636      # 1 iff, in addition, every other row is a loose row (rho = RHO_MIN): the wave takes the loose loop variant
 S_LR, S_UR, S_ER, S_ZR = 4, 8, 24, 26         # pointer pairs: l, u, Eprev, z rows (s[6:7] = the wave's stream block)
 GV_RHO0, GV_RINV0, GV_RHOEQ, GV_RINVEQ = 5, 6, 7, 8      # inputs (VGPRs, wave-uniform floats)
 GLUE_PTRS = (S_SP, 36, 38, 40)                           # SGPR pairs of the block pointers for the stream stores
@@ -1600,7 +1641,7 @@ def glue_program(s, eq_rows, p, res, rp):
         pos.setdefault(it, []).append(q)
     e = Emit()
     v = lambda r: "v%d" % r
-    V_RMIN, V_RIMIN, V_F, V_NF, V_TOL, V_FLAG = 9, 10, 11, 12, 13, 14
+    V_RMIN, V_RIMIN, V_F, V_NF, V_TOL, V_FLAG, V_LFLAG = 9, 10, 11, 12, 13, 14, 15
     R = 44
     V_L, V_U, V_E, V_Z = 16, 16 + R, 16 + 2 * R, 16 + 3 * R
 
@@ -1620,6 +1661,7 @@ def glue_program(s, eq_rows, p, res, rp):
     for reg, val in ((V_RMIN, np.float32(QP_RHO_MIN)), (V_RIMIN, np.float32(1.0 / QP_RHO_MIN)), (V_F, F), (V_NF, -F), (V_TOL, TOL)):
         e("v_mov_b32", v(reg), f32bits(float(val)))
     e("v_mov_b32", v(V_FLAG), 1.0)
+    e("v_mov_b32", v(V_LFLAG), 1.0)
     # a row's items go to three regions of the stream (1/rho list, per-row items, the residual stream): four block
     # pointers are kept, least recently used replaced
     ptrs = [[sreg, None, 0] for sreg in GLUE_PTRS]          # [SGPR pair, block, last use]
@@ -1685,6 +1727,8 @@ def glue_program(s, eq_rows, p, res, rp):
                         put(q, ls)
                     put(res.it_ls[i], ls)
                 else:
+                    e("v_cmp_eq_f32", "vcc", v(rho), v(V_RMIN))                 # a loose row? (the loose loop variant)
+                    e("v_cndmask_b32", v(V_LFLAG), 0, v(V_LFLAG), "vcc")
                     for what, reg in (("rinv", rinv), ("l", ls), ("u", us), ("rho", rho)):
                         for q in pos.get((what, i), []):
                             put(q, reg)
@@ -1702,6 +1746,8 @@ def glue_program(s, eq_rows, p, res, rp):
     sc.run(ops)
     base, off = lds_addr(GLUE_FLAG)
     e("ds_write_b32", base, v(V_FLAG), off)
+    base, off = lds_addr(LOOSE_FLAG)
+    e("ds_write_b32", base, v(V_LFLAG), off)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
     written = sorted(q for lst in pos.values() for q in lst)
     assert written == list(range(p.n_stream + len(p.extra)))

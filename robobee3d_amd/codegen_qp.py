@@ -458,6 +458,11 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("      const unsigned s_sigma = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.sigma));")
     E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
     E("      const unsigned s_iters = __builtin_amdgcn_readfirstlane((unsigned)(a.max_iter - 1));")
+    E("      // every inequality row of the wave a loose row (planar p5f: all 87 are): the loop variant that streams nothing per row")
+    E("      if (__all(LDSQ(%d) == T(1.0)))" % asmqp.LOOSE_FLAG)
+    E("        BQP_%s_ASM_LOOSE(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
+      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s);" % (U, RHO_ARGS))
+    E("      else")
     E("      BQP_%s_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
       "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s);" % (U, RHO_ARGS))
     mark(5)
@@ -531,27 +536,29 @@ def glue_macro(name, ins):
     return "\n".join(out) + "\n"
 
 
-def asm_macro(name, ins, plan):
-    """csrc/gen/bqp_<name>_asm.h: the instruction stream of asmqp.program as one asm volatile statement"""
+def asm_macro(name, ins, plan, loose=False):
+    """csrc/gen/bqp_<name>_asm.h: the instruction stream of asmqp.program as one asm volatile statement
+    (loose: the variant for waves whose inequality rows are all loose rows, asmqp.S_RIMIN; same interface, fast start only)"""
     from . import asmqp
-    used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1]
+    used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1] + ([asmqp.S_RIMIN, asmqp.S_RHOMIN] if loose else [])
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
     lab7 = [k for k, t_ in enumerate(ins) if t_ == ("label", "7")][0]
     out = ["// GENERATED by robobee3d_amd/asmqp.py via codegen_qp.py -- do not edit.",
-           "// Middle ADMM iterations of the %s structure, fp32, one lane per robot, one wave per CU: %d instructions, %d"
-           % (name, len(ins), sum(1 for t_ in ins[lab7:] if t_[0] != "label")),
+           "// %s ADMM iterations of the %s structure, fp32, one lane per robot, one wave per CU: %d instructions, %d"
+           % ("LOOSE variant (every inequality row a loose row: nothing streamed per row, no clipping) of the" if loose else "Middle",
+              name, len(ins), sum(1 for t_ in ins[lab7:] if t_[0] != "label")),
            "// from the loop label on (loop body + epilogue). Stream block: %d items per iteration + %d loaded once."
-           % (plan.n_stream, len(plan.extra)),
+           % (plan.n_stream, len(plan.extra))] + ([] if loose else [
            "#pragma once",
            "constexpr int BQP_%s_ASM_STREAM_ITEMS = %d, BQP_%s_ASM_ROWS = %d;" % (name.upper(), plan.n_stream + len(plan.extra),
-                                                                          name.upper(), plan.R_END),
+                                                                          name.upper(), plan.R_END)]) + [
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[4:5] = row workspace, s[6:7] = the wave's stream",
            "// block, s10 = 4*B, s11 = iterations (>= 1), s20..s23 = alpha, 1 - alpha, sigma, 1/rho_eq (float bits);",
            "// s30 != 0: fast start (asmqp.prologue_fast: the block factorises; no hand-off rows) with s[24:25], s[26:27], s[28:29] =",
            "// the caller's x, y, z rows; min |d_k| of the factorisation -> LDS word %d;" % asmqp.FAC_MIN,
            "// s31 / s34 / s35 = rho, 1/rho, rho_eq (float bits): rho of a row is selected from its streamed 1/rho",
-           "#define BQP_%s_ASM(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast, rho0, rinv0, rhoeq) asm volatile( \\" % name.upper()]
+           "#define BQP_%s_ASM%s(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast, rho0, rinv0, rhoeq) asm volatile( \\" % (name.upper(), "_LOOSE" if loose else "")]
     for t_ in ins:
         out.append('  "%s\\n" \\' % asmqp.fmt(t_))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(ws), "{s[6:7]}"(sblk), "{s10}"(stride), '
@@ -633,6 +640,7 @@ def generate():
             from . import asmqp
             res = asmqp.ResPlan(s, ASM_STRUCTURES[name], ASM_RES_ITEM0)
             ins, plan = asmqp.program(s, ASM_STRUCTURES[name], res)
+            ins_loose, _ = asmqp.program(s, ASM_STRUCTURES[name], res, loose=True)
             assert plan.n_stream + len(plan.extra) <= ASM_RES_ITEM0
             plan.res = res
             assert plan.res.end <= ASM_STREAM_ITEMS
@@ -642,7 +650,9 @@ def generate():
             glins = asmqp.glue_program(s, ASM_STRUCTURES[name], plan, plan.res, plan.ruiz)
             asm_body = emit_structure(name, s, asm=plan)
             asm_hdr = "bqp_%s_asm.h" % name
-            files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + ruiz_macro(name, rins, plan.ruiz) + \
+            assert plan.ruiz.LW_END <= asmqp.LW_FLAGS
+            files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + asm_macro(name, ins_loose, plan, loose=True) + \
+                ruiz_macro(name, rins, plan.ruiz) + \
                 ruiz_macro(name, rsins, plan.ruiz, rs=True) + res_macro(name, resins) + glue_macro(name, glins) + \
                 loader_macro(name, "XYZ", [(s.n, 0), (s.m, s.n), (s.m, s.n + s.m)]) + \
                 loader_macro(name, "LUE", [(s.m, 0), (s.m, s.m), (s.m, 2 * s.m)])

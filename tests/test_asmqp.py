@@ -439,3 +439,44 @@ def asmqp_fault():
 def _sx(a):
     from robobee3d_amd import asmqp
     return asmqp.uni_scalar_operand(a, sign_extend_bug=True)
+
+
+@pytest.mark.parametrize("iters", [0, 2])
+def test_loose_loop_variant_is_bit_identical_to_the_general_loop(prog, iters):
+    """asmqp.program(..., loose=True): when every inequality row is a loose row (rho = RHO_MIN, bounds beyond +-1e26 -- the
+    reference's planar p5f problem, planar/mpc_osqp_p5f.py:94-97) the variant that takes rho and 1 / rho from SGPRs, never
+    clips and streams nothing per inequality row must leave EXACTLY the words the general loop leaves (fast start, the
+    block's own factorisation included). And it really is shorter."""
+    from robobee3d_amd import codegen_qp
+    asmqp, ins, p = prog
+    s = p.s
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
+    ins_l, pl = asmqp.program(s, eq, res, loose=True)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    gen = [i for i in range(p.m) if i not in set(eq)]
+    rng = np.random.default_rng(3)
+    d = _data(p, 4, eq)
+    d["rho"][gen] = f(np.array([1e-6]))[0]
+    d["rinv"] = f(np.float32(1.0) / d["rho"].astype(np.float32))
+    d["l"][gen], d["u"][gen] = -1e26, 1e26
+    A = f(rng.normal(size=s.nnzA))
+    Pv = f(np.abs(rng.normal(size=s.nnzP)) + 0.5)
+    S = np.zeros(res.end, np.float32)
+    for q, (what, i) in enumerate(p.stream + p.extra):
+        S[q] = {"rinv": d["rinv"], "l": d["l"], "u": d["u"], "rho": d["rho"], "q": d["q"]}[what][i]
+    S[res.it_A:res.it_A + s.nnzA] = A
+    for j, it in res.it_p.items():
+        S[it] = Pv[res.pidx[j]]
+    arrs = [d[k].astype(np.float32) for k in ("x", "y", "z")]
+    out = []
+    for prog_ins in (ins, ins_l):
+        lds = asmqp.simulate(prog_ins, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, (1.6, 0.5, float(np.float32(0.01))),
+                             regions=[(asmqp.S_XI, arrs[0].copy()), (asmqp.S_YI, arrs[1].copy()), (asmqp.S_ZI, arrs[2].copy())],
+                             sgpr={asmqp.S_FAST: 1})
+        out.append(np.concatenate([lds[p.LW_X:p.LW_X + p.n], lds[p.LW_Y:p.LW_Y + p.m], lds[p.LW_Z:p.LW_Z + len(gen)],
+                                   lds[p.LW_XP:p.LW_XP + p.n], lds[p.LW_DY:p.LW_DY + p.m], lds[asmqp.FAC_MIN:asmqp.FAC_MIN + 1]]))
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+    loop = lambda L: [k for k, t in enumerate(L) if t == ("label", "8")][0] - [k for k, t in enumerate(L) if t == ("label", "7")][0]
+    assert loop(ins_l) <= 0.83 * loop(ins)
+    assert sum(1 for t in ins_l if t[0] == "global_load_dword") < 0.5 * sum(1 for t in ins if t[0] == "global_load_dword")

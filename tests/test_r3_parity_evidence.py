@@ -27,8 +27,12 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
 
 
-def test_p5f_fp32_assembly_route_against_the_table_oracle(torch_cuda, margin):
-    """BASELINE configs[3]'s kernel (fp32, n = 87, m = 164, 50 iterations per tick) for 5 consecutive ticks of a ragged
+@pytest.mark.parametrize("ulim", [None, 4.0], ids=["reference_bounds", "finite_input_limits"])
+def test_p5f_fp32_assembly_route_against_the_table_oracle(torch_cuda, margin, ulim):
+    """(ulim: the reference's problem has infinite state / input bounds, planar/mpc_osqp_p5f.py:94-97 -- every inequality row
+    is a loose row and the wave takes the LOOSE variant of the loop; with finite input limits +-ulim the same waves take
+    the general loop: rho = 0.1 rows, streamed bounds, active clipping.)
+    BASELINE configs[3]'s kernel (fp32, n = 87, m = 164, 50 iterations per tick) for 5 consecutive ticks of a ragged
     batch (B = 200: three full waves and 8 lanes), every tick compared with osqp_table.solve(dtype=float32) on the SAME
     per-robot A values (read back from the GPU's own getLin), warm start carried on both sides independently. Tick 1 is
     a cold start (the wave is refused by the all-assembly route and takes C++ glue around the assembly blocks), ticks
@@ -45,10 +49,14 @@ def test_p5f_fp32_assembly_route_against_the_table_oracle(torch_cuda, margin):
     y0[3] = rng.uniform(-0.1, 0.1, B)
     mpc.y.copy_(torch.as_tensor(y0).cuda())
     st, perm = mpc.st, mpc.qp.s.perm
+    if ulim is not None:
+        mpc.l[-10:] = -ulim          # the last N rows of the identity block: umin <= u_k <= umax
+        mpc.u[-10:] = ulim
     f = lambda t: t.cpu().numpy()
     z32 = lambda r: np.zeros((r, B), np.float32)
     x, y, z, E = z32(87), z32(164), z32(164), np.ones((164, B), np.float32)
     flips = 0
+    clipped = 0
     for ti in range(2, 7):
         t = 0.002 * ti
         mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * t))
@@ -68,7 +76,10 @@ def test_p5f_fp32_assembly_route_against_the_table_oracle(torch_cuda, margin):
         margin(lab + "|dua_res - ref|", float(np.max(np.abs(info[1] - r["dua_res"]))), 2e-5)
         flips += int(np.count_nonzero(f(mpc.qp.status) != r["status"]))
         assert set(np.unique(f(mpc.qp.status))).issubset({1, 2, -2})
+        if ulim is not None:
+            clipped += int(np.count_nonzero(np.abs(np.abs(r["sol_x"][-10:]) - ulim) < 1e-3))
     margin("status flips over 5 ticks x 200 robots", flips, 50)
+    assert ulim is None or clipped > 0          # the limits are active: the projection does clip
 
 
 ITER_TOL_N5 = 3e-3    # measured 6e-4 .. 1e-3 (the N = 3 bound against the reference is 1e-3)
