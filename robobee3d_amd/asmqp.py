@@ -34,7 +34,7 @@ import struct
 
 import numpy as np
 
-from .asmgen import Emit, f32bits
+from .asmgen import Emit, f32bits, pk as _pk
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -67,6 +67,7 @@ def lds_addr(word):
 # generation-time switches (experiments; the defaults are what ships): where the bounds of the leaf equality rows live
 # ('V': registers, 'A': the AGPRs behind 1/D then LDS), 1/rho of some inequality rows resident in the free LDS words,
 # rho selected instead of streamed
+PACK_LOOSE = os.environ.get("UMPC_QP_PACK_LOOSE", "1") == "1"      # packed row updates in the loose variant (A/B switch)
 KNOB = dict(leafeq=os.environ.get("UMPC_QP_LEAFEQ", "V"), rinv_lds=os.environ.get("UMPC_QP_RINV_LDS", "1") == "1",
             rho_select=os.environ.get("UMPC_QP_RHO_SELECT", "0") == "1")
 
@@ -93,7 +94,17 @@ class Plan:
         for j in range(n):
             assert pinv[j] not in leafk
         self.nonleaf = [k for k in range(nk) if k not in leafk]
-        self.wreg = {k: V_W + q for q, k in enumerate(self.nonleaf)}
+        # W registers: the unknowns of the variables x_0 .. x_{n-1} on consecutive registers from an EVEN base (x_j, x_j+1 an
+        # aligned pair for even j: the packed row updates of the loose loop variant take two box rows per instruction),
+        # the other non-leaf unknowns around them
+        xk = [pinv[j] for j in range(n)]
+        others = [k for k in self.nonleaf if k not in set(xk)]
+        xbase = V_W + (V_W % 2)
+        assert len(others) >= xbase - V_W
+        self.wreg = {k: xbase + j for j, k in enumerate(xk)}
+        for q, k in enumerate(others):
+            self.wreg[k] = V_W + q if q < xbase - V_W else xbase + n + q - (xbase - V_W)
+        assert sorted(self.wreg.values()) == list(range(V_W, V_W + len(self.nonleaf)))
         for r in self.rows:
             if r["leaf"]:
                 assert r["r"] in self.wreg, "a leaf row must hang off a non-leaf unknown"
@@ -114,14 +125,30 @@ class Plan:
         # L storage: leaf entries in row order, then the solve entries in forward order (walked backwards by the
         # backward solve)
         self.solve_entries = [(L_i[j], c, j) for c in self.nonleaf for j in range(L_p[c], L_p[c + 1])]
-        order = [r["j"] for r in self.rows if r["leaf"]] + [j for (_, _, j) in self.solve_entries]
-        assert sorted(order) == list(range(len(L_i)))
-        self.lpos = {j: p for p, j in enumerate(order)}
+        # Pairs of leaf inequality rows (i, i + 1) for the packed row updates of the loose variant: their y words are an
+        # aligned pair when LW_Y + i is even, their variables' W registers (x_j, x_j+1 on consecutive registers) likewise;
+        # their z words and L entries are PLACED on aligned pairs below (paired rows first in both orders).
         self.LW_L, self.LW_X = 0, len(L_i)
         self.LW_Y = self.LW_X + n
-        self.LW_Z = self.LW_Y + m
-        gen = [r["i"] for r in self.rows if not r["eq"]]
+        cand = {r["i"]: r for r in self.rows if r["leaf"] and not r["eq"]}
+        self.pairs, used = [], set()
+        for i in sorted(cand):
+            if i in used or i + 1 not in cand or (self.LW_Y + i) % 2:
+                continue
+            a_, b_ = cand[i], cand[i + 1]
+            wa, wb = self.wreg[a_["r"]], self.wreg[b_["r"]]
+            if wa % 2 == 0 and wb == wa + 1:
+                self.pairs.append((a_, b_))
+                used.update((i, i + 1))
+        pflat = [r for ab in self.pairs for r in ab]
+        order = [r["j"] for r in pflat] + [r["j"] for r in self.rows if r["leaf"] and not r["eq"] and r["i"] not in used] + \
+                [r["j"] for r in self.rows if r["leaf"] and r["eq"]] + [j for (_, _, j) in self.solve_entries]
+        assert sorted(order) == list(range(len(L_i)))
+        self.lpos = {j: p for p, j in enumerate(order)}
+        self.LW_Z = self.LW_Y + m + (self.LW_Y + m) % 2          # even: (z_i, z_i+1) of a row pair share an aligned pair
+        gen = [r["i"] for r in pflat] + [r["i"] for r in self.rows if not r["eq"] and r["i"] not in used]
         self.zpos = {i: q for q, i in enumerate(gen)}
+        gen = sorted(gen)                                     # (the stream below is consumed in row order)
         self.LW_END = self.LW_Z + len(gen)
         assert self.LW_END <= 640
         # Words that are constant over the iterations and find a home on chip are loaded ONCE (prologue) instead of streamed
@@ -186,6 +213,7 @@ class Sched:
         self.sp_block = 0
         self.lds_at, self.vm_at = {}, {}    # issue position -> instruction index (for merging waits, see MERGE_*)
         self.vm_done = -1                   # VMEM loads up to this issue index are known to have arrived
+        self.at_base, self.n_at = getattr(plan, "V_AT", None), N_AT      # temporaries of the AGPR reads (even base for 'A2')
 
     def vm_wait(self, pos):
         """the VMEM load with issue index `pos` must have arrived (loads arrive in order): emits a wait unless an earlier one
@@ -203,6 +231,14 @@ class Sched:
         base, off = lds_addr(word)
         self.lds_at[self.nlds] = len(self.e.ins)
         self.e("ds_write_b32", base, "v%d" % reg, off)
+        self.nlds += 1
+
+    def lds_write2(self, word, reg):
+        """words `word`, `word + 1` (even word: the same float4 of the lane) <- the aligned pair v[reg:reg+1]"""
+        assert word % 2 == 0 and reg % 2 == 0
+        base, off = lds_addr(word)
+        self.lds_at[self.nlds] = len(self.e.ins)
+        self.e("ds_write_b64", base, "v[%d:%d]" % (reg, reg + 1), off)
         self.nlds += 1
 
     def issue_stream(self, idx):
@@ -266,9 +302,17 @@ class Sched:
             while next_acc < n and next_acc < i + max(1, self.la):
                 for q, src in enumerate(ops[next_acc].get("srcs", [])):
                     if src[0] == "A":
-                        t = p.V_AT + acc_rr % N_AT
+                        t = self.at_base + acc_rr % self.n_at
                         acc_rr += 1
                         e("v_accvgpr_read_b32", "v%d" % t, "a%d" % src[1])
+                        atemp[(next_acc, q)] = t
+                    elif src[0] == "A2":                  # two AGPR words into an aligned temporary pair
+                        acc_rr += acc_rr % 2
+                        t = self.at_base + acc_rr % self.n_at
+                        acc_rr += 2
+                        assert t % 2 == 0 and self.n_at % 2 == 0
+                        e("v_accvgpr_read_b32", "v%d" % t, "a%d" % src[1])
+                        e("v_accvgpr_read_b32", "v%d" % (t + 1), "a%d" % src[2])
                         atemp[(next_acc, q)] = t
                 next_acc += 1
             # stream: keep the landing registers full ahead of the consumer
@@ -292,7 +336,7 @@ class Sched:
             for q, src in enumerate(op["srcs"]):
                 if src[0] == "V":
                     regs.append(src[1])
-                elif src[0] == "A":
+                elif src[0] in ("A", "A2"):
                     regs.append(atemp.pop((i, q)))
                 elif src[0] == "S":
                     idx = src[1]
@@ -373,8 +417,35 @@ def body(e, p, capture=False, loose=False):
         assert p.stream[land[0]] == item, (item, land[0])
         land[0] += 1
         return ("S", land[0] - 1)
+    # ---- the loose variant's middle iterations take the leaf inequality rows (p5f: the 87 box rows) TWO per packed
+    # instruction: rows i, i+1 whose y words, z words, L entries and variables' W registers are aligned pairs (Plan lays
+    # them out that way). The capturing iteration keeps the scalar form (delta_y words are not pair-aligned).
+    VP = lambda r_: ("v[%d:%d]" % (r_, r_ + 1), 0, 1)
+    SB = lambda sreg, h: ("s[%d:%d]" % (sreg - sreg % 2, sreg - sreg % 2 + 1), h, h)
+    paired = {}
+    if loose and not capture and PACK_LOOSE:
+        for a_, b_ in p.pairs:
+            assert (p.LW_Y + a_["i"]) % 2 == 0 and (p.LW_Z + p.zpos[a_["i"]]) % 2 == 0 and p.zpos[b_["i"]] == p.zpos[a_["i"]] + 1
+            assert p.lpos[a_["j"]] % 2 == 0 and p.lpos[b_["j"]] == p.lpos[a_["j"]] + 1
+            paired[a_["i"]] = b_
+            paired[b_["i"]] = None            # handled with its partner
+        sc.at_base, sc.n_at = p.V_LAND, 8         # (the landing registers are idle in this variant) pairs of 1/D words
+    TPK = lambda set_, q: p.V_LAND + 8 + 8 * (set_ % 3) + q          # three sets of packed temporaries, also landing registers
+    assert not paired or p.NLAND >= 32
     for r in p.rows:
         i, k = r["i"], r["k"]
+        if i in paired:
+            if paired[i] is None:
+                continue
+            rb = paired[i]
+
+            def f2(g, r=r, cnt=len(ops)):
+                t = T(2 * (cnt % 4))                 # (rotating temporaries: no back-to-back reuse of one pair)
+                _pk(e, "v_pk_fma_f32", t, [SB(S_RIMIN, 0), VP(g[0]), VP(g[1])], [1, 0, 0])      # z - y / rho
+                wr = p.wreg[r["r"]]
+                _pk(e, "v_pk_fma_f32", wr, [VP(g[2]), VP(t), VP(wr)])                           # W(x_j) += (-L) rhs
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])], f2)
+            continue
         if r["eq"] and not r["leaf"]:
             def f(g, k=k):
                 wait_pre(p.wreg[k])
@@ -415,9 +486,36 @@ def body(e, p, capture=False, loose=False):
         compute()
         sc.lds_write(p.LW_DY + i, reg)
     # ---- P6: row updates (auxil.c:203-228); leaf rows re-form their multiplier from the final unknown of their variable
+    npk = [0]
     for r in p.rows:
         i, k = r["i"], r["k"]
         yw = p.LW_Y + i
+        if i in paired:
+            if paired[i] is None:
+                continue
+            rb = paired[i]
+            zw = p.LW_Z + p.zpos[i]
+
+            def fp(g, r=r, yw=yw, zw=zw):
+                # the scalar row update below, two rows per instruction (same operations on each half)
+                y, z, L_, di = VP(g[0]), VP(g[1]), VP(g[2]), VP(g[3])
+                a_, b_, c_ = TPK(npk[0], 0), TPK(npk[0], 2), TPK(npk[0], 4)
+                npk[0] += 1
+                rinv, rho = SB(S_RIMIN, 0), SB(S_RHOMIN, 1)
+                wr = p.wreg[r["r"]]
+                _pk(e, "v_pk_fma_f32", a_, [rinv, y, z], [1, 0, 0])              # t3 = z - y / rho
+                _pk(e, "v_pk_mul_f32", b_, [VP(a_), di])                         # nu = t3 / d ...
+                _pk(e, "v_pk_fma_f32", b_, [L_, VP(wr), VP(b_)])                 # ... + (-L) x~_j
+                _pk(e, "v_pk_fma_f32", a_, [rinv, VP(b_), VP(a_)])               # z~
+                _pk(e, "v_pk_mul_f32", b_, [SB(S_OMA, S_OMA % 2), z])            # (1 - alpha) z
+                _pk(e, "v_pk_fma_f32", a_, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # t = alpha z~ + (1 - alpha) z
+                _pk(e, "v_pk_fma_f32", b_, [rinv, y, VP(a_)])                    # z_new = t + y / rho (infinite bounds: no clip)
+                _pk(e, "v_pk_add_f32", a_, [VP(a_), VP(b_)], [0, 1])             # t - z_new
+                _pk(e, "v_pk_fma_f32", c_, [rho, VP(a_), y])                     # y_new = y + rho (t - z_new)
+                sc.lds_write2(zw, b_)
+                sc.lds_write2(yw, c_)
+            op([("L", yw), ("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
+            continue
         if r["eq"]:
             if r["leaf"]:
                 def f(g, r=r, i=i, yw=yw):
@@ -702,6 +800,10 @@ def fmt(t):
     m = t[0]
     if m == "label":
         return "%s:" % t[1]
+    if isinstance(t[-1], dict):          # VOP3P (packed) instruction: operands + op_sel / op_sel_hi / neg_lo / neg_hi
+        d = t[-1]
+        return "%s %s %s" % (m, ", ".join(str(x) for x in t[1:-1]),
+                             " ".join("%s:[%s]" % (k, ",".join(map(str, d[k]))) for k in ("op_sel", "op_sel_hi", "neg_lo", "neg_hi")))
     a = [("0x%x" % x if isinstance(x, int) and m in ("s_mov_b32", "v_add_u32", "v_and_b32", "v_mov_b32") else str(x)) for x in t[1:]]
     if m.startswith("ds_"):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
@@ -950,6 +1052,30 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
                 lds[w + h] = bits2f(V[lo + h])
         elif m == "ds_write_b32":
             lds[ldsword(t[1], t[3])] = bits2f(V[int(t[2][1:])])
+        elif m == "ds_write_b64":
+            lo = int(t[2][2:t[2].index(":")])
+            w = ldsword(t[1], t[3])
+            lds[w], lds[w + 1] = bits2f(V[lo]), bits2f(V[lo + 1])
+        elif m in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
+            d = t[-1]
+            srcs = t[2:-1]
+            dlo = int(t[1][2:t[1].index(":")])
+
+            def half(x, sel):
+                lo_ = int(x[2:x.index(":")])
+                return bits2f(V[lo_ + sel]) if x[0] == "v" else bits2f(SG[lo_ + sel])
+            out2 = []
+            for hi in (0, 1):
+                sel = d["op_sel_hi"] if hi else d["op_sel"]
+                ng = d["neg_hi"] if hi else d["neg_lo"]
+                vals = [np.float64(half(x, sel[q])) * (-1 if ng[q] else 1) for q, x in enumerate(srcs)]
+                if m == "v_pk_fma_f32":
+                    out2.append(f32(vals[0] * vals[1] + vals[2]))
+                elif m == "v_pk_mul_f32":
+                    out2.append(f32(f32(vals[0]) * f32(vals[1])))
+                else:
+                    out2.append(f32(f32(vals[0]) + f32(vals[1])))
+            V[dlo], V[dlo + 1] = f32bits(float(out2[0])), f32bits(float(out2[1]))     # both halves from the OLD registers
         elif m == "v_accvgpr_read_b32":
             V[int(t[1][1:])] = A[int(t[2][1:])]
         elif m == "v_fma_f32":

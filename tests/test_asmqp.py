@@ -37,7 +37,7 @@ def _data(p, seed, eq):
 
 def _run(asmqp, ins, p, d, iters, eq, sigma=1e-6):
     n, m, nk = p.n, p.m, p.nk
-    gen = [i for i in range(m) if i not in set(eq)]
+    gen = sorted(p.zpos, key=lambda i: p.zpos[i])          # the inequality rows in the order of their z words
     W = np.zeros(p.R_END, np.float32)
     for j, pos in p.lpos.items():
         W[p.R_L + pos] = -d["L"][j]
