@@ -67,6 +67,7 @@ def lds_addr(word):
 # generation-time switches (experiments; the defaults are what ships): where the bounds of the leaf equality rows live
 # ('V': registers, 'A': the AGPRs behind 1/D then LDS), 1/rho of some inequality rows resident in the free LDS words,
 # rho selected instead of streamed
+PACK_PARTS = os.environ.get("UMPC_QP_PACK_PARTS", "1234")     # (diagnostics) 1: rhs of x, 2: 1/D scaling, 3: x update, 4: equality rows
 PACK_LOOSE = os.environ.get("UMPC_QP_PACK_LOOSE", "1") == "1"      # packed row updates in the loose variant (A/B switch)
 KNOB = dict(leafeq=os.environ.get("UMPC_QP_LEAFEQ", "V"), rinv_lds=os.environ.get("UMPC_QP_RINV_LDS", "1") == "1",
             rho_select=os.environ.get("UMPC_QP_RHO_SELECT", "0") == "1")
@@ -98,12 +99,28 @@ class Plan:
         # aligned pair for even j: the packed row updates of the loose loop variant take two box rows per instruction),
         # the other non-leaf unknowns around them
         xk = [pinv[j] for j in range(n)]
-        others = [k for k in self.nonleaf if k not in set(xk)]
         xbase = V_W + (V_W % 2)
-        assert len(others) >= xbase - V_W
         self.wreg = {k: xbase + j for j, k in enumerate(xk)}
-        for q, k in enumerate(others):
-            self.wreg[k] = V_W + q if q < xbase - V_W else xbase + n + q - (xbase - V_W)
+        # ... and the unknowns of consecutive non-leaf EQUALITY rows (i, i + 1) whose y words are an aligned pair (LW_Y + i
+        # even) on aligned register pairs too: their row updates and right-hand sides pack the same way
+        LW_Y_ = len(L_i) + n
+        nl_eq = {r["i"]: r["k"] for r in self.rows if r["eq"] and not r["leaf"]}
+        self.eqpairs, usede = [], set()
+        for i in sorted(nl_eq):
+            if i not in usede and i + 1 in nl_eq and (LW_Y_ + i) % 2 == 0:
+                self.eqpairs.append((i, i + 1))
+                usede.update((i, i + 1))
+        paired_k = [nl_eq[i] for ab in self.eqpairs for i in ab]
+        rest = [k for k in self.nonleaf if k not in set(xk) and k not in set(paired_k)]
+        free = [r_ for r_ in range(V_W, V_W + len(self.nonleaf)) if r_ not in set(self.wreg.values())]
+        evens = [r_ for r_ in free if r_ % 2 == 0 and r_ + 1 in free]
+        taken = set()
+        for q in range(0, len(paired_k), 2):
+            base = next(r_ for r_ in evens if r_ not in taken and r_ + 1 not in taken)
+            taken.update((base, base + 1))
+            self.wreg[paired_k[q]], self.wreg[paired_k[q + 1]] = base, base + 1
+        for k, r_ in zip(rest, [r_ for r_ in free if r_ not in taken]):
+            self.wreg[k] = r_
         assert sorted(self.wreg.values()) == list(range(V_W, V_W + len(self.nonleaf)))
         for r in self.rows:
             if r["leaf"]:
@@ -400,8 +417,26 @@ def body(e, p, capture=False, loose=False):
     def wait_pre(reg):
         sc.vm_wait(pre_pos[reg])
     # ---- P1: W_x = sigma x - q (q preloaded)
+    pack = loose and not capture and PACK_LOOSE          # the loose variant's middle iterations: two entries per instruction
+    VP = lambda r_: ("v[%d:%d]" % (r_, r_ + 1), 0, 1)
+    SB = lambda sreg, h: ("s[%d:%d]" % (sreg - sreg % 2, sreg - sreg % 2 + 1), h, h)
+    xpair = lambda j: pack and j + 1 < n and (p.LW_X + j) % 2 == 0 and p.wreg[p.pinv[j]] % 2 == 0 and \
+        p.wreg[p.pinv[j + 1]] == p.wreg[p.pinv[j]] + 1
+    jskip = set()
     for j in range(n):
         k = p.pinv[j]
+        if j in jskip:
+            continue
+        if "1" in PACK_PARTS and xpair(j):
+            jskip.add(j + 1)
+
+            def f2x(r, j=j):
+                wr = p.wreg[p.pinv[j]]
+                wait_pre(wr)
+                wait_pre(wr + 1)
+                _pk(e, "v_pk_fma_f32", wr, [SB(S_SIGMA, S_SIGMA % 2), VP(r[0]), VP(wr)], [0, 0, 1])
+            op([("L", p.LW_X + j)], f2x)
+            continue
 
         def f(r, k=k):
             wait_pre(p.wreg[k])
@@ -422,6 +457,8 @@ def body(e, p, capture=False, loose=False):
     # them out that way). The capturing iteration keeps the scalar form (delta_y words are not pair-aligned).
     VP = lambda r_: ("v[%d:%d]" % (r_, r_ + 1), 0, 1)
     SB = lambda sreg, h: ("s[%d:%d]" % (sreg - sreg % 2, sreg - sreg % 2 + 1), h, h)
+    eqfirst = {a_ for (a_, b_) in p.eqpairs if p.wreg[p.rows[a_]["k"]] % 2 == 0 and p.wreg[p.rows[b_]["k"]] == p.wreg[p.rows[a_]["k"]] + 1}
+    eqskip = set()
     paired = {}
     if loose and not capture and PACK_LOOSE:
         for a_, b_ in p.pairs:
@@ -445,6 +482,18 @@ def body(e, p, capture=False, loose=False):
                 wr = p.wreg[r["r"]]
                 _pk(e, "v_pk_fma_f32", wr, [VP(g[2]), VP(t), VP(wr)])                           # W(x_j) += (-L) rhs
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])], f2)
+            continue
+        if pack and "4" in PACK_PARTS and i in eqskip:
+            continue
+        if pack and "4" in PACK_PARTS and i in eqfirst:
+            eqskip.add(i + 1)
+
+            def f2e(g, k=k):
+                wr = p.wreg[k]
+                wait_pre(wr)
+                wait_pre(wr + 1)
+                _pk(e, "v_pk_fma_f32", wr, [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(wr)], [1, 0, 0])
+            op([("L", p.LW_Y + i)], f2e)
             continue
         if r["eq"] and not r["leaf"]:
             def f(g, k=k):
@@ -472,8 +521,18 @@ def body(e, p, capture=False, loose=False):
     # ---- solves over the non-leaf unknowns (qdldl.c:250-293)
     for (r_, c, j) in p.solve_entries:
         op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
-    for k in p.nonleaf:
-        op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
+    kof = {reg: k for k, reg in p.wreg.items()}
+    kdone = set()
+    for reg in sorted(kof) if pack else [p.wreg[k] for k in p.nonleaf]:      # (by register when pairing: a pair is visited once)
+        k = kof[reg]
+        if k in kdone:
+            continue
+        if "2" in PACK_PARTS and pack and reg % 2 == 0 and reg + 1 in kof:
+            k1 = kof[reg + 1]
+            kdone.add(k1)
+            op([("A2", k, k1)], lambda g, reg=reg: _pk(e, "v_pk_mul_f32", reg, [VP(reg), VP(g[0])]))
+        else:
+            op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
     for (r_, c, j) in reversed(p.solve_entries):
         op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
     ops.append(dict(flush=True))
@@ -487,6 +546,7 @@ def body(e, p, capture=False, loose=False):
         sc.lds_write(p.LW_DY + i, reg)
     # ---- P6: row updates (auxil.c:203-228); leaf rows re-form their multiplier from the final unknown of their variable
     npk = [0]
+    eqskip2 = set()
     for r in p.rows:
         i, k = r["i"], r["k"]
         yw = p.LW_Y + i
@@ -527,6 +587,19 @@ def body(e, p, capture=False, loose=False):
                     e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
                     sc.lds_write(yw, T(1))
                 op([("L", yw), ("L", p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
+            elif pack and "4" in PACK_PARTS and i in eqskip2:
+                pass
+            elif pack and "4" in PACK_PARTS and i in eqfirst:
+                eqskip2.add(i + 1)
+
+                def f2u(g, k=k, yw=yw):
+                    t = TPK(npk[0], 0)
+                    npk[0] += 1
+                    wr = p.wreg[k]
+                    _pk(e, "v_pk_add_f32", t, [VP(wr), VP(g[0])], [0, 1])                  # nu - y
+                    _pk(e, "v_pk_fma_f32", t, [SB(S_ALPHA, S_ALPHA % 2), VP(t), VP(g[0])])  # y + alpha (nu - y)
+                    sc.lds_write2(yw, t)
+                op([("L", yw)], f2u)
             else:
                 def f(g, k=k, yw=yw, i=i):
                     e("v_sub_f32", v(T(1)), W(k), v(g[0]))
@@ -591,8 +664,22 @@ def body(e, p, capture=False, loose=False):
         op(srcs, f)
     assert land[0] == (0 if loose else p.n_land)
     # ---- x <- alpha x~ + (1 - alpha) x
+    jskip = set()
     for j in range(n):
         k = p.pinv[j]
+        if j in jskip:
+            continue
+        if "3" in PACK_PARTS and xpair(j):
+            jskip.add(j + 1)
+
+            def fx2(g, j=j):
+                t = TPK(j // 2, 6)
+                wr = p.wreg[p.pinv[j]]
+                _pk(e, "v_pk_mul_f32", t, [SB(S_OMA, S_OMA % 2), VP(g[0])])
+                _pk(e, "v_pk_fma_f32", t, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(t)])
+                sc.lds_write2(p.LW_X + j, t)
+            op([("L", p.LW_X + j)], fx2)
+            continue
 
         def f(g, k=k, j=j):
             t = T(6 + j % 2)
