@@ -50,7 +50,7 @@ write = counters(os.path.join(src, "write", "pmc_counter_collection.csv"))["WRIT
 fkb, wkb = fetch[-1][0], write[-1][0]          # the timed dispatch = the second 500-step launch
 alg = 1208
 traffic = dict(
-    command="rocprofv3 --output-format csv --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline ; the same with --pmc WRITE_SIZE "
+    command="rocprofv3 --output-format csv --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --no-side-configs --no-precondition ; the same with --pmc WRITE_SIZE "
             "(separate passes, no trace domains; timed dispatch = the second 500-step launch); tools/run_profiles.sh",
     kernel=KERNEL, batch=B, dtype="f32", plant="rk4", steps_per_launch=K, max_iter=50, nsub=25,
     FETCH_SIZE_KB_per_launch=fkb, WRITE_SIZE_KB_per_launch=wkb,
@@ -70,7 +70,7 @@ dur_ns = c2["SQ_WAVE_CYCLES"][-1][1]
 waves = per["SQ_WAVES"]
 sq = dict(
     command="rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -- "
-            "python3 bench.py --no-cpu-baseline --steps 100 --warmup 100 ; second pass --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
+            "python3 bench.py --no-cpu-baseline --no-side-configs --no-precondition --steps 100 --warmup 100 ; second pass --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
             "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE",
     kernel=KERNEL, batch=B, dtype="f32", plant="rk4", steps_per_launch=KS, max_iter=50, nsub=25, waves=waves, per_launch=per,
     per_wave_step=dict(valu_instructions=per["SQ_INSTS_VALU"] / waves / KS, salu=per["SQ_INSTS_SALU"] / waves / KS,

@@ -14,10 +14,10 @@ dst = os.path.join(ROOT, "profiles")
 CFG = {
     "c4": dict(name="config4_p5f", kernel="bqp_fixed_p5f10_asm_kernel", B=16384, dtype="f32", units_per_dispatch=1,
                unit="robot-tick", alg_bytes=(2 * (87 + 2 * 164) + 15) * 4,
-               command="bench.py --no-cpu-baseline --workload p5f --steps 20 --warmup 5"),
+               command="bench.py --no-cpu-baseline --no-side-configs --no-precondition --workload p5f --steps 20 --warmup 5"),
     "c2": dict(name="config2_f64", kernel="umpc_rollout_kernel", B=4096, dtype="f64", units_per_dispatch=20,
                unit="robot-step", alg_bytes=2 * 1208,
-               command="bench.py --no-cpu-baseline --dtype f64 --batch 4096 --plant euler --steps 20 --warmup 5"),
+               command="bench.py --no-cpu-baseline --no-side-configs --no-precondition --dtype f64 --batch 4096 --plant euler --steps 20 --warmup 5"),
 }
 
 

@@ -5,8 +5,8 @@ set -o pipefail
 OUT=${1:-gpurun_out/prof_small}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-C4="python3 bench.py --no-cpu-baseline --workload p5f --steps 20 --warmup 5"
-C2="python3 bench.py --no-cpu-baseline --dtype f64 --batch 4096 --plant euler --steps 20 --warmup 5"
+C4="python3 bench.py --no-cpu-baseline --no-side-configs --no-precondition --workload p5f --steps 20 --warmup 5"
+C2="python3 bench.py --no-cpu-baseline --no-side-configs --no-precondition --dtype f64 --batch 4096 --plant euler --steps 20 --warmup 5"
 for cfg in c4 c2; do
   if [ $cfg = c4 ]; then CMD=$C4; else CMD=$C2; fi
   rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/${cfg}_fetch" -o pmc -- $CMD > "$OUT/${cfg}_fetch.log" 2>&1 || exit 1
