@@ -353,3 +353,27 @@ def test_assembly_kernel_options_agree_with_the_cpp_kernel(torch_cuda, margin):
         if "wl" in opts:
             margin(lab + "|d u4| / rate limit", float((np.abs(a[4] - c[4]) / np.array([5.0, 0.01, 0.01, 0.01])[:, None]).max()), 5e-2)
             margin(lab + "|d w0|", float(np.abs(a[5] - c[5]).max()), 2e-3)
+
+
+def test_batch_beyond_the_old_31_bit_workspace_limit(torch_cuda):
+    """Round 2 sent batches with WS_ROWS x B x 4 >= 2^31 (B >~ 960 k on one GPU) to the C++ kernel silently: the assembly
+    stream formed workspace offsets in 32 bits. Its workspace pointer is now the first row it uses (85 rows, not 559), so
+    a million robots per GPU (the 288 GB of HBM hold far more) stay on the all-assembly kernel -- and robot i still
+    computes what it computes in a small batch (lanes are independent; same start, same steps)."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions_device
+    B, K = 1048576, 2
+    assert 559 * B * 4 >= (1 << 31)
+    m = BatchUprightMPC(B, torch.float32, plant_mode=1)
+    st, ref, _ = hover_initial_conditions_device(B, 20201118, torch.float32)
+    m.set_state(st, ref)
+    m.rollout(K)
+    assert m.kernel_name == "umpc_rollout_asm_kernel"
+    for lo in (0, B - 4096):
+        s = BatchUprightMPC(4096, torch.float32, plant_mode=1)
+        st4, ref4, _ = hover_initial_conditions_device(4096, 20201118, torch.float32, index_offset=lo)
+        s.set_state(st4, ref4)
+        s.rollout(K)
+        assert torch.equal(s.state, m.state[:, lo:lo + 4096]) and torch.equal(s.out, m.out[:, lo:lo + 4096])
+        assert torch.equal(s.ctrl, m.ctrl[:, lo:lo + 4096])
+    assert bool(torch.isfinite(m.state).all()) and float((m.status > 0).float().mean()) > 0.99
