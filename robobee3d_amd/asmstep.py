@@ -16,14 +16,16 @@ auxil.c:103-145 (classification), scaling.c:44-156 (Ruiz), kkt.c:184-222 + qdldl
 osqp.c:354-370 + auxil.c:164-228 (iterations, asmgen.py), auxil.c:243-362, 684-789 + osqp.c:524-573 (residuals,
 status), auxil.c:517-565 (store_solution), template/genqp.py:24-30 (vector field; RK4 is build-defined).
 
-Arithmetic vs the C++ statement of the same step (csrc/umpc_step.h, kept for fp64 / tasks / per-robot weights /
-Euler plant / WL coupling): phase C works in UNSCALED variables (xu = D x, yu = E y / c; the residual norms are
+Arithmetic vs the C++ statement of the same step (csrc/umpc_step.h, kept for fp64 and as the cross-check of this
+stream): phase C works in UNSCALED variables (xu = D x, yu = E y / c; the residual norms are
 algebraically the reference's Einv / Dinv / cinv-weighted norms), sums are associated for packed arithmetic, 1/x is
 v_rcp_f32 + one Newton step. Everything is checked on CPU by interpreting the emitted instructions
 (asmgen.simulate) against the oracle before it reaches a GPU (tests/test_asm_step.py).
 
-Scope of this fast path: fp32, task generator off, batch-constant weights, no WL coupling (both plant steps);
-optional per-robot Ib / thrust gain / actualT0 / stats / status / info. umpc_mi355x.hip dispatches.
+Scope of this path: fp32, both plant steps; optional per-robot Ib / thrust gain / actualT0 / stats / status / info and --
+round 3 -- the SURVEY 8(f) workloads as options of the same stream: a task table (flight_tasks.py generators: 8 floats per
+step, scalar loads), per-robot objective weights (gain sweeps; parked in AGPRs across Ruiz and the loop), the fused WL step
+(funapprox.c:118-165) and a completion word for hosts that poll (the B = 1 drop-in). umpc_mi355x.hip dispatches.
 """
 import os
 import struct

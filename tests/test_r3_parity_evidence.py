@@ -67,18 +67,18 @@ def test_p5f_fp32_assembly_route_against_the_table_oracle(torch_cuda, margin, ul
         torch.cuda.synchronize()
         got = {k: f(getattr(mpc.qp, k)).astype(np.float64) for k in ("x", "y", "z", "sol_x", "sol_y", "Eprev")}
         lab = "tick %d: " % (ti - 1)
-        margin(lab + "iterates x, y, z  |d| / max(1, |ref|)", max(_rel(got[k], r[k]) for k in ("x", "y", "z")), 2e-5)
+        margin(lab + "iterates x, y, z  |d| / max(1, |ref|)", max(_rel(got[k], r[k]) for k in ("x", "y", "z")), 1.2e-5)
         margin(lab + "sol_x, sol_y  |d| / max(1, |ref|)", max(_rel(got[k], r[k]) for k in ("sol_x", "sol_y")), 6e-5)
-        margin(lab + "E (Ruiz row scaling) relative", float(np.max(np.abs(got["Eprev"] / r["E"] - 1))), 2e-5)
+        margin(lab + "E (Ruiz row scaling) relative", float(np.max(np.abs(got["Eprev"] / r["E"] - 1))), 1e-6)
         info = f(mpc.qp.info).astype(np.float64)
         # residuals of a converged fp32 iterate are differences of nearly equal numbers: magnitudes agree, digits do not
-        margin(lab + "|pri_res - ref|", float(np.max(np.abs(info[0] - r["pri_res"]))), 2e-5)
-        margin(lab + "|dua_res - ref|", float(np.max(np.abs(info[1] - r["dua_res"]))), 2e-5)
+        margin(lab + "|pri_res - ref|", float(np.max(np.abs(info[0] - r["pri_res"]))), 1e-5)
+        margin(lab + "|dua_res - ref|", float(np.max(np.abs(info[1] - r["dua_res"]))), 3.5e-5)
         flips += int(np.count_nonzero(f(mpc.qp.status) != r["status"]))
         assert set(np.unique(f(mpc.qp.status))).issubset({1, 2, -2})
         if ulim is not None:
             clipped += int(np.count_nonzero(np.abs(np.abs(r["sol_x"][-10:]) - ulim) < 1e-3))
-    margin("status flips over 5 ticks x 200 robots", flips, 50)
+    margin("status flips over 5 ticks x 200 robots", flips, 10)
     assert ulim is None or clipped > 0          # the limits are active: the projection does clip
 
 
@@ -191,18 +191,18 @@ def test_reference_closed_loop_log_replayed_on_the_gpu(torch_cuda, margin):
         Y[ti] = np.hstack((s[0:3], s[9:12], s[12:18]))
         U[ti] = u[:, 0].cpu().numpy()
     lab = "fp32 controller + fp64 plant: "
-    margin(lab + "|p - ref log| mm", float(np.abs(Y[:, 0:3] - g["y"][:, 0:3]).max()), 1e-3)
-    margin(lab + "|s - ref log|, |dq - ref log|", float(np.abs(Y[:, 3:] - g["y"][:, 3:]).max()), 1e-4)
+    margin(lab + "|p - ref log| mm", float(np.abs(Y[:, 0:3] - g["y"][:, 0:3]).max()), 6e-4)
+    margin(lab + "|s - ref log|, |dq - ref log|", float(np.abs(Y[:, 3:] - g["y"][:, 3:]).max()), 6e-5)
     margin(lab + "|thrust - ref log|", float(np.abs(U[:, 0] - g["u"][:, 0]).max()), 3e-5)
     margin(lab + "|moment - ref log| / max(2e-2, 1e-3 |u|)",
-           float((np.abs(U[:, 1:] - g["u"][:, 1:]) / np.maximum(2e-2, 1e-3 * np.abs(g["u"][:, 1:]))).max()), 3.0)
+           float((np.abs(U[:, 1:] - g["u"][:, 1:]) / np.maximum(2e-2, 1e-3 * np.abs(g["u"][:, 1:]))).max()), 1.0)
     rows = sorted(fire)
-    margin(lab + "|accdes - ref log| at the 96 fires", float(np.abs(ACC[rows] - g["accdes"][rows]).max()), 1e-4)
+    margin(lab + "|accdes - ref log| at the 96 fires", float(np.abs(ACC[rows] - g["accdes"][rows]).max()), 3e-5)
     met = np.array([np.mean(np.sum(Y[:, :3] ** 2, axis=1)), np.mean(np.sum(U[:, 1:3] ** 2, axis=1))])
-    margin(lab + "logMetric pair, relative", float(np.max(np.abs(met / g["metric"] - 1))), 1e-4)
+    margin(lab + "logMetric pair, relative", float(np.max(np.abs(met / g["metric"] - 1))), 2e-4)
     assert np.linalg.norm(Y[-1, :3]) < 0.02 and abs(Y[-1, 5] - 1) < 1e-4      # hover converges to the origin, upright
     # (b), (c): the product's own harness at the recorded schedule, one precision throughout
-    for tdt, name, bp, bs, bm in ((torch.float32, "fp32 harness: ", 5e-3, 5e-4, 1e-3), (torch.float64, "fp64 harness: ", 5e-3, 5e-4, 1e-3)):
+    for tdt, name, bp, bs, bm in ((torch.float32, "fp32 harness: ", 1e-3, 1e-4, 1.5e-4), (torch.float64, "fp64 harness: ", 1e-3, 1e-4, 1.5e-4)):
         m = BatchUprightMPC(2, tdt, plant_mode=0)
         m.set_state(np.repeat(st, 2, 1), np.repeat(ref, 2, 1))
         log = m.control_test_log(500.0, robots=(0, 1), fire=g["fire"])
@@ -251,9 +251,9 @@ def test_bounds_reject_path_documented_difference(torch_cuda, oracle_built, stru
         assert upc.status() in (1, 2, -2)
     # errors of earlier calls feed later ones through the warm start: the sequence band of
     # test_reference_boundary_dropin_sequence (1e-4 / 3x the moment band / 1e-4)
-    margin("Tmax < 0: product vs canonical oracle |d thrust| (12-call sequence)", wt, 1e-4)
-    margin("Tmax < 0: product vs canonical oracle |d moment| / max(2e-2, 1e-3|u|)", wm, 3.0)
-    margin("Tmax < 0: product vs canonical oracle |d accdes|", wa, 1e-4)
+    margin("Tmax < 0: product vs canonical oracle |d thrust| (12-call sequence)", wt, 5e-6)
+    margin("Tmax < 0: product vs canonical oracle |d moment| / max(2e-2, 1e-3|u|)", wm, 0.15)
+    margin("Tmax < 0: product vs canonical oracle |d accdes|", wa, 6e-6)
     assert dref > 1.0, dref     # ... and it is NOT the reference's placeholder solve (moments differ by O(1..10))
 
 
@@ -344,15 +344,15 @@ def test_assembly_kernel_options_agree_with_the_cpp_kernel(torch_cuda, margin):
                         ([wl.u.cpu().numpy().astype(np.float64), wl.w0.cpu().numpy().astype(np.float64)] if wl else [])
         a, c = res["auto"], res["cpp"]
         lab = "asm vs C++ kernel, options %s: " % "+".join(opts)
-        margin(lab + "|dp| mm", float(np.abs(a[0][0:3] - c[0][0:3]).max()), 1.5e-3)
-        margin(lab + "|dR|, |ddq|", float(np.abs(a[0][3:] - c[0][3:]).max()), 3e-4)
-        margin(lab + "|d thrust|", float(np.abs(a[1][0] - c[1][0]).max()), 1e-4)
-        margin(lab + "|d moment| / max(2e-2, 1e-3|u|)", float((np.abs(a[1][1:3] - c[1][1:3]) / np.maximum(2e-2, 1e-3 * np.abs(c[1][1:3]))).max()), 3.0)
-        margin(lab + "stats relative", float(np.max(np.abs(a[2] - c[2]) / (1e-6 + np.abs(c[2])))), 2e-3)
-        margin(lab + "|d T0 accumulator|", float(np.abs(a[3] - c[3]).max()), 1e-4)
+        margin(lab + "|dp| mm", float(np.abs(a[0][0:3] - c[0][0:3]).max()), 5e-4)
+        margin(lab + "|dR|, |ddq|", float(np.abs(a[0][3:] - c[0][3:]).max()), 6e-5)
+        margin(lab + "|d thrust|", float(np.abs(a[1][0] - c[1][0]).max()), 1e-5)
+        margin(lab + "|d moment| / max(2e-2, 1e-3|u|)", float((np.abs(a[1][1:3] - c[1][1:3]) / np.maximum(2e-2, 1e-3 * np.abs(c[1][1:3]))).max()), 0.6)
+        margin(lab + "stats relative", float(np.max(np.abs(a[2] - c[2]) / (1e-6 + np.abs(c[2])))), 3e-4)
+        margin(lab + "|d T0 accumulator|", float(np.abs(a[3] - c[3]).max()), 4e-6)
         if "wl" in opts:
-            margin(lab + "|d u4| / rate limit", float((np.abs(a[4] - c[4]) / np.array([5.0, 0.01, 0.01, 0.01])[:, None]).max()), 5e-2)
-            margin(lab + "|d w0|", float(np.abs(a[5] - c[5]).max()), 2e-3)
+            margin(lab + "|d u4| / rate limit", float((np.abs(a[4] - c[4]) / np.array([5.0, 0.01, 0.01, 0.01])[:, None]).max()), 1.2e-3)
+            margin(lab + "|d w0|", float(np.abs(a[5] - c[5]).max()), 2.5e-4)
 
 
 def test_batch_beyond_the_old_31_bit_workspace_limit(torch_cuda):
