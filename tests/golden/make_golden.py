@@ -219,6 +219,59 @@ def plant(mods):
     print("plant.npz: 128 cases")
 
 
+def models():
+    """the reference's own ca6 wrench map and (M, h) terms (template/ca6dynamics.py:35-50) and its
+    ThrustStrokeDev vector field (template/FlappingModels3D.py:19-38), evaluated by IMPORTING those two modules from
+    where they lie. What they import and this image lacks computes nothing here:
+      * `autograd.numpy` is numpy's function set wrapped for differentiation -- forward values are numpy's own; the
+        name is bound to the installed numpy (no gradient is taken by the functions called);
+      * `controlutils.py.model.Model` is only the base class of ThrustStrokeDev (an un-vendored submodule; `dynamics`
+        uses nothing of it) and `controlutils.py.kinematics` is imported but unused: empty placeholders;
+      * `Rotation.as_dcm` is scipy's pre-1.4 name of `Rotation.as_matrix` (same function, renamed; removed in 1.6):
+        answered with `as_matrix` while the fixture is generated.
+    The inputs are the cases of tests/test_models.py."""
+    import numpy
+    from scipy.spatial.transform import Rotation
+    ag = types.ModuleType("autograd")
+    ag.numpy = numpy
+    sys.modules.setdefault("autograd", ag)
+    sys.modules.setdefault("autograd.numpy", numpy)
+    cu, cupy, cumodel, cukin = (types.ModuleType(n) for n in ("controlutils", "controlutils.py", "controlutils.py.model",
+                                                               "controlutils.py.kinematics"))
+    cumodel.Model = type("Model", (), {})
+    cu.py, cupy.model, cupy.kinematics = cupy, cumodel, cukin
+    for m in (cu, cupy, cumodel, cukin):
+        sys.modules.setdefault(m.__name__, m)
+    sys.path.insert(0, REF_T)
+    import ca6dynamics
+    import FlappingModels3D
+    if not hasattr(Rotation, "as_dcm"):
+        # (the scipy type is immutable: the module's own name `Rotation` is pointed at a forwarder whose rotation objects
+        # answer `as_dcm()` with scipy's `as_matrix()`)
+        class _OldNameRotation:
+            @staticmethod
+            def from_rotvec(v):
+                return types.SimpleNamespace(as_dcm=Rotation.from_rotvec(v).as_matrix)
+        FlappingModels3D.Rotation = _OldNameRotation
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from test_models import _cases
+    n = 64
+    y6, u6, y12, u4 = _cases(n, 1)
+    w = np.stack([ca6dynamics.wrenchMap(u6[k]) for k in range(n)])
+    Ms, hs = [], []
+    for k in range(n):
+        Rb = y6[k, 3:12].reshape(3, 3).T                              # column-major in the state vector
+        q = np.hstack((y6[k, :3], Rotation.from_matrix(Rb).as_quat()))
+        M, h = ca6dynamics.dynamicsTerms(q, y6[k, 12:])
+        Ms.append(np.array(M, float)); hs.append(np.array(h, float))
+    tsd = FlappingModels3D.ThrustStrokeDev()
+    yd = np.stack([tsd.dynamics(y12[k], u4[k]) for k in range(n)])
+    np.savez_compressed(os.path.join(HERE, "models.npz"), y6=y6, u6=u6, y12=y12, u4=u4, ca6_w=w, ca6_M=np.stack(Ms),
+                        ca6_h=np.stack(hs), tsd_ydot=yd, ca6_const=np.array([ca6dynamics.ycp, ca6dynamics.mb, ca6dynamics.g]),
+                        tsd_const=np.array([tsd.m, tsd.ycp, FlappingModels3D.g]), tsd_Ib=np.array(tsd.Ib, float))
+    print("models.npz", w.shape, yd.shape)
+
+
 def tasks(mods):
     ft = mods[2]
     ts = np.linspace(0, 1200, 49)
@@ -469,6 +522,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "nan":
         nan_branch()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "models":
+        models()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "reject":
         bounds_reject()
         sys.exit(0)
@@ -499,4 +555,5 @@ if __name__ == "__main__":
     planar_p5f()
     nan_branch()
     bounds_reject()
+    models()
     mpc_wl_loop(mods)
