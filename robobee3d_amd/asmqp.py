@@ -1633,6 +1633,11 @@ def res_program(s, eq_rows, ap, res):
 
     def store(which, reg):
         b = PTR[which]
+        # Stores count in vmcnt like loads, in issue order: the scheduler must know about them, or its `vmcnt(N)` before a
+        # landing item (N = the LOADS issued since) also drains every store issued since -- an exposed HBM write latency per
+        # row (round 2: 82 us for this 7.7 k-instruction block). Registered as VMEM operations nobody waits for.
+        sc.vm_at[sc.nvm] = len(e.ins)
+        sc.nvm += 1
         e("global_store_dword", "v0", v(reg), "s[%d:%d]" % (b, b + 1), 0)
         e("s_add_u32", "s%d" % b, "s%d" % b, "s%d" % S_STRIDE)
         e("s_addc_u32", "s%d" % (b + 1), "s%d" % (b + 1), 0)
