@@ -1636,6 +1636,8 @@ def res_program(s, eq_rows, ap, res):
         # Stores count in vmcnt like loads, in issue order: the scheduler must know about them, or its `vmcnt(N)` before a
         # landing item (N = the LOADS issued since) also drains every store issued since -- an exposed HBM write latency per
         # row (round 2: 82 us for this 7.7 k-instruction block). Registered as VMEM operations nobody waits for.
+        if os.environ.get("UMPC_QP_RES_NOSTORE") == "1":          # (timing experiment: wrong results)
+            return
         sc.vm_at[sc.nvm] = len(e.ins)
         sc.nvm += 1
         e("global_store_dword", "v0", v(reg), "s[%d:%d]" % (b, b + 1), 0)
