@@ -114,11 +114,16 @@ class Plan:
         rest = [k for k in self.nonleaf if k not in set(xk) and k not in set(paired_k)]
         free = [r_ for r_ in range(V_W, V_W + len(self.nonleaf)) if r_ not in set(self.wreg.values())]
         evens = [r_ for r_ in free if r_ % 2 == 0 and r_ + 1 in free]
-        taken = set()
+        taken, kept = set(), []
         for q in range(0, len(paired_k), 2):
-            base = next(r_ for r_ in evens if r_ not in taken and r_ + 1 not in taken)
+            base = next((r_ for r_ in evens if r_ not in taken and r_ + 1 not in taken), None)
+            if base is None:                                  # no aligned pair left: these two rows stay unpaired
+                rest += [paired_k[q], paired_k[q + 1]]
+                continue
             taken.update((base, base + 1))
             self.wreg[paired_k[q]], self.wreg[paired_k[q + 1]] = base, base + 1
+            kept.append(self.eqpairs[q // 2])
+        self.eqpairs = kept
         for k, r_ in zip(rest, [r_ for r_ in free if r_ not in taken]):
             self.wreg[k] = r_
         assert sorted(self.wreg.values()) == list(range(V_W, V_W + len(self.nonleaf)))

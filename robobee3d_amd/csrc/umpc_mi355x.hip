@@ -677,8 +677,9 @@ uint32_t g_next_id = 1;
 constexpr uint32_t kMagic = 0x554d5043u;  // "UMPC"
 constexpr int O_STATE = 0, O_REF = 18, O_AT0 = O_REF + 9, O_OUT = O_AT0 + 1, O_INFO = O_OUT + 9, O_L = O_INFO + 2,
               O_U = O_L + 39, O_Q = O_U + 39, O_PX = O_Q + 45, O_AX = O_PX + 45, O_STATUS = O_AX + 48,
-              O_T0DBG = O_STATUS + 1, O_DONE0 = O_T0DBG + 1 + 14 /* own cache line */, O_DONE1 = O_DONE0 + 16,
-              O_TOTAL = O_DONE1 + 16;
+              O_T0DBG = O_STATUS + 1, O_DONE0 = (O_T0DBG + 1 + 15) / 16 * 16 /* each completion word on a 64-byte line of its own */,
+              O_DONE1 = O_DONE0 + 16, O_TOTAL = O_DONE1 + 16;
+static_assert(O_DONE0 % 16 == 0 && O_DONE0 > O_T0DBG, "completion words: own cache lines behind the I/O words");
 
 uint32_t pod_id(const UprightMPC_t *up) {
   uint32_t w[2];
