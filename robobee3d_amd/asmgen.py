@@ -117,7 +117,15 @@ def w_reg(s, k, xs, zs):
     return V_W + xs[o] if o < s.nx else V_WZ + zs[o - s.nx]
 
 
-def solve_schedule(s, reg, direction, allowed=None):
+# EXPERIMENT, off by default (UMPC_ASM_BCAST=1): broadcast-source pairs in the solves -- two entries of one column whose rows
+# are slot partners (forwards), two entries of one row whose columns are (backwards) as ONE packed instruction with the
+# source broadcast: 150 -> 140 / 141 instructions per solve, 778 -> 759 per iteration. Measured on the MI355X (same box,
+# K = 500): 0.12145 / 0.12175 ms per step against 0.1220 / 0.1224 -- 0.4 % for 2.4 % fewer instructions (the packed ops
+# lengthen dependent chains), and it moves the rounding of every iterate. Not shipped.
+BCAST = os.environ.get("UMPC_ASM_BCAST", "0") == "1"
+
+
+def solve_schedule(s, reg, direction, allowed=None, same_src=False):
     """List-schedules one triangular solve. Ops are the L entries j = (row r, column c): forward W[r] -= L_j W[c]
     (ready once W[c] is final), backward W[c] -= L_j W[r] (ready once W[r] is final). Two ready ops whose destination
     registers AND source registers each form an aligned pair are issued as one packed instruction; an op whose
@@ -130,7 +138,10 @@ def solve_schedule(s, reg, direction, allowed=None):
         ops = [(c, r, j) for (r, c, j) in ops]
 
     def ok(o, o2):
-        return (o2[2] != o[2] and reg[o2[0]] == (reg[o[0]] ^ 1) and reg[o2[1]] == (reg[o[1]] ^ 1)
+        # partner destinations; partner sources, or (same_src) ONE source broadcast to both halves: two entries of one
+        # column whose rows are slot partners
+        return (o2[2] != o[2] and reg[o2[0]] == (reg[o[0]] ^ 1)
+                and (reg[o2[1]] == (reg[o[1]] ^ 1) or (same_src and o2[1] == o[1]))
                 and (allowed is None or frozenset((o[2], o2[2])) in allowed))
     indeg = {k: 0 for k in range(nk)}
     for (d, _, _) in ops:
@@ -176,29 +187,84 @@ def solve_plan(s):
     even position (an LDS float4 holds two pairs; an AGPR pair is fetched with two v_accvgpr_read)."""
     xs, zs, _, _ = slot_maps(s)
     reg = [w_reg(s, k, xs, zs) for k in range(s.nk)]
-    fwd = solve_schedule(s, reg, "fwd")
+    fwd = solve_schedule(s, reg, "fwd", same_src=BCAST)
+    # Broadcast couples for the BACKWARD solve: two forward singles (r <- c), (r <- c') into the same unknown r whose
+    # columns c, c' are slot partners become, backwards, (c <- r), (c' <- r): partner destinations, one source -- one
+    # packed instruction with the source broadcast, if their L entries are an aligned pair in storage. The earlier of the
+    # two forward ops is moved next to the later one (legal: W[r] is read by nobody before all its updates are done, and
+    # the source of the delayed op stays final), so the storage order below makes them adjacent.
+    couples, late = {}, {}
+    if BCAST:
+        singles = [(k, g[0]) for k, g in enumerate(fwd) if len(g) == 1]
+        used = set()
+        for a_, (ka, oa) in enumerate(singles):
+            if oa[2] in used:
+                continue
+            for kb, ob in singles[a_ + 1:]:
+                if ob[2] not in used and ob[0] == oa[0] and reg[ob[1]] == (reg[oa[1]] ^ 1):
+                    couples[oa[2]] = ob[2]
+                    used.update((oa[2], ob[2]))
+                    break
+        moved = {j for j in couples}                    # the earlier op of every couple leaves its place ...
+        late = {jb: ja for ja, jb in couples.items()}   # ... and is re-inserted right before its partner
+        byj = {g[0][2]: g for g in fwd if len(g) == 1}
+        out = []
+        for g in fwd:
+            if len(g) == 1 and g[0][2] in moved:
+                continue
+            if len(g) == 1 and g[0][2] in late:
+                out.append(byj[late[g[0][2]]])
+            out.append(g)
+        fwd = out
     # The reversed forward order with the roles of row and column swapped is a legal backward order (an entry of
     # column r follows every entry of row r in the forward solve) with the same pairs, and it walks the storage
-    # backwards: each LDS float4 is fetched once per solve.
+    # backwards: each LDS float4 is fetched once per solve. A forward pair with ONE source (two rows of a column) has ONE
+    # destination backwards: two singles there; a couple is two singles forwards and one pair backwards.
     bwd = []
-    for g in reversed(fwd):
-        h = [(sr, d, j) for (d, sr, j) in g]
-        if len(h) == 2 and reg[h[0][0]] % 2:
-            h.reverse()
-        bwd.append(tuple(h))
-    order, pending = [], []
-    for g in fwd:
-        if len(g) == 2 and len(order) % 2:
-            pending.append(g)      # wait for a single to restore the parity
+    k = len(fwd) - 1
+    while k >= 0:
+        g = fwd[k]
+        if len(g) == 1 and g[0][2] in late:                         # (its partner is fwd[k - 1])
+            ob, oa = g[0], fwd[k - 1][0]
+            h = [(oa[1], oa[0], oa[2]), (ob[1], ob[0], ob[2])]      # (dst c, src r, j), (dst c', src r, j')
+            if reg[h[0][0]] % 2:
+                h.reverse()
+            bwd.append(tuple(h))
+            k -= 2
             continue
-        order += [o[2] for o in g]
+        h = [(sr, d, j) for (d, sr, j) in g]
+        if len(h) == 2 and h[0][0] == h[1][0]:                      # one destination: not a pair in this direction
+            bwd.append((h[1],))
+            bwd.append((h[0],))
+        else:
+            if len(h) == 2 and reg[h[0][0]] % 2:
+                h.reverse()
+            bwd.append(tuple(h))
+        k -= 1
+    # storage: in order of first use by the forward solve; pairs and couples adjacent on an even position
+    units = []
+    k = 0
+    while k < len(fwd):
+        g = fwd[k]
+        if len(g) == 1 and g[0][2] in couples and k + 1 < len(fwd) and len(fwd[k + 1]) == 1 and fwd[k + 1][0][2] == couples[g[0][2]]:
+            units.append([g[0][2], fwd[k + 1][0][2]])
+            k += 2
+        else:
+            units.append([o[2] for o in g])
+            k += 1
+    order, pending = [], []
+    for u in units:
+        if len(u) == 2 and len(order) % 2:
+            pending.append(u)      # wait for a single to restore the parity
+            continue
+        order += u
         while pending and len(order) % 2 == 0:
-            order += [o[2] for o in pending.pop(0)]
+            order += pending.pop(0)
     assert not pending, "odd number of single entries before a trailing pair"
     pos = [0] * len(s.L_i)
     for p_, j in enumerate(order):
         pos[j] = p_
-    for g in fwd:
+    for g in fwd + bwd:
         if len(g) == 2:
             a, b = pos[g[0][2]], pos[g[1][2]]
             assert a // 2 == b // 2, "paired entries must share an aligned pair"
@@ -265,7 +331,7 @@ class Fetcher:
         self.nds = 0          # ds_reads issued so far in this body
         self.waited = -1      # issue index of the last ds_read known to have returned
         self.lds_ahead = int(os.environ.get("UMPC_ASM_LDS_AHEAD", "12"))  # ops between a ds_read and its first consumer
-        self.merge = 1        # also wait for this many later reads if they are already issued
+        self.merge = int(os.environ.get("UMPC_ASM_LDS_MERGE", "1"))   # also wait for this many later reads if they are already issued
 
     def run(self, ops):
         e = self.e

@@ -179,7 +179,7 @@ def test_per_robot_weights(program, oracle_built):
         a = _arrays(st, ref, b, weights=W)
         asmstep.simulate(ins, a, dict(K=K, maxIter=50, nsub=25, plant=1), asmstep.host_floats())
         _check_band(a, s64, out_o, b)
-        np.testing.assert_allclose(a["stats"], stats_o[:, b], rtol=1e-4)
+        np.testing.assert_allclose(a["stats"], stats_o[:, b], rtol=3e-4)     # (sum of squared moments: extreme gains amplify round-off)
     # the table with the batch constants == no table (same weights; reciprocal by Newton vs the host's division)
     a0, a1 = _arrays(st, ref, 0), _arrays(st, ref, 0, weights=np.tile(np.array([1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2])[:, None], (1, B)))
     for a in (a0, a1):
