@@ -55,6 +55,13 @@ WS_ROWS = 559
 V_W, V_WZ, V_X, V_Y, V_Z = 2, 48, 88, 134, 174
 V_RING, V_AT, V_TT, V_END = 214, 230, 238, 246
 N_ATP = 4  # AGPR-read temporaries, in pairs
+# LDS ring slots of the Fetcher. EXPERIMENT (asmstep.py, UMPC_ASM_RING=6 together with UMPC_ASM_XV=0): two more slots in
+# v246..v253 instead of ten L words there; set by asmstep for its own stream only (module state, like XV_COUNT)
+NRING = 4
+
+
+def ring_base(slot):
+    return V_RING + 4 * slot if slot < 4 else 246 + 4 * (slot - 4)
 A_L, A_D, A_Q, A_LO, A_M = 0, 53, 137, 182, 218
 S_WS, S_CTRL, S_STRIDE, S_ITERS = 4, 6, 10, 11
 S_P, S_CNT, S_P2 = 12, 14, 16
@@ -330,8 +337,8 @@ class Fetcher:
         self.e, self.la = e, la
         self.nds = 0          # ds_reads issued so far in this body
         self.waited = -1      # issue index of the last ds_read known to have returned
-        self.lds_ahead = int(os.environ.get("UMPC_ASM_LDS_AHEAD", "12"))  # ops between a ds_read and its first consumer
-        self.merge = int(os.environ.get("UMPC_ASM_LDS_MERGE", "1"))   # also wait for this many later reads if they are already issued
+        self.lds_ahead = int(os.environ.get("UMPC_ASM_LDS_AHEAD", "12" if NRING == 4 else "20"))  # ops between a ds_read and its first consumer
+        self.merge = int(os.environ.get("UMPC_ASM_LDS_MERGE", "1" if NRING == 4 else "2"))   # also wait for this many later reads if they are already issued
 
     def run(self, ops):
         e = self.e
@@ -340,7 +347,7 @@ class Fetcher:
         # one when another quad needs a slot (the backward solve revisits quads that straddle two rows)
         inst_of = [None] * n
         insts = []  # dict(quad, first, last, slot, prev, issued)
-        slots = [None] * 4  # instance index resident in each slot
+        slots = [None] * NRING  # instance index resident in each slot
         for i, op in enumerate(ops):
             if op["src"] and op["src"][0] == "L":
                 qd = op["src"][1] // 4
@@ -349,14 +356,14 @@ class Fetcher:
                     insts[hit[0]]["last"] = i
                     inst_of[i] = hit[0]
                     continue
-                free = [sl for sl in range(4) if slots[sl] is None]
-                sl = free[0] if free else min(range(4), key=lambda q: insts[slots[q]]["last"])
+                free = [sl for sl in range(NRING) if slots[sl] is None]
+                sl = free[0] if free else min(range(NRING), key=lambda q: insts[slots[q]]["last"])
                 insts.append(dict(quad=qd, first=i, last=i, slot=sl, prev=slots[sl], issued=None))
                 slots[sl] = len(insts) - 1
                 inst_of[i] = slots[sl]
 
         def issue(it):
-            e("ds_read_b128", "v[%d:%d]" % (V_RING + 4 * it["slot"], V_RING + 4 * it["slot"] + 3), "v1",
+            e("ds_read_b128", "v[%d:%d]" % (ring_base(it["slot"]), ring_base(it["slot"]) + 3), "v1",
               it["quad"] * 1024)
             it["issued"] = self.nds
             self.nds += 1
@@ -403,7 +410,7 @@ class Fetcher:
                     upto = min(self.nds - 1, it["issued"] + self.merge)
                     e("s_waitcnt", "lgkmcnt(%d)" % min(15, self.nds - 1 - upto))
                     self.waited = upto if self.nds - 1 - upto <= 15 else it["issued"]
-                op["emit"](V_RING + 4 * it["slot"] + op["src"][1] % 4)
+                op["emit"](ring_base(it["slot"]) + op["src"][1] % 4)
 
 
 # ---- packed (VOP3P) operand helpers: every operand is a 64-bit register pair plus a half select ----

@@ -82,7 +82,13 @@ PARAM_BYTES = _o
 VFIRST, VEND = 2, 256
 XV_N, XV_B = 10, 246      # L entries kept in VGPRs beyond the loop's fixed layout (asmgen.XV_COUNT / XV_BASE)
 # generator switches for A/B timing of variants on one box (tools/build_variant.py); defaults = the shipped kernel
+# v246..v255 hold either ten L words (UMPC_ASM_RING=4) or two more slots of the LDS read ring plus two L words (6, the
+# default: with six slots the reads run 20 operations ahead and waits merge in pairs, 1.2 % faster, profiles/README.md)
+OPT_RING = int(os.environ.get("UMPC_ASM_RING", "6"))
+assert OPT_RING in (4, 6)
 OPT_XV = os.environ.get("UMPC_ASM_XV", "1") == "1"
+if OPT_RING == 6:
+    XV_N, XV_B = 2, 254
 # LIMIT_FAST: wave-wide min / max test that skips the exact limit_scaling sequence (-1 500 instructions per step).
 # Measured SLOWER on the MI355X (same box, K = 500: 0.1261 vs 0.1239 ms per step): five VALU -> SGPR -> s_cbranch_vccz
 # round trips per Ruiz pass cost more than the 150 instructions they skip. Off.
@@ -871,9 +877,9 @@ class StepGen:
         for c, r in last_row.items():
             done_at.setdefault(r, []).append(c)
         nL, Dinv = {}, {}
-        # ten more L entries live in v246..v255 through the loop (2 AGPR reads per iteration each otherwise)
+        # XV_N more L entries live in v246..v255 through the loop (2 AGPR reads per iteration each otherwise)
         asmgen.XV_COUNT, asmgen.XV_BASE = (XV_N if OPT_XV else 0), XV_B
-        pool.reserve(XV_B, XV_N)
+        pool.reserve(246, 10)         # L words and/or ring slots (OPT_RING)
         t = pool.get()
 
         def retire_dinv(k):
@@ -964,7 +970,7 @@ class StepGen:
     def admm(self):
         e, pool, st, s = self.e, self.pool, self.st, self.s
         nx, nc = s.nx, s.nc
-        left = set(range(VFIRST, VEND)) - pool.free_ - set(range(XV_B, XV_B + XV_N))
+        left = set(range(VFIRST, VEND)) - pool.free_ - set(range(246, 256))
         assert not left, "phase A leaked registers: %s" % sorted(left)
         pool.reserve(V_W, V_X - V_W)
         pool.reserve(V_X, V_Y - V_X)
@@ -998,7 +1004,7 @@ class StepGen:
         # x, y, thrust-row z, delta_x (x part of W), delta_y (z part of W) stay where they are; z == l on the dynamics rows
         for i in range(st.neq):
             pool.free(V_Z + st.zs[i], kill=True)
-        pool.free_range(XV_B, XV_N)
+        pool.free_range(246, 10)
 
     # ---- phase C ------------------------------------------------------------------------------------------
     def phase_c(self):
@@ -1774,10 +1780,12 @@ class StepGen:
         top = self.label()
         e("label", top)
         try:
+            asmgen.NRING = OPT_RING
             self.phase_a()      # factor() switches asmgen's extra-VGPR L homes on (module state) ...
             self.admm()
         finally:
             asmgen.XV_COUNT = 0  # ... for this stream only: asmgen.program() of the C++ kernel must not see them
+            asmgen.NRING = 4
         self.phase_c()
         e("s_add_i32", sg(S_STEP), sg(S_STEP), 1)
         e("s_cmp_lt_i32", sg(S_STEP), sg(S_INT["K"]))
