@@ -12,7 +12,9 @@ reference runs per MPC step (template/uprightmpc2/ C sources), for an arbitrary 
 Every scalar operation is carried out in the requested dtype in the reference's order (numpy never contracts
 a*b+c), so with dtype float32 and the reference's KKT permutation this file reproduces the compiled reference
 bit-for-bit on the uprightmpc2 N = 3 fixtures (tests/test_bqp.py pins it that way: parity status PINNED through
-tests/golden/seq_iter*.npz). It performs its own symbolic analysis from (A pattern, perm) and shares no code
+tests/golden/seq_iter*.npz). On a second structure, permutation and setting set (scaling 0, check_termination 25,
+rho 5.694) it reproduces every status / iteration count of the reference's other compiled controller, planar/code
+(OSQP 0.5.0 EMBEDDED 1), over the 44 calls of tests/golden/planar_code.npz (tests/test_planar_code.py). It performs its own symbolic analysis from (A pattern, perm) and shares no code
 with robobee3d_amd/. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
 """
 import numpy as np

@@ -493,6 +493,74 @@ def planar_p5f():
 
 
 
+def planar_code():
+    """The reference's SECOND generated controller, planar/code (emosqp of OSQP 0.5.0, EMBEDDED 1, DFLOAT, n = 46,
+    m = 82, scaling 0, rho 5.694, check_termination 25, max_iter 50: planar/code/include/workspace.h:1068-1071), compiled
+    where it lies (oracle/Makefile, oracle/planar_ref_host.cpp) and driven the way its host does (planar/mcuqp/main.cpp:
+    131: osqp_solve on the workspace, warm start carried) plus the vector updates of its API (osqp.c:756,785). A box
+    MPC in the (Aeq; I) form of planar/mpc_osqp.py:84-100 -- the family of config 4 (planar/mpc_osqp_p5f.py:120-128).
+    Pins the general-structure solver (oracle/osqp_table.py, then the product's batch QP) on a second structure,
+    permutation and settings. Row classes stay as generated (EMBEDDED 1 never re-types rho_vec: auxil.c, `#if EMBEDDED
+    != 1` around update_rho_vec in osqp_update_bounds), so the updates keep loose rows loose and equalities equal."""
+    import planarbind
+    rng = np.random.default_rng(20201121)
+    r0 = planarbind.PlanarRef()
+    rec = dict(n=r0.n, m=r0.m, A_p=r0.A_p, A_i=r0.A_i, P_i=r0.P_i, perm=r0.perm, L_p=r0.L_p, L_i=r0.L_i, P_x=r0.P_x, A_x=r0.A_x,
+               q0=r0.q, l0=r0.l, u0=r0.u, rho_vec=r0.rho_vec, L_x=r0.L_x, Dinv=r0.Dinv,
+               settings=np.array([r0.rho, r0.sigma, r0.alpha, r0.eps_abs, r0.eps_rel, r0.eps_prim_inf, r0.eps_dual_inf], np.float32),
+               isettings=np.array([r0.max_iter, r0.check_termination, r0.scaling, r0.warm_start, r0.scaled_termination], np.int32))
+    calls = []
+
+    def call(r, ctrl, chk, **kw):
+        pre = dict(x0=kw.pop("wx"), y0=kw.pop("wy"), z0=kw.pop("wz"))
+        o = r.solve(**kw)
+        calls.append(dict(ctrl=ctrl, chk=chk, q=kw.get("q", r0.q), l=kw.get("l", r0.l), u=kw.get("u", r0.u), **pre,
+                          **{k: o[k] for k in ("sol_x", "sol_y", "x", "y", "z", "pri_res", "dua_res", "status", "iter", "rc_update")}))
+        return o
+
+    zero = lambda: dict(wx=np.zeros(r0.n, np.float32), wy=np.zeros(r0.m, np.float32), wz=np.zeros(r0.m, np.float32))
+    carry = lambda o: dict(wx=o["x"], wy=o["y"], wz=o["z"])
+    # controller A: what main.cpp does -- osqp_solve on the generated vectors, four times
+    w = zero()
+    for k in range(4):
+        o = call(r0, 0, 25, **w)
+        w = carry(o)
+    # controller B: 36 calls with new vectors (state, cost, the finite boxes), warm start carried; every sixth call
+    # with check_termination 0 (exactly 50 iterations, the setting of the uprightmpc2 path)
+    rB = planarbind.PlanarRef()
+    fin = np.where((np.abs(r0.l) < 1e19) & (r0.l != r0.u))[0]          # rows 38, 44, ..., 68 (tilt) and 72..81 (inputs)
+    w = zero()
+    for k in range(36):
+        chk = 0 if k % 6 == 5 else 25
+        rB.set(50, chk)
+        a = 0.02 if k < 18 else 1.0                      # small moves (warm starts that converge) and large ones
+        q = (r0.q * (1 + 0.5 * a * rng.normal(size=r0.n))).astype(np.float32)
+        l, u = r0.l.copy(), r0.u.copy()
+        l[:6] = u[:6] = (r0.l[:6] * (1 + 0.4 * a * rng.normal(size=6)) + 1e-3 * a * rng.normal(size=6)).astype(np.float32)
+        lo = np.abs(rng.normal(size=len(fin))) * np.where(fin < 72, 4e-3, 6e-2)
+        hi = np.abs(rng.normal(size=len(fin))) * np.where(fin < 72, 4e-3, 6e-2)
+        if k % 3:                                         # two calls in three with boxes tight enough to bind
+            l[fin], u[fin] = (-lo).astype(np.float32), hi.astype(np.float32)
+        o = call(rB, 1, chk, q=q, l=l, u=u, **w)
+        w = carry(o)
+    # controller C: a tilt box that contradicts the dynamics -> primal infeasibility certificate, OSQP_NAN in the
+    # solution and a cold start (auxil.c store_solution), then a feasible call from that cold start
+    rC = planarbind.PlanarRef()
+    l, u = r0.l.copy(), r0.u.copy()
+    l[44], u[44] = 1.0, 2.0
+    w = zero()
+    for k in range(3):
+        o = call(rC, 2, 25, l=l, u=u, **w)
+        w = carry(o)
+    o = call(rC, 2, 25, l=r0.l.copy(), u=r0.u.copy(), **w)
+    for k in calls[0]:
+        rec["c_" + k] = np.array([c[k] for c in calls])
+    st = rec["c_status"]
+    print("planar_code: %d calls; status counts %s; iterations %s" % (len(calls), {int(v): int((st == v).sum()) for v in np.unique(st)},
+          {int(v): int((rec["c_iter"] == v).sum()) for v in np.unique(rec["c_iter"])}))
+    np.savez_compressed(os.path.join(HERE, "planar_code.npz"), **rec)
+
+
 def reactive(mods):
     """reactiveController samples (template_controllers.py:282-296) and the reference's own
     controlTest(None, 100, useMPC=False, taulim=10) log (uprightmpc2.py:87-159, the call of gainTuningSims :297)."""
@@ -528,6 +596,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "reject":
         bounds_reject()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "planarcode":
+        planar_code()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wl":
         wl_step()
         sys.exit(0)
@@ -556,4 +627,5 @@ if __name__ == "__main__":
     nan_branch()
     bounds_reject()
     models()
+    planar_code()
     mpc_wl_loop(mods)
