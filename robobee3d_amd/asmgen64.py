@@ -148,6 +148,80 @@ class Fetch:
             ops[i]["emit"](regs)
 
 
+SCHED_LAT = int(os.environ.get("UMPC_ASM64_SCHED_LAT", "0"))
+SCHED_SLACK = int(os.environ.get("UMPC_ASM64_SCHED_SLACK", "2"))
+
+
+def list_schedule(ops, lat=None):
+    """Reorders the rhs / solve operations so that an operation follows the one that produced its operand by at least
+    `lat` issue slots where the dependence graph allows (one wave per SIMD: nothing else hides a dependent fp64 FMA's
+    latency). Every word keeps the order of ITS updates (read-after-write, write-after-read and write-after-write
+    edges on the W words), so each value is rounded exactly as in program order. Priority: longest latency-weighted path
+    to the end; ties in program order (= storage order of L, which keeps the two words of an LDS quad together)."""
+    lat = SCHED_LAT if lat is None else lat
+    if lat <= 0:
+        return ops
+    n = len(ops)
+    preds = [[] for _ in range(n)]      # (op, is_raw)
+    last_w, readers = {}, {}
+    for i, o in enumerate(ops):
+        for w in o["rd"]:
+            if w in last_w:
+                preds[i].append((last_w[w], True))
+            readers.setdefault(w, []).append(i)
+        w = o["wr"]
+        if w in last_w:
+            preds[i].append((last_w[w], True))      # read-modify-write of the word
+        for r in readers.get(w, ()):
+            if r != i:
+                preds[i].append((r, False))
+        last_w[w] = i
+        readers[w] = []
+    succs = [[] for _ in range(n)]
+    for i in range(n):
+        for (p_, raw) in preds[i]:
+            succs[p_].append((i, raw))
+    prio = [0] * n
+    for i in range(n - 1, -1, -1):
+        prio[i] = max([prio[j] + (lat if raw else 1) for (j, raw) in succs[i]] or [0])
+    npred = [len(set(p_ for p_, _ in preds[i])) for i in range(n)]
+    pset = [set(p_ for p_, _ in preds[i]) for i in range(n)]
+    rawset = [set(p_ for p_, raw in preds[i] if raw) for i in range(n)]
+    issued_at = {}
+    quad_of = [next((src[1] >> 1 for src in o["srcs"] if src[0] == "L"), None) for o in ops]
+    recent = []
+    ready = [i for i in range(n) if npred[i] == 0]
+    out, t = [], 0
+    remaining = [len(ps) for ps in pset]
+    users = [sorted(set(j for j, _ in succs[i])) for i in range(n)]
+    while ready:
+        def avail(i):
+            return max([issued_at[p_] + lat for p_ in rawset[i]] or [0])
+        ok = [i for i in ready if avail(i) <= t]
+        if ok:
+            # an operation whose LDS quad is still in the ring (its partner word was consumed a moment ago) first
+            best = max(prio[i] for i in ok)
+            near = [i for i in ok if quad_of[i] in recent and prio[i] >= best - SCHED_SLACK * lat]
+            pick = min(near) if near else max(ok, key=lambda i: (prio[i], -i))
+        else:
+            pick = min(ready, key=lambda i: (avail(i), -prio[i], i))
+        ready.remove(pick)
+        if quad_of[pick] is not None:
+            if quad_of[pick] in recent:
+                recent.remove(quad_of[pick])
+            recent.append(quad_of[pick])
+            del recent[:-(NSLOT - 3)]
+        issued_at[pick] = t
+        out.append(ops[pick])
+        t += 1
+        for j in users[pick]:
+            remaining[j] -= 1
+            if remaining[j] == 0:
+                ready.append(j)
+    assert len(out) == n
+    return out
+
+
 def _words(lo, hi):
     """LDS quads covering words [lo, hi): list of (quad, [words of the range in it])"""
     out = []
@@ -265,35 +339,38 @@ def body(e, s, first, capture):
             waited[0] = pos
     ops = []
 
-    def op(srcs, fn):
-        ops.append(dict(srcs=srcs, emit=fn))
+    def op(srcs, fn, wr, rd=()):
+        """wr / rd: the W word (original index) the operation updates / the other W words it reads"""
+        ops.append(dict(srcs=srcs, emit=fn, wr=wr, rd=tuple(rd)))
     # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178), q / l already in W
     for j in range(nx):
-        op([("L", LW_X + j)], lambda r, j=j: (wait_pre(j), e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j)))))
+        op([("L", LW_X + j)], lambda r, j=j: (wait_pre(j), e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j)))), j)
     for i in range(neq):
         if first:
             op([("L", LW_Y + i), ("A", A_Z + 2 * i)],
-               lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])))
+               lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])), nx + i)
         else:
             op([("L", LW_Y + i)], lambda r, i=i: (wait_pre(nx + i),
-                                                  e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i)))))
+                                                  e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i)))), nx + i)
     for k in range(N):
         i = neq + k
-        op([("L", LW_Y + i)], lambda r, i=i, k=k: e("v_fma_f64", vp(W(nx + i)), "-" + vp(RINV3(k)), vp(r[0]), vp(Z3(k))))
+        op([("L", LW_Y + i)], lambda r, i=i, k=k: e("v_fma_f64", vp(W(nx + i)), "-" + vp(RINV3(k)), vp(r[0]), vp(Z3(k))), nx + i)
     # ---- forward solve (qdldl.c:250-262), columns ascending, entries ascending: W[r] -= L_j W[c]
     for c in range(nk):
         for j in range(s.L_p[c], s.L_p[c + 1]):
             r_ = s.L_i[j]
-            op([("L", j)], lambda r, r_=r_, c=c: e("v_fma_f64", vp(WK(r_)), "-" + vp(r[0]), vp(WK(c)), vp(WK(r_))))
+            op([("L", j)], lambda r, r_=r_, c=c: e("v_fma_f64", vp(WK(r_)), "-" + vp(r[0]), vp(WK(c)), vp(WK(r_))),
+               s.perm[r_], [s.perm[c]])
     # ---- diagonal (qdldl.c:289)
     for k in range(nk):
-        op([("A", A_D + 2 * k)], lambda r, k=k: e("v_mul_f64", vp(WK(k)), vp(WK(k)), vp(r[0])))
+        op([("A", A_D + 2 * k)], lambda r, k=k: e("v_mul_f64", vp(WK(k)), vp(WK(k)), vp(r[0])), s.perm[k])
     # ---- backward solve (qdldl.c:264-277), the storage walked backwards: W[c] -= L_j W[r]
     for c in range(nk - 1, -1, -1):
         for j in range(s.L_p[c + 1] - 1, s.L_p[c] - 1, -1):
             r_ = s.L_i[j]
-            op([("L", j)], lambda r, r_=r_, c=c: e("v_fma_f64", vp(WK(c)), "-" + vp(r[0]), vp(WK(r_)), vp(WK(c))))
-    Fetch(e).run(ops)
+            op([("L", j)], lambda r, r_=r_, c=c: e("v_fma_f64", vp(WK(c)), "-" + vp(r[0]), vp(WK(r_)), vp(WK(c))),
+               s.perm[c], [s.perm[r_]])
+    Fetch(e).run(list_schedule(ops))
     # ---- x <- alpha x~ + (1 - alpha) x   (auxil.c:188-201); x_prev of a capturing iteration -> workspace
     def lds_store(word, reg):
         """one word of a capture -> LDS (the capturing iteration is the last one: the L words are dead)"""

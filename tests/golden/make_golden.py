@@ -495,7 +495,8 @@ def planar_p5f():
 
 def planar_code():
     """The reference's SECOND generated controller, planar/code (emosqp of OSQP 0.5.0, EMBEDDED 1, DFLOAT, n = 46,
-    m = 82, scaling 0, rho 5.694, check_termination 25, max_iter 50: planar/code/include/workspace.h:1068-1071), compiled
+    m = 82, scaling 0, rho 5.694, check_termination 25, max_iter 50: planar/code/include/workspace.h:1068-1071; the output of
+    planar/mpc_thrust_strokedev.py:199-200 for its 'hover' parameters :31), compiled
     where it lies (oracle/Makefile, oracle/planar_ref_host.cpp) and driven the way its host does (planar/mcuqp/main.cpp:
     131: osqp_solve on the workspace, warm start carried) plus the vector updates of its API (osqp.c:756,785). A box
     MPC in the (Aeq; I) form of planar/mpc_osqp.py:84-100 -- the family of config 4 (planar/mpc_osqp_p5f.py:120-128).
