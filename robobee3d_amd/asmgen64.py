@@ -50,6 +50,35 @@ LW_X, LW_Y, LW_END = 213, 258, 297
 # phase A, z, x_prev and delta_y of the last iteration, the thrust-row bounds
 PC_DS, PC_ES, PC_Z, PC_XP, PC_DY, PC_LO3, PC_UP3 = 0, 45, 84, 123, 168, 207, 210
 LDS_BYTES_PER_LANE = 2560
+# Round 3: from the second iteration on q and l come from AGPR homes instead of L2 (one VMEM instruction costs a lone
+# wave ~14 ns, two v_accvgpr_read ~4.4: tools/microbench_vmem.hip), and their structural zeros cost nothing:
+#   a168..a253   l of the 16 dynamics rows that can be non-zero, then the 27 entries of q that can be (the z words of the
+#                first iteration are dead by then; filled at the end of the first iteration)
+A_H = 168
+HOMES = os.environ.get("UMPC_ASM64_HOMES", "1") == "1"
+
+
+def rhs_structure(s):
+    """(q entries, dynamics rows) whose right-hand-side data can be non-zero (uprightmpc2.c:126-207: q on the y part and
+    the dp triples; l = u on rows 0..5 (-y1), 18..23, 24..26 and 32 (dt g)); everything else is +-0 after scaling too.
+    The same facts as asmstep.Struct.qzero / lzero (tests/test_asm64_schedule.py compares them)."""
+    assert s.N == 3
+    NY = symbolic.NY
+    qnz = list(range(s.N * NY)) + [s.N * NY + k * NY + i for k in range(s.N) for i in range(3)]
+    lnz = sorted(set(range(6)) | set(range(18, 24)) | set(range(24, 27)) | {32})
+    return qnz, lnz
+
+
+def homes(s):
+    """{('l', row) | ('q', column): first AGPR of its home}"""
+    qnz, lnz = rhs_structure(s)
+    h = {}
+    for i in lnz:
+        h[("l", i)] = A_H + 2 * len(h)
+    for j in qnz:
+        h[("q", j)] = A_H + 2 * len(h)
+    assert A_H + 2 * len(h) <= 256
+    return h
 
 
 def f64bits(v):
@@ -342,16 +371,29 @@ def body(e, s, first, capture):
     def op(srcs, fn, wr, rd=()):
         """wr / rd: the W word (original index) the operation updates / the other W words it reads"""
         ops.append(dict(srcs=srcs, emit=fn, wr=wr, rd=tuple(rd)))
-    # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178), q / l already in W
+    # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178). First iteration (and HOMES off): q / l already in W;
+    # later iterations with HOMES: q, l from their AGPR homes, structural zeros dropped
+    hm = homes(s) if HOMES else None
+    use_h = HOMES and not first
     for j in range(nx):
-        op([("L", LW_X + j)], lambda r, j=j: (wait_pre(j), e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j)))), j)
+        if not use_h:
+            op([("L", LW_X + j)], lambda r, j=j: (wait_pre(j), e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j)))), j)
+        elif ("q", j) in hm:
+            op([("L", LW_X + j), ("A", hm[("q", j)])], lambda r, j=j: e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(r[1])), j)
+        else:
+            op([("L", LW_X + j)], lambda r, j=j: e("v_mul_f64", vp(W(j)), sS, vp(r[0])), j)
     for i in range(neq):
         if first:
             op([("L", LW_Y + i), ("A", A_Z + 2 * i)],
                lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])), nx + i)
-        else:
+        elif not use_h:
             op([("L", LW_Y + i)], lambda r, i=i: (wait_pre(nx + i),
                                                   e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i)))), nx + i)
+        elif ("l", i) in hm:
+            op([("L", LW_Y + i), ("A", hm[("l", i)])],
+               lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])), nx + i)
+        else:
+            op([("L", LW_Y + i)], lambda r, i=i: e("v_mul_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi), nx + i)
     for k in range(N):
         i = neq + k
         op([("L", LW_Y + i)], lambda r, i=i, k=k: e("v_fma_f64", vp(W(nx + i)), "-" + vp(RINV3(k)), vp(r[0]), vp(Z3(k))), nx + i)
@@ -378,7 +420,7 @@ def body(e, s, first, capture):
         e("ds_write_b64", base, vp(reg), off + 8 * half)
         return 1
     quads = _words(LW_X, LW_X + nx)
-    if not first:
+    if not first and not HOMES:
         _row_ptr(e, S_P, S_WS, FAC_Q)      # the next iteration's q follows the update into each group of W_x registers
     for g in range(0, len(quads), NSLOT):
         grp = quads[g:g + NSLOT]
@@ -393,22 +435,22 @@ def body(e, s, first, capture):
                 e("v_mul_f64", vp(t), sO, vp(r))
                 e("v_fma_f64", vp(t if capture else r), sA, vp(W(j)), vp(t))
             nw += _write_quad(e, qd, ws, {w: (V_TT + 2 * ((w - LW_X) % N_TT) if capture else where[w]) for w in ws})
-        if not first:
+        if not first and not HOMES:
             for qd, ws in grp:
                 for w in ws:
                     e("global_load_dwordx2", vp(W(w - LW_X)), "v0", sp(S_P))
                     _adv(e, S_P)
+    lrows = [i for i in range(neq) if not HOMES or ("l", i) in hm]
     if first:
         # l of the dynamics rows (the new z there) -> the W_x registers the x update has just freed, one round trip for
-        # all 36 rows; q follows after the row update
-        _row_ptr(e, S_P, S_WS, FAC_LOEQ)
-        for i in range(neq):
+        # all rows (HOMES: for the 16 that can be non-zero); q follows after the row update
+        for i in lrows:
+            _row_ptr(e, S_P, S_WS, FAC_LOEQ + i)
             e("global_load_dwordx2", vp(W(i)), "v0", sp(S_P))
-            _adv(e, S_P)
         e("s_waitcnt", "vmcnt(0)")
     # ---- z, y  (auxil.c:203-228, qdldl_interface.c:364-366, proj.c:4-14)
     quads = _words(LW_Y, LW_Y + nc)
-    if not first:
+    if not first and not HOMES:
         _row_ptr(e, S_P, S_WS, FAC_LOEQ)   # ... and l into each group of W_z registers
     for g in range(0, len(quads), NSLOT):
         grp = quads[g:g + NSLOT]
@@ -442,9 +484,11 @@ def body(e, s, first, capture):
                 e("v_fma_f64", vp(t1), vp(nu), rinv, vp(t1))                   # z~
                 e("v_mul_f64", vp(t2), sO, vp(zr))
                 e("v_fma_f64", vp(t1), sA, vp(t1), vp(t2))                     # t = alpha z~ + (1-alpha) z
-                if i < neq:
+                if i < neq and i in lrows:
                     e("v_add_f64", vp(t2), vp(t1), "-" + vp(lr))               # z <- l
                     e("v_mul_f64", vp(t2), vp(t2), rho)
+                elif i < neq:
+                    e("v_mul_f64", vp(t2), vp(t1), rho)                        # z <- l == 0
                 else:
                     e("v_fma_f64", vp(t3), vp(r), rinv, vp(t1))
                     e("v_max_f64", vp(t3), vp(t3), vp(LO3(k3)))
@@ -456,15 +500,25 @@ def body(e, s, first, capture):
                 e("v_add_f64", vp(r), vp(r), vp(t2))
                 newreg[w] = r
             nw += _write_quad(e, qd, ws, newreg)
-        if not first:
+        if not first and not HOMES:
             for qd, ws in grp:
                 for w in ws:
                     if w - LW_Y < neq:
                         e("global_load_dwordx2", vp(W(nx + w - LW_Y)), "v0", sp(S_P))
                         _adv(e, S_P)
-    if first:
+    if first and not HOMES:
         preload_q(e, s)
         preload_l(e, s, neq)
+    elif first:
+        # the z words of the first iteration (a168..) are dead: l (still in the W_x registers) and q take their homes there
+        for i in lrows:
+            e("v_accvgpr_write_b32", "a%d" % hm[("l", i)], "v%d" % W(i))
+            e("v_accvgpr_write_b32", "a%d" % (hm[("l", i)] + 1), "v%d" % (W(i) + 1))
+        for (kind, j), a_ in sorted(hm.items(), key=lambda kv: kv[1]):
+            if kind == "q":
+                _row_ptr(e, S_P, S_WS, FAC_Q + j)
+                e("global_load_dwordx2", "a[%d:%d]" % (a_, a_ + 1), "v0", sp(S_P))
+        e("s_waitcnt", "vmcnt(0)")
 
 
 def epilogue(e, s):
@@ -473,7 +527,17 @@ def epilogue(e, s):
     nx, nc = s.nx, s.nc
     N = s.N
     neq = 2 * N * symbolic.NY
-    e("s_waitcnt", "vmcnt(0)")      # the last preloads: W_z of the dynamics rows holds l
+    e("s_waitcnt", "vmcnt(0)")      # HOMES off: the last preloads, W_z of the dynamics rows holds l (= z there)
+    if HOMES:
+        hm = homes(s)
+        for i in range(neq):
+            r = V_W + 2 * (nx + i)
+            if ("l", i) in hm:
+                e("v_accvgpr_read_b32", "v%d" % r, "a%d" % hm[("l", i)])
+                e("v_accvgpr_read_b32", "v%d" % (r + 1), "a%d" % (hm[("l", i)] + 1))
+            else:
+                e("v_mov_b32", "v%d" % r, 0)
+                e("v_mov_b32", "v%d" % (r + 1), 0)
     e("s_mov_b64", sp(S_P), sp(S_CTRL))
     quads = _words(LW_X, LW_X + nx + nc)
     for g in range(0, len(quads), NSLOT):

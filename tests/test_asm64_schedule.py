@@ -188,3 +188,15 @@ def test_fp64_completion_model_catches_a_missing_wait(oracle_built, prog):
     stripped = [t for t in ins if t[0] != "s_waitcnt"]
     with pytest.raises(AssertionError):
         _case(oracle_built, g, stripped, s, seq, 0, 2)
+
+
+def test_rhs_structure_is_the_fp32_generators():
+    """asmgen64.rhs_structure (which q entries / dynamics rows get an AGPR home in the fp64 loop, the others being
+    structural zeros of uprightmpc2.c:126-207) states the same facts as asmstep.Struct.qzero / lzero of the fp32 stream."""
+    from robobee3d_amd import asmgen64, asmstep, symbolic
+    s = symbolic.analyse(3)
+    st = asmstep.Struct(3)
+    qnz, lnz = asmgen64.rhs_structure(s)
+    assert set(qnz) == set(range(s.nx)) - set(st.qzero) and set(lnz) == set(range(st.neq)) - set(st.lzero)
+    h = asmgen64.homes(s)
+    assert len(h) == 43 and max(h.values()) + 1 <= 255 and min(h.values()) == asmgen64.A_H
