@@ -665,6 +665,22 @@ def write(path=None, N=3, perm=None):
         out.append('  "%s\\n" \\' % fmt(t_))
     out.append('  : : "{v1}"(ldsaddr), "{s11}"(passes) \\')
     out.append("  : " + ", ".join(rclob) + ")")
+    # the residual norms
+    sins, _ = resid_program(N, perm)
+    sclob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + ['"a%d"' % i for i in range(256)] + \
+            ['"s%d"' % i for i in [S_P, S_P + 1]]
+    out += ["// The residual norms of the fp64 step (auxil.c:243-307): %d instructions. LDS words in: x, y, z, D, E where the ADMM"
+            % len(sins),
+            "// block left them, RS_PAR.. (T0 dt, s0 dt[3], Btau dt[6]), RS_C c, RS_W.. the eight weights, RS_DT dt; out: RS_OUT..",
+            "// = pri_res, dua_res before the division by c, |z|, |Ax|, |q|, |A'y|, |Px| norms, NaN accumulator.",
+            "namespace umpcasm64 { constexpr int RS_PAR = %d, RS_C = %d, RS_W = %d, RS_DT = %d, RS_OUT = %d; }"
+            % (RS_PAR, RS_C, RS_W, RS_DT, RS_OUT),
+            "// inputs: v0 = 8*robot, v1 = lane LDS address (16*lane), s[4:5] = workspace, s10 = 8*B",
+            "#define UMPC_RESID_ASM64(voff, ldsaddr, ws, stride) asm volatile( \\"]
+    for t_ in sins:
+        out.append('  "%s\\n" \\' % fmt(t_))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(ws), "{s10}"(stride) \\')
+    out.append("  : " + ", ".join(sclob) + ")")
     txt = "\n".join(out) + "\n"
     old = open(path).read() if os.path.exists(path) else None
     if old != txt:
@@ -1081,4 +1097,211 @@ def ruiz_program(N=3, perm=None):
     base, off, _ = lds_addr(RZ_C)
     e("ds_write_b64", base, vp(RV_C), off + 8 * (RZ_C & 1))
     e("s_waitcnt", "lgkmcnt(0)")
+    return e.ins, s
+
+
+# ---------------------------------------------------------------------------
+# Residual norms of the fp64 step (update_info, auxil.c:243-307) as one assembly block  (round 3)
+# ---------------------------------------------------------------------------
+# hipcc's fp64 phase C keeps D, E (84 doubles), the 39 / 45 accumulators and the 111 scaled entries of A it has
+# decided to reuse alive at once, parks ~450 words in scratch and AGPRs and fetches them back one exposed load at a
+# time: 38.7 of the 341 us step (tools/f64_timing.py). Here:
+#
+#   v4..v81     E (39)             v82..v159   A x accumulators (pass 1), then y (pass 2)
+#   v160..v179  T0 dt, s0 dt[3], Btau dt[6] (the raw per-robot entries of A)     v180:181 dt    v182:183 c
+#   v184..v199  pri, dua (before 1/c), |z|, |Ax|, |q|, |A'y|, |Px| norms and the NaN accumulator
+#   v200..v215  D_j, x_j / z_i stream (double-buffered ds_read_b64)              v216..v241 temporaries
+#   a0..a89     q (the 27 entries that can be non-zero, global loads issued first)   a90..a105  the eight weights
+#
+# Pass 1 walks the columns: A x with the entry re-derived as (raw * E_i) * D_j (the factorisation consumed the
+# equilibrated copy), then the row norms. Pass 2 walks them again for A' y and the dual terms. Arithmetic =
+# UMPC_GEN_A_MUL_SCALED / UMPC_GEN_AT_MUL_SCALED and the two norm loops of csrc/umpc_step.h operation by operation
+# (umpc_recip = v_rcp_f64 + two Newton steps; fmax = v_max_f64; x + 0 and max(n, |t * 0|) dropped for the 18
+# structural zeros of q), so the C++ status logic that follows sees the values it computed itself before.
+#
+# LDS words on entry: x, y (LW_X, LW_Y), z, D, E (PC_Z, PC_DS, PC_ES) from the ADMM block; RS_PAR.. the ten raw
+# entries, RS_C c, RS_W.. the eight weights (ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom), RS_DT dt -- written by the
+# C++ side just before. On exit RS_OUT.. = pri_res, dua_res * c (before the division), |z|, |Ax|, |q|, |A'y|, |Px|,
+# NaN accumulator.
+RS_PAR, RS_C, RS_W, RS_DT, RS_OUT = 297, 307, 308, 316, 297
+SV_E, SV_R, SV_PAR, SV_DT, SV_C, SV_N, SV_S, SV_T = 4, 82, 160, 180, 182, 184, 200, 216
+SA_Q, SA_W = 0, 90
+N_PRI, N_DUA, N_Z, N_AX, N_Q, N_ATY, N_PX, N_NAN = range(8)
+
+
+def weight_class(s, j):
+    """index into (ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom) of column j's raw P entry: PXRAW_OF, csrc/umpc_step.h"""
+    N, NY, NU = s.N, symbolic.NY, 3
+    if j < 2 * N * NY:
+        if j % NY < 3:
+            return (3 if j // NY == N - 1 else 2) if j < N * NY else (5 if (j - N * NY) // NY == N - 1 else 4)
+        return 0 if j < N * NY else 1
+    return 6 if (j - 2 * N * NY) % NU == 0 else 7
+
+
+def resid_program(N=3, perm=None):
+    s = symbolic.analyse(N, perm)
+    nx, nc = s.nx, s.nc
+    qnz, _ = rhs_structure(s)
+    e = Emit()
+    E = lambda i: SV_E + 2 * i
+    R = lambda i: SV_R + 2 * i
+    T = lambda k: SV_T + 2 * k
+    NRM = lambda k: SV_N + 2 * k
+    PAR = lambda k: SV_PAR + 2 * k
+
+    def rd64(dst, word):
+        base, off, half = lds_addr(word)
+        e("ds_read_b64", vp(dst), base, off + 8 * half)
+
+    def load_words(lo, n, reg_of):
+        """LDS words lo..lo+n-1 -> consecutive register pairs reg_of(k) (k = word - lo); returns the LDS instructions issued"""
+        cnt = 0
+        for qd, ws in _words(lo, lo + n):
+            base, off, _ = lds_addr(2 * qd)
+            if len(ws) == 2:
+                assert reg_of(ws[1] - lo) == reg_of(ws[0] - lo) + 2
+                e("ds_read_b128", "v[%d:%d]" % (reg_of(ws[0] - lo), reg_of(ws[0] - lo) + 3), base, off)
+            else:
+                e("ds_read_b64", vp(reg_of(ws[0] - lo)), base, off + 8 * (ws[0] & 1))
+            cnt += 1
+        return cnt
+
+    def recip(y, v_, a_):
+        e("v_rcp_f64", vp(y), vp(v_))
+        e("s_nop", 0)
+        for _ in range(2):
+            e("v_fma_f64", vp(a_), "-" + vp(v_), vp(y), 1.0)
+            e("v_fma_f64", vp(y), vp(y), vp(a_), vp(y))
+
+    def raw_of(tag):
+        if tag[0] == "c":
+            assert tag[1] in (1.0, -1.0)
+            return ("c", tag[1])
+        if tag[0] == "dt":
+            return ("v", SV_DT)
+        if tag[0] == "T0dt":
+            return ("v", PAR(0))
+        if tag[0] == "s0":
+            return ("v", PAR(1 + tag[1]))
+        assert tag[0] == "Btau"
+        return ("v", PAR(4 + tag[1]))
+
+    def scaled_entry(dst, tmp, p_, i, dreg):
+        """dst <- (raw * E_i) * D_j"""
+        kind, val = raw_of(s.A_tag[p_])
+        if kind == "c":
+            e("v_mul_f64", vp(dst), ("-" if val < 0 else "") + vp(E(i)), vp(dreg))     # (+-1 * E) * D: the sign is exact
+        else:
+            e("v_mul_f64", vp(tmp), vp(val), vp(E(i)))
+            e("v_mul_f64", vp(dst), vp(tmp), vp(dreg))
+
+    # ---- prologue
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
+    e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
+    for j in qnz:
+        _row_ptr(e, S_P, S_WS, FAC_Q + j)
+        e("global_load_dwordx2", "a[%d:%d]" % (SA_Q + 2 * j, SA_Q + 2 * j + 1), "v0", sp(S_P))
+    load_words(PC_ES, nc, lambda k: E(k))
+    load_words(RS_PAR, 10, lambda k: PAR(k))
+    rd64(SV_C, RS_C)
+    rd64(SV_DT, RS_DT)
+    load_words(RS_W, 8, lambda k: T(k))
+    e("s_waitcnt", "lgkmcnt(0)")
+    for k in range(8):
+        e("v_accvgpr_write_b32", "a%d" % (SA_W + 2 * k), "v%d" % T(k))
+        e("v_accvgpr_write_b32", "a%d" % (SA_W + 2 * k + 1), "v%d" % (T(k) + 1))
+    for r in list(range(SV_R, SV_R + 2 * nc)) + list(range(SV_N, SV_N + 16)):
+        e("v_mov_b32", "v%d" % r, 0)
+    DB = lambda j: SV_S + 4 * (j & 1)            # D_j
+    XB = lambda j: SV_S + 4 * (j & 1) + 2        # x_j (pass 1, pass 2) / z_i (row norms share the x buffers)
+    ZB = lambda i: SV_S + 8 + 2 * (i & 1)
+
+    # ---- pass 1: A x, column by column (entries of a column ascending, as the macro)
+    rd64(DB(0), PC_DS + 0)
+    rd64(XB(0), LW_X + 0)
+    for j in range(nx):
+        if j + 1 < nx:
+            rd64(DB(j + 1), PC_DS + j + 1)
+            rd64(XB(j + 1), LW_X + j + 1)
+        e("s_waitcnt", "lgkmcnt(%d)" % (2 if j + 1 < nx else 0))
+        ent = list(range(s.A_p[j], s.A_p[j + 1]))
+        # the product of entry k + 1 is formed before the accumulation of entry k (no back-to-back dependence)
+        for k, p_ in enumerate(ent):
+            if k == 0:
+                scaled_entry(T(0), T(2), p_, s.A_i[p_], DB(j))
+            if k + 1 < len(ent):
+                scaled_entry(T((k + 1) & 1), T(2), ent[k + 1], s.A_i[ent[k + 1]], DB(j))
+            i = s.A_i[p_]
+            e("v_fma_f64", vp(R(i)), vp(T(k & 1)), vp(XB(j)), vp(R(i)))
+    # ---- row norms
+    rd64(ZB(0), PC_Z + 0)
+    for i in range(nc):
+        if i + 1 < nc:
+            rd64(ZB(i + 1), PC_Z + i + 1)
+        einv, a_, d_, t_ = T(0), T(1), T(2), T(3)
+        recip(einv, E(i), a_)
+        e("s_waitcnt", "lgkmcnt(%d)" % (1 if i + 1 < nc else 0))
+        e("v_add_f64", vp(d_), vp(R(i)), "-" + vp(ZB(i)))
+        e("v_mul_f64", vp(t_), vp(einv), vp(d_))
+        e("v_mul_f64", vp(T(4)), vp(einv), vp(ZB(i)))
+        e("v_mul_f64", vp(T(5)), vp(einv), vp(R(i)))
+        e("v_max_f64", vp(NRM(N_PRI)), vp(NRM(N_PRI)), "|" + vp(t_) + "|")
+        e("v_fma_f64", vp(NRM(N_NAN)), 0.0, vp(d_), vp(NRM(N_NAN)))
+        e("v_max_f64", vp(NRM(N_Z)), vp(NRM(N_Z)), "|" + vp(T(4)) + "|")
+        e("v_max_f64", vp(NRM(N_AX)), vp(NRM(N_AX)), "|" + vp(T(5)) + "|")
+    # ---- pass 2: y -> the accumulator registers; A' y and the dual terms column by column
+    load_words(LW_Y, nc, lambda k: R(k))
+    rd64(DB(0), PC_DS + 0)
+    rd64(XB(0), LW_X + 0)
+    e("s_waitcnt", "vmcnt(0)")              # q has long arrived
+    for j in range(nx):
+        if j + 1 < nx:
+            rd64(DB(j + 1), PC_DS + j + 1)
+            rd64(XB(j + 1), LW_X + j + 1)
+        e("s_waitcnt", "lgkmcnt(%d)" % (2 if j + 1 < nx else 0))
+        aty, dinv, a_, px, qj, r_ = T(3), T(4), T(5), T(6), T(7), T(8)
+        ent = list(range(s.A_p[j], s.A_p[j + 1]))
+        recip(dinv, DB(j), a_)
+        e("v_accvgpr_read_b32", "v%d" % px, "a%d" % (SA_W + 2 * weight_class(s, j)))
+        e("v_accvgpr_read_b32", "v%d" % (px + 1), "a%d" % (SA_W + 2 * weight_class(s, j) + 1))
+        if j in qnz:
+            e("v_accvgpr_read_b32", "v%d" % qj, "a%d" % (SA_Q + 2 * j))
+            e("v_accvgpr_read_b32", "v%d" % (qj + 1), "a%d" % (SA_Q + 2 * j + 1))
+        for k, p_ in enumerate(ent):
+            if k == 0:
+                scaled_entry(T(0), T(2), p_, s.A_i[p_], DB(j))
+            if k + 1 < len(ent):
+                scaled_entry(T((k + 1) & 1), T(2), ent[k + 1], s.A_i[ent[k + 1]], DB(j))
+            i = s.A_i[p_]
+            e("v_fma_f64", vp(aty), vp(T(k & 1)), vp(R(i)), 0.0 if k == 0 else vp(aty))
+        if not ent:
+            e("v_mov_b32", "v%d" % aty, 0)
+            e("v_mov_b32", "v%d" % (aty + 1), 0)
+        # Pxj = (((PXRAW * D) * D) * c) * x
+        e("v_mul_f64", vp(px), vp(px), vp(DB(j)))
+        e("v_mul_f64", vp(px), vp(px), vp(DB(j)))
+        e("v_mul_f64", vp(px), vp(px), vp(SV_C))
+        e("v_mul_f64", vp(px), vp(px), vp(XB(j)))
+        if j in qnz:
+            e("v_add_f64", vp(r_), vp(qj), vp(px))
+            e("v_add_f64", vp(r_), vp(r_), vp(aty))
+            e("v_mul_f64", vp(T(9)), vp(dinv), vp(qj))
+        else:
+            e("v_add_f64", vp(r_), vp(px), vp(aty))          # (0 + Pxj) + A'y_j
+        e("v_mul_f64", vp(T(10)), vp(dinv), vp(r_))
+        e("v_mul_f64", vp(T(11)), vp(dinv), vp(aty))
+        e("v_mul_f64", vp(T(12)), vp(dinv), vp(px))
+        e("v_max_f64", vp(NRM(N_DUA)), vp(NRM(N_DUA)), "|" + vp(T(10)) + "|")
+        e("v_fma_f64", vp(NRM(N_NAN)), 0.0, vp(r_), vp(NRM(N_NAN)))
+        if j in qnz:
+            e("v_max_f64", vp(NRM(N_Q)), vp(NRM(N_Q)), "|" + vp(T(9)) + "|")
+        e("v_max_f64", vp(NRM(N_ATY)), vp(NRM(N_ATY)), "|" + vp(T(11)) + "|")
+        e("v_max_f64", vp(NRM(N_PX)), vp(NRM(N_PX)), "|" + vp(T(12)) + "|")
+    # ---- the eight results -> LDS
+    for qd, ws in _words(RS_OUT, RS_OUT + 8):
+        _write_quad(e, qd, ws, {w: NRM(w - RS_OUT) for w in ws})
+    e("s_waitcnt", "lgkmcnt(0)")
+    assert SV_T + 2 * 13 <= V_END
     return e.ins, s

@@ -534,6 +534,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 // six intervals (assemble, Ruiz, D/E + factor, ADMM, residuals/extraction, plant) replace accdes in out rows 3..8
 #ifdef UMPC_PHASE_TIMING
   long long tmark[7];
+  long long asm64_stamps[6] = {0, 0, 0, 0, 0, 0};
 #define UMPC_TMARK(k) tmark[k] = __builtin_amdgcn_s_memrealtime()
 #else
 #define UMPC_TMARK(k)
@@ -713,6 +714,10 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     const unsigned voff = bb * 8u, stride = (unsigned)a.B * 8u;
     const int iters = prm.maxIter;
     UMPC_ADMM_ASM64(voff, ldsaddr, a.ws, a.ctrl, stride, iters);
+#ifdef UMPC_ASM64_TIMING   /* header generated with UMPC_ASM64_TIMING=1: the block's own stamps, LDS words 297..302 (the residual block reuses them) */
+#pragma unroll
+    for (int k = 0; k < 6; ++k) asm64_stamps[k] = __builtin_bit_cast(long long, LDSF_W(297 + k));
+#endif
   } else if constexpr (ASM32) {
     // generated gfx950 assembly (umpc_admm_asm.h): reads FAC_* and x,y,z, runs maxIter iterations with
     // a static VGPR/AGPR/LDS placement, writes x,y,z back and x_prev / delta_y of the last iteration
@@ -794,11 +799,12 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   }
   T p0[3], R0[9], dq0[6];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) p0[i] = GLD(a.state, i);
-#pragma unroll
   for (int i = 0; i < 9; ++i) R0[i] = GLD(a.state, 3 + i);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) dq0[i] = GLD(a.state, 12 + i);
+  // (fp64 assembly route: p and dq are fetched after the residual block, which clobbers the register files)
+#define UMPC_PC_LOAD_PDQ() do { \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) p0[i] = GLD(a.state, i); \
+  _Pragma("unroll") for (int i = 0; i < 6; ++i) dq0[i] = GLD(a.state, 12 + i); } while (0)
+  if constexpr (!ASM64) UMPC_PC_LOAD_PDQ();
   int status = ST_UNSOLVED;
   T pri_res = T(0), dua_res = T(0);
   T u0 = T(0), u1 = T(0), u2 = T(0), dy1[NY];
@@ -806,10 +812,11 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     T Ds[NX], Es[NC];
     const T cscale = GLD(a.ws, WS_C);
     const T cinv = T(1) / cscale;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) Ds[j] = PC_DS_(j);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) Es[i] = PC_ES_(i);
+    // (fp64 assembly route: D and E are fetched AFTER the residual block, which clobbers the register files)
+#define UMPC_PC_LOAD_DE() do { \
+    _Pragma("unroll") for (int j = 0; j < NX; ++j) Ds[j] = PC_DS_(j); \
+    _Pragma("unroll") for (int i = 0; i < NC; ++i) Es[i] = PC_ES_(i); } while (0)
+    if constexpr (!ASM64) UMPC_PC_LOAD_DE();
     // raw entries of A: the scaled matrix is re-derived entry by entry as (raw * E_i) * D_j wherever it is
     // needed (the factorisation consumed the equilibrated copy); nothing of size 111 is ever live here
     T dtT0, s0dt[3], Btaudt[6];
@@ -832,6 +839,27 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     // > OSQP_INFTY is an accident of the evaluation order. `nanacc` turns every such step into OSQP_NON_CVX (what
     // the reference reports on tests/golden/nan_branch.npz): NaN-propagating sum of the residual entries.
     T nanacc = T(0);
+    if constexpr (ASM64) {
+      // the norms as generated fp64 assembly (asmgen64.resid_program): its inputs next to x, y, z, D, E in LDS
+      namespace r64 = umpcasm64;
+      LDSF_W(r64::RS_PAR) = dtT0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) LDSF_W(r64::RS_PAR + 1 + r) = s0dt[r];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) LDSF_W(r64::RS_PAR + 4 + r) = Btaudt[r];
+      LDSF_W(r64::RS_C) = cscale;
+      LDSF_W(r64::RS_DT) = prm.dt;
+      const T w8[8] = {wt.ws, wt.wds, wt.wpr, wt.wpf, wt.wvr, wt.wvf, wt.wthrust, wt.wmom};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) LDSF_W(r64::RS_W + k) = w8[k];
+      const unsigned voff = bb * 8u, stride = (unsigned)a.B * 8u;
+      UMPC_RESID_ASM64(voff, ldsaddr, a.ws, stride);
+      pri_res = LDSF_W(r64::RS_OUT + 0); dua_res = LDSF_W(r64::RS_OUT + 1);
+      nz = LDSF_W(r64::RS_OUT + 2); nAx = LDSF_W(r64::RS_OUT + 3); nq = LDSF_W(r64::RS_OUT + 4);
+      nAty = LDSF_W(r64::RS_OUT + 5); nPx = LDSF_W(r64::RS_OUT + 6); nanacc = LDSF_W(r64::RS_OUT + 7);
+      UMPC_PC_LOAD_DE();
+      UMPC_PC_LOAD_PDQ();
+    } else {
     {
       T Ax[NC];
 #pragma unroll
@@ -863,6 +891,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
         nAty = umpc_max(nAty, umpc_abs(dinv * Aty[j]));
         nPx = umpc_max(nPx, umpc_abs(dinv * Pxj));
       }
+    }
     }
     dua_res = cinv * dua_res;
 
@@ -945,6 +974,8 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     for (int i = 0; i < NY; ++i) dy1[i] = XV(NY * N + i) * Ds[NY * N + i];
 #undef DT_
 #undef ET_
+#undef UMPC_PC_LOAD_DE
+#undef UMPC_PC_LOAD_PDQ
   }
 
   // ---- extraction (uprightmpc2.c:253-269) ----
@@ -1043,9 +1074,7 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   for (int i = 0; i < 6; ++i) GLD(a.out, 3 + i) = T(tmark[i + 1] - tmark[i]);
 #ifdef UMPC_ASM64_TIMING   /* header generated with UMPC_ASM64_TIMING=1: the block's own stamps, LDS words 297..302 */
   if constexpr (ASM64) {
-    long long st[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) st[k] = __builtin_bit_cast(long long, LDSF_W(297 + k));
+    const long long *st = asm64_stamps;
     // out rows 0..2: block prologue, (first iteration .. loop), epilogue; rows 3.. keep the phase intervals
     GLD(a.out, 0) = T(st[1] - st[0]); GLD(a.out, 1) = T(st[4] - st[1]); GLD(a.out, 2) = T(st[5] - st[4]);
   }

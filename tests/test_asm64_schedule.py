@@ -200,3 +200,79 @@ def test_rhs_structure_is_the_fp32_generators():
     assert set(qnz) == set(range(s.nx)) - set(st.qzero) and set(lnz) == set(range(st.neq)) - set(st.lzero)
     h = asmgen64.homes(s)
     assert len(h) == 43 and max(h.values()) + 1 <= 255 and min(h.values()) == asmgen64.A_H
+
+
+def _resid_numpy(s, g, x, y, z, D, E, par, c, w8, dt, q):
+    """update_info's norms as csrc/umpc_step.h states them (auxil.c:243-307), plain float64 with exact divisions"""
+    def raw(tag):
+        return {"c": lambda: tag[1], "dt": lambda: dt, "T0dt": lambda: par[0], "s0": lambda: par[1 + tag[1]],
+                "Btau": lambda: par[4 + tag[1]]}[tag[0]]()
+    Ax, Aty = np.zeros(s.nc), np.zeros(s.nx)
+    for j in range(s.nx):
+        for p in range(s.A_p[j], s.A_p[j + 1]):
+            i = s.A_i[p]
+            a = (raw(s.A_tag[p]) * E[i]) * D[j]
+            Ax[i] += a * x[j]
+            Aty[j] += a * y[i]
+    Px = np.array([(((w8[g.weight_class(s, j)] * D[j]) * D[j]) * c) * x[j] for j in range(s.nx)])
+    return dict(pri=np.abs((Ax - z) / E).max(), dua=np.abs(((q + Px) + Aty) / D).max(), nz=np.abs(z / E).max(),
+                nAx=np.abs(Ax / E).max(), nq=np.abs(q / D).max(), nAty=np.abs(Aty / D).max(), nPx=np.abs(Px / D).max())
+
+
+def test_generated_fp64_residual_block_matches_numpy():
+    """asmgen64.resid_program (round 3: the residual norms of the fp64 step as assembly instead of hipcc's phase C):
+    interpreted on random iterates, scalings and raw matrix parameters against a numpy statement of the same norms;
+    a NaN in x reaches the NaN accumulator."""
+    from robobee3d_amd import asmgen64 as g, asmgen
+    ins, s = g.resid_program()
+    rng = np.random.default_rng(11)
+    qnz, _ = g.rhs_structure(s)
+    for trial in range(4):
+        x, y, z = rng.normal(size=s.nx), rng.normal(size=s.nc) * 10, rng.normal(size=s.nc)
+        D, E = np.exp(rng.normal(size=s.nx)), np.exp(rng.normal(size=s.nc))
+        par, c, w8, dt = rng.normal(size=10), float(np.exp(rng.normal())), np.exp(rng.normal(size=8)), 5.0
+        q = np.zeros(s.nx)
+        q[qnz] = rng.normal(size=len(qnz)) * 3
+        if trial == 3:
+            x[7] = np.nan
+        lds = np.zeros(320)
+        lds[g.LW_X:g.LW_X + s.nx], lds[g.LW_Y:g.LW_Y + s.nc], lds[g.PC_Z:g.PC_Z + s.nc] = x, y, z
+        lds[g.PC_DS:g.PC_DS + s.nx], lds[g.PC_ES:g.PC_ES + s.nc] = D, E
+        lds[g.RS_PAR:g.RS_PAR + 10], lds[g.RS_C], lds[g.RS_DT] = par, c, dt
+        lds[g.RS_W:g.RS_W + 8] = w8
+        ws, ctrl = np.zeros(asmgen.WS_ROWS), np.zeros(4)
+        ws[asmgen.FAC_Q:asmgen.FAC_Q + s.nx] = q
+        g.simulate(ins, ws, ctrl, 1, lds)
+        out = lds[g.RS_OUT:g.RS_OUT + 8]
+        if trial == 3:
+            assert np.isnan(out[g.N_NAN])
+            continue
+        ref = _resid_numpy(s, g, x, y, z, D, E, par, c, w8, dt, q)
+        for k, name in ((g.N_PRI, "pri"), (g.N_DUA, "dua"), (g.N_Z, "nz"), (g.N_AX, "nAx"), (g.N_Q, "nq"), (g.N_ATY, "nAty"),
+                        (g.N_PX, "nPx")):
+            assert abs(out[k] - ref[name]) <= 1e-12 * max(1.0, abs(ref[name])), (trial, name, out[k], ref[name])
+        assert out[g.N_NAN] == 0.0
+
+
+def test_fp64_residual_stream_assembles_and_fits():
+    import os, re, subprocess, tempfile
+    from robobee3d_amd import asmgen64 as g
+    ins, s = g.resid_program()
+    for t in ins:
+        for x in t[1:]:
+            if isinstance(x, str):
+                for a, b in re.findall(r"v\[(\d+):(\d+)\]", x):
+                    assert int(b) < g.V_END
+                for a, b in re.findall(r"a\[(\d+):(\d+)\]", x):
+                    assert int(b) < 256
+    mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("\n".join(g.fmt(t) for t in ins) + "\n")
+    try:
+        r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[:3000]
+    finally:
+        os.unlink(f.name)
