@@ -905,6 +905,9 @@ RV_A, RV_QL, RV_C, RV_T = 4, 226, 228, 230
 RV_ONEHI = 245                               # high word of 1.0 (set after the prologue, which lands quads in v230..v245)
 RA_ET, RA_P, RA_Q = 0, 78, 168
 S_MINS, S_MAXS = 30, 32                      # 1e-4, 1e4 (doubles in SGPR pairs)
+# Round 3: the cost scaling c is carried as a scalar through the passes (the norms see c * P_j, c * sum|P|, c * max|q|) and
+# applied to P and q once on the way out, instead of 90 AGPR read / multiply / write triples per pass (rounding only)
+CARRY_C = os.environ.get("UMPC_ASM64_RUIZ_CARRY_C", "1") == "1"
 
 
 def ruiz_program(N=3, perm=None):
@@ -1022,11 +1025,15 @@ def ruiz_program(N=3, perm=None):
         pj, t, dt = T(6), T(0), T(1)
         acc_read(pj, RA_P + 2 * j)
         first = True
+        pn = pj
+        if CARRY_C:      # P and q are kept WITHOUT the accumulated cost scaling c; the norms see c * P_j
+            pn = T(3)
+            e("v_mul_f64", vp(pn), vp(pj), vp(RV_C))
         for p_ in range(s.A_p[j], s.A_p[j + 1]):
-            e("v_max_f64", vp(t), "|" + vp(pj if first else t) + "|", "|" + vp(A(p_)) + "|")
+            e("v_max_f64", vp(t), "|" + vp(pn if first else t) + "|", "|" + vp(A(p_)) + "|")
             first = False
         if first:
-            e("v_max_f64", vp(t), "|" + vp(pj) + "|", "|" + vp(pj) + "|")
+            e("v_max_f64", vp(t), "|" + vp(pn) + "|", "|" + vp(pn) + "|")
         limit(t, dt)
         rsqrt(dt, t, T(2), T(3))
         e("v_mul_f64", vp(pj), vp(pj), vp(dt))
@@ -1052,6 +1059,9 @@ def ruiz_program(N=3, perm=None):
     e("v_mov_b32", "v%d" % T(0), b & 0xFFFFFFFF)
     e("v_mov_b32", "v%d" % (T(0) + 1), b >> 32)
     recip(T(1), T(0), T(2))
+    if CARRY_C:          # sum |P_j| and max |q_j| were formed without c (both commute with a positive factor up to rounding)
+        e("v_mul_f64", vp(T(4)), vp(T(4)), vp(RV_C))
+        e("v_mul_f64", vp(T(5)), vp(T(5)), vp(RV_C))
     e("v_mul_f64", vp(T(2)), vp(T(4)), vp(T(1)))
     e("v_fma_f64", vp(T(3)), "-" + vp(T(0)), vp(T(2)), vp(T(4)))
     e("v_fma_f64", vp(T(4)), vp(T(3)), vp(T(1)), vp(T(2)))              # pmean / nx
@@ -1060,11 +1070,11 @@ def ruiz_program(N=3, perm=None):
     limit(T(4), T(0))
     recip(T(5), T(4), T(0))                                              # ct
     e("v_mul_f64", vp(RV_C), vp(RV_C), vp(T(5)))
-    for j in range(nx):
+    for j in range(nx if not CARRY_C else 0):
         acc_read(T(j % 2), RA_P + 2 * j)
         e("v_mul_f64", vp(T(j % 2)), vp(T(j % 2)), vp(T(5)))
         acc_write(RA_P + 2 * j, T(j % 2))
-    for j in range(nx):
+    for j in range(nx if not CARRY_C else 0):
         kind, reg = qhome(j)
         if kind == "a":
             acc_read(T(2 + j % 2), reg)
@@ -1092,6 +1102,8 @@ def ruiz_program(N=3, perm=None):
                     else:
                         e("v_mov_b32", "v%d" % r, "v%d" % reg)
                         e("v_mov_b32", "v%d" % (r + 1), "v%d" % (reg + 1))
+                    if CARRY_C:      # the accumulated cost scaling, once
+                        e("v_mul_f64", vp(r), vp(r), vp(RV_C))
                     regs[w_] = r
                 _write_quad(e, qd, ws, regs)
     base, off, _ = lds_addr(RZ_C)
