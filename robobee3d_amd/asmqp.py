@@ -57,6 +57,7 @@ LW_FLAGS = 636                                      # LDS words 636..639: LOOSE_
 # 4-5 loads per row and iteration). Same operations on the same values: bit-identical results. The glue block decides
 # per wave (LDS word LOOSE_FLAG).
 S_RIMIN, S_RHOMIN = 36, 37                            # 1 / RHO_MIN, RHO_MIN as float bits (set by the loose program itself)
+Y0_VARIANT = os.environ.get("UMPC_QP_Y0", "1") == "1"   # the loose program carries the y == 0 variant of its loop (program())
 
 
 def lds_addr(word):
@@ -197,6 +198,22 @@ class Plan:
         self.stream += [("l", r["i"]) for r in self.rows if r["eq"] and not r["leaf"]]
         self.n_stream = len(self.stream)
         self.extra = list(self.once)                           # loaded once (prologue), after the per-iteration items
+        # The y0 variant of the loose loop (see program()): the multipliers of the loose rows are exactly zero and need no
+        # LDS word, so q takes the y words of the inequality rows (in row order: q_j, q_j+1 stay an aligned pair where the
+        # rows' y words are), and l of non-leaf equality rows takes the words behind z that the general loop keeps 1/rho
+        # in (aligned pairs for the packed row pairs first). Items without a home stay in the per-iteration preloads.
+        self.ineq = gen
+        self.y0_home = {}
+        for j, i in zip(range(n), gen):
+            self.y0_home[("q", j)] = self.LW_Y + i
+        spare = list(range(self.LW_END + self.LW_END % 2, LW_FLAGS))
+        for (a_, b_) in self.eqpairs:
+            if len(spare) >= 2:
+                self.y0_home[("l", a_)], self.y0_home[("l", b_)] = spare[0], spare[1]
+                spare = spare[2:]
+        for item in self.stream[self.n_land:]:
+            if spare and item not in self.y0_home:
+                self.y0_home[item] = spare.pop(0)
         # row-major hand-off rows (floats, [row][B])
         self.R_L, self.R_DI = 0, len(L_i)
         self.R_X = self.R_DI + nk
@@ -385,11 +402,15 @@ class Sched:
             op["emit"](regs)
 
 
-def preloads(e, p):
-    """the tail of the stream: q -> W_x, l of the non-leaf equality rows -> their W registers (in place operands)"""
-    idx = p.n_land
+def preloads(e, p, homes=()):
+    """the tail of the stream: q -> W_x, l of the non-leaf equality rows -> their W registers (in place operands);
+    homes: items that live in LDS in this variant (y0) and are not loaded"""
+    idx = p.n_land - 1
     blk = None
     for (what, q) in p.stream[p.n_land:]:
+        idx += 1
+        if (what, q) in homes:
+            continue
         if idx // BLOCK != blk:
             # pointer = this wave's block + (idx // BLOCK) * 4096
             e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (idx // BLOCK) * BLOCK * 256)
@@ -397,10 +418,9 @@ def preloads(e, p):
             blk = idx // BLOCK
         k = p.pinv[q] if what == "q" else p.pinv[p.n + q]
         e("global_load_dword", "v%d" % p.wreg[k], "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
-        idx += 1
 
 
-def body(e, p, capture=False, loose=False):
+def body(e, p, capture=False, loose=False, y0=False):
     """capture: the LAST iteration -- x_prev and delta_y go to rows R_XP / R_DY (auxil.c:362-512 consumes them)
     loose: every inequality row is a loose row (see S_RIMIN above)"""
     n, m = p.n, p.m
@@ -408,7 +428,10 @@ def body(e, p, capture=False, loose=False):
     sA, sO, sS, sRe = ("s%d" % r for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINVEQ))
     W = lambda k: v(p.wreg[k])
     T = lambda q: p.V_TT + q
-    npre = p.n_stream - p.n_land
+    assert loose or not y0
+    homes = p.y0_home if y0 else {}
+    pre_items = [it for it in p.stream[p.n_land:] if it not in homes]
+    npre = len(pre_items)
     sc = Sched(e, p, npre)
     e("s_mov_b64", "s[%d:%d]" % (S_SP, S_SP + 1), "s[%d:%d]" % (S_S, S_S + 1))
     ops = []
@@ -416,7 +439,7 @@ def body(e, p, capture=False, loose=False):
     def op(srcs, fn):
         ops.append(dict(srcs=srcs, emit=fn))
     pre_pos = {}                         # W register preloaded -> index of its load among the preloads
-    for q, (what, idx) in enumerate(p.stream[p.n_land:]):
+    for q, (what, idx) in enumerate(pre_items):
         pre_pos[p.wreg[p.pinv[idx] if what == "q" else p.pinv[n + idx]]] = q
 
     def wait_pre(reg):
@@ -432,7 +455,16 @@ def body(e, p, capture=False, loose=False):
         k = p.pinv[j]
         if j in jskip:
             continue
-        if "1" in PACK_PARTS and xpair(j):
+        qh = homes.get(("q", j))
+        if qh is not None and "1" in PACK_PARTS and xpair(j) and qh % 2 == 0 and homes.get(("q", j + 1)) == qh + 1:
+            jskip.add(j + 1)
+            op([("L", p.LW_X + j), ("L", qh)], lambda r, j=j: _pk(e, "v_pk_fma_f32", p.wreg[p.pinv[j]],
+                                                                  [SB(S_SIGMA, S_SIGMA % 2), VP(r[0]), VP(r[1])], [0, 0, 1]))
+            continue
+        if qh is not None:
+            op([("L", p.LW_X + j), ("L", qh)], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
+            continue
+        if "1" in PACK_PARTS and xpair(j) and ("q", j + 1) not in homes:
             jskip.add(j + 1)
 
             def f2x(r, j=j):
@@ -486,11 +518,17 @@ def body(e, p, capture=False, loose=False):
                 _pk(e, "v_pk_fma_f32", t, [SB(S_RIMIN, 0), VP(g[0]), VP(g[1])], [1, 0, 0])      # z - y / rho
                 wr = p.wreg[r["r"]]
                 _pk(e, "v_pk_fma_f32", wr, [VP(g[2]), VP(t), VP(wr)])                           # W(x_j) += (-L) rhs
+            if y0:       # y == 0: the rhs is z
+                op([("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])],
+                   lambda g, r=r: _pk(e, "v_pk_fma_f32", p.wreg[r["r"]], [VP(g[1]), VP(g[0]), VP(p.wreg[r["r"]])]))
+                continue
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])], f2)
             continue
         if pack and "4" in PACK_PARTS and i in eqskip:
             continue
-        if pack and "4" in PACK_PARTS and i in eqfirst:
+        lh = homes.get(("l", i))
+        if pack and "4" in PACK_PARTS and i in eqfirst and (lh is None) == (homes.get(("l", i + 1)) is None) and \
+                (lh is None or (lh % 2 == 0 and homes[("l", i + 1)] == lh + 1)):
             eqskip.add(i + 1)
 
             def f2e(g, k=k):
@@ -498,17 +536,28 @@ def body(e, p, capture=False, loose=False):
                 wait_pre(wr)
                 wait_pre(wr + 1)
                 _pk(e, "v_pk_fma_f32", wr, [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(wr)], [1, 0, 0])
-            op([("L", p.LW_Y + i)], f2e)
+            if lh is not None:       # l from its LDS home
+                op([("L", p.LW_Y + i), ("L", lh)], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
+                                                                       [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0]))
+            else:
+                op([("L", p.LW_Y + i)], f2e)
             continue
         if r["eq"] and not r["leaf"]:
             def f(g, k=k):
                 wait_pre(p.wreg[k])
                 e("v_fma_f32", W(k), "-" + v(g[0]), sRe, W(k))
-            op([("L", p.LW_Y + i)], f)
+            if lh is not None:
+                op([("L", p.LW_Y + i), ("L", lh)], lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[0]), sRe, v(g[1])))
+            else:
+                op([("L", p.LW_Y + i)], f)
         elif r["eq"]:
             op([("L", p.LW_Y + i), ("L", p.lpos[r["j"]]), src_of(("l", i))],
                lambda g, r=r, i=i: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
                                     e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0)))))
+        elif y0 and not r["leaf"]:
+            op([("L", p.LW_Z + p.zpos[i])], lambda g, k=k: e("v_mov_b32", W(k), v(g[0])))
+        elif y0:
+            op([("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])], lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0])))
         elif loose and not r["leaf"]:
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i])],
                lambda g, k=k: e("v_fma_f32", W(k), "-s%d" % S_RIMIN, v(g[0]), v(g[1])))
@@ -579,7 +628,23 @@ def body(e, p, capture=False, loose=False):
                 _pk(e, "v_pk_fma_f32", c_, [rho, VP(a_), y])                     # y_new = y + rho (t - z_new)
                 sc.lds_write2(zw, b_)
                 sc.lds_write2(yw, c_)
-            op([("L", yw), ("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
+            def fp0(g, r=r, zw=zw):
+                # y == 0: t3 = z, z_new = t, y_new = 0 -- five of the nine operations, no y word
+                z, L_, di = VP(g[0]), VP(g[1]), VP(g[2])
+                a_, b_ = TPK(npk[0], 0), TPK(npk[0], 2)
+                npk[0] += 1
+                rinv = SB(S_RIMIN, 0)
+                wr = p.wreg[r["r"]]
+                _pk(e, "v_pk_mul_f32", b_, [z, di])                              # nu = z / d ...
+                _pk(e, "v_pk_fma_f32", b_, [L_, VP(wr), VP(b_)])                 # ... + (-L) x~_j
+                _pk(e, "v_pk_fma_f32", a_, [rinv, VP(b_), z])                    # z~
+                _pk(e, "v_pk_mul_f32", b_, [SB(S_OMA, S_OMA % 2), z])            # (1 - alpha) z
+                _pk(e, "v_pk_fma_f32", a_, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new = alpha z~ + (1 - alpha) z
+                sc.lds_write2(zw, a_)
+            if y0:
+                op([("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp0)
+            else:
+                op([("L", yw), ("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
             continue
         if r["eq"]:
             if r["leaf"]:
@@ -614,6 +679,24 @@ def body(e, p, capture=False, loose=False):
                 op([("L", yw)], f)
             continue
         zw = p.LW_Z + p.zpos[i]
+        if y0:
+            def f0(g, r=r, k=k, zw=zw):
+                z = v(g[0])
+                t3, nu, t2, tt = (v(T(q)) for q in range(4))
+                if r["leaf"]:
+                    e("v_mul_f32", nu, z, v(g[2]))
+                    e("v_fmac_f32", nu, v(g[1]), W(r["r"]))
+                else:
+                    nu = W(k)
+                e("v_fma_f32", t3, "s%d" % S_RIMIN, nu, z)                    # z~
+                e("v_mul_f32", t2, sO, z)
+                e("v_fma_f32", tt, sA, t3, t2)                                # z_new = alpha z~ + (1 - alpha) z
+                if capture:
+                    e("v_mov_b32", v(T(5)), 0)                                # delta_y = rho (t - z_new) = 0
+                    store_dy(r["i"], lambda: None, T(5))
+                sc.lds_write(zw, T(3))
+            op([("L", zw)] + ([("L", p.lpos[r["j"]]), ("A", k)] if r["leaf"] else []), f0)
+            continue
         if loose:
             srcs, nfix = [("L", yw), ("L", zw)], 2
         else:
@@ -696,7 +779,7 @@ def body(e, p, capture=False, loose=False):
         op([("L", p.LW_X + j)], f)
     sc.run(ops)
     if not capture:
-        preloads(e, p)
+        preloads(e, p, homes)
 
 
 def _row_ptr(e, sreg, row, base=S_W):
@@ -743,7 +826,45 @@ def prologue(e, p):
     prologue_tail(e, p)
 
 
-def prologue_tail(e, p, loose=False):
+def y0_fill(e, p):
+    """y0 variant: the items that have an LDS home (Plan.y0_home) are fetched from the stream ONCE, through the W registers"""
+    items = p.stream + p.extra
+    todo = sorted(p.y0_home.items(), key=lambda kv: items.index(kv[0]))
+    assert len(todo) <= len(p.nonleaf)
+    blk = None
+    for q, (item, word) in enumerate(todo):
+        idx = items.index(item)
+        if idx // BLOCK != blk:
+            blk = idx // BLOCK
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, blk * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        e("global_load_dword", "v%d" % (V_W + q), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
+    e("s_waitcnt", "vmcnt(0)")
+    for q, (item, word) in enumerate(todo):
+        base, off = lds_addr(word)
+        e("ds_write_b32", base, "v%d" % (V_W + q), off)
+    e("s_waitcnt", "lgkmcnt(0)")
+
+
+def y0_restore(e, p):
+    """y0 variant, after the last iteration: the y words that held q are the multipliers again (zero)"""
+    words = sorted(w for (what, _), w in p.y0_home.items() if what == "q")
+    z4 = p.V_TT
+    for r in range(4):
+        e("v_mov_b32", "v%d" % (z4 + r), 0)
+    k = 0
+    while k < len(words):
+        w = words[k]
+        base, off = lds_addr(w)
+        if w % 4 == 0 and words[k:k + 4] == [w, w + 1, w + 2, w + 3]:
+            e("ds_write_b128", base, "v[%d:%d]" % (z4, z4 + 3), off)
+            k += 4
+        else:
+            e("ds_write_b32", base, "v%d" % z4, off)
+            k += 1
+
+
+def prologue_tail(e, p, loose=False, homes=()):
     """once-only stream items (l of the leaf equality rows) -> their registers; the first iteration's preloads"""
     idx = p.n_stream
     assert len(p.extra) <= len(p.nonleaf)
@@ -770,7 +891,7 @@ def prologue_tail(e, p, loose=False):
         e("v_mov_b32", "v%d" % p.V_RHO0, "s%d" % S_RHO0)
         e("v_mov_b32", "v%d" % p.V_RHOEQ, "s%d" % S_RHOEQ)
         e("v_mov_b32", "v%d" % p.V_RHOMIN, f32bits(float(np.float32(RHO_MIN_F32))))
-    preloads(e, p)
+    preloads(e, p, homes)
 
 
 def epilogue(e, p):
@@ -783,7 +904,7 @@ S_FAST, S_XI, S_YI, S_ZI = 30, 24, 26, 28    # fast start: flag, the caller's x,
 FAC_MIN = 638                                # LDS word: min |d_k| of the factorisation (0 = a zero pivot)
 
 
-def prologue_fast(e, p, res, loose=False):
+def prologue_fast(e, p, res, loose=False, y0check=False):
     """KKT fill + LDL' inside the block (factor_emit): the equilibrated A and P come from the wave's residual stream (written
     by the Ruiz block), 1/rho of the inequality rows from the loop's stream, the warm start straight from the caller's rows.
     -L lands in the loop's LDS words, 1/D in its AGPRs: no hand-off rows at all."""
@@ -801,7 +922,7 @@ def prologue_fast(e, p, res, loose=False):
         e("global_load_dword", "v%d" % reg, "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
     # A -> LDS words LW_X.. (the x, y, z words: the warm start arrives after the factorisation)
     assert p.LW_X + s.nnzA <= 640
-    G = V_END - V_W
+    G = V_END - V_W - (1 if y0check else 0)      # landing registers V_W ..; y0check keeps the last one as its accumulator
     for g in range(0, s.nnzA, G):
         ks = list(range(g, min(s.nnzA, g + G)))
         for q, k in enumerate(ks):
@@ -835,6 +956,9 @@ def prologue_fast(e, p, res, loose=False):
     # the warm start: x, y, z of the inequality rows -> LDS
     rows = [(S_XI, j, p.LW_X + j) for j in range(p.n)] + [(S_YI, i, p.LW_Y + i) for i in range(p.m)] + \
            [(S_ZI, i, p.LW_Z + p.zpos[i]) for i in gen]
+    v_or = V_END - 1             # y0check: OR of the multipliers' bits over the inequality rows
+    if y0check:
+        e("v_mov_b32", "v%d" % v_or, 0)
     for g in range(0, len(rows), G):
         grp = rows[g:g + G]
         last = None
@@ -849,7 +973,11 @@ def prologue_fast(e, p, res, loose=False):
         for q, (sb, row, word) in enumerate(grp):
             base, off = lds_addr(word)
             e("ds_write_b32", base, "v%d" % (V_W + q), off)
+            if y0check and sb == S_YI and row in p.zpos:
+                e("v_or_b32", "v%d" % v_or, "v%d" % v_or, "v%d" % (V_W + q))
         e("s_waitcnt", "lgkmcnt(0)")
+    if y0check:
+        return v_or
     prologue_tail(e, p, loose)
 
 
@@ -858,12 +986,46 @@ def program(s, eq_rows, res=None, loose=False):
     res: a ResPlan -> the block also holds the fast start (prologue_fast), taken when s30 != 0"""
     p = Plan(s, eq_rows)
     e = Emit()
+
+    def loop(**kw):
+        e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
+        e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
+        e("s_cbranch_scc1", "8f")
+        e("label", "7")
+        body(e, p, loose=loose, **kw)
+        e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+        e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
+        e("s_cbranch_scc1", "7b")
+        e("label", "8")
+        body(e, p, capture=True, loose=loose, **kw)
     if loose:
         # the loose variant exists for the all-assembly route only: always the fast start (the caller passes s30 != 0)
         assert res is not None
         e("s_mov_b32", "s%d" % S_RIMIN, f32bits(float(np.float32(1.0 / QP_RHO_MIN))))
         e("s_mov_b32", "s%d" % S_RHOMIN, f32bits(float(np.float32(QP_RHO_MIN))))
-        prologue_fast(e, p, res, loose=True)
+        if not Y0_VARIANT:
+            prologue_fast(e, p, res, loose=True)
+        else:
+            # y0: a loose row's multiplier moves by rho (t - z_new) with z_new = t + y / rho unclipped, so a multiplier that
+            # starts at exactly 0 stays exactly 0 (z_new = t, delta_y = rho * 0) -- in the reference as here. When the warm start
+            # has y == 0 on every inequality row of the wave (a cold start, or any earlier result of this loop), the iterations
+            # below drop those 87 words and their operations (same values: bit-identical), and q / l move into the freed LDS
+            # words instead of being loaded from the stream every iteration. Any other warm start takes the loop after label 20.
+            v_or = prologue_fast(e, p, res, loose=True, y0check=True)
+            e("v_and_b32", "v%d" % v_or, 0x7FFFFFFF, "v%d" % v_or)
+            e("v_cmp_ne_u32", "vcc", 0, "v%d" % v_or)
+            e("s_cbranch_vccnz", "20f")
+            y0_fill(e, p)
+            prologue_tail(e, p, True, p.y0_home)
+            loop(y0=True)
+            y0_restore(e, p)
+            e("s_branch", "29f")
+            e("label", "20")
+            prologue_tail(e, p, True)
+            loop()
+            e("label", "29")
+            epilogue(e, p)
+            return e.ins, p
     else:
         if res is not None:
             e("s_cmp_lg_u32", "s%d" % S_FAST, 0)
@@ -930,7 +1092,7 @@ def uni_scalar_operand(v, sign_extend_bug=False):
     return (hi << 32) | lo
 
 
-def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_agpr=False, base_xform=None):
+def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_agpr=False, base_xform=None, count=None):
     """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
     Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there).
     Addresses are formed as the ISA does for global_* with an SGPR base: SGPR pair (64 bits) + zero-extended 32-bit VGPR
@@ -1120,6 +1282,15 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
             V[int(t[1][1:])] = (t[2] + int(V[int(t[3][1:])])) & 0xFFFFFFFF
         elif m == "v_and_b32":
             V[int(t[1][1:])] = t[2] & int(V[int(t[3][1:])])
+        elif m == "v_or_b32":
+            V[int(t[1][1:])] = int(V[int(t[2][1:])]) | int(V[int(t[3][1:])])
+        elif m == "v_cmp_ne_u32":
+            SG["vcc"] = int(t[2] != int(V[int(t[3][1:])]))
+        elif m == "s_cbranch_vccnz":
+            if SG["vcc"]:
+                lab, d = t[1][:-1], t[1][-1]
+                cands = labels[lab]
+                pc = min(c for c in cands if c > pc) if d == "f" else max(c for c in cands if c < pc)
         elif m == "v_lshrrev_b32":
             V[int(t[1][1:])] = int(V[int(t[3][1:])]) >> t[2]
         elif m == "global_load_dword":
@@ -1187,6 +1358,8 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
         else:
             raise ValueError("unknown instruction %r" % (t,))
         pc += 1
+    if count is not None:
+        count.append(nexec)          # instructions executed (which variant of a loop ran)
     if ret_agpr:
         return lds, np.array([bits2f(b) for b in A], np.float32)
     return lds

@@ -441,12 +441,19 @@ def _sx(a):
     return asmqp.uni_scalar_operand(a, sign_extend_bug=True)
 
 
+_Y0_COUNTS = {}
+
+
+@pytest.mark.parametrize("zero_y", [False, True])
 @pytest.mark.parametrize("iters", [0, 2])
-def test_loose_loop_variant_is_bit_identical_to_the_general_loop(prog, iters):
+def test_loose_loop_variant_is_bit_identical_to_the_general_loop(prog, iters, zero_y):
     """asmqp.program(..., loose=True): when every inequality row is a loose row (rho = RHO_MIN, bounds beyond +-1e26 -- the
     reference's planar p5f problem, planar/mpc_osqp_p5f.py:94-97) the variant that takes rho and 1 / rho from SGPRs, never
     clips and streams nothing per inequality row must leave EXACTLY the words the general loop leaves (fast start, the
-    block's own factorisation included). And it really is shorter."""
+    block's own factorisation included). And it really is shorter.
+    zero_y: the warm start has y == 0 on every inequality row (a cold start, or an earlier result of the loop): the loose
+    program then takes its y0 loop (no multiplier words for those rows, q and l of the packed equality rows in LDS instead of
+    the per-iteration loads) -- still bit for bit the general loop's words, in fewer instructions again."""
     from robobee3d_amd import codegen_qp
     asmqp, ins, p = prog
     s = p.s
@@ -468,15 +475,22 @@ def test_loose_loop_variant_is_bit_identical_to_the_general_loop(prog, iters):
     S[res.it_A:res.it_A + s.nnzA] = A
     for j, it in res.it_p.items():
         S[it] = Pv[res.pidx[j]]
+    if zero_y:
+        d["y"][gen] = 0.0
     arrs = [d[k].astype(np.float32) for k in ("x", "y", "z")]
-    out = []
+    out, nexec = [], []
     for prog_ins in (ins, ins_l):
         lds = asmqp.simulate(prog_ins, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, (1.6, 0.5, float(np.float32(0.01))),
                              regions=[(asmqp.S_XI, arrs[0].copy()), (asmqp.S_YI, arrs[1].copy()), (asmqp.S_ZI, arrs[2].copy())],
-                             sgpr={asmqp.S_FAST: 1})
+                             sgpr={asmqp.S_FAST: 1}, count=nexec)
         out.append(np.concatenate([lds[p.LW_X:p.LW_X + p.n], lds[p.LW_Y:p.LW_Y + p.m], lds[p.LW_Z:p.LW_Z + len(gen)],
                                    lds[p.LW_XP:p.LW_XP + p.n], lds[p.LW_DY:p.LW_DY + p.m], lds[asmqp.FAC_MIN:asmqp.FAC_MIN + 1]]))
     assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+    if zero_y:
+        assert not out[1][p.n:p.n + p.m][gen].any()            # the multipliers of the loose rows: exactly zero, restored
+    _Y0_COUNTS[(iters, zero_y)] = nexec[1]
+    if (iters, True) in _Y0_COUNTS and (iters, False) in _Y0_COUNTS and iters:
+        assert _Y0_COUNTS[(iters, True)] < 0.97 * _Y0_COUNTS[(iters, False)]     # the y0 loop ran, and is shorter
     loop = lambda L: [k for k, t in enumerate(L) if t == ("label", "8")][0] - [k for k, t in enumerate(L) if t == ("label", "7")][0]
     assert loop(ins_l) <= 0.83 * loop(ins)
     assert sum(1 for t in ins_l if t[0] == "global_load_dword") < 0.5 * sum(1 for t in ins if t[0] == "global_load_dword")

@@ -878,3 +878,42 @@ def test_gpu_infeasibility_certificates_nan_and_cold_start():
             assert np.isnan(sol[:, 0]).all() and np.isfinite(sol[:, 3]).all()
             assert not qp.x[:, 0].any().item() and not qp.y[:, 0].any().item() and not qp.z[:, 0].any().item()
             np.testing.assert_allclose(sol[:, 3], ref["sol_x"][:, 3], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_loose_loop_y0_variant_and_its_fallback_agree(margin):
+    """The loose loop of the p5f assembly route has two bodies (asmqp.program): the y0 one when the warm start has y == 0
+    on every inequality row of the wave (cold start, or any earlier result of the loop: a loose row's multiplier stays
+    exactly 0), the general loose one otherwise. Same ticks from (a) the cold start and (b) the cold start with
+    multipliers of 1e-30 planted on the inequality rows of every robot: (b) runs the other body on every wave, and a
+    multiplier of 1e-30 moves nothing a float can see (y / rho = 1e-24 against z ~ 1): the iterates must agree to the
+    last bits. A ragged batch; waves of (a) keep y == 0 on those rows through warm-started ticks."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    B = 200
+    mpc = PlanarP5fMPC(B, torch.float32)
+    assert mpc.qp.kernel_name == "p5f10+asm"
+    mpc.y[0] = torch.linspace(-0.1, 0.1, B).to(mpc.y)
+    mpc.y[3] = torch.linspace(0.1, -0.1, B).to(mpc.y)
+    n, m = mpc.qp.n, mpc.qp.m
+    ineq = slice(m - n, m)                      # planar/mpc_osqp_p5f.py:120-128: the identity block below the dynamics rows
+    res = []
+    for plant in (False, True):
+        mpc.qp.reset()
+        if plant:
+            mpc.qp.y[ineq] = 1e-30
+        ys = []
+        for ti in (2, 3, 4):
+            mpc.linearise(15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti))
+            mpc.qp.solve(mpc.Pv, mpc.Av, mpc.q, mpc.l, mpc.u)
+            ys.append(mpc.qp.y[ineq].abs().max().item())
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy().astype(np.float64).copy() for t in (mpc.qp.x, mpc.qp.y, mpc.qp.z, mpc.qp.sol_x, mpc.qp.sol_y)]
+                   + [mpc.qp.status.cpu().numpy().copy()])
+        if not plant:
+            assert ys == [0.0, 0.0, 0.0]          # exactly zero after every tick: the y0 body ran, and keeps running
+        else:
+            assert 0.0 < ys[0] < 1e-25            # the planted multipliers decay like round-off, never to an exact zero
+    worst = max(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) for a, b in zip(res[0][:5], res[1][:5]))
+    margin("y0 body vs general loose body, 3 ticks, B = 200: iterates / solution, |d| / max(1, |ref|)", worst, 1e-12)
+    assert np.array_equal(res[0][5], res[1][5]) and np.all(res[0][5] == 1)
