@@ -58,6 +58,8 @@ LW_FLAGS = 636                                      # LDS words 636..639: LOOSE_
 # per wave (LDS word LOOSE_FLAG).
 S_RIMIN, S_RHOMIN = 36, 37                            # 1 / RHO_MIN, RHO_MIN as float bits (set by the loose program itself)
 Y0_VARIANT = os.environ.get("UMPC_QP_Y0", "1") == "1"   # the loose program carries the y == 0 variant of its loop (program())
+Y0_DLEAF = os.environ.get("UMPC_QP_Y0_DLEAF", "1") == "1"    # ... with 1/d of the leaf loose rows in an SGPR (S_DLEAF)
+S_DLEAF = 38
 
 
 def lds_addr(word):
@@ -214,6 +216,16 @@ class Plan:
         for item in self.stream[self.n_land:]:
             if spare and item not in self.y0_home:
                 self.y0_home[item] = spare.pop(0)
+        # ... and 1/d of a leaf loose row is ONE number (its unknown is eliminated first: d = -1/rho_min, nothing folded in),
+        # which the y0 loop keeps in an SGPR; the AGPRs of those rows take the items that are still homeless
+        self.y0_dleaf = [r["k"] for r in self.rows if r["leaf"] and not r["eq"]]
+        apool = list(self.y0_dleaf) if Y0_DLEAF else []
+        for (a_, b_) in self.eqpairs:
+            if ("l", a_) not in self.y0_home and len(apool) >= 2:
+                self.y0_home[("l", a_)], self.y0_home[("l", b_)] = ("A", apool.pop(0)), ("A", apool.pop(0))
+        for item in self.stream[self.n_land:]:
+            if apool and item not in self.y0_home:
+                self.y0_home[item] = ("A", apool.pop(0))
         # row-major hand-off rows (floats, [row][B])
         self.R_L, self.R_DI = 0, len(L_i)
         self.R_X = self.R_DI + nk
@@ -456,6 +468,9 @@ def body(e, p, capture=False, loose=False, y0=False):
         if j in jskip:
             continue
         qh = homes.get(("q", j))
+        if isinstance(qh, tuple):
+            op([("L", p.LW_X + j), qh], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
+            continue
         if qh is not None and "1" in PACK_PARTS and xpair(j) and qh % 2 == 0 and homes.get(("q", j + 1)) == qh + 1:
             jskip.add(j + 1)
             op([("L", p.LW_X + j), ("L", qh)], lambda r, j=j: _pk(e, "v_pk_fma_f32", p.wreg[p.pinv[j]],
@@ -527,8 +542,15 @@ def body(e, p, capture=False, loose=False, y0=False):
         if pack and "4" in PACK_PARTS and i in eqskip:
             continue
         lh = homes.get(("l", i))
-        if pack and "4" in PACK_PARTS and i in eqfirst and (lh is None) == (homes.get(("l", i + 1)) is None) and \
-                (lh is None or (lh % 2 == 0 and homes[("l", i + 1)] == lh + 1)):
+        lh1 = homes.get(("l", i + 1))
+        lsrc = lambda h: h if isinstance(h, tuple) else ("L", h)
+        if pack and "4" in PACK_PARTS and i in eqfirst and isinstance(lh, tuple) and isinstance(lh1, tuple):
+            eqskip.add(i + 1)           # both bounds in AGPR homes: read as a pair
+            op([("L", p.LW_Y + i), ("A2", lh[1], lh1[1])], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
+                                                                           [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0]))
+            continue
+        if pack and "4" in PACK_PARTS and i in eqfirst and not isinstance(lh, tuple) and not isinstance(lh1, tuple) and \
+                (lh is None) == (lh1 is None) and (lh is None or (lh % 2 == 0 and lh1 == lh + 1)):
             eqskip.add(i + 1)
 
             def f2e(g, k=k):
@@ -547,7 +569,7 @@ def body(e, p, capture=False, loose=False, y0=False):
                 wait_pre(p.wreg[k])
                 e("v_fma_f32", W(k), "-" + v(g[0]), sRe, W(k))
             if lh is not None:
-                op([("L", p.LW_Y + i), ("L", lh)], lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[0]), sRe, v(g[1])))
+                op([("L", p.LW_Y + i), lsrc(lh)], lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[0]), sRe, v(g[1])))
             else:
                 op([("L", p.LW_Y + i)], f)
         elif r["eq"]:
@@ -630,7 +652,8 @@ def body(e, p, capture=False, loose=False, y0=False):
                 sc.lds_write2(yw, c_)
             def fp0(g, r=r, zw=zw):
                 # y == 0: t3 = z, z_new = t, y_new = 0 -- five of the nine operations, no y word
-                z, L_, di = VP(g[0]), VP(g[1]), VP(g[2])
+                z, L_ = VP(g[0]), VP(g[1])
+                di = SB(S_DLEAF, S_DLEAF % 2) if Y0_DLEAF else VP(g[2])
                 a_, b_ = TPK(npk[0], 0), TPK(npk[0], 2)
                 npk[0] += 1
                 rinv = SB(S_RIMIN, 0)
@@ -642,7 +665,7 @@ def body(e, p, capture=False, loose=False, y0=False):
                 _pk(e, "v_pk_fma_f32", a_, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new = alpha z~ + (1 - alpha) z
                 sc.lds_write2(zw, a_)
             if y0:
-                op([("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp0)
+                op([("L", zw), ("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
             else:
                 op([("L", yw), ("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
             continue
@@ -684,7 +707,7 @@ def body(e, p, capture=False, loose=False, y0=False):
                 z = v(g[0])
                 t3, nu, t2, tt = (v(T(q)) for q in range(4))
                 if r["leaf"]:
-                    e("v_mul_f32", nu, z, v(g[2]))
+                    e("v_mul_f32", nu, z, "s%d" % S_DLEAF if Y0_DLEAF else v(g[2]))
                     e("v_fmac_f32", nu, v(g[1]), W(r["r"]))
                 else:
                     nu = W(k)
@@ -695,7 +718,7 @@ def body(e, p, capture=False, loose=False, y0=False):
                     e("v_mov_b32", v(T(5)), 0)                                # delta_y = rho (t - z_new) = 0
                     store_dy(r["i"], lambda: None, T(5))
                 sc.lds_write(zw, T(3))
-            op([("L", zw)] + ([("L", p.lpos[r["j"]]), ("A", k)] if r["leaf"] else []), f0)
+            op([("L", zw)] + ([("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A", k)]) if r["leaf"] else []), f0)
             continue
         if loose:
             srcs, nfix = [("L", yw), ("L", zw)], 2
@@ -838,9 +861,12 @@ def y0_fill(e, p):
             blk = idx // BLOCK
             e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, blk * BLOCK * 256)
             e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
-        e("global_load_dword", "v%d" % (V_W + q), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
+        dst = "a%d" % word[1] if isinstance(word, tuple) else "v%d" % (V_W + q)
+        e("global_load_dword", dst, "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
     e("s_waitcnt", "vmcnt(0)")
     for q, (item, word) in enumerate(todo):
+        if isinstance(word, tuple):
+            continue
         base, off = lds_addr(word)
         e("ds_write_b32", base, "v%d" % (V_W + q), off)
     e("s_waitcnt", "lgkmcnt(0)")
@@ -848,7 +874,7 @@ def y0_fill(e, p):
 
 def y0_restore(e, p):
     """y0 variant, after the last iteration: the y words that held q are the multipliers again (zero)"""
-    words = sorted(w for (what, _), w in p.y0_home.items() if what == "q")
+    words = sorted(w for (what, _), w in p.y0_home.items() if what == "q" and not isinstance(w, tuple))
     z4 = p.V_TT
     for r in range(4):
         e("v_mov_b32", "v%d" % (z4 + r), 0)
@@ -1015,6 +1041,10 @@ def program(s, eq_rows, res=None, loose=False):
             e("v_and_b32", "v%d" % v_or, 0x7FFFFFFF, "v%d" % v_or)
             e("v_cmp_ne_u32", "vcc", 0, "v%d" % v_or)
             e("s_cbranch_vccnz", "20f")
+            if Y0_DLEAF and p.y0_dleaf:
+                e("v_accvgpr_read_b32", "v%d" % v_or, "a%d" % p.y0_dleaf[0])
+                e("s_nop", 0)
+                e("v_readfirstlane_b32", "s%d" % S_DLEAF, "v%d" % v_or)
             y0_fill(e, p)
             prologue_tail(e, p, True, p.y0_home)
             loop(y0=True)
@@ -1282,6 +1312,8 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
             V[int(t[1][1:])] = (t[2] + int(V[int(t[3][1:])])) & 0xFFFFFFFF
         elif m == "v_and_b32":
             V[int(t[1][1:])] = t[2] & int(V[int(t[3][1:])])
+        elif m == "v_readfirstlane_b32":
+            SG[int(t[1][1:])] = int(V[int(t[2][1:])])
         elif m == "v_or_b32":
             V[int(t[1][1:])] = int(V[int(t[2][1:])]) | int(V[int(t[3][1:])])
         elif m == "v_cmp_ne_u32":

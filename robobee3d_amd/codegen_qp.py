@@ -540,7 +540,7 @@ def asm_macro(name, ins, plan, loose=False):
     """csrc/gen/bqp_<name>_asm.h: the instruction stream of asmqp.program as one asm volatile statement
     (loose: the variant for waves whose inequality rows are all loose rows, asmqp.S_RIMIN; same interface, fast start only)"""
     from . import asmqp
-    used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1] + ([asmqp.S_RIMIN, asmqp.S_RHOMIN] if loose else [])
+    used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1] + ([asmqp.S_RIMIN, asmqp.S_RHOMIN, asmqp.S_DLEAF] if loose else [])
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
     lab7 = [k for k, t_ in enumerate(ins) if t_ == ("label", "7")][0]
