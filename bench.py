@@ -607,9 +607,9 @@ def main():
                          # SURVEY 8d asks for all three rooflines; the one that binds is vector issue
                          "flops": {"achieved": 1.1e5 * B * spl / (kern_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
                                    "peak": 157.3, "note": "~1.1e5 flop per robot-step (SURVEY 8d); MI355X fp32 vector peak"},
-                         "lds": {"achieved": (args.max_iter * 78 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
+                         "lds": {"achieved": (args.max_iter * 76 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
                                  "unit": "GB/s", "peak": 256 * 128 * 2.4,
-                                 "note": "78 ds_read_b128 per ADMM iteration per lane + hand-off; peak 128 B/clk/CU"},
+                                 "note": "76 ds_read_b128 per ADMM iteration per lane (asmstep.py's loop) + hand-off; peak 128 B/clk/CU"},
                          "valu_issue": valu_issue(valu_per_wave_step, B, spl, kern_ms, valu_src) if valu_per_wave_step else None,
                          "note": "path is VALU-issue bound, not HBM bound (DESIGN.md): ~1.1e5 flop per 1208 B"},
             "check": {"nonfinite_state_values": nbad,
