@@ -292,6 +292,14 @@ class Sched:
         self.e("ds_write_b64", base, "v[%d:%d]" % (reg, reg + 1), off)
         self.nlds += 1
 
+    def lds_write4(self, word, reg):
+        """words word .. word + 3 (one float4 of the lane) <- v[reg:reg+3] (even reg)"""
+        assert word % 4 == 0 and reg % 2 == 0
+        base, off = lds_addr(word)
+        self.lds_at[self.nlds] = len(self.e.ins)
+        self.e("ds_write_b128", base, "v[%d:%d]" % (reg, reg + 3), off)
+        self.nlds += 1
+
     def issue_stream(self, idx):
         e, p = self.e, self.p
         while idx // BLOCK > self.sp_block:
@@ -1442,6 +1450,38 @@ def reference_iterations(p, d, iters, alpha, sigma):
 # Arithmetic = the pass of codegen_qp.emit_structure statement by statement, except that 1/sqrt is v_rsq_f32 + one Newton
 # step and the two divisions v_rcp_f32 + Newton (+ a correction step for csum / n): each within an ulp of the IEEE results.
 RZ_MIN, RZ_MAX = 1e-4, 1e4
+RUIZ_WQ = os.environ.get("UMPC_QP_RUIZ_WQ", "1") == "1"
+
+
+class QuadWriter:
+    """Collects a run of consecutive LDS words in the register quad v[base:base+3] (word w in register base + w % 4) and writes
+    them back with the widest instructions: reg(w) names the register the producing instruction must write, done(w, last)
+    is called after it."""
+
+    def __init__(self, sc, base):
+        self.sc, self.base, self.lo = sc, base, None
+
+    def reg(self, w):
+        return self.base + w % 4
+
+    def done(self, w, last=False):
+        if self.lo is None:
+            self.lo = w
+        if w % 4 != 3 and not last:
+            return
+        lo, q0 = self.lo, w - w % 4
+        self.lo = None
+        have = set(range(lo, w + 1))
+        if have == set(range(q0, q0 + 4)):
+            self.sc.lds_write4(q0, self.base)
+            return
+        for h in (0, 2):
+            if {q0 + h, q0 + h + 1} <= have:
+                self.sc.lds_write2(q0 + h, self.base + h)
+            else:
+                for z in (q0 + h, q0 + h + 1):
+                    if z in have:
+                        self.sc.lds_write(z, self.base + z % 4)
 
 
 class RuizPlan:
@@ -1456,6 +1496,10 @@ class RuizPlan:
         self.V_TT = self.V_AT + N_AT
         self.NT = 14
         assert self.V_TT + self.NT <= V_END
+        # three register quads that collect consecutive words of A, D and E for one ds_write_b128 each (round 3: the pass
+        # wrote its 505 words back one ds_write_b32 at a time)
+        self.V_WQ = (max(self.V_TT + self.NT, 211) + 1) // 2 * 2        # (v210 = V_RLANE is an input of the block)
+        self.WQ = RUIZ_WQ and self.V_WQ + 12 <= V_END
         self.n_land = 0
         self.A_DT, self.A_P = 0, self.n
         self.A_Q = self.A_P + self.nnzP
@@ -1609,6 +1653,7 @@ def ruiz_program(s, res=None):
             e("v_rsq_f32", ET(i), ET(i))        # in place; the next VALU instruction (the next row's compare, or the
         op([], fe)                               # csum initialisation) does not read it: no trans-use wait state needed
     # ---- apply; csum in T(4), qn in T(5), dt of the column in T(7)
+    wqa, wqd, wqe = (QuadWriter(sc, p.V_WQ + 4 * z) for z in range(3))
     op([], lambda g: (e("v_mov_b32", v(T(4)), 0), e("v_mov_b32", v(T(5)), 0)))
     for j in range(n):
         op([("A", p.A_DT + j)], lambda g: e("v_mov_b32", v(T(7)), v(g[0])))
@@ -1621,24 +1666,34 @@ def ruiz_program(s, res=None):
             op([("A", p.A_P + p.pidx[j])], fp)
         for q in range(p.A_p[j], p.A_p[j + 1]):
             def fa(g, q=q, i=p.A_i[q]):
-                t = T(8 + q % 4)
+                t = wqa.reg(p.LW_A + q) if p.WQ else T(8 + q % 4)
                 e("v_mul_f32", v(t), v(g[0]), ET(i))
                 e("v_mul_f32", v(t), v(t), v(T(7)))
-                sc.lds_write(p.LW_A + q, t)
+                if p.WQ:
+                    wqa.done(p.LW_A + q, q == p.nnzA - 1)
+                else:
+                    sc.lds_write(p.LW_A + q, t)
             op([("L", p.LW_A + q)], fa)
 
         def fq(g, j=j):
             e("v_mul_f32", v(T(6)), v(g[0]), v(T(7)))
             e("v_accvgpr_write_b32", "a%d" % (p.A_Q + j), v(T(6)))
             e("v_max_f32", v(T(5)), ab(v(T(6))), v(T(5)))
-            e("v_mul_f32", v(T(12)), v(T(7)), v(g[1]))
-            sc.lds_write(p.LW_D + j, T(12))
+            t = wqd.reg(p.LW_D + j) if p.WQ else T(12)
+            e("v_mul_f32", v(t), v(T(7)), v(g[1]))
+            if p.WQ:
+                wqd.done(p.LW_D + j, j == n - 1)
+            else:
+                sc.lds_write(p.LW_D + j, T(12))
         op([("A", p.A_Q + j), ("L", p.LW_D + j)], fq)
     for i in range(m):
         def fv(g, i=i):
-            t = T(8 + i % 4)
+            t = wqe.reg(p.LW_EV + i) if p.WQ else T(8 + i % 4)
             e("v_mul_f32", v(t), ET(i), v(g[0]))
-            sc.lds_write(p.LW_EV + i, t)
+            if p.WQ:
+                wqe.done(p.LW_EV + i, i == m - 1)
+            else:
+                sc.lds_write(p.LW_EV + i, t)
         op([("L", p.LW_EV + i)], fv)
 
     # ---- cost scaling: ct = 1 / limit(max(csum / n, limit(qn)))
