@@ -440,6 +440,21 @@ def preloads(e, p, homes=()):
         e("global_load_dword", "v%d" % p.wreg[k], "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
 
 
+def couples(words):
+    """words: the (even) LDS words pair-wise results are written to, in emission order. Two consecutive pairs that fill one
+    aligned float4 are written with ONE ds_write_b128 (an LDS instruction costs a lone wave ~6 ns whatever its width):
+    returns ({word of the first pair of a couple}, {word of the second})"""
+    first, second = set(), set()
+    for a_, b_ in zip(words, words[1:]):
+        if a_ % 4 == 0 and b_ == a_ + 2 and a_ not in second:
+            first.add(a_)
+            second.add(b_)
+    return first, second
+
+
+PAIR_QUADS = os.environ.get("UMPC_QP_PAIR_QUADS", "1") == "1"
+
+
 def body(e, p, capture=False, loose=False, y0=False):
     """capture: the LAST iteration -- x_prev and delta_y go to rows R_XP / R_DY (auxil.c:362-512 consumes them)
     loose: every inequality row is a loose row (see S_RIMIN above)"""
@@ -631,6 +646,15 @@ def body(e, p, capture=False, loose=False, y0=False):
     # ---- P6: row updates (auxil.c:203-228); leaf rows re-form their multiplier from the final unknown of their variable
     npk = [0]
     eqskip2 = set()
+    zc1 = zc2 = yc1 = yc2 = xc1 = xc2 = frozenset()
+    if pack and PAIR_QUADS:
+        assert (p.V_LAND + 8) % 2 == 0
+        if y0:
+            zc1, zc2 = couples([p.LW_Z + p.zpos[r["i"]] for r in p.rows if paired.get(r["i"]) is not None])
+        if "4" in PACK_PARTS:
+            yc1, yc2 = couples([p.LW_Y + i for i in sorted(eqfirst)])
+        if "3" in PACK_PARTS:
+            xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j)])
     for r in p.rows:
         i, k = r["i"], r["k"]
         yw = p.LW_Y + i
@@ -662,8 +686,12 @@ def body(e, p, capture=False, loose=False, y0=False):
                 # y == 0: t3 = z, z_new = t, y_new = 0 -- five of the nine operations, no y word
                 z, L_ = VP(g[0]), VP(g[1])
                 di = SB(S_DLEAF, S_DLEAF % 2) if Y0_DLEAF else VP(g[2])
-                a_, b_ = TPK(npk[0], 0), TPK(npk[0], 2)
-                npk[0] += 1
+                if zw in zc1:                                        # first pair of a float4: the second one writes both
+                    a_, b_ = TPK(npk[0], 4), TPK(npk[0], 0)
+                elif zw in zc2:
+                    a_, b_ = TPK(npk[0], 6), TPK(npk[0], 2)
+                else:
+                    a_, b_ = TPK(npk[0], 0), TPK(npk[0], 2)
                 rinv = SB(S_RIMIN, 0)
                 wr = p.wreg[r["r"]]
                 _pk(e, "v_pk_mul_f32", b_, [z, di])                              # nu = z / d ...
@@ -671,7 +699,12 @@ def body(e, p, capture=False, loose=False, y0=False):
                 _pk(e, "v_pk_fma_f32", a_, [rinv, VP(b_), z])                    # z~
                 _pk(e, "v_pk_mul_f32", b_, [SB(S_OMA, S_OMA % 2), z])            # (1 - alpha) z
                 _pk(e, "v_pk_fma_f32", a_, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new = alpha z~ + (1 - alpha) z
-                sc.lds_write2(zw, a_)
+                if zw in zc2:
+                    sc.lds_write4(zw - 2, TPK(npk[0], 4))
+                elif zw not in zc1:
+                    sc.lds_write2(zw, a_)
+                if zw not in zc1:
+                    npk[0] += 1
             if y0:
                 op([("L", zw), ("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
             else:
@@ -694,12 +727,16 @@ def body(e, p, capture=False, loose=False, y0=False):
                 eqskip2.add(i + 1)
 
                 def f2u(g, k=k, yw=yw):
-                    t = TPK(npk[0], 0)
-                    npk[0] += 1
+                    t = TPK(npk[0], 4 if yw in yc1 else 6 if yw in yc2 else 0)
                     wr = p.wreg[k]
                     _pk(e, "v_pk_add_f32", t, [VP(wr), VP(g[0])], [0, 1])                  # nu - y
                     _pk(e, "v_pk_fma_f32", t, [SB(S_ALPHA, S_ALPHA % 2), VP(t), VP(g[0])])  # y + alpha (nu - y)
-                    sc.lds_write2(yw, t)
+                    if yw in yc2:
+                        sc.lds_write4(yw - 2, TPK(npk[0], 4))
+                    elif yw not in yc1:
+                        sc.lds_write2(yw, t)
+                    if yw not in yc1:
+                        npk[0] += 1
                 op([("L", yw)], f2u)
             else:
                 def f(g, k=k, yw=yw, i=i):
@@ -792,11 +829,15 @@ def body(e, p, capture=False, loose=False, y0=False):
             jskip.add(j + 1)
 
             def fx2(g, j=j):
-                t = TPK(j // 2, 6)
+                xw = p.LW_X + j
+                t = TPK(j // 4, 4) if xw in xc1 else TPK(j // 4, 6) if xw in xc2 else TPK(j // 2, 6)
                 wr = p.wreg[p.pinv[j]]
                 _pk(e, "v_pk_mul_f32", t, [SB(S_OMA, S_OMA % 2), VP(g[0])])
                 _pk(e, "v_pk_fma_f32", t, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(t)])
-                sc.lds_write2(p.LW_X + j, t)
+                if xw in xc2:
+                    sc.lds_write4(xw - 2, TPK(j // 4, 4))
+                elif xw not in xc1:
+                    sc.lds_write2(xw, t)
             op([("L", p.LW_X + j)], fx2)
             continue
 
