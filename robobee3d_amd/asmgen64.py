@@ -56,6 +56,7 @@ LDS_BYTES_PER_LANE = 2560
 #                first iteration are dead by then; filled at the end of the first iteration)
 A_H = 168
 HOMES = os.environ.get("UMPC_ASM64_HOMES", "1") == "1"
+FUSE = os.environ.get("UMPC_ASM64_FUSE", "1") == "1"       # the x / y updates leave the NEXT iteration's right-hand side in W
 
 
 def rhs_structure(s):
@@ -372,31 +373,39 @@ def body(e, s, first, capture):
         """wr / rd: the W word (original index) the operation updates / the other W words it reads"""
         ops.append(dict(srcs=srcs, emit=fn, wr=wr, rd=tuple(rd)))
     # ---- rhs: W = [sigma x - q ; z - y / rho]  (auxil.c:164-178). First iteration (and HOMES off): q / l already in W;
-    # later iterations with HOMES: q, l from their AGPR homes, structural zeros dropped
+    # later iterations with HOMES: q, l from their AGPR homes, structural zeros dropped. FUSE: the middle iterations have no
+    # rhs phase at all -- the x and y updates of the iteration before leave the next right-hand side in the W registers (the
+    # updated word is in a register there: no second LDS read of x and y; same operations on the same values)
     hm = homes(s) if HOMES else None
-    use_h = HOMES and not first
-    for j in range(nx):
-        if not use_h:
-            op([("L", LW_X + j)], lambda r, j=j: (wait_pre(j), e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j)))), j)
-        elif ("q", j) in hm:
-            op([("L", LW_X + j), ("A", hm[("q", j)])], lambda r, j=j: e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(r[1])), j)
-        else:
-            op([("L", LW_X + j)], lambda r, j=j: e("v_mul_f64", vp(W(j)), sS, vp(r[0])), j)
-    for i in range(neq):
-        if first:
-            op([("L", LW_Y + i), ("A", A_Z + 2 * i)],
-               lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])), nx + i)
-        elif not use_h:
-            op([("L", LW_Y + i)], lambda r, i=i: (wait_pre(nx + i),
-                                                  e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i)))), nx + i)
-        elif ("l", i) in hm:
-            op([("L", LW_Y + i), ("A", hm[("l", i)])],
-               lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])), nx + i)
-        else:
-            op([("L", LW_Y + i)], lambda r, i=i: e("v_mul_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi), nx + i)
-    for k in range(N):
-        i = neq + k
-        op([("L", LW_Y + i)], lambda r, i=i, k=k: e("v_fma_f64", vp(W(nx + i)), "-" + vp(RINV3(k)), vp(r[0]), vp(Z3(k))), nx + i)
+    fuse = HOMES and FUSE
+    fused_here = fuse and not first and not capture          # this body's updates form the next rhs
+
+    def add_rhs(first_style):
+        use_h = HOMES and not first_style
+        for j in range(nx):
+            if not use_h:
+                op([("L", LW_X + j)], lambda r, j=j: (wait_pre(j), e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(W(j)))), j)
+            elif ("q", j) in hm:
+                op([("L", LW_X + j), ("A", hm[("q", j)])], lambda r, j=j: e("v_fma_f64", vp(W(j)), sS, vp(r[0]), "-" + vp(r[1])), j)
+            else:
+                op([("L", LW_X + j)], lambda r, j=j: e("v_mul_f64", vp(W(j)), sS, vp(r[0])), j)
+        for i in range(neq):
+            if first_style:
+                op([("L", LW_Y + i), ("A", A_Z + 2 * i)],
+                   lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])), nx + i)
+            elif not use_h:
+                op([("L", LW_Y + i)], lambda r, i=i: (wait_pre(nx + i),
+                                                      e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(W(nx + i)))), nx + i)
+            elif ("l", i) in hm:
+                op([("L", LW_Y + i), ("A", hm[("l", i)])],
+                   lambda r, i=i: e("v_fma_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi, vp(r[1])), nx + i)
+            else:
+                op([("L", LW_Y + i)], lambda r, i=i: e("v_mul_f64", vp(W(nx + i)), "-" + vp(r[0]), sRi), nx + i)
+        for k in range(N):
+            i = neq + k
+            op([("L", LW_Y + i)], lambda r, i=i, k=k: e("v_fma_f64", vp(W(nx + i)), "-" + vp(RINV3(k)), vp(r[0]), vp(Z3(k))), nx + i)
+    if first or not fuse:
+        add_rhs(first)
     # ---- forward solve (qdldl.c:250-262), columns ascending, entries ascending: W[r] -= L_j W[c]
     for c in range(nk):
         for j in range(s.L_p[c], s.L_p[c + 1]):
@@ -434,6 +443,14 @@ def body(e, s, first, capture):
                     nw += lds_store(PC_XP + j, r)
                 e("v_mul_f64", vp(t), sO, vp(r))
                 e("v_fma_f64", vp(t if capture else r), sA, vp(W(j)), vp(t))
+                if fused_here:          # the next iteration's W_x = sigma x_new - q
+                    if ("q", j) in hm:
+                        ah = V_AT + 2 * (j % N_AT)
+                        e("v_accvgpr_read_b32", "v%d" % ah, "a%d" % hm[("q", j)])
+                        e("v_accvgpr_read_b32", "v%d" % (ah + 1), "a%d" % (hm[("q", j)] + 1))
+                        e("v_fma_f64", vp(W(j)), sS, vp(r), "-" + vp(ah))
+                    else:
+                        e("v_mul_f64", vp(W(j)), sS, vp(r))
             nw += _write_quad(e, qd, ws, {w: (V_TT + 2 * ((w - LW_X) % N_TT) if capture else where[w]) for w in ws})
         if not first and not HOMES:
             for qd, ws in grp:
@@ -470,6 +487,14 @@ def body(e, s, first, capture):
                         e("v_mul_f64", vp(t2), sA, vp(t1))
                         nw += lds_store(PC_DY + i, t2)
                     e("v_fma_f64", vp(r), sA, vp(t1), vp(r))
+                    if fused_here:      # the next iteration's W_z = l - y_new / rho
+                        if ("l", i) in hm:
+                            ah = V_AT + 2 * (i % N_AT)
+                            e("v_accvgpr_read_b32", "v%d" % ah, "a%d" % hm[("l", i)])
+                            e("v_accvgpr_read_b32", "v%d" % (ah + 1), "a%d" % (hm[("l", i)] + 1))
+                            e("v_fma_f64", vp(nu), "-" + vp(r), sRi, vp(ah))
+                        else:
+                            e("v_mul_f64", vp(nu), "-" + vp(r), sRi)
                     newreg[w] = r
                     continue
                 if i < neq:     # first iteration, dynamics row: z_prev from its AGPR, l (= new z) from W_x[i]
@@ -498,6 +523,8 @@ def body(e, s, first, capture):
                 if capture:
                     nw += lds_store(PC_DY + i, t2)
                 e("v_add_f64", vp(r), vp(r), vp(t2))
+                if fused_here and i >= neq:     # thrust rows: the next iteration's W_z = z_new - y_new / rho
+                    e("v_fma_f64", vp(nu), "-" + rinv, vp(r), vp(zr))
                 newreg[w] = r
             nw += _write_quad(e, qd, ws, newreg)
         if not first and not HOMES:
@@ -519,6 +546,12 @@ def body(e, s, first, capture):
                 _row_ptr(e, S_P, S_WS, FAC_Q + j)
                 e("global_load_dwordx2", "a[%d:%d]" % (a_, a_ + 1), "v0", sp(S_P))
         e("s_waitcnt", "vmcnt(0)")
+        if fuse and not capture:
+            # FUSE: the first iteration hands the second its right-hand side the classic way (x, y from LDS, q and l from the
+            # homes just filled); from then on every iteration's updates do it for the next one
+            ops = []
+            add_rhs(False)
+            Fetch(e).run(ops)
 
 
 def epilogue(e, s):
