@@ -59,6 +59,7 @@ LW_FLAGS = 636                                      # LDS words 636..639: LOOSE_
 S_RIMIN, S_RHOMIN = 36, 37                            # 1 / RHO_MIN, RHO_MIN as float bits (set by the loose program itself)
 Y0_VARIANT = os.environ.get("UMPC_QP_Y0", "1") == "1"   # the loose program carries the y == 0 variant of its loop (program())
 Y0_DLEAF = os.environ.get("UMPC_QP_Y0_DLEAF", "1") == "1"    # ... with 1/d of the leaf loose rows in an SGPR (S_DLEAF)
+Y0_FUSE = os.environ.get("UMPC_QP_Y0_FUSE", "1") == "1"      # ... and the updates forming the next iteration's right-hand side
 S_DLEAF = 38
 
 
@@ -455,9 +456,12 @@ def couples(words):
 PAIR_QUADS = os.environ.get("UMPC_QP_PAIR_QUADS", "1") == "1"
 
 
-def body(e, p, capture=False, loose=False, y0=False):
+def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
     """capture: the LAST iteration -- x_prev and delta_y go to rows R_XP / R_DY (auxil.c:362-512 consumes them)
-    loose: every inequality row is a loose row (see S_RIMIN above)"""
+    loose: every inequality row is a loose row (see S_RIMIN above)
+    rhs / fuse (y0 bodies): fuse -- the row and x updates leave the NEXT iteration's right-hand side in the W registers (the new
+    x, y, z words are in registers there: no second LDS read, and a leaf row's L entry is fetched once instead of twice);
+    rhs=False -- the iteration before did that, this body starts at the solves"""
     n, m = p.n, p.m
     v = lambda r: "v%d" % r
     sA, sO, sS, sRe = ("s%d" % r for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINVEQ))
@@ -479,6 +483,7 @@ def body(e, p, capture=False, loose=False, y0=False):
 
     def wait_pre(reg):
         sc.vm_wait(pre_pos[reg])
+    rhs_ops_start = len(ops)
     # ---- P1: W_x = sigma x - q (q preloaded)
     pack = loose and not capture and PACK_LOOSE          # the loose variant's middle iterations: two entries per instruction
     VP = lambda r_: ("v[%d:%d]" % (r_, r_ + 1), 0, 1)
@@ -617,6 +622,8 @@ def body(e, p, capture=False, loose=False, y0=False):
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), src_of(("rinv", i)), ("L", p.lpos[r["j"]])],
                lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[2]), v(g[0]), v(g[1])),
                                e("v_fmac_f32", W(r["r"]), v(g[3]), v(T(0)))))
+    if not rhs:                  # (the definitions above are needed below; the operations are not)
+        del ops[rhs_ops_start:]
     # ---- solves over the non-leaf unknowns (qdldl.c:250-293)
     for (r_, c, j) in p.solve_entries:
         op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
@@ -655,9 +662,80 @@ def body(e, p, capture=False, loose=False, y0=False):
             yc1, yc2 = couples([p.LW_Y + i for i in sorted(eqfirst)])
         if "3" in PACK_PARTS:
             xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j)])
+    assert not fuse or (y0 and pack and not capture and PAIR_QUADS and Y0_DLEAF)
+    # fuse: the updates run eq rows, then the inequality rows that are not part of a fused pair, then the box-row pairs together with
+    # the x update of their two variables (a variable's W register is rewritten there: every row that reads it as x~ went before),
+    # then the other x updates, then the right-hand-side pushes of the leaf rows that could not be fused
+    B_EQ, B_OTHER, B_PAIR, B_PUSH = [], [], [], []
+    xbase = min(p.wreg[p.pinv[j]] for j in range(n))
+    fused_x = set()                     # variables whose x update is part of a fused pair operation
+
+    def rop(bucket, srcs, fn):
+        (bucket if fuse else ops).append(dict(srcs=srcs, emit=fn))
+
+    def fusable(r, rb):
+        """box-row pair (r, rb) <-> x pair (j, j + 1) with q in an aligned LDS pair"""
+        j = p.wreg[r["r"]] - xbase
+        if not (0 <= j < n - 1 and p.pinv[j] == r["r"] and p.pinv[j + 1] == rb["r"] and xpair(j)):
+            return None
+        # (a variable that another leaf row pushes into as well keeps the classic order of its pushes: row order)
+        if any(o["leaf"] and o["r"] in (r["r"], rb["r"]) and o is not r and o is not rb for o in p.rows):
+            return None
+        qh = homes.get(("q", j))
+        if isinstance(qh, tuple) or qh is None or qh % 2 or homes.get(("q", j + 1)) != qh + 1:
+            return None
+        return j
+    fpairs = [(r, paired[r["i"]], fusable(r, paired[r["i"]])) for r in p.rows if fuse and paired.get(r["i"]) is not None]
+    fpairs = [(r, rb, j) for (r, rb, j) in fpairs if j is not None]
+    fzc1, fzc2 = couples([p.LW_Z + p.zpos[r["i"]] for (r, _, _) in fpairs]) if fuse else (set(), set())
+    fxc1, fxc2 = couples([p.LW_X + j for (_, _, j) in fpairs]) if fuse else (set(), set())
+    fused_rows = {r["i"] for (r, _, _) in fpairs} | {rb["i"] for (_, rb, _) in fpairs}
+    for (_, _, j) in fpairs:
+        fused_x.update((j, j + 1))
+    if fuse:      # the remaining pairs couple among themselves
+        zc1, zc2 = couples([p.LW_Z + p.zpos[r["i"]] for r in p.rows if paired.get(r["i"]) is not None and r["i"] not in fused_rows])
+        xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j) and j not in fused_x])
     for r in p.rows:
         i, k = r["i"], r["k"]
         yw = p.LW_Y + i
+        if i in fused_rows:
+            if paired[i] is None:
+                continue
+            rb = paired[i]
+            zw = p.LW_Z + p.zpos[i]
+            j = next(j_ for (r_, _, j_) in fpairs if r_ is r)
+
+            def ffused(g, r=r, zw=zw, j=j):
+                z, L_, xq, qq = VP(g[0]), VP(g[1]), VP(g[2]), VP(g[3])
+                di = SB(S_DLEAF, S_DLEAF % 2)
+                c = npk[0]
+                a_ = TPK(c, 4) if zw in fzc1 else TPK(c, 6) if zw in fzc2 else TPK(c, 4)
+                b_ = TPK(c, 0) if zw not in fzc2 else TPK(c, 2)
+                xw = p.LW_X + j
+                xt = T(0) if xw in fxc1 else T(2) if xw in fxc2 else T(0)
+                rinv = SB(S_RIMIN, 0)
+                wr = p.wreg[r["r"]]
+                _pk(e, "v_pk_mul_f32", b_, [z, di])                              # nu = z / d ...
+                _pk(e, "v_pk_fma_f32", b_, [L_, VP(wr), VP(b_)])                 # ... + (-L) x~_j
+                _pk(e, "v_pk_fma_f32", a_, [rinv, VP(b_), z])                    # z~
+                _pk(e, "v_pk_mul_f32", b_, [SB(S_OMA, S_OMA % 2), z])            # (1 - alpha) z
+                _pk(e, "v_pk_fma_f32", a_, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new
+                if zw in fzc2:
+                    sc.lds_write4(zw - 2, TPK(c, 4))
+                elif zw not in fzc1:
+                    sc.lds_write2(zw, a_)
+                _pk(e, "v_pk_mul_f32", xt, [SB(S_OMA, S_OMA % 2), xq])           # x update of the two variables
+                _pk(e, "v_pk_fma_f32", xt, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(xt)])
+                if xw in fxc2:
+                    sc.lds_write4(xw - 2, T(0))
+                elif xw not in fxc1:
+                    sc.lds_write2(xw, xt)
+                _pk(e, "v_pk_fma_f32", wr, [SB(S_SIGMA, S_SIGMA % 2), VP(xt), qq], [0, 0, 1])   # next rhs: sigma x_new - q ...
+                _pk(e, "v_pk_fma_f32", wr, [L_, VP(a_), VP(wr)])                 # ... + (-L) z_new  (y == 0)
+                if zw not in fzc1:
+                    npk[0] += 1
+            rop(B_PAIR, [("L", zw), ("L", p.lpos[r["j"]]), ("L", p.LW_X + j), ("L", homes[("q", j)])], ffused)
+            continue
         if i in paired:
             if paired[i] is None:
                 continue
@@ -706,7 +784,10 @@ def body(e, p, capture=False, loose=False, y0=False):
                 if zw not in zc1:
                     npk[0] += 1
             if y0:
-                op([("L", zw), ("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
+                rop(B_OTHER, [("L", zw), ("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
+                if fuse:          # the pair's pushes into the next rhs: after the x updates
+                    B_PUSH.append(dict(srcs=[("L", zw), ("L", p.lpos[r["j"]])],
+                                       emit=lambda g, r=r: _pk(e, "v_pk_fma_f32", p.wreg[r["r"]], [VP(g[1]), VP(g[0]), VP(p.wreg[r["r"]])])))
             else:
                 op([("L", yw), ("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
             continue
@@ -720,7 +801,11 @@ def body(e, p, capture=False, loose=False, y0=False):
                     store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
                     e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
                     sc.lds_write(yw, T(1))
-                op([("L", yw), ("L", p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
+                rop(B_EQ, [("L", yw), ("L", p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
+                if fuse:          # its push into the next rhs (the classic operation), after the x updates
+                    B_PUSH.append(dict(srcs=[("L", yw), ("L", p.lpos[r["j"]]), src_of(("l", i))],
+                                       emit=lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
+                                                            e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0))))))
             elif pack and "4" in PACK_PARTS and i in eqskip2:
                 pass
             elif pack and "4" in PACK_PARTS and i in eqfirst:
@@ -735,16 +820,30 @@ def body(e, p, capture=False, loose=False, y0=False):
                         sc.lds_write4(yw - 2, TPK(npk[0], 4))
                     elif yw not in yc1:
                         sc.lds_write2(yw, t)
+                    if fuse:          # next rhs: l - y_new / rho_eq (the solution words in W are consumed)
+                        _pk(e, "v_pk_fma_f32", wr, [VP(t), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0])
                     if yw not in yc1:
                         npk[0] += 1
-                op([("L", yw)], f2u)
+                lh_, lh1_ = homes.get(("l", i)), homes.get(("l", i + 1))
+                if fuse:
+                    lsrc2 = ("A2", lh_[1], lh1_[1]) if isinstance(lh_, tuple) and isinstance(lh1_, tuple) else ("L", lh_)
+                    assert isinstance(lh_, tuple) == isinstance(lh1_, tuple) and (isinstance(lh_, tuple) or (lh_ % 2 == 0 and lh1_ == lh_ + 1))
+                    rop(B_EQ, [("L", yw), lsrc2], f2u)
+                else:
+                    op([("L", yw)], f2u)
             else:
                 def f(g, k=k, yw=yw, i=i):
                     e("v_sub_f32", v(T(1)), W(k), v(g[0]))
                     store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
                     e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
                     sc.lds_write(yw, T(1))
-                op([("L", yw)], f)
+                    if fuse:
+                        e("v_fma_f32", W(k), "-" + v(T(1)), sRe, v(g[1]))
+                if fuse:
+                    lh_ = homes[("l", i)]
+                    rop(B_EQ, [("L", yw), lh_ if isinstance(lh_, tuple) else ("L", lh_)], f)
+                else:
+                    op([("L", yw)], f)
             continue
         zw = p.LW_Z + p.zpos[i]
         if y0:
@@ -763,7 +862,12 @@ def body(e, p, capture=False, loose=False, y0=False):
                     e("v_mov_b32", v(T(5)), 0)                                # delta_y = rho (t - z_new) = 0
                     store_dy(r["i"], lambda: None, T(5))
                 sc.lds_write(zw, T(3))
-            op([("L", zw)] + ([("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A", k)]) if r["leaf"] else []), f0)
+                if fuse and not r["leaf"]:
+                    e("v_mov_b32", W(k), tt)                                  # next rhs of the row: z_new (y == 0)
+            rop(B_OTHER, [("L", zw)] + ([("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A", k)]) if r["leaf"] else []), f0)
+            if fuse and r["leaf"]:
+                B_PUSH.append(dict(srcs=[("L", zw), ("L", p.lpos[r["j"]])],
+                                   emit=lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0]))))
             continue
         if loose:
             srcs, nfix = [("L", yw), ("L", zw)], 2
@@ -820,12 +924,14 @@ def body(e, p, capture=False, loose=False, y0=False):
         op(srcs, f)
     assert land[0] == (0 if loose else p.n_land)
     # ---- x <- alpha x~ + (1 - alpha) x
-    jskip = set()
+    if fuse:
+        ops.extend(B_EQ + B_OTHER + B_PAIR)
+    jskip = set(fused_x)
     for j in range(n):
         k = p.pinv[j]
         if j in jskip:
             continue
-        if "3" in PACK_PARTS and xpair(j):
+        if "3" in PACK_PARTS and xpair(j) and j + 1 not in fused_x:
             jskip.add(j + 1)
 
             def fx2(g, j=j):
@@ -838,8 +944,14 @@ def body(e, p, capture=False, loose=False, y0=False):
                     sc.lds_write4(xw - 2, TPK(j // 4, 4))
                 elif xw not in xc1:
                     sc.lds_write2(xw, t)
-            op([("L", p.LW_X + j)], fx2)
-            continue
+                if fuse:          # next rhs: sigma x_new - q
+                    _pk(e, "v_pk_fma_f32", wr, [SB(S_SIGMA, S_SIGMA % 2), VP(t), VP(g[1])], [0, 0, 1])
+            qh_ = homes.get(("q", j))
+            if fuse and not (isinstance(qh_, int) and qh_ % 2 == 0 and homes.get(("q", j + 1)) == qh_ + 1):
+                jskip.discard(j + 1)          # (no aligned q pair: the two variables go one at a time below)
+            else:
+                op([("L", p.LW_X + j)] + ([("L", qh_)] if fuse else []), fx2)
+                continue
 
         def f(g, k=k, j=j):
             t = T(6 + j % 2)
@@ -848,7 +960,13 @@ def body(e, p, capture=False, loose=False, y0=False):
             e("v_mul_f32", v(t), sO, v(g[0]))
             e("v_fma_f32", v(t), sA, W(k), v(t))
             sc.lds_write(p.LW_X + j, t)
-        op([("L", p.LW_X + j)], f)
+            if fuse:
+                e("v_fma_f32", W(k), sS, v(t), "-" + v(g[1]))
+        qh_ = homes.get(("q", j))
+        op([("L", p.LW_X + j)] + ([qh_ if isinstance(qh_, tuple) else ("L", qh_)] if fuse else []), f)
+    if fuse:
+        ops.append(dict(flush=True))          # the pushes read words this body has written
+        ops.extend(B_PUSH)
     sc.run(ops)
     if not capture:
         preloads(e, p, homes)
@@ -1096,7 +1214,29 @@ def program(s, eq_rows, res=None, loose=False):
                 e("v_readfirstlane_b32", "s%d" % S_DLEAF, "v%d" % v_or)
             y0_fill(e, p)
             prologue_tail(e, p, True, p.y0_home)
-            loop(y0=True)
+            if not Y0_FUSE:
+                loop(y0=True)
+            else:
+                # four bodies: the first iteration forms its right-hand side the classic way and, like every middle one, leaves
+                # the NEXT one's in the W registers; the capturing iteration starts at the solves; a single iteration is plain
+                e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
+                e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
+                e("s_cbranch_scc1", "30f")
+                body(e, p, loose=True, y0=True, rhs=True, fuse=True)
+                e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+                e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
+                e("s_cbranch_scc1", "8f")
+                e("label", "7")
+                body(e, p, loose=True, y0=True, rhs=False, fuse=True)
+                e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+                e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
+                e("s_cbranch_scc1", "7b")
+                e("label", "8")
+                body(e, p, capture=True, loose=True, y0=True, rhs=False)
+                e("s_branch", "31f")
+                e("label", "30")
+                body(e, p, capture=True, loose=True, y0=True)
+                e("label", "31")
             y0_restore(e, p)
             e("s_branch", "29f")
             e("label", "20")
