@@ -494,3 +494,39 @@ def test_loose_loop_variant_is_bit_identical_to_the_general_loop(prog, iters, ze
     loop = lambda L: [k for k, t in enumerate(L) if t == ("label", "8")][0] - [k for k, t in enumerate(L) if t == ("label", "7")][0]
     assert loop(ins_l) <= 0.83 * loop(ins)
     assert sum(1 for t in ins_l if t[0] == "global_load_dword") < 0.5 * sum(1 for t in ins if t[0] == "global_load_dword")
+
+
+def test_lds_write_combiners():
+    """asmqp.couples / asmqp.QuadWriter (round 3: an LDS instruction costs a lone wave the same whatever its width): which
+    pair writes share a ds_write_b128, and which instructions a run of consecutive words is written back with."""
+    from robobee3d_amd import asmqp
+    # pairs at words 8, 10 | 12, 14 fill two float4; 18 is alone (16 is missing); 20, 22 couple; a repeated word never couples twice
+    first, second = asmqp.couples([8, 10, 12, 14, 18, 20, 22])
+    assert first == {8, 12, 20} and second == {10, 14, 22}
+    assert asmqp.couples([2, 4, 6]) == ({4}, {6}) and asmqp.couples([]) == (set(), set())
+
+    class Rec:
+        def __init__(self):
+            self.log = []
+
+        def lds_write(self, w, r):
+            self.log.append(("b32", w, r))
+
+        def lds_write2(self, w, r):
+            assert w % 2 == 0 and r % 2 == 0
+            self.log.append(("b64", w, r))
+
+        def lds_write4(self, w, r):
+            assert w % 4 == 0 and r % 2 == 0
+            self.log.append(("b128", w, r))
+    sc = Rec()
+    qw = asmqp.QuadWriter(sc, 100)
+    words = list(range(341, 352))                      # a run that starts at position 1 of its float4 and ends at position 3
+    for w in words:
+        assert qw.reg(w) == 100 + w % 4
+        qw.done(w, w == words[-1])
+    assert sc.log == [("b32", 341, 101), ("b64", 342, 102), ("b128", 344, 100), ("b128", 348, 100)]
+    sc.log.clear()
+    for w in (0, 1, 2, 3, 4, 5):                       # ... and a run that ends in the middle of one
+        qw.done(w, w == 5)
+    assert sc.log == [("b128", 0, 100), ("b64", 4, 100)]
