@@ -92,6 +92,20 @@ int umpcLastStatus(const UprightMPC_t *up);
 void umpcRelease(UprightMPC_t *up);
 /* Number of drop-in controllers currently holding device state (diagnostics / tests). */
 int umpcLiveControllers(void);
+/* Opt-in reference compatibility switches of ONE controller (flags OR-ed; returns the previous flags, -1 when `up`
+ * carries no live controller). A controller starts with the flags of the environment variable UMPC_COMPAT (decimal)
+ * at umpcInit time, 0 when it is unset.
+ *   UMPC_COMPAT_BOUNDS_REJECT  reproduce osqp_update_bounds' early return (template/uprightmpc2/osqp.c:801-808) whose
+ *     value umpcUpdate drops (uprightmpc2.c:246): when ANY assembled l[i] > u[i] (reachable with TtoWmax < 0) NO bound
+ *     of that call is applied and the step solves with the bounds the reference's workspace still holds -- Tmax is fixed
+ *     by umpcInit in this library, so every call of such a controller is rejected and those are the generated
+ *     workspace's placeholder l = 0, u = 1e30 on all 39 rows (workspace.c:476-557), every row an inequality at
+ *     rho = 0.1 -- while q, P and A are the new ones; up->l / up->u still show the assembled
+ *     (crossed) pair, as in the reference. Such a call runs on the general-structure solver (Part 5), not on the
+ *     specialised stream (its dynamics rows are hard-wired equalities): milliseconds, not 0.1 ms. Without the flag the
+ *     crossed pair is applied as assembled. tests/golden/bounds_reject.npz pins both behaviours. */
+#define UMPC_COMPAT_BOUNDS_REJECT 1
+int umpcSetCompat(UprightMPC_t *up, int flags);
 
 /* ------------------------------------------------------------------ */
 /* Part 2: batched controllers                                         */

@@ -20,7 +20,7 @@ STATE_ROWS, CTRL_ROWS, REF_ROWS, OUT_ROWS, STAT_ROWS = 18, 127, 9, 9, 2
 NX, NC, NADATA = 45, 39, 48
 
 # every symbol include/umpc_mi355x.h declares
-EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease", "umpcLiveControllers",
+EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease", "umpcLiveControllers", "umpcSetCompat",
            "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
@@ -126,15 +126,23 @@ def _validate_resources(res):
 def build(force=False, verbose=False):
     """Generate umpc_gen.h / umpc_admm_asm.h and compile the HIP library for gfx950 (works without a GPU).
     One object per translation unit (recompiled only when it or its headers changed), then one link."""
-    from . import asmgen, asmgen64, asmstep, codegen, codegen_qp
+    from . import asmgen, asmgen64, asmstep, codegen, codegen_n3, codegen_qp
+    sw = asmgen.generator_switches()
+    if sw:
+        # build() REWRITES the tracked generated headers and the shipped .so: a stray A/B switch in a test, bench or
+        # profile shell must not change the kernels silently (one of them, UMPC_ASM_LIMIT_FAST, changes the numerics).
+        # Variants are built by tools/build_variant.py into robobee3d_amd/variants/ and selected with UMPC_LIB.
+        raise RuntimeError("generator switches are set in the environment (%s): refusing to regenerate the shipped kernels; "
+                           "unset them, or build a variant with tools/build_variant.py" % " ".join("%s=%s" % kv for kv in sw.items()))
     gen, _ = codegen.write()
+    gn3 = codegen_n3.write()
     gasm, _ = asmgen.write()
     gasm64 = asmgen64.write()[0]
     gstep, _ = asmstep.write()
     greg, gqp_units = codegen_qp.write()
     hdr = os.path.join(ROOT, "include", "umpc_mi355x.h")
     csrc = os.path.join(HERE, "csrc")
-    units = [(SRC, [gen, gasm, gasm64, gstep, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
+    units = [(SRC, [gen, gasm, gasm64, gstep, gn3, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
              (SRC_BQP, [hdr, greg, os.path.join(csrc, "umpc_bqp_common.h"), os.path.join(csrc, "umpc_err.h")])]
     gen_hdrs = [os.path.join(csrc, "gen", f) for f in os.listdir(os.path.join(csrc, "gen")) if f.endswith(".h")]
     units += [(u, [os.path.join(csrc, "umpc_bqp_common.h")] + gen_hdrs) for u in gqp_units]
@@ -242,6 +250,7 @@ def lib():
         L.umpcNAssemble.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(NParams)] + [C.c_void_p] * 10
         L.umpcNExtract.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 5
         L.umpcLastStatus.restype = C.c_int
+        L.umpcSetCompat.restype = C.c_int
         _lib = L
     return _lib
 

@@ -43,6 +43,23 @@ from . import symbolic
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+# Generation-time switches are read from the environment when the generator modules are imported (A/B timing of kernel
+# variants, tools/build_variant.py). Everything that matches these prefixes changes the emitted instruction streams;
+# the names below it are RUN-time diagnostics of the host side and do not.
+SWITCH_PREFIXES = ("UMPC_ASM_", "UMPC_ASM64_", "UMPC_QP_", "UMPC_X_")
+NOT_SWITCHES = ("UMPC_QP_KERNEL",)
+
+
+def generator_switches():
+    """{name: value} of the generator switches present in the environment (empty = the shipped kernels)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(SWITCH_PREFIXES) and k not in NOT_SWITCHES}
+
+
+def switch_banner():
+    """one comment line for a generated header: which switches produced it"""
+    sw = generator_switches()
+    return "// generator switches: " + (" ".join("%s=%s" % kv for kv in sw.items()) if sw else "none (defaults = the shipped kernels)")
+
 XV_COUNT, XV_BASE = 0, 246   # asmstep.py: storage positions NLDS+NVZ .. +XV_COUNT-1 of L live in VGPRs XV_BASE.. (free there)
 NLDS = 160  # L storage positions kept in LDS
 NVZ = 36    # positions NLDS .. NLDS+NVZ-1 move into the z registers of the dynamics rows after the first iteration
@@ -752,7 +769,7 @@ def write(path=None, N=3, perm=None):
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
     lab7 = [k for k, t in enumerate(ins) if t == ("label", "7")][0]
     lab8 = [k for k, t in enumerate(ins) if t == ("label", "8")][0]
-    out = ["// GENERATED by robobee3d_amd/asmgen.py -- do not edit.",
+    out = ["// GENERATED by robobee3d_amd/asmgen.py -- do not edit.", switch_banner(),
            "// ADMM phase of the fp32 step kernel: %d instructions, middle-iteration body %d." % (len(ins), lab8 - lab7),
            "#pragma once",
            "namespace umpcasm {",

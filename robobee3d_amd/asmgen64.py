@@ -35,7 +35,7 @@ qdldl.c:250-293, proj.c:4-14.
 import os
 import struct
 
-from . import symbolic
+from . import asmgen, symbolic
 from .asmgen import (Emit, _row_ptr, _adv, FAC_Q, FAC_LOEQ, FAC_M, WS_DS, WS_ES, WS_ROWS,
                      S_WS, S_CTRL, S_STRIDE, S_ITERS, S_P, S_CNT, S_P2, S_ALPHA, S_OMA, S_SIGMA, S_RINV, S_RHO)
 
@@ -667,7 +667,7 @@ def write(path=None, N=3, perm=None):
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
     lab7 = [k for k, t in enumerate(ins) if t == ("label", "7")][0]
     lab8 = [k for k, t in enumerate(ins) if t == ("label", "8")][0]
-    out = ["// GENERATED by robobee3d_amd/asmgen64.py -- do not edit.",
+    out = ["// GENERATED by robobee3d_amd/asmgen64.py -- do not edit.", asmgen.switch_banner(),
            "// ADMM phase of the fp64 small-batch step kernel: %d instructions, middle-iteration body %d." % (len(ins), lab8 - lab7),
            "#pragma once",
            "namespace umpcasm64 {",

@@ -1853,7 +1853,7 @@ def write(path=None, N=3, perm=None):
     used_s = sorted(set(range(4, 102)))
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, 256)] + ['"a%d"' % i for i in range(256)] + \
            ['"s%d"' % i for i in used_s]
-    out = ["// GENERATED by robobee3d_amd/asmstep.py -- do not edit.",
+    out = ["// GENERATED by robobee3d_amd/asmstep.py -- do not edit.", asmgen.switch_banner(),
            "// The all-assembly fp32 step kernel body: %d instructions (K closed-loop steps of one wavefront)." % len(ins),
            "#pragma once", "#include <stdint.h>", "namespace umpcasm {",
            "// parameter block read by the kernel with s_load (byte offsets are part of the generated code)",

@@ -544,7 +544,8 @@ def asm_macro(name, ins, plan, loose=False):
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
     lab7 = [k for k, t_ in enumerate(ins) if t_ == ("label", "7")][0]
-    out = ["// GENERATED by robobee3d_amd/asmqp.py via codegen_qp.py -- do not edit.",
+    from . import asmgen
+    out = ["// GENERATED by robobee3d_amd/asmqp.py via codegen_qp.py -- do not edit.", asmgen.switch_banner(),
            "// %s ADMM iterations of the %s structure, fp32, one lane per robot, one wave per CU: %d instructions, %d"
            % ("LOOSE variant (every inequality row a loose row: nothing streamed per row, no clipping) of the" if loose else "Middle",
               name, len(ins), sum(1 for t_ in ins[lab7:] if t_[0] != "label")),

@@ -2,6 +2,7 @@
 // No torch, no reference code, no CPU fallback: every entry point launches a kernel.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include UMPC_STEP_ASM_HEADER
 #include "umpc_models.h"
 #include "umpc_err.h"
+#include "umpc_n3_general.h"   // the N = 3 QP as data for the general-structure solver (compat bounds-reject path only)
 
 namespace {
 
@@ -670,6 +672,10 @@ struct Single {
   hipStream_t stream = nullptr, stream2 = nullptr;      // step kernel | debug-field kernel
   int status = umpc::ST_UNSOLVED;
   unsigned seq = 0;        // call counter: the kernels write it to the completion words of the mapped buffer
+  const UprightMPC_t *owner = nullptr;   // the POD umpcInit built this controller for (a by-value COPY of that POD aliases it)
+  int compat = 0;          // opt-in reference compatibility flags (umpcSetCompat)
+  void *gqp = nullptr;     // general-structure solver handle (created on the first rejected call)
+  float *gbuf = nullptr;   // its device arrays (layout: compat_reject_step)
 };
 std::mutex g_mu;
 std::map<uint32_t, Single> g_single;
@@ -678,7 +684,8 @@ constexpr uint32_t kMagic = 0x554d5043u;  // "UMPC"
 constexpr int O_STATE = 0, O_REF = 18, O_AT0 = O_REF + 9, O_OUT = O_AT0 + 1, O_INFO = O_OUT + 9, O_L = O_INFO + 2,
               O_U = O_L + 39, O_Q = O_U + 39, O_PX = O_Q + 45, O_AX = O_PX + 45, O_STATUS = O_AX + 48,
               O_T0DBG = O_STATUS + 1, O_DONE0 = (O_T0DBG + 1 + 15) / 16 * 16 /* each completion word on a 64-byte line of its own */,
-              O_DONE1 = O_DONE0 + 16, O_TOTAL = O_DONE1 + 16;
+              O_DONE1 = O_DONE0 + 16, O_LU = O_DONE1 + 16 /* compat reject path: the kept bounds l | u */,
+              O_TOTAL = O_LU + 2 * 39;
 static_assert(O_DONE0 % 16 == 0 && O_DONE0 > O_T0DBG, "completion words: own cache lines behind the I/O words");
 
 uint32_t pod_id(const UprightMPC_t *up) {
@@ -692,11 +699,71 @@ void release_locked(uint32_t id) {
   Single &s = it->second;
   if (s.stream) (void)hipStreamSynchronize(s.stream);
   if (s.stream2) { (void)hipStreamSynchronize(s.stream2); (void)hipStreamDestroy(s.stream2); }
+  if (s.gqp) umpcQPDestroy(s.gqp);
+  if (s.gbuf) (void)hipFree(s.gbuf);
   if (s.h) umpcBatchDestroy(s.h);
   if (s.ctrl) (void)hipFree(s.ctrl);
   if (s.host) (void)hipHostFree(s.host);
   if (s.stream) (void)hipStreamDestroy(s.stream);
   g_single.erase(it);
+}
+
+// One call of the reference's REJECT path (osqp.c:801-808: any l_new[i] > u_new[i] => osqp_update_bounds returns 1 before
+// touching anything; uprightmpc2.c:246 drops the value and goes on): the step solves with the bounds the workspace still
+// holds and the NEW q, P, A. A controller's Tmax is fixed by umpcInit here (the kernels take it from the parameter block, not
+// from the POD), so crossed bounds mean EVERY call of this controller is rejected and the workspace still holds the generated
+// placeholder l = 0, u = 1e30 (workspace.c:476-557) (osqp_update_lin_cost / osqp_update_P_A are not skipped). The kept bounds need not make the dynamics rows
+// equalities, so this runs on the general-structure solver (umpc_bqp.hip) with the controller's own warm start x, y, z,
+// T0 and thrust-row E. Device arrays in s.gbuf (floats): Pv 45 | q 45 | l 39 | u 39 | par 10 | Av 111 | cst 111 | E 39 |
+// sol_x 45 | sol_y 39 | info 6 | src 111 (int32).
+int compat_reject_step(Single &s, const UprightMPC_t *up) {
+  static_assert(umpcn3::N == N && umpcn3::NX == NX && umpcn3::NC == NC && umpcn3::NNZA == NNZA, "umpc_n3_general.h is the N = 3 structure");
+  constexpr int O_PV = 0, O_QV = O_PV + NX, O_LV = O_QV + NX, O_UV = O_LV + NC, O_PAR = O_UV + NC, O_AV = O_PAR + 10,
+                O_CST = O_AV + NNZA, O_E = O_CST + NNZA, O_SX = O_E + NC, O_SY = O_SX + NX, O_INF = O_SY + NC,
+                O_SRC = O_INF + 6, O_END = O_SRC + NNZA;
+  if (!s.gqp) {
+    umpcQPSettings st;
+    umpcQPDefaultSettings(&st);
+    st.max_iter = s.h->prm.maxIter;
+    s.gqp = umpcQPCreate(umpcn3::kBlob, umpcn3::BLOB_WORDS, 1, UMPC_F32, &st);
+    if (!s.gqp) return 1;
+    if (hipMalloc((void **)&s.gbuf, O_END * sizeof(float)) != hipSuccess) { umpcQPDestroy(s.gqp); s.gqp = nullptr; return 1; }
+    float tmp[O_END];
+    memset(tmp, 0, sizeof(tmp));
+    for (int k = 0; k < NNZA; ++k) tmp[O_CST + k] = umpcn3::kIsDt[k] ? (float)s.h->prm.dt : umpcn3::kCst[k];
+    for (int k = 0; k < NC; ++k) tmp[O_E + k] = 1.0f;
+    memcpy(tmp + O_SRC, umpcn3::kSrc, NNZA * sizeof(int32_t));
+    if (hipMemcpy(s.gbuf, tmp, sizeof(tmp), hipMemcpyHostToDevice) != hipSuccess) return 1;
+  }
+  float *g = s.gbuf, *d = s.hdev;
+  umpcNParams np;
+  const umpc_batch_params_t &bp = s.h->prm;
+  np.dt = bp.dt; np.g = bp.g; np.TtoWmax = bp.TtoWmax; np.ws = bp.ws; np.wds = bp.wds; np.wpr = bp.wpr; np.wpf = bp.wpf;
+  np.wvr = bp.wvr; np.wvf = bp.wvf; np.wthrust = bp.wthrust; np.wmom = bp.wmom;
+  for (int i = 0; i < 3; ++i) np.Ib[i] = bp.Ib[i];
+  (void)up;
+  // T0 of this call sits in the mapped word O_AT0 (already actualT0-or-accumulator); the kernels update it in place
+  int rc = umpcNAssemble(1, UMPC_F32, N, &np, d + O_STATE, d + O_REF, d + O_AT0, nullptr, g + O_PV, g + O_QV, g + O_LV,
+                         g + O_UV, g + O_PAR, s.stream);
+  if (!rc) rc = umpcQPGather(1, UMPC_F32, NNZA, g + O_CST, (const int32_t *)(g + O_SRC), g + O_PAR, g + O_AV, s.stream);
+  if (rc) return 1;
+  // the bounds the reference's workspace still holds, handed over in the mapped buffer
+  float *lu = s.host + O_LU;
+  for (int i = 0; i < NC; ++i) { lu[i] = 0.0f; lu[NC + i] = 1e30f; }
+  // thrust-row E of the previous call lives in the controller record (rows 124..126); rows 0..35 keep the general solver's own
+  if (hipMemcpyAsync(g + O_E + 36, s.ctrl + 124, 3 * sizeof(float), hipMemcpyDeviceToDevice, s.stream) != hipSuccess) return 1;
+  rc = umpcQPSolve(s.gqp, g + O_PV, g + O_AV, g + O_QV, d + O_LU, d + O_LU + NC, s.ctrl, s.ctrl + NX, s.ctrl + NX + NC, g + O_E,
+                   g + O_SX, g + O_SY, (int32_t *)(d + O_STATUS), g + O_INF, s.stream);
+  if (!rc) rc = umpcNExtract(1, UMPC_F32, N, bp.dt, d + O_STATE, g + O_SX, d + O_AT0, d + O_OUT, s.stream);
+  if (rc) return 1;
+  if (hipMemcpyAsync(s.ctrl + 124, g + O_E + 36, 3 * sizeof(float), hipMemcpyDeviceToDevice, s.stream) != hipSuccess ||
+      hipMemcpyAsync(s.ctrl + 123, d + O_AT0, sizeof(float), hipMemcpyDeviceToDevice, s.stream) != hipSuccess ||
+      hipMemcpyAsync(d + O_INFO, g + O_INF, 2 * sizeof(float), hipMemcpyDeviceToDevice, s.stream) != hipSuccess)
+    return 1;
+  const hipError_t e = hipStreamSynchronize(s.stream);
+  if (e != hipSuccess) { fail(e, "umpcUpdate (compat bounds-reject path)"); return 1; }
+  s.h->last_kernel = "bqp_solve_kernel";
+  return 0;
 }
 }  // namespace
 
@@ -706,7 +773,13 @@ void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, floa
   // Re-initialising a POD that already carries a live controller (the reference allows it: a gain sweep, a Simulink
   // or MCU start / stop) releases the previous controller first -- its batch handle, ctrl record, pinned buffer and
   // stream -- instead of orphaning them. An uninitialised POD matching both the magic and a live id is not a concern.
-  release_locked(pod_id(up));
+  // Only when THIS address is the POD the controller was built for: a by-value copy of a live POD (`b = a;
+  // umpcInit(&b, ...)`, which the reference's plain-value struct allows) carries a's id but must not destroy a's
+  // controller -- it simply gets its own. (Copies that are not re-initialised alias one controller.)
+  {
+    auto it = g_single.find(pod_id(up));
+    if (it != g_single.end() && it->second.owner == up) release_locked(it->first);
+  }
   // host-visible part of uprightmpc2.c:19-118
   memset(up, 0, sizeof(*up));
   up->dt = dt; up->g = g; up->Tmax = TtoWmax * g;
@@ -747,6 +820,8 @@ void umpcInit(UprightMPC_t *up, float dt, float g, float TtoWmax, float ws, floa
   (void)hipStreamSynchronize(s.stream);
   const uint32_t id = g_next_id++, w[2] = {kMagic, id};
   memcpy(up->smin, w, sizeof(w));
+  s.owner = up;
+  if (const char *c = getenv("UMPC_COMPAT")) s.compat = atoi(c);
   g_single[id] = s;
 }
 
@@ -770,7 +845,19 @@ int umpcUpdate(UprightMPC_t *up, float uquad[3], float accdes[6], const float p0
   float *d = s.hdev;
   // UMPC_DROPIN_TWO_LAUNCHES=1: the round-2 form (assembly kernel + step kernel + stream synchronisation), for A/B timing
   static const bool two_launches = getenv("UMPC_DROPIN_TWO_LAUNCHES") != nullptr || getenv("UMPC_NO_ASM_STEP") != nullptr;
-  if (two_launches || s.h->prm.maxIter < 1) {
+  bool rejected = false;
+  if (s.compat & UMPC_COMPAT_BOUNDS_REJECT) {
+    // osqp.c:801-808 on the bounds as assembled (the debug-field kernel's l, u: what up->l / up->u show in the reference too)
+    int rc = assemble_launch(s.h, d + O_STATE, s.ctrl, d + O_REF, nullptr, d + O_AT0, d + O_L, d + O_U, d + O_Q,
+                             d + O_PX, d + O_AX, s.stream);
+    if (rc) return 1;
+    const hipError_t e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
+    for (int i = 0; i < UMPC_NC; ++i) rejected = rejected || (hb[O_L + i] > hb[O_U + i]);
+  }
+  if (rejected) {
+    if (compat_reject_step(s, up)) return 1;
+  } else if (two_launches || s.h->prm.maxIter < 1) {
     int rc = assemble_launch(s.h, d + O_STATE, s.ctrl, d + O_REF, nullptr, d + O_AT0, d + O_L, d + O_U, d + O_Q,
                              d + O_PX, d + O_AX, s.stream);
     if (!rc)
@@ -794,18 +881,27 @@ int umpcUpdate(UprightMPC_t *up, float uquad[3], float accdes[6], const float p0
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
     volatile unsigned *f0 = (volatile unsigned *)(hb + O_DONE0), *f1 = (volatile unsigned *)(hb + O_DONE1);
-    // a healthy call completes in ~0.15 ms; after ~50 ms of polling fall back to the stream (which also reports a fault)
+    // a healthy call completes in ~0.15 ms: poll for at most 50 ms of wall clock (checked every 256 polls), then fall
+    // back to the streams, which also report a fault
     bool done = false;
-    for (long spin = 0; spin < 20000000L; ++spin) {
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+    for (unsigned spin = 1;; ++spin) {
       if (*f0 == seq && *f1 == seq) { done = true; break; }
+      if ((spin & 255u) == 0 && std::chrono::steady_clock::now() > t_end) break;
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#endif
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (!done) {
       e = hipStreamSynchronize(s.stream);
       const hipError_t e2 = hipStreamSynchronize(s.stream2);
-      if (e != hipSuccess || e2 != hipSuccess || *f0 != seq || *f1 != seq) {
+      if (e != hipSuccess || e2 != hipSuccess) {
         fail(e != hipSuccess ? e : e2, "umpcUpdate: kernel did not complete");
+        return 1;
+      }
+      if (*f0 != seq || *f1 != seq) {
+        g_err = "umpcUpdate: both streams drained without error but a completion word was not written";
         return 1;
       }
     }
@@ -839,6 +935,14 @@ int umpcLastStatus(const UprightMPC_t *up) {
 int umpcLiveControllers(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   return (int)g_single.size();
+}
+int umpcSetCompat(UprightMPC_t *up, int flags) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_single.find(pod_id(up));
+  if (it == g_single.end()) return -1;
+  const int prev = it->second.compat;
+  it->second.compat = flags;
+  return prev;
 }
 void umpcRelease(UprightMPC_t *up) {
   std::lock_guard<std::mutex> lk(g_mu);

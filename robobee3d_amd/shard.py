@@ -16,12 +16,27 @@ def world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def free_port():
+    """A TCP port that is free on 127.0.0.1 right now (rendezvous ports are never fixed numbers: a shared node may run
+    several jobs)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def init(backend=None, device=None, force=False):
     """force: initialise the process group even for world_size 1 (rehearsal of the RCCL path on a one-GPU box)"""
     rank, ws, local_rank = world()
     if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            # a launcher (torchrun, bench.py's self-launch) always provides the port; only a lone process that forces a
+            # group (world_size 1) gets here, and it may pick any free one
+            if ws > 1:
+                raise RuntimeError("MASTER_PORT is not set: start the ranks with torch.distributed.run (or `python bench.py "
+                                   "--gpus N`, which picks a free port itself)")
+            os.environ["MASTER_PORT"] = str(free_port())
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl" and device is not None:

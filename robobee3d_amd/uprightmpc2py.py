@@ -18,6 +18,9 @@ import numpy as np
 from . import _lib
 
 
+COMPAT_BOUNDS_REJECT = 1     # include/umpc_mi355x.h UMPC_COMPAT_BOUNDS_REJECT
+
+
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -61,6 +64,14 @@ class UprightMPC2C:
     def status(self):
         """OSQP status code of the last update (extension; the reference drops it)."""
         return int(self._L.umpcLastStatus(C.byref(self.umpc)))
+
+    def set_compat(self, flags):
+        """umpcSetCompat (extension): opt-in reference compatibility switches, e.g. COMPAT_BOUNDS_REJECT = the reference's
+        handling of crossed bounds (osqp.c:801-808 + uprightmpc2.c:246). Returns the previous flags."""
+        rc = int(self._L.umpcSetCompat(C.byref(self.umpc), C.c_int(int(flags))))
+        if rc < 0:
+            raise RuntimeError("umpcSetCompat: no live controller")
+        return rc
 
 
 class WLCon:

@@ -77,3 +77,31 @@ def test_codegen_is_deterministic():
     a, _ = asmgen.program()
     b, _ = asmgen.program()
     assert a == b
+
+
+_IMPORT_LINES = """
+import sys
+sys.path[:] = [p for p in sys.path if p not in ("", %(root)r)] + [%(root)r]
+from uprightmpc2py import UprightMPC2C # C version               (template/template_controllers.py:5, verbatim)
+from uprightmpc2py import UprightMPC2C, WLCon                    # (template/robobee_test_controllers.py:9, verbatim)
+import inspect, uprightmpc2py, os
+assert os.path.dirname(os.path.abspath(uprightmpc2py.__file__)) == %(root)r
+sig = inspect.signature(UprightMPC2C.update)
+# template/uprightmpc2.py:139 calls update with SIX arguments; template/uprightmpc2/py/uprightmpc2py.cpp:38 has seven
+assert list(sig.parameters)[1:] == ["p0", "R0", "dq0", "pdes", "dpdes", "sdes", "actualT0"]
+assert sig.parameters["actualT0"].default == -1.0
+assert list(inspect.signature(UprightMPC2C.__init__).parameters)[1:] == ["dt", "g", "TtoWmax", "ws", "wds", "wpr", "wpf",
+    "wvr", "wvf", "wthrust", "wmom", "Ib", "maxIter"]
+assert list(inspect.signature(WLCon.__init__).parameters)[1:] == ["u0", "umin", "umax", "dumax", "Qw", "controlRate", "popts"]
+print("ok")
+"""
+
+
+def test_reference_import_lines_run_unchanged(lib):
+    """`from uprightmpc2py import UprightMPC2C, WLCon` -- the import the reference executes -- works
+    with only the repository root added to sys.path (a top-level module, not a one-line edit of the reference)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _IMPORT_LINES % dict(root=ROOT)], capture_output=True, text=True,
+                       cwd="/", env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]

@@ -11,9 +11,32 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                            ("asmgen64", "umpc_admm_asm64.h"), ("asmstep", "umpc_step_asm.h")])
 def test_committed_header_is_current(tmp_path, module, fname):
     import importlib
-    for k in ("UMPC_ASM64_TIMING", "UMPC_ASM64_AHEAD", "UMPC_ASM64_MERGE", "UMPC_ASM_XV", "UMPC_ASM_LIMIT_FAST"):
-        assert k not in os.environ, "generator switches must be off for this comparison"
+    from robobee3d_amd import asmgen
+    assert not asmgen.generator_switches(), "generator switches must be off for this comparison"
     mod = importlib.import_module("robobee3d_amd." + module)
     out = str(tmp_path / fname)
     mod.write(out)
     assert open(out).read() == open(os.path.join(CSRC, fname)).read(), "%s is stale: run __graft_entry__.build()" % fname
+
+
+def test_committed_headers_say_which_switches_made_them():
+    """every committed instruction stream carries the switch banner of a default-environment generation"""
+    for fname in ("umpc_admm_asm.h", "umpc_admm_asm64.h", "umpc_step_asm.h"):
+        head = open(os.path.join(CSRC, fname)).read(400)
+        assert "// generator switches: none (defaults = the shipped kernels)" in head, fname
+
+
+def test_build_refuses_generator_switches(monkeypatch):
+    """_lib.build() rewrites tracked headers and the shipped library, so it must refuse to run under a stray
+    A/B switch (variants go through tools/build_variant.py into robobee3d_amd/variants/)."""
+    from robobee3d_amd import _lib, asmgen
+    monkeypatch.setenv("UMPC_ASM_LIMIT_FAST", "1")
+    assert asmgen.generator_switches() == {"UMPC_ASM_LIMIT_FAST": "1"}
+    assert "UMPC_ASM_LIMIT_FAST=1" in asmgen.switch_banner()
+    before = {f: os.path.getmtime(os.path.join(CSRC, f)) for f in ("umpc_step_asm.h", "umpc_admm_asm.h")}
+    with pytest.raises(RuntimeError, match="generator switches"):
+        _lib.build()
+    assert before == {f: os.path.getmtime(os.path.join(CSRC, f)) for f in before}
+    monkeypatch.setenv("UMPC_QP_KERNEL", "tables")       # a run-time diagnostic, not a generator switch
+    monkeypatch.delenv("UMPC_ASM_LIMIT_FAST")
+    assert asmgen.generator_switches() == {}

@@ -221,3 +221,38 @@ def test_live_reference_matches_fixture(structure):
         uq, ac = r.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k],
                           seq["sdes"][k], float(seq["actualT0"][k]))
         assert np.array_equal(uq, seq["uquad"][k]) and np.array_equal(ac, seq["accdes"][k])
+
+
+def test_status_boundary_restatement_and_cpu_flip_distances(oracle_built, structure, margin):
+    """tests/status_boundary.py (the checker the GPU golden test uses for status flips) against the reference's own
+    record: its float64 restatement of compute_pri_tol / compute_dua_tol + the two-stage test of osqp.c:555-573
+    reproduces EVERY status word of the 256-call fixture from the reference's pri_res / dua_res, and the status flips
+    between the reference and the oracle's canonical fp32 evaluation of the same algorithm all sit at that boundary
+    (what a flip 'away from the boundary' is measured against)."""
+    import status_boundary as sb
+    seq = golden("seq_iter50.npz")
+    n = len(seq["p0"])
+    for k in range(n):
+        ep, ed = sb.thresholds(structure, seq, k)
+        pri, dua = float(seq["pri_res"][k]), float(seq["dua_res"][k])
+        want = 1 if (pri < ep and dua < ed) else 2 if (pri < 10 * ep and dua < 10 * ed) else -2
+        assert want == int(seq["status"][k]), k
+    o = oracle_built.Oracle(np.float32, perm=structure["perm"])
+    stat = np.zeros(n, np.int32)
+    for k in range(n):
+        o.set_canonical(True, seq["pre_E3"][k])
+        o.set_iterates(seq["pre_x"][k], seq["pre_y"][k], seq["pre_z"][k])
+        o.set_T0(float(seq["pre_T0"][k]))
+        o.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k], seq["sdes"][k],
+                 float(seq["actualT0"][k]))
+        stat[k] = o.get("status_val")[0]
+    nflip, worst, arg = sb.worst_flip(structure, seq, stat)
+    assert 0 < nflip <= 32
+    margin("canonical fp32 oracle vs reference: worst flip factor (%d flips)" % nflip, worst, 8.0)
+    # the helper does fail a flip away from the boundary: a robot the reference solved with both residuals >= 20x
+    # inside its tolerances, reported as MAX_ITER_REACHED
+    far = [k for k in range(n) if seq["status"][k] == 1 and
+           max(seq["pri_res"][k] / sb.thresholds(structure, seq, k)[0], seq["dua_res"][k] / sb.thresholds(structure, seq, k)[1]) < 0.05]
+    if far:
+        assert sb.flip_distance(structure, seq, far[0], -2) > 8.0
+        assert sb.flip_distance(structure, seq, far[0], 2) > 8.0

@@ -257,6 +257,72 @@ def test_bounds_reject_path_documented_difference(torch_cuda, oracle_built, stru
     assert dref > 1.0, dref     # ... and it is NOT the reference's placeholder solve (moments differ by O(1..10))
 
 
+def test_bounds_reject_compat_switch_reproduces_the_reference(torch_cuda, margin):
+    """Round 4: with umpcSetCompat(up, UMPC_COMPAT_BOUNDS_REJECT) the drop-in reproduces the REFERENCE on
+    crossed bounds (TtoWmax < 0): osqp_update_bounds returns before applying anything (osqp.c:801-808), umpcUpdate drops
+    the value (uprightmpc2.c:246), the step solves with the bounds the workspace still holds -- the generated placeholder
+    l = 0, u = 1e30, every row an inequality at rho = 0.1 (workspace.c:476-557) -- and the new q, P, A. Checked against the
+    12 calls of the COMPILED REFERENCE in tests/golden/bounds_reject.npz: commands inside the fp32 band of a warm-started
+    sequence (test_reference_boundary_dropin_sequence's), every status word equal, up->l / up->u the assembled (crossed)
+    pair; then the default (switch off) is still the documented canonical behaviour (thrust driven to Tmax)."""
+    from robobee3d_amd.uprightmpc2py import COMPAT_BOUNDS_REJECT, UprightMPC2C
+    seq = golden("bounds_reject.npz")
+    Ib = np.array([3333., 3333., 1000.])
+    upc = UprightMPC2C(5, 9.81e-3, -2.0, 1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2, Ib, 50)
+    assert upc.set_compat(COMPAT_BOUNDS_REJECT) == 0
+    wt = wm = wa = 0.0
+    nstat = 0
+    for k in range(len(seq["p0"])):
+        uq, ac = upc.update(seq["p0"][k], seq["R0"][k], seq["dq0"][k], seq["pdes"][k], seq["dpdes"][k], seq["sdes"][k],
+                            float(seq["actualT0"][k]))
+        l, u, _ = upc.vectors()
+        assert np.all(l[36:] > u[36:])
+        ru, ra = seq["uquad"][k].astype(np.float64), seq["accdes"][k].astype(np.float64)
+        wt = max(wt, abs(float(uq[0]) - ru[0]))
+        wm = max(wm, float(np.max(np.abs(uq[1:] - ru[1:]) / np.maximum(2e-2, 1e-3 * np.abs(ru[1:])))))
+        wa = max(wa, float(np.max(np.abs(ac - ra))))
+        nstat += int(upc.status() != int(seq["status"][k]))
+    margin("compat bounds-reject vs the compiled reference |d thrust| (12-call sequence)", wt, 1e-4)
+    margin("compat bounds-reject vs the compiled reference |d moment| / max(2e-2, 1e-3|u|)", wm, 3.0)
+    margin("compat bounds-reject vs the compiled reference |d accdes|", wa, 1e-4)
+    margin("compat bounds-reject: status words differing from the reference's (of 12)", nstat, 2)
+    # default (no switch): the documented canonical behaviour, NOT the reference's placeholder solve
+    upd = UprightMPC2C(5, 9.81e-3, -2.0, 1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2, Ib, 50)
+    uq_d, _ = upd.update(seq["p0"][0], seq["R0"][0], seq["dq0"][0], seq["pdes"][0], seq["dpdes"][0], seq["sdes"][0],
+                         float(seq["actualT0"][0]))
+    assert np.max(np.abs(uq_d[1:] - seq["uquad"][0][1:])) > 1.0
+
+
+def test_init_on_a_copy_of_a_live_pod_does_not_destroy_the_original(torch_cuda):
+    """`b = a; umpcInit(&b, ...)` (the reference's plain-value struct allows it) gives b its own controller and
+    leaves a's alive; re-initialising a in place still releases a's previous controller."""
+    import ctypes as C
+    from robobee3d_amd import _lib
+    L = _lib.lib()
+    seq = golden("seq_iter50.npz")
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    Ib = f32([3333.0, 3333.0, 1000.0])
+    prm = [C.c_float(v) for v in (5.0, 9.81e-3, 2.0, 1e1, 1e3, 1.0, 5.0, 1e3, 2e3, 1e-1, 1e-2)]
+    n0 = L.umpcLiveControllers()
+    a = _lib.UprightMPC_t()
+    L.umpcInit(C.byref(a), *prm, fp(Ib), C.c_int(50))
+    b = _lib.UprightMPC_t()
+    C.memmove(C.byref(b), C.byref(a), C.sizeof(a))          # b = a
+    L.umpcInit(C.byref(b), *prm, fp(Ib), C.c_int(50))
+    assert L.umpcLiveControllers() == n0 + 2
+    args = [f32(seq["p0"][0]), f32(seq["R0"][0].T.ravel()), f32(seq["dq0"][0]), f32(seq["pdes"][0]),
+            f32(seq["dpdes"][0]), f32(seq["sdes"][0])]
+    ua, ub, ac = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(6, np.float32)
+    assert L.umpcUpdate(C.byref(a), fp(ua), fp(ac), *[fp(x) for x in args], C.c_float(-1.0)) == 0     # a is still alive
+    assert L.umpcUpdate(C.byref(b), fp(ub), fp(ac), *[fp(x) for x in args], C.c_float(-1.0)) == 0
+    assert np.array_equal(ua, ub)
+    L.umpcInit(C.byref(a), *prm, fp(Ib), C.c_int(50))       # in place: releases a's previous controller
+    assert L.umpcLiveControllers() == n0 + 2
+    L.umpcRelease(C.byref(a)); L.umpcRelease(C.byref(b))
+    assert L.umpcLiveControllers() == n0
+
+
 def test_reinitialising_a_pod_releases_the_previous_controller(torch_cuda):
     """The reference allows umpcInit on the same UprightMPC_t again (a gain sweep re-creates controllers,
     template/uprightmpc2.py:272-303; Simulink / MCU start and stop): here that must release the previous controller's

@@ -13,9 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_two_rank_gloo_shard_equals_single_process(tmp_path, oracle_built):
     per_rank, K = 48, 3
     out = str(tmp_path / "gathered.npz")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
+    from robobee3d_amd import shard
+    port = str(shard.free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "tests", "_shard_worker.py"), out, str(per_rank), str(K)]
     subprocess.run(cmd, check=True, env=env, cwd=ROOT, timeout=300, stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL)
@@ -65,6 +67,32 @@ def test_bench_self_launches_n_ranks():
     assert len(j["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in j["ms_per_step_per_rank"])
     assert j["ms_per_step_per_rank"][1] > j["ms_per_step_per_rank"][0]      # the dry-run ranks sleep 1 + rank ms per launch
     assert j["collectives"] == {"backend": "gloo", "world_size": 2, "gathered_robots": 192}
+
+
+def test_config5_shape_dry_run_on_eight_ranks():
+    """BASELINE configs[4]'s exact shape -- 2^17 robots per rank x 8 ranks = 2^20, Monte-Carlo draws keyed
+    by the global robot index -- through bench.py's own launcher on eight gloo ranks (CPU, no kernel): ONE line,
+    world size 8, 2^20 robots gathered in global order (bench.py asserts the order on rank 0), one time per rank. This
+    rehearses the rendezvous / sharding / gather of the 8-GPU run; it measures nothing and claims nothing about hardware."""
+    import json
+    r = _bench(["--gpus", "8", "--monte-carlo", "--batch", "131072", "--steps", "2", "--warmup", "1", "--dry-run"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["dry_run"] is True and j["value"] is None
+    assert j["config"]["global_batch"] == 2 ** 20 and j["config"]["robots_per_gpu"] == 2 ** 17
+    assert j["collectives"] == {"backend": "gloo", "world_size": 8, "gathered_robots": 2 ** 20}
+    assert len(j["ms_per_step_per_rank"]) == 8
+    assert j["ms_per_step"] is None          # dry run: nothing was measured (the per-rank entries are the ranks' sleeps)
+
+
+def test_rendezvous_ports_are_never_fixed():
+    """no literal rendezvous port left in the product, the bench or the tests (a collision risk on a shared node)"""
+    import re
+    for rel in ("robobee3d_amd/shard.py", "bench.py", "tests/test_gpu_parity.py", "tests/test_shard_gloo.py"):
+        txt = open(os.path.join(ROOT, rel)).read()
+        assert not re.search(r"[\"']295\d\d[\"']", txt), rel
 
 
 def test_bench_launcher_propagates_failure():

@@ -9,12 +9,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from robobee3d_amd import _lib, asmstep  # noqa: E402
+from robobee3d_amd import _lib, asmgen, asmstep  # noqa: E402
 
 name = sys.argv[1]
 vdir = os.path.join(ROOT, "robobee3d_amd", "variants")
 os.makedirs(vdir, exist_ok=True)
-_lib.build()                                   # everything else up to date (objects of the other units are reused)
+# everything else up to date (objects of the other units are reused): the default build, in a child process WITHOUT the
+# generator switches -- _lib.build() refuses to regenerate the shipped kernels under them
+clean = {k: v for k, v in os.environ.items() if k not in asmgen.generator_switches()}
+subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from robobee3d_amd import _lib; _lib.build()" % ROOT],
+               check=True, env=clean)
 hdr = os.path.join(vdir, "umpc_step_asm.h")
 asmstep.write(hdr)
 obj = os.path.join(vdir, name + ".o")
