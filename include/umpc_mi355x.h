@@ -209,7 +209,13 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
  * fp64: the C++ kernel with L and 1/D in LDS and the Ruiz passes and the ADMM phase as generated fp64 assembly
  * (robobee3d_amd/asmgen64.py; one workgroup per CU at a time, maxIter >= 1, batches up to ~4.8e5 robots), else the all-C++
  * kernel.
- * 1: always the C++ kernel -- fp32 around the assembly ADMM loop, fp64 with the C++ loop (ablation / cross-check). */
+ * In its scope the fp32 all-assembly stream exists in two forms with equal results up to rounding: one LANE per robot
+ * (64 robots per wavefront: throughput; B = 65 536 is one wave per SIMD) and one lane QUAD per robot (robobee3d_amd/
+ * asmquad.py: 16 robots per wavefront, ADMM iterations 2.. split over three lanes, ~0.6x the instructions per step:
+ * latency). Automatic = the quad form for B <= 16 384 (and for the B = 1 drop-in of Part 1), the lane form above.
+ * 1: always the C++ kernel -- fp32 around the assembly ADMM loop, fp64 with the C++ loop (ablation / cross-check).
+ * 2 / 3 (fp32): the all-assembly stream in its lane / quad form whatever the batch size (a run that must equal another
+ * batch size's run bit for bit -- a shard against the whole -- pins the form). */
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode);
 
 /* Static facts */

@@ -297,12 +297,16 @@ class Struct:
 # The generator
 # ----------------------------------------------------------------------------------------------------------
 class StepGen:
-    def __init__(self, N=3, perm=None):
+    def __init__(self, N=3, perm=None, quad=False):
+        """quad: one robot per lane QUAD (asmquad.py) -- every phase runs redundantly in the four lanes of a quad and the
+        ADMM iterations from the second on split the unknowns over lanes 0..2; the stream of the latency-bound shapes
+        (B = 1 drop-in, batches that cannot give every SIMD a wave)."""
         self.st = Struct(N, perm)
         self.s = self.st.s
         self.e = Emit()
         self.pool = Pool(self.e)
         self.lab = 20
+        self.quad = quad
 
     # ---- small emit helpers -----------------------------------------------------------------------------
     def label(self):
@@ -878,7 +882,7 @@ class StepGen:
             done_at.setdefault(r, []).append(c)
         nL, Dinv = {}, {}
         # XV_N more L entries live in v246..v255 through the loop (2 AGPR reads per iteration each otherwise)
-        asmgen.XV_COUNT, asmgen.XV_BASE = (XV_N if OPT_XV else 0), XV_B
+        asmgen.XV_COUNT, asmgen.XV_BASE = (XV_N if OPT_XV and not self.quad else 0), XV_B   # (quad: v254 / v255 hold y)
         pool.reserve(246, 10)         # L words and/or ring slots (OPT_RING)
         t = pool.get()
 
@@ -985,6 +989,25 @@ class StepGen:
         plan = st.plan
         zk = dict(qzero=st.qzero, lzero=st.lzero) if OPT_ZSKIP else {}
         asmgen.body(e, s, first=True, capture=True, plan=plan, delta_in_w=True, **zk)
+        if self.quad:
+            # iterations 2..maxIter on the lane quad: entry transposition, the quad bodies, the broadcast back into the
+            # one-lane homes phase C reads (asmquad.section); nothing else of the stream changes
+            from . import asmquad
+            lab6 = self.label()
+            e("s_cmp_lt_i32", sg(S_ITERS), 2)
+            e("s_cbranch_scc1", lab6 + "f")
+            asmquad.section(e, asmquad.QuadPlan(st), self.label)
+            e("label", lab6)
+        else:
+            self._admm_rest(plan, zk)
+        # x, y, thrust-row z, delta_x (x part of W), delta_y (z part of W) stay where they are; z == l on the dynamics rows
+        for i in range(st.neq):
+            pool.free(V_Z + st.zs[i], kill=True)
+        pool.free_range(246, 10)
+
+
+    def _admm_rest(self, plan, zk):
+        e, s = self.e, self.s
         for p_ in range(NVZ):      # the z registers of the dynamics rows take the L entries parked in a0..a35
             e("v_accvgpr_read_b32", v(V_Z + p_), "a%d" % (A_L + p_))
         lab7, lab8, lab6 = self.label(), self.label(), self.label()
@@ -1001,10 +1024,6 @@ class StepGen:
         e("s_cbranch_scc1", lab6 + "f")
         asmgen.body(e, s, first=False, capture=True, plan=plan, lv=True, delta_in_w=True, **zk)
         e("label", lab6)
-        # x, y, thrust-row z, delta_x (x part of W), delta_y (z part of W) stay where they are; z == l on the dynamics rows
-        for i in range(st.neq):
-            pool.free(V_Z + st.zs[i], kill=True)
-        pool.free_range(246, 10)
 
     # ---- phase C ------------------------------------------------------------------------------------------
     def phase_c(self):
@@ -1843,31 +1862,46 @@ def fmt(t):
         return "buffer_wbl2 %s" % t[1]
     if m == "s_waitcnt":
         return "s_waitcnt " + " ".join(a)
+    if m.endswith("_dpp"):          # the DPP control follows the operands without a comma
+        return "%s %s %s" % (m, ", ".join(a[:-1]), t[-1])
     return "%s %s%s" % (m, ", ".join(a), mods)
 
 
-def write(path=None, N=3, perm=None):
-    path = path or os.path.join(HERE, "csrc", "umpc_step_asm.h")
-    g = StepGen(N, perm)
-    ins = [t for t in g.program() if t[0] != "kill"]
+PSEUDO = ("kill", "quad_begin", "quad_end")      # markers for the CPU interpreters, not instructions
+
+
+def write(path=None, N=3, perm=None, quad=False):
+    """quad: the one-robot-per-lane-quad stream (asmquad.py) -> csrc/umpc_step_asm_quad.h, macro UMPC_STEP_ASM_QUAD; it
+    shares struct StepParams with the one-lane header, which must be included first."""
+    path = path or os.path.join(HERE, "csrc", "umpc_step_asm_quad.h" if quad else "umpc_step_asm.h")
+    g = StepGen(N, perm, quad=quad)
+    ins = [t for t in g.program() if t[0] not in PSEUDO]
     used_s = sorted(set(range(4, 102)))
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, 256)] + ['"a%d"' % i for i in range(256)] + \
            ['"s%d"' % i for i in used_s]
-    out = ["// GENERATED by robobee3d_amd/asmstep.py -- do not edit.", asmgen.switch_banner(),
-           "// The all-assembly fp32 step kernel body: %d instructions (K closed-loop steps of one wavefront)." % len(ins),
-           "#pragma once", "#include <stdint.h>", "namespace umpcasm {",
-           "// parameter block read by the kernel with s_load (byte offsets are part of the generated code)",
-           "struct StepParams {"]
-    for n in PTRS:
-        out.append("  const void *%s;" % n)
-    for n in INTS:
-        out.append("  int32_t %s;" % n)
-    for n in FLOATS:
-        out.append("  float %s;" % n)
-    out += ["};", "static_assert(sizeof(StepParams) == %d, \"StepParams layout\");" % ((PARAM_BYTES + 7) // 8 * 8),
-            "constexpr int STEP_LDS_BYTES_PER_LANE = %d;" % (NLDS * 4), "}  // namespace umpcasm",
-            "// inputs: v0 = 4 * robot, v1 = lane LDS address, s[4:5] = &StepParams (kernarg)",
-            "#define UMPC_STEP_ASM(voff, ldsaddr, params) asm volatile( \\"]
+    if quad:
+        out = ["// GENERATED by robobee3d_amd/asmstep.py (quad=True) + asmquad.py -- do not edit.", asmgen.switch_banner(),
+               "// The all-assembly fp32 step kernel body, ONE ROBOT PER LANE QUAD (16 robots per wavefront): %d instructions."
+               % len(ins),
+               "// Every lane of a quad gets the same v0 (= 4 * robot) and its own LDS slice; include umpc_step_asm.h first (StepParams).",
+               "#pragma once",
+               "#define UMPC_STEP_ASM_QUAD(voff, ldsaddr, params) asm volatile( \\"]
+    else:
+        out = ["// GENERATED by robobee3d_amd/asmstep.py -- do not edit.", asmgen.switch_banner(),
+               "// The all-assembly fp32 step kernel body: %d instructions (K closed-loop steps of one wavefront)." % len(ins),
+               "#pragma once", "#include <stdint.h>", "namespace umpcasm {",
+               "// parameter block read by the kernel with s_load (byte offsets are part of the generated code)",
+               "struct StepParams {"]
+        for n in PTRS:
+            out.append("  const void *%s;" % n)
+        for n in INTS:
+            out.append("  int32_t %s;" % n)
+        for n in FLOATS:
+            out.append("  float %s;" % n)
+        out += ["};", "static_assert(sizeof(StepParams) == %d, \"StepParams layout\");" % ((PARAM_BYTES + 7) // 8 * 8),
+                "constexpr int STEP_LDS_BYTES_PER_LANE = %d;" % (NLDS * 4), "}  // namespace umpcasm",
+                "// inputs: v0 = 4 * robot, v1 = lane LDS address, s[4:5] = &StepParams (kernarg)",
+                "#define UMPC_STEP_ASM(voff, ldsaddr, params) asm volatile( \\"]
     for t in ins:
         out.append('  "%s\\n" \\' % fmt(t))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(params) \\')
@@ -2026,6 +2060,9 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
     cmpf = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: a > b, "ge": lambda a, b: a >= b,
             "eq": lambda a, b: a == b, "u": lambda a, b: (a != a) or (b != b)}
     pc = nexec = 0
+    nquad = [0]
+    self_neq = 2 * 3 * symbolic.NY
+    simulate.last_quad_instructions = 0
     with np.errstate(all="ignore"):
         while pc < len(ins):
             t = ins[pc]
@@ -2036,6 +2073,27 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
                 continue
             if m == "label":
                 pc += 1
+                continue
+            if m == "quad_begin":
+                # the one-robot-per-quad section (asmquad.py): the four lanes of a quad have run everything so far
+                # redundantly, so each starts from THIS lane's registers, AGPRs and LDS slice; afterwards the four lanes must
+                # agree on every one-lane home of the loop's outputs, and nothing else may be read again (poisoned)
+                from . import asmquad
+                assert exec_ == 1
+                V4, A4, L4 = np.tile(V, (4, 1)), np.tile(A, (4, 1)), np.tile(lds, (4, 1))
+                pc, nq = asmquad.simulate(ins, pc, V4, A4, L4, S)
+                nexec += nq
+                nquad[0] += nq
+                keep = set([0, 1]) | set(range(V_W, V_Z)) | set(range(V_Z + self_neq, V_Z + 40))
+                for r in range(256):
+                    if r in keep:
+                        assert (V4[1:4, r] == V4[0, r]).all(), "lanes of the quad disagree on v%d after the quad section" % r
+                        V[r] = V4[0, r]
+                    else:
+                        V[r] = POISON
+                assert (A4[1:4, A_LO:] == A4[0, A_LO:]).all()
+                A[:] = A4[0]
+                A[:A_LO] = POISON          # L, 1/D, q homes were consumed; bounds, thrust-row words and weights stay
                 continue
             nexec += 1
             assert nexec < max_exec, "runaway program"
@@ -2195,6 +2253,7 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
             else:
                 raise ValueError("unknown instruction %r" % (t,))
             pc += 1
+    simulate.last_quad_instructions = nquad[0]
     return nexec
 
 

@@ -17,6 +17,7 @@
 #define UMPC_STEP_ASM_HEADER "umpc_step_asm.h"
 #endif
 #include UMPC_STEP_ASM_HEADER
+#include "umpc_step_asm_quad.h"   // the same stream with one robot per lane QUAD (asmquad.py): the latency-bound shapes
 #include "umpc_models.h"
 #include "umpc_err.h"
 #include "umpc_n3_general.h"   // the N = 3 QP as data for the general-structure solver (compat bounds-reject path only)
@@ -91,6 +92,27 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_asm_kernel(const umpcasm:
   (void)prm;
   const void *pp = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
   UMPC_STEP_ASM(voff, ldsaddr, pp);
+}
+
+// One robot per lane QUAD (asmquad.py): 16 robots per wavefront. The four lanes of a quad get the SAME robot offset, run
+// every phase redundantly (each on its own LDS slice; their global stores write identical words to identical addresses)
+// and split the unknowns of ADMM iterations 2..maxIter over lanes 0..2 -- ~340 instructions per iteration instead of
+// 804. For batches that cannot give every SIMD a wave of its own anyway (B <= kQuadMaxB) and for the B = 1 drop-in.
+constexpr int kQuadMaxB = 16384;      // 1024 waves of 16 robots: one per SIMD
+__global__ __launch_bounds__(kBlock) void umpc_rollout_asm_quad_kernel(const umpcasm::StepParams prm, int B) {
+  __shared__ float4 lds[(umpcasm::STEP_LDS_BYTES_PER_LANE / 16) * kBlock];
+  const int b = blockIdx.x * (kBlock / 4) + (int)(threadIdx.x >> 2);
+  if (b >= B) return;                 // (whole quads: the generated stream keeps EXEC as it finds it)
+  const unsigned ldsaddr = (unsigned)(size_t)(&lds[threadIdx.x]);
+  const unsigned voff = (unsigned)b * 4u;
+  (void)prm;
+  const void *pp = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  UMPC_STEP_ASM_QUAD(voff, ldsaddr, pp);
+}
+// UMPC_QUAD=0 keeps every batch on the one-lane kernel, UMPC_QUAD=<n> moves the switch-over batch size (A/B timing)
+static int quad_max_b() {
+  static const int v = [] { const char *e_ = getenv("UMPC_QUAD"); return e_ ? atoi(e_) : kQuadMaxB; }();
+  return v;
 }
 
 template <typename T>
@@ -333,7 +355,7 @@ struct umpc_batch {
   double t_ms = 0;               // time of the next MPC step (advanced by every rollout)
   const void *weights = nullptr;  // [8][B] device table or null
   void *ws;  // [WS_ROWS][B] scratch the step parks Ruiz scalings / x_prev / delta_y in
-  int step_kernel = 0;            // 0 = automatic (all-assembly fast path when it applies), 1 = always the C++ / loop-assembly kernel
+  int step_kernel = 0;            // 0 = automatic, 1 = always the C++ / loop-assembly kernel, 2 / 3 = the all-assembly stream with one lane / one lane quad per robot
   umpc::WLDev *wl = nullptr;      // device copy of the WL parameters (umpcBatchSetWL), null = no coupling
   void *wlu = nullptr, *wlw = nullptr;
   float wl_md2 = 0.f;             // M0[2,2] of the WL coupling (host copy, for the kernel's mb g)
@@ -395,7 +417,7 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
     // (32-bit lane offsets inside one array: the largest is ctrl, 127 rows; the kernel's workspace pointer is the row it
     // parks D, E, c in, so the 559-row workspace does not count)
     const bool fits = (size_t)UMPC_CTRL_ROWS * (size_t)h->B * 4 < ((size_t)1 << 31);
-    if (!no_asm && h->step_kernel == 0 && fits && K >= 1 && h->prm.maxIter >= 1) {
+    if (!no_asm && h->step_kernel != 1 && fits && K >= 1 && h->prm.maxIter >= 1) {
       umpcasm::StepParams p = make_step_params(h, K, nsub, state, ctrl, ref, actualT0, Ib, gain, out, stats, status, info);
       // SURVEY 8(f) options of the same stream: task generator (a table of K entries written by a K-thread kernel ahead
       // of the launch, same stream), per-robot weights, the fused WL step
@@ -415,6 +437,13 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
       static const int skew_us10 = [] { const char *e_ = getenv("UMPC_ASM_SKEW_US"); return e_ ? (int)(atof(e_) * 10) : 0; }();
       static const int skew_groups = [] { const char *e_ = getenv("UMPC_ASM_SKEW_GROUPS"); return e_ ? atoi(e_) : 4; }();
       const int skew_ticks = (h->B >= 32768 && K >= 2) ? skew_us10 * 10 : 0;
+      if (h->step_kernel == 3 || (h->step_kernel == 0 && h->B <= quad_max_b())) {
+        hipLaunchKernelGGL(umpc_rollout_asm_quad_kernel, dim3((h->B + kBlock / 4 - 1) / (kBlock / 4)), dim3(kBlock), 0,
+                           (hipStream_t)stream, p, h->B);
+        h->last_kernel = "umpc_rollout_asm_quad_kernel";
+        hipError_t eq = hipGetLastError();
+        return eq == hipSuccess ? 0 : fail(eq, "umpcBatchRollout");
+      }
       hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, p, h->B, skew_ticks,
                          skew_groups < 1 ? 1 : skew_groups);
       h->last_kernel = "umpc_rollout_asm_kernel";
@@ -559,7 +588,7 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights) {
   return 0;
 }
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode) {
-  if (!h || mode < 0 || mode > 1) { g_err = "umpcBatchSetStepKernel: bad argument"; return -1; }
+  if (!h || mode < 0 || mode > 3 || (mode > 1 && h->dtype != UMPC_F32)) { g_err = "umpcBatchSetStepKernel: bad argument"; return -1; }
   h->step_kernel = mode;
   return 0;
 }
@@ -873,11 +902,14 @@ int umpcUpdate(UprightMPC_t *up, float uquad[3], float accdes[6], const float p0
     umpcasm::StepParams p = make_step_params(s.h, 1, 0, d + O_STATE, s.ctrl, d + O_REF, d + O_AT0, nullptr, nullptr, d + O_OUT,
                                              nullptr, (int32_t *)(d + O_STATUS), d + O_INFO);
     p.done = d + O_DONE0; p.seq = (int)seq;
-    hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1, 0, 1);
+    if (quad_max_b() >= 1)
+      hipLaunchKernelGGL(umpc_rollout_asm_quad_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1);
+    else
+      hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1, 0, 1);
     hipLaunchKernelGGL(umpc_dropin_debug_kernel, dim3(1), dim3(64), 0, s.stream2, make_dev<float>(s.h->prm),
                        (const float *)(d + O_STATE), (const float *)(d + O_REF), (const float *)(d + O_T0DBG), d + O_L, d + O_U,
                        d + O_Q, d + O_PX, d + O_AX, (unsigned *)(d + O_DONE1), seq);
-    s.h->last_kernel = "umpc_rollout_asm_kernel";
+    s.h->last_kernel = quad_max_b() >= 1 ? "umpc_rollout_asm_quad_kernel" : "umpc_rollout_asm_kernel";
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
     volatile unsigned *f0 = (volatile unsigned *)(hb + O_DONE0), *f1 = (volatile unsigned *)(hb + O_DONE1);

@@ -326,6 +326,7 @@ def test_full_size_hover_properties(torch_cuda):
     st2, ref2 = hover_initial_conditions(n, 20201118, index_offset=off)
     np.testing.assert_array_equal(st2, st[:, off:off + n])
     sub = BatchUprightMPC(n, torch.float32)
+    sub.set_step_kernel("lane")     # the whole batch ran the lane form of the stream; 4096 robots alone would take the quad form
     sub.set_state(st2, ref2)
     sub.rollout(K)
     np.testing.assert_array_equal(sub.state.cpu().numpy(), mpc.state[:, off:off + n].cpu().numpy())
@@ -735,3 +736,104 @@ print(" ".join("%%.9g" %% v for v in list(u) + list(acc)))
             assert abs(vals[0] - seq["uquad"][k][0]) <= TOL_T * sc
             assert np.all(np.abs(vals[1:3] - seq["uquad"][k][1:]) <= sc * tol_tau(seq["uquad"][k][1:]))
             assert np.abs(vals[3:] - seq["accdes"][k]).max() <= TOL_A * sc
+
+
+def test_quad_form_of_the_stream_on_the_gpu(torch_cuda, oracle_built, margin):
+    """Round 4: the one-robot-per-lane-quad form of the all-assembly stream (asmquad.py), the form
+    batches of <= 16 384 robots and the B = 1 drop-in take. (a) it is what "auto" dispatches there; (b) against the lane
+    form on the same 4 096 robots over 6 closed-loop steps: equal up to the rounding of a different summation order,
+    every status word equal or both at the tolerance boundary family; (c) robot i computes in a ragged batch (37
+    robots: a wave with 5 of its 16 quads live) and alone (B = 1) bit for bit what it computes among 4 096 -- quads are
+    independent, dead quads stay dead through the EXEC switches of the entry transposition; (d) the quad form at the
+    headline size equals its own small-batch run bit for bit too (forced: throughput there is the lane form's job);
+    (e) against the fp64 oracle on a sample, the quad form is inside the closed-loop fp32 band."""
+    torch = torch_cuda
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    B, K = 4096, 6
+    st, ref = hover_initial_conditions(B, 20201118)
+    res = {}
+    for form in ("auto", "lane", "quad"):
+        m = BatchUprightMPC(B, torch.float32, plant_mode=1)
+        m.set_step_kernel(form)
+        m.set_state(st, ref)
+        m.rollout(K // 2)
+        m.rollout(K - K // 2)
+        assert m.kernel_name == ("umpc_rollout_asm_kernel" if form == "lane" else "umpc_rollout_asm_quad_kernel")
+        res[form] = [t.cpu().numpy().astype(np.float64) for t in (m.state, m.out, m.stats, m.ctrl)] + [m.status.cpu().numpy()]
+    for k in range(5):
+        assert np.array_equal(res["auto"][k], res["quad"][k])
+    a, c = res["quad"], res["lane"]
+    lab = "quad vs lane form, B = 4096, K = 6: "
+    margin(lab + "|dp| mm", float(np.abs(a[0][0:3] - c[0][0:3]).max()), 5e-4)
+    margin(lab + "|dR|, |ddq|", float(np.abs(a[0][3:] - c[0][3:]).max()), 6e-5)
+    margin(lab + "|d thrust|", float(np.abs(a[1][0] - c[1][0]).max()), 1e-5)
+    margin(lab + "|d moment| / max(2e-2, 1e-3|u|)", float((np.abs(a[1][1:3] - c[1][1:3]) / np.maximum(2e-2, 1e-3 * np.abs(c[1][1:3]))).max()), 0.6)
+    margin(lab + "stats relative", float(np.max(np.abs(a[2] - c[2]) / (1e-6 + np.abs(c[2])))), 1e-3)
+    margin(lab + "status words that differ (of 4096)", float(np.sum(a[4] != c[4])), 64)
+    assert set(np.unique(a[4])).issubset({1, 2, -2})
+    # (c) ragged and single
+    for n, off in ((37, 1000), (1, 4095), (16, 0), (17, 2048)):
+        sub = BatchUprightMPC(n, torch.float32, plant_mode=1)
+        sub.set_state(st[:, off:off + n], ref[:, off:off + n])
+        sub.rollout(K // 2)
+        sub.rollout(K - K // 2)
+        assert sub.kernel_name == "umpc_rollout_asm_quad_kernel"
+        assert np.array_equal(sub.state.cpu().numpy().astype(np.float64), a[0][:, off:off + n]), (n, off)
+        assert np.array_equal(sub.out.cpu().numpy().astype(np.float64), a[1][:, off:off + n])
+        assert np.array_equal(sub.ctrl.cpu().numpy().astype(np.float64), a[3][:, off:off + n])
+        assert np.array_equal(sub.status.cpu().numpy(), a[4][off:off + n])
+    # (d) forced quad form at the headline size
+    Bb = 65536
+    stb, refb = hover_initial_conditions(Bb, 20201118)
+    big = BatchUprightMPC(Bb, torch.float32, plant_mode=1)
+    big.set_step_kernel("quad")
+    big.set_state(stb, refb)
+    big.rollout(K // 2)
+    big.rollout(K - K // 2)
+    assert big.kernel_name == "umpc_rollout_asm_quad_kernel"
+    assert np.array_equal(big.state[:, :B].cpu().numpy().astype(np.float64), a[0])
+    assert bool(torch.isfinite(big.state).all())
+    # (e) oracle on a sample
+    perm = np.array(__import__("robobee3d_amd._lib", fromlist=["lib"]).lib().umpcKKTPerm().contents)
+    sel = np.arange(0, B, 128)
+    s_o = np.ascontiguousarray(st[:, sel], np.float64)
+    ctrl = np.zeros((127, len(sel))); ctrl[124:] = 1
+    out_o, _, _ = oracle_built.batch_rollout(s_o, ctrl, np.ascontiguousarray(ref[:, sel], np.float64), K, dtype=np.float64,
+                                             perm=perm, plant_mode=1)
+    margin("quad form vs fp64 oracle (32 robots, K = 6): |dp| mm", float(np.abs(a[0][0:3, sel] - s_o[0:3]).max()), 1e-3)
+    margin("quad form vs fp64 oracle: |dR|, |ddq|", float(np.abs(a[0][3:, sel] - s_o[3:]).max()), 1e-4)
+    margin("quad form vs fp64 oracle: |d thrust|", float(np.abs(a[1][0, sel] - out_o[0]).max()), TOL_T)
+    margin("quad form vs fp64 oracle: |d moment| / max(2e-2, 1e-3|u|)",
+           float((np.abs(a[1][1:3, sel] - out_o[1:3]) / tol_tau(out_o[1:3])).max()), 1.0)
+
+
+def test_dropin_runs_the_quad_form(torch_cuda):
+    """umpcUpdate (B = 1) dispatches the quad form; UMPC_QUAD=0 in a fresh process restores the lane form, and the two
+    agree inside the single-step band on the first call of the reference fixture."""
+    import os
+    import subprocess
+    import sys
+    from robobee3d_amd import _lib
+    from robobee3d_amd.uprightmpc2py import UprightMPC2C
+    seq = golden("seq_iter50.npz")
+    upc = UprightMPC2C(5, 9.81e-3, 2, 1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2, np.array([3333., 3333., 1000.]), 50)
+    uq, ac = upc.update(seq["p0"][0], seq["R0"][0], seq["dq0"][0], seq["pdes"][0], seq["dpdes"][0], seq["sdes"][0],
+                        float(seq["actualT0"][0]))
+    assert abs(uq[0] - seq["uquad"][0][0]) <= TOL_T and np.all(np.abs(uq[1:] - seq["uquad"][0][1:]) <= tol_tau(seq["uquad"][0][1:]))
+    assert np.abs(ac - seq["accdes"][0]).max() <= TOL_A
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys
+sys.path.append(%r)
+import numpy as np
+from robobee3d_amd.uprightmpc2py import UprightMPC2C
+seq = np.load(%r)
+upc = UprightMPC2C(5, 9.81e-3, 2, 1e1, 1e3, 1, 5, 1e3, 2e3, 1e-1, 1e-2, np.array([3333., 3333., 1000.]), 50)
+u, a = upc.update(seq["p0"][0], seq["R0"][0], seq["dq0"][0], seq["pdes"][0], seq["dpdes"][0], seq["sdes"][0], float(seq["actualT0"][0]))
+print(" ".join("%%.9g" %% v for v in list(u) + list(a)))
+""" % (root, os.path.join(root, "tests", "golden", "seq_iter50.npz"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/", env=dict(os.environ, UMPC_QUAD="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lane = np.array([float(t) for t in r.stdout.strip().splitlines()[-1].split()])
+    assert abs(lane[0] - uq[0]) <= TOL_T and np.all(np.abs(lane[1:3] - uq[1:]) <= tol_tau(uq[1:]))
+    assert np.abs(lane[3:] - ac).max() <= TOL_A

@@ -58,7 +58,7 @@ def test_closed_loop_with_task_matches_oracle(oracle_built, case):
     m32.set_state(st.astype(np.float32), ref.astype(np.float32))
     m32.set_task(names[task], t_ms=t0, **dict(zip(kwn, tp)))
     m32.rollout(K)
-    assert m32.kernel_name == "umpc_rollout_asm_kernel"      # the task generators are an option of the all-assembly stream
+    assert m32.kernel_name in ("umpc_rollout_asm_kernel", "umpc_rollout_asm_quad_kernel")      # the task generators are an option of the all-assembly stream
     s32 = m32.state.cpu().numpy().astype(np.float64)
     # straightAcc commands a 2 m/s velocity step: moments saturate at the clip and positions reach 40 mm,
     # so the fp32 band is relative there
@@ -112,7 +112,7 @@ def test_gain_sweep_per_robot_weights_match_oracle(oracle_built):
     m32.set_state(st.astype(np.float32), ref.astype(np.float32))
     m32.set_weights(W.astype(np.float32))
     m32.rollout(K)
-    assert m32.kernel_name == "umpc_rollout_asm_kernel"
+    assert m32.kernel_name in ("umpc_rollout_asm_kernel", "umpc_rollout_asm_quad_kernel")
     s32 = m32.state.cpu().numpy().astype(np.float64)
     s_o32 = st.astype(np.float32)
     c32 = np.zeros((127, B), np.float32); c32[124:] = 1
