@@ -214,8 +214,9 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
  * asmquad.py: 16 robots per wavefront, ADMM iterations 2.. split over three lanes, ~0.6x the instructions per step:
  * latency). Automatic = the quad form for B <= 16 384 (and for the B = 1 drop-in of Part 1), the lane form above.
  * 1: always the C++ kernel -- fp32 around the assembly ADMM loop, fp64 with the C++ loop (ablation / cross-check).
- * 2 / 3 (fp32): the all-assembly stream in its lane / quad form whatever the batch size (a run that must equal another
- * batch size's run bit for bit -- a shard against the whole -- pins the form). */
+ * 2 / 3: the assembly path in its lane / quad form whatever the batch size (a run that must equal another batch size's
+ * run bit for bit -- a shard against the whole -- pins the form). fp64 has the same two forms of its assembly ADMM phase
+ * (robobee3d_amd/asmquad64.py; automatic = the quad form for B <= 4 096, one workgroup per CU in one round). */
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode);
 
 /* Static facts */

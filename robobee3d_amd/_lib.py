@@ -138,12 +138,13 @@ def build(force=False, verbose=False):
     gn3 = codegen_n3.write()
     gasm, _ = asmgen.write()
     gasm64 = asmgen64.write()[0]
+    gasm64q = asmgen64.write_quad()[0]
     gstep, _ = asmstep.write()
     gquad, _ = asmstep.write(quad=True)
     greg, gqp_units = codegen_qp.write()
     hdr = os.path.join(ROOT, "include", "umpc_mi355x.h")
     csrc = os.path.join(HERE, "csrc")
-    units = [(SRC, [gen, gasm, gasm64, gstep, gquad, gn3, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
+    units = [(SRC, [gen, gasm, gasm64, gasm64q, gstep, gquad, gn3, hdr] + [os.path.join(csrc, f) for f in ("umpc_step.h", "umpc_models.h", "umpc_err.h")]),
              (SRC_BQP, [hdr, greg, os.path.join(csrc, "umpc_bqp_common.h"), os.path.join(csrc, "umpc_err.h")])]
     gen_hdrs = [os.path.join(csrc, "gen", f) for f in os.listdir(os.path.join(csrc, "gen")) if f.endswith(".h")]
     units += [(u, [os.path.join(csrc, "umpc_bqp_common.h")] + gen_hdrs) for u in gqp_units]

@@ -344,7 +344,8 @@ def prologue(e, s):
     preload_q(e, s)
 
 
-def body(e, s, first, capture):
+def body(e, s, first, capture, handoff=True):
+    """handoff=False (the quad form, asmquad64.py): the first iteration does not form the next iteration's right-hand side"""
     nx, nc, nk = s.nx, s.nc, s.nk
     N = s.N
     neq = 2 * N * symbolic.NY
@@ -546,7 +547,7 @@ def body(e, s, first, capture):
                 _row_ptr(e, S_P, S_WS, FAC_Q + j)
                 e("global_load_dwordx2", "a[%d:%d]" % (a_, a_ + 1), "v0", sp(S_P))
         e("s_waitcnt", "vmcnt(0)")
-        if fuse and not capture:
+        if fuse and not capture and handoff:
             # FUSE: the first iteration hands the second its right-hand side the classic way (x, y from LDS, q and l from the
             # homes just filled); from then on every iteration's updates do it for the next one
             ops = []
@@ -600,8 +601,8 @@ def epilogue(e, s):
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
 
 
-def program(N=3, perm=None):
-    """maxIter >= 1 (the caller takes the C++ loop otherwise)"""
+def program(N=3, perm=None, quad=False):
+    """maxIter >= 1 (the caller takes the C++ loop otherwise). quad: iterations 2.. on the lane quad (asmquad64.py)"""
     s = symbolic.analyse(N, perm)
     e = Emit()
     timing = os.environ.get("UMPC_ASM64_TIMING") == "1"      # diagnostic builds: 100 MHz stamps -> spare LDS words 297..
@@ -615,7 +616,15 @@ def program(N=3, perm=None):
     # the captures overwrite L in LDS, so only the LAST iteration captures: a single iteration is its own variant
     e("s_cmp_lt_i32", "s%d" % S_ITERS, 2)
     e("s_cbranch_scc1", "4f")
-    body(e, s, first=True, capture=False)
+    if quad:
+        from . import asmquad64
+        body(e, s, first=True, capture=False, handoff=False)
+        stamp(2)
+        asmquad64.section(e, asmquad64.plan_for(s), s)
+        stamp(3)
+        e("s_branch", "6f")
+    else:
+        body(e, s, first=True, capture=False)
     stamp(2)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_ITERS, 2)
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
@@ -655,7 +664,52 @@ def fmt(t):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
     if m == "s_waitcnt":
         return "s_waitcnt " + " ".join(a)
+    if m.endswith("_dpp") or (isinstance(t[-1], str) and t[-1].startswith("offset:")):     # trailing control / offset: no comma
+        return "%s %s %s" % (m, ", ".join(a[:-1]), t[-1])
     return "%s %s" % (m, ", ".join(a))
+
+
+PSEUDO = ("quad_begin", "quad_end")
+
+
+def write_quad(path=None, N=3, perm=None):
+    """csrc/umpc_admm_asm64_quad.h: the ADMM phase with one robot per lane quad (asmquad64.py) as UMPC_ADMM_ASM64_QUAD, and
+    csrc/umpc_quad64_tab.h, the constant table of per-lane coefficient addresses it reads through s[8:9]."""
+    from . import asmquad64
+    path = path or os.path.join(HERE, "csrc", "umpc_admm_asm64_quad.h")
+    ins, s = program(N, perm, quad=True)
+    ins = [t for t in ins if t[0] not in PSEUDO]
+    used_s = [S_P, S_P + 1, S_CNT, S_P2, S_P2 + 1] + list(range(S_ALPHA, S_RHO + 2)) + list(range(30, 38))
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
+           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
+    l17 = [k for k, t in enumerate(ins) if t == ("label", "17")][0]
+    l18 = [k for k, t in enumerate(ins) if t == ("label", "18")][0]
+    out = ["// GENERATED by robobee3d_amd/asmgen64.py (quad=True) + asmquad64.py -- do not edit.", asmgen.switch_banner(),
+           "// ADMM phase of the fp64 small-batch step kernel, ONE ROBOT PER LANE QUAD: %d instructions, middle-iteration body %d."
+           % (len(ins), l18 - l17),
+           "#pragma once",
+           "// inputs: v0 = 8*robot (the same in the four lanes of a quad), v1 = lane LDS address (16*lane), s[4:5] = workspace,",
+           "// s[6:7] = ctrl, s[8:9] = umpcquad64::kTab, s10 = 8*B, s11 = maxIter >= 1",
+           "#define UMPC_ADMM_ASM64_QUAD(voff, ldsaddr, ws, ctrl, tab, stride, iters) asm volatile( \\"]
+    for t in ins:
+        out.append('  "%s\\n" \\' % fmt(t))
+    out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(ws), "{s[6:7]}"(ctrl), "{s[8:9]}"(tab), "{s10}"(stride), "{s11}"(iters) \\')
+    out.append("  : " + ", ".join(clob) + ")")
+    txt = "\n".join(out) + "\n"
+    if not os.path.exists(path) or open(path).read() != txt:
+        with open(path, "w") as fh:
+            fh.write(txt)
+    tab = asmquad64.table(asmquad64.plan_for(s))
+    tpath = os.path.join(os.path.dirname(path), "umpc_quad64_tab.h")
+    ttxt = "// GENERATED by robobee3d_amd/asmgen64.py (write_quad) -- do not edit.\n#pragma once\n#include <stdint.h>\n" \
+           "// byte offset, from the lane's LDS base, of the entry of L that lane class (lane & 3) multiplies with in solve\n" \
+           "// instruction q of the quad loop (asmquad64.table); the zero word where it has none\n" \
+           "namespace umpcquad64 {\n__device__ const uint32_t kTab[4][%d] = {\n%s\n};\n}  // namespace umpcquad64\n" % (
+               tab.shape[1], ",\n".join("  {" + ", ".join(str(int(x)) for x in row) + "}" for row in tab))
+    if not os.path.exists(tpath) or open(tpath).read() != ttxt:
+        with open(tpath, "w") as fh:
+            fh.write(ttxt)
+    return path, len(ins), l18 - l17
 
 
 def write(path=None, N=3, perm=None):
@@ -725,9 +779,11 @@ def write(path=None, N=3, perm=None):
 # ---------------------------------------------------------------------------
 # CPU interpreter (one lane), exact-rounded float64
 # ---------------------------------------------------------------------------
-def simulate(ins, mem_ws, mem_ctrl, iters, lds):
+def simulate(ins, mem_ws, mem_ctrl, iters, lds, perm=None):
     """mem_ws: float64[WS_ROWS], mem_ctrl: float64[123], lds: float64[320] (L in words 0..212, 1/D in 213..296 on entry).
-    Updates the memories in place; returns the executed instruction count."""
+    Updates the memories in place; returns the executed instruction count. perm: the KKT permutation of the program (only
+    the quad form needs it, for its plan)."""
+    quad_perm_ = perm
     import numpy as np
     from fractions import Fraction
     V = np.zeros(256, np.uint32)
@@ -804,9 +860,36 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds):
         return set()
 
     pc = nexec = 0
+    simulate.last_quad_instructions = 0
     while pc < len(ins):
         t = ins[pc]
         m = t[0]
+        if m == "quad_begin":
+            # the one-robot-per-quad section (asmquad64.py): the four lanes of a quad ran everything so far redundantly, so
+            # each starts from this lane's registers, AGPRs and LDS slice; afterwards the four slices and the thrust-row
+            # words must agree, and the other registers are poisoned (the epilogue may only read what the exit restored)
+            from . import asmquad64
+            assert ins[pc + 1] == ("s_waitcnt", "vmcnt(0) lgkmcnt(0)")      # the section starts by draining the one-lane body's LDS writes
+            pend["lgkmcnt"].clear(); pend["vmcnt"].clear()
+            s_ = symbolic.analyse(3, quad_perm_)
+            V4, A4 = np.tile(V, (4, 1)), np.tile(A, (4, 1))
+            L4 = np.tile(np.asarray(lds, np.float64), (4, 1))
+            pc, nq = asmquad64.simulate(ins, pc, V4, A4, L4, S, asmquad64.table(asmquad64.plan_for(s_)))
+            nexec += nq
+            simulate.last_quad_instructions = nq
+            for ln in range(1, 4):
+                assert np.array_equal(L4[ln, :asmquad64.ZERO_WORD], L4[0, :asmquad64.ZERO_WORD]), "LDS slices of the quad disagree"
+            lds[:] = L4[0]
+            keep = {0, 1, V_B1, V_B2} | set(range(V_C, V_RING))
+            for r in range(256):
+                if r in keep:
+                    assert (V4[1:, r] == V4[0, r]).all(), r
+                    V[r] = V4[0, r]
+                else:
+                    V[r] = 0x7ff8dead if r % 2 else 0xdeadbeef      # a NaN pattern in every pair
+            A[:] = A4[0]
+            A[:A_H] = 0x7ff8dead
+            continue
         nexec += 1
         assert nexec < 2000000, "runaway program"
         if m == "s_waitcnt":

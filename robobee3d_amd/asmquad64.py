@@ -1,0 +1,551 @@
+"""ONE ROBOT PER LANE QUAD, fp64: ADMM iterations 2..maxIter of the small-batch fp64 step (asmgen64.py, BASELINE config 2:
+B = 4 096) -- the fp64 counterpart of asmquad.py. 4 096 robots are 64 one-lane waves on 64 of the chip's 256 CUs; with
+four lanes per robot they are 256 waves, one per CU (the fp64 loop owns its CU's LDS), and each iteration is ~950
+instructions with 311 fp64 operations instead of 1 483 with 786.
+
+Same idea as asmquad.py (its docstring has the reasoning): the phases around the loop run redundantly in the four lanes
+of a quad, the loop keeps a third of the unknowns in each of lanes 0..2, a triangular-solve operation runs in the lane
+of its destination, operations with one destination and one source register share an instruction (asmquad.QuadPlan is
+used unchanged). What differs for eight-byte words:
+
+  * v_fma_f64 is VOP3: no DPP operand. A source that lives in another lane is fetched with two v_mov_b32_dpp (low, high
+    word) into a temporary pair right before its consumer; consecutive consumers of one (register, selection) reuse it.
+  * a lane owns 121 words of VGPRs: W, x, y, 1/D and the thrust-row words (92 words) leave no room for the 189
+    coefficient words. They are NOT moved at all: every lane already holds the whole factor in its own LDS slice
+    (phase A wrote it there for the one-lane first iteration), so instruction q reads, in lane l, the word of L that lane
+    needs -- ds_read_b64 with a PER-LANE address. The 189 addresses per lane class are a constant table
+    (`table()`, csrc/umpc_quad64_tab.h), added to the lane's LDS base once per step and parked in AGPRs; a lane with
+    nothing to do in an instruction reads a word that holds 0.0. Reading 8 bytes at a per-lane word of the
+    [quad][lane] layout is conflict-free (the bank is decided by the lane, not by the word).
+  * q and l of the lane's unknowns sit in AGPR pairs (read once per iteration), composed from the one-lane homes.
+
+Exit: x, y, x_prev and delta_y of the capturing iteration go back to EVERY lane's LDS slice (two DPP moves + one
+ds_write_b64 per word), the thrust-row z to its registers: the epilogue and phase C read what they always read.
+Arithmetic = asmgen64.body's, operation for operation, except the order in which an unknown's updates are added up.
+
+Reference mapping: template/uprightmpc2/osqp.c:354-370, auxil.c:164-228, qdldl.c:250-293 (through asmgen64.body).
+"""
+import struct
+
+import numpy as np
+
+from . import asmquad, symbolic
+from .asmgen import S_ALPHA, S_CNT, S_ITERS, S_OMA, S_RHO, S_RINV, S_SIGMA
+from .asmquad import IX_EQ, IX_T, qperm
+
+# ---- VGPR words (first register of the pair); the block may use v2..v245, v172..v201 are the one-lane thrust-row words
+QYT, QZT, QLO3, QUP3, QRHO3, QRINV3 = 118, 120, 122, 124, 126, 128
+T_ADDR = [218, 219, 220, 221, 242, 243, 244, 245]          # LDS addresses of the next coefficient reads (ring of NRING)
+T_COEF = [222, 224, 226, 228, 234, 236, 238, 240]          # coefficient words in flight (ring of NRING)
+T_SRC = [230, 232]                     # sources fetched from another lane
+T_A = [234, 236, 238, 240]             # AGPR read / update temporaries (outside the solves: the ring is idle there)
+T_X = [242, 244]
+NRING = 8
+RD_AHEAD = 6                           # coefficient reads run this many solve instructions ahead (~100+ cycles of LDS latency
+                                       # for a lone wave at ~25 cycles per solve instruction); addresses one further
+STAGE = 4                              # entry staging: the (idle) W words, v4..v59 = 14 float4
+AQ, AL, ATAB = 0, 32, 56               # AGPRs: q (16 words), l (12 words), 189 coefficient addresses
+NTAB = 196                             # table row length (dwords): the 194 solve instructions + padding to whole dwordx4 loads
+ZERO_WORD = 319                        # this lane's LDS word that holds 0.0
+S_L0, S_L1, S_L2, S_EXEC, S_TAB = 30, 32, 34, 36, 8
+
+
+def QW(ix):
+    return 4 + 2 * ix
+
+
+def QX(ix):
+    return 62 + 2 * ix
+
+
+def QY(ix):
+    return 94 + 2 * ix
+
+
+def QDI(ix):
+    return 130 + 2 * ix if ix < 21 else 202 + 2 * (ix - 21)
+
+
+def vp(n):
+    return "v[%d:%d]" % (n, n + 1)
+
+
+def sp(n):
+    return "s[%d:%d]" % (n, n + 1)
+
+
+def rel_addr(word):
+    """byte offset of LDS word `word` from the lane's LDS base (asmgen64's [quad of two words][lane] layout)"""
+    return (word >> 1) * 1024 + 8 * (word & 1)
+
+
+def plan_for(s):
+    class _St:      # the two facts QuadPlan needs of asmstep.Struct
+        pass
+    st = _St()
+    st.s, st.neq = s, 2 * s.N * symbolic.NY
+    return asmquad.QuadPlan(st)
+
+
+def table(plan):
+    """uint32 [4][NTAB]: for lane class l (lane & 3) and solve instruction q (forward instructions first) the byte offset,
+    from the lane's LDS base, of the entry of L that lane multiplies with -- the zero word where it has none."""
+    tab = np.full((4, NTAB), rel_addr(ZERO_WORD), np.uint32)
+    for q, ins in enumerate(plan.fwd + plan.bwd):
+        for ln, o in ins["ops"].items():
+            tab[ln, q] = rel_addr(o[2])
+    return tab
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def entry(e, plan, s):
+    from . import asmgen64 as g
+    nx, nc, nk, neq = s.nx, s.nc, s.nk, 2 * s.N * symbolic.NY
+    v = lambda n: "v%d" % n
+    masks = (S_L0, S_L1, S_L2)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    e("s_mov_b64", sp(S_EXEC), "exec")
+    for ln, m in enumerate(masks):
+        e("s_mov_b32", "s%d" % m, 0x11111111 << ln)
+        e("s_mov_b32", "s%d" % (m + 1), 0x11111111 << ln)
+        e("s_and_b64", sp(m), sp(m), sp(S_EXEC))
+    # the coefficient-address table first: its loads land while everything else is moved
+    tb = T_X[0]
+    e("v_bfe_u32", v(tb), "v1", 4, 2)
+    e("v_mul_u32_u24", v(tb), NTAB * 4, v(tb))
+    # zero: the quad words of lanes that own nothing (lane 3, pads) and the AGPR words of q / l
+    zero = [QX(k) for k in range(16)] + [QY(k) for k in range(12)] + [QYT, QZT, QLO3, QUP3, QRHO3, QRINV3] + \
+           [QDI(k) for k in range(asmquad.NQW)]
+    for r in zero:
+        e("v_mov_b32", v(r), 0)
+        e("v_mov_b32", v(r + 1), 0)
+    # ---- 1/D (AGPR pairs, permuted order) -> QDI; thrust-row words
+    mv = {0: [], 1: [], 2: []}
+    for k in range(nk):
+        ln, ix = plan.home[k]
+        mv[ln].append(("a", QDI(ix), g.A_D + 2 * k))
+    for k in range(s.N):
+        Z3, LO3, UP3, RHO3, RINV3 = (g.V_C + 2 * (q * s.N + k) for q in range(5))
+        for dst, src in ((QZT, Z3), (QLO3, LO3), (QUP3, UP3), (QRHO3, RHO3), (QRINV3, RINV3)):
+            mv[k].append(("v", dst, src))
+    for ln in range(3):
+        e("s_mov_b64", "exec", sp(masks[ln]))
+        for kind, dst, src in mv[ln]:
+            for h in range(2):
+                if kind == "a":
+                    e("v_accvgpr_read_b32", v(dst + h), "a%d" % (src + h))
+                else:
+                    e("v_mov_b32", v(dst + h), v(src + h))
+    e("s_mov_b64", "exec", sp(S_EXEC))
+    # ---- q, l: one-lane homes (a168..) -> the lane's AGPR words a0..a55 (zero where the entry is structurally zero)
+    e("v_mov_b32", v(T_A[0]), 0)
+    for a_ in range(AQ, ATAB):
+        e("v_accvgpr_write_b32", "a%d" % a_, v(T_A[0]))
+    hm = g.homes(s)
+    byl = {0: [], 1: [], 2: []}
+    for (kind, idx), a_ in hm.items():
+        if kind == "q":
+            ln, ix = plan.xhome[idx]
+            byl[ln].append((AQ + 2 * ix, a_))
+        else:
+            ln, ix = plan.zhome[idx]
+            byl[ln].append((AL + 2 * (ix - IX_EQ), a_))
+    for ln in range(3):
+        e("s_mov_b64", "exec", sp(masks[ln]))
+        for k, (dst, src) in enumerate(sorted(byl[ln])):
+            t = T_A[k % 4]
+            for h in range(2):
+                e("v_accvgpr_read_b32", v(t + h), "a%d" % (src + h))
+            for h in range(2):
+                e("v_accvgpr_write_b32", "a%d" % (dst + h), v(t + h))
+    e("s_mov_b64", "exec", sp(S_EXEC))
+    # ---- x, y: LDS words -> quad words, 14 float4 per round through the W words
+    words = [(g.LW_X + j, plan.xhome[j][0], QX(plan.xhome[j][1])) for j in range(nx)]
+    for i in range(nc):
+        ln, ix = plan.zhome[i]
+        words.append((g.LW_Y + i, ln, QY(ix - IX_EQ) if i < neq else QYT))
+    byquad = {}
+    for w, ln, dst in words:
+        byquad.setdefault(w >> 1, []).append((w, ln, dst))
+    quads = sorted(byquad)
+    for base in range(0, len(quads), 14):
+        chunk = quads[base:base + 14]
+        for k, qd in enumerate(chunk):
+            b_, off, _ = g.lds_addr(2 * qd)
+            e("ds_read_b128", "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), b_, off)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for ln in range(3):
+            todo = [(STAGE + 4 * k + 2 * (w & 1), dst) for k, qd in enumerate(chunk) for (w, l2, dst) in byquad[qd] if l2 == ln]
+            if not todo:
+                continue
+            e("s_mov_b64", "exec", sp(masks[ln]))
+            for src, dst in todo:
+                e("v_mov_b32", v(dst), v(src))
+                e("v_mov_b32", v(dst + 1), v(src + 1))
+        e("s_mov_b64", "exec", sp(S_EXEC))
+    # ---- the zero word, and the table: dword + lane LDS base -> AGPR
+    e("v_mov_b32", v(T_A[0]), 0)
+    e("v_mov_b32", v(T_A[0] + 1), 0)
+    b_, off, half = g.lds_addr(ZERO_WORD)
+    e("ds_write_b64", b_, vp(T_A[0]), off + 8 * half)
+    nld = NTAB // 4
+    for base in range(0, nld, 14):
+        n = min(14, nld - base)
+        for k in range(n):
+            e("global_load_dwordx4", "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), v(tb), sp(S_TAB), "offset:%d" % (16 * (base + k)))
+        e("s_waitcnt", "vmcnt(0)")
+        for k in range(4 * n):
+            q = 4 * base + k
+            if q < plan.ncoef:
+                e("v_add_u32", v(STAGE + k), v(STAGE + k), "v1")
+                e("v_accvgpr_write_b32", "a%d" % (ATAB + q), v(STAGE + k))
+    e("s_waitcnt", "lgkmcnt(0)")
+    e("s_nop", 4)
+
+
+def body(e, plan, s, capture):
+    v = lambda n: "v%d" % n
+    sA, sO, sS, sRi = (sp(r) for r in (S_ALPHA, S_OMA, S_SIGMA, S_RINV))
+    # ---- rhs
+    for ix in range(15):
+        t = T_A[ix % 4]
+        e("v_accvgpr_read_b32", v(t), "a%d" % (AQ + 2 * ix))
+        e("v_accvgpr_read_b32", v(t + 1), "a%d" % (AQ + 2 * ix + 1))
+        e("v_fma_f64", vp(QW(ix)), sS, vp(QX(ix)), "-" + vp(t))
+    for ix in range(12):
+        t = T_A[(ix + 3) % 4]
+        e("v_accvgpr_read_b32", v(t), "a%d" % (AL + 2 * ix))
+        e("v_accvgpr_read_b32", v(t + 1), "a%d" % (AL + 2 * ix + 1))
+        e("v_fma_f64", vp(QW(IX_EQ + ix)), "-" + vp(QY(ix)), sRi, vp(t))
+    e("v_fma_f64", vp(QW(IX_T)), "-" + vp(QRINV3), vp(QYT), vp(QZT))
+    e("s_nop", 1)
+    # ---- solves: address (AGPR) three instructions ahead, coefficient read two ahead, the other lane's source right
+    # before its consumer
+    seq = [("op", q, ins) for q, ins in enumerate(plan.fwd)] + [("diag",)] + \
+          [("op", len(plan.fwd) + q, ins) for q, ins in enumerate(plan.bwd)]
+    opsidx = [k for k, it in enumerate(seq) if it[0] == "op"]
+    pos = {k: n for n, k in enumerate(opsidx)}          # sequence index -> running op number
+    nops = len(opsidx)
+
+    def addr(n):
+        if n < nops:
+            e("v_accvgpr_read_b32", v(T_ADDR[n % NRING]), "a%d" % (ATAB + seq[opsidx[n]][1]))
+
+    def read(n):
+        if n < nops:
+            e("ds_read_b64", vp(T_COEF[n % NRING]), v(T_ADDR[n % NRING]), 0)
+    for n in range(RD_AHEAD + 1):
+        addr(n)
+    for n in range(RD_AHEAD):
+        read(n)
+    lastw = [None, None]
+    cached = [None, None]           # (sreg, perm) held by T_SRC[k]
+    nsrc = 0
+    for k, it in enumerate(seq):
+        if it[0] == "diag":
+            for ix in range(asmquad.NQW):
+                if ix != 15:
+                    e("v_mul_f64", vp(QW(ix)), vp(QW(ix)), vp(QDI(ix)))
+            lastw, cached = [None, None], [None, None]
+            continue
+        n = pos[k]
+        addr(n + RD_AHEAD + 1)
+        read(n + RD_AHEAD)
+        _, q, ins = it
+        d, sr = QW(ins["d"]), QW(ins["s"])
+        if ins["perm"] == [0, 1, 2, 3]:
+            src = sr
+        else:
+            key = (sr, tuple(ins["perm"]))
+            if key in cached:
+                src = T_SRC[cached.index(key)]
+            else:
+                slot = nsrc % 2
+                nsrc += 1
+                if sr == lastw[0]:
+                    e("s_nop", 1)
+                elif sr == lastw[1]:
+                    e("s_nop", 0)
+                e("v_mov_b32_dpp", v(T_SRC[slot]), v(sr), qperm(ins["perm"]))
+                e("v_mov_b32_dpp", v(T_SRC[slot] + 1), v(sr + 1), qperm(ins["perm"]))
+                cached[slot] = key
+                src = T_SRC[slot]
+        outstanding = min(RD_AHEAD, nops - 1 - n)      # coefficient reads issued behind this one
+        e("s_waitcnt", "lgkmcnt(%d)" % outstanding)
+        e("v_fma_f64", vp(d), "-" + vp(T_COEF[n % NRING]), vp(src), vp(d))
+        lastw = [d, lastw[0]]
+        cached = [None if (c is not None and c[0] == d) else c for c in cached]     # a fetched copy of d is stale now
+    # ---- x <- alpha x~ + (1 - alpha) x; capturing: x_new into W (x stays x_prev)
+    for ix in range(15):
+        t = T_A[ix % 4]
+        e("v_mul_f64", vp(t), sO, vp(QX(ix)))
+        e("v_fma_f64", vp(QW(ix) if capture else QX(ix)), sA, vp(QW(ix)), vp(t))
+    # ---- dynamics rows: delta_y = alpha (nu - y)
+    for ix in range(12):
+        t = T_A[(ix + 3) % 4]
+        e("v_add_f64", vp(t), vp(QW(IX_EQ + ix)), "-" + vp(QY(ix)))
+        if capture:
+            e("v_mul_f64", vp(QW(IX_EQ + ix)), sA, vp(t))
+        e("v_fma_f64", vp(QY(ix)), sA, vp(t), vp(QY(ix)))
+    # ---- thrust rows (lanes 0..2 of one word)
+    t1, t2, t3 = T_X[0], T_X[1], T_A[0]
+    nu, y, z = QW(IX_T), QYT, QZT
+    e("v_fma_f64", vp(t1), "-" + vp(y), vp(QRINV3), vp(z))
+    e("v_fma_f64", vp(t1), vp(nu), vp(QRINV3), vp(t1))
+    e("v_mul_f64", vp(t2), sO, vp(z))
+    e("v_fma_f64", vp(t1), sA, vp(t1), vp(t2))
+    e("v_fma_f64", vp(t3), vp(y), vp(QRINV3), vp(t1))
+    e("v_max_f64", vp(t3), vp(t3), vp(QLO3))
+    e("v_min_f64", vp(z), vp(t3), vp(QUP3))
+    e("v_add_f64", vp(t2), vp(t1), "-" + vp(z))
+    e("v_mul_f64", vp(t2), vp(t2), vp(QRHO3))
+    e("v_add_f64", vp(y), vp(y), vp(t2))
+    if capture:
+        e("v_mov_b32", v(nu), v(t2))
+        e("v_mov_b32", v(nu + 1), v(t2 + 1))
+
+
+def exit_(e, plan, s):
+    """x (new, in W), x_prev (in x), y, delta_y (in W) -> every lane's LDS slice; thrust-row z -> its one-lane registers"""
+    from . import asmgen64 as g
+    nx, nc, neq = s.nx, s.nc, 2 * s.N * symbolic.NY
+    v = lambda n: "v%d" % n
+    e("s_nop", 1)
+    temps = list(T_COEF)            # eight distinct words (the solves are over: the ring is idle)
+    cnt = [0]
+
+    def put(word, src, ln):
+        t = temps[cnt[0] % len(temps)]
+        cnt[0] += 1
+        e("v_mov_b32_dpp", v(t), v(src), qperm([ln] * 4))
+        e("v_mov_b32_dpp", v(t + 1), v(src + 1), qperm([ln] * 4))
+        b_, off, half = g.lds_addr(word)
+        e("ds_write_b64", b_, vp(t), off + 8 * half)
+    for j in range(nx):
+        ln, ix = plan.xhome[j]
+        put(g.LW_X + j, QW(ix), ln)
+        put(g.PC_XP + j, QX(ix), ln)
+    for i in range(nc):
+        ln, ix = plan.zhome[i]
+        if i < neq:
+            put(g.LW_Y + i, QY(ix - IX_EQ), ln)
+            put(g.PC_DY + i, QW(ix), ln)
+        else:
+            k = i - neq
+            put(g.LW_Y + i, QYT, ln)
+            put(g.PC_DY + i, QW(IX_T), ln)
+            e("v_mov_b32_dpp", v(g.V_C + 2 * k), v(QZT), qperm([ln] * 4))
+            e("v_mov_b32_dpp", v(g.V_C + 2 * k + 1), v(QZT + 1), qperm([ln] * 4))
+    # l of the dynamics rows back to its one-lane AGPR homes (the table took them; the epilogue reads z = l there)
+    hm = g.homes(s)
+    for k, ((kind, idx), a_) in enumerate(sorted(hm.items(), key=lambda kv: kv[1])):
+        if kind != "l":
+            continue
+        ln, ix = plan.zhome[idx]
+        t, t2 = temps[k % len(temps)], temps[(k + 4) % len(temps)]
+        for h in range(2):
+            e("v_accvgpr_read_b32", v(t + h), "a%d" % (AL + 2 * (ix - IX_EQ) + h))
+        e("s_nop", 1)
+        for h in range(2):
+            e("v_mov_b32_dpp", v(t2 + h), v(t + h), qperm([ln] * 4))
+        for h in range(2):
+            e("v_accvgpr_write_b32", "a%d" % (a_ + h), v(t2 + h))
+    e("s_waitcnt", "lgkmcnt(0)")
+
+
+def section(e, plan, s):
+    sg = lambda n: "s%d" % n
+    e("quad_begin",)
+    entry(e, plan, s)
+    e("s_sub_i32", sg(S_CNT), sg(S_ITERS), 2)
+    e("s_cmp_lt_i32", sg(S_CNT), 1)
+    e("s_cbranch_scc1", "18f")
+    e("label", "17")
+    body(e, plan, s, capture=False)
+    e("s_sub_i32", sg(S_CNT), sg(S_CNT), 1)
+    e("s_cmp_gt_i32", sg(S_CNT), 0)
+    e("s_cbranch_scc1", "17b")
+    e("label", "18")
+    body(e, plan, s, capture=True)
+    exit_(e, plan, s)
+    e("quad_end",)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU interpreter of the section on the four lanes of a quad, exact-rounded float64
+# ---------------------------------------------------------------------------------------------------------------------
+def simulate(ins, pc, V, A, lds, S, tab, max_exec=400000):
+    """ins[pc] == ("quad_begin",). V, A: uint32 [4][256]; lds: float64 [4][320], each lane's own slice by WORD; S: the
+    calling interpreter's SGPR dict (constants as 64-bit pairs, S_ITERS); tab: table() of the plan. LDS addresses are
+    taken relative to the lane's base (v1 must be equal in the four images: the caller runs with v1 = 0). Returns
+    (pc behind ("quad_end",), executed instructions)."""
+    from fractions import Fraction
+    u32 = np.uint32
+    exec_ = np.ones(4, bool)
+    masks, labels, scc = {}, {}, 0
+    for k, t in enumerate(ins):
+        if t[0] == "label":
+            labels.setdefault(t[1], []).append(k)
+    TAB_BASE = 1 << 44
+    S[S_TAB], S[S_TAB + 1] = TAB_BASE & 0xFFFFFFFF, TAB_BASE >> 32
+    vi = lambda x: int(x[1:])
+    lohi = lambda x: int(x[2:x.index(":")])
+
+    def f64(lo, hi):
+        return struct.unpack("<d", struct.pack("<Q", int(lo) | (int(hi) << 32)))[0]
+
+    def getd(x, ln):
+        if isinstance(x, float):
+            return x
+        neg = x.startswith("-")
+        if neg:
+            x = x[1:]
+        lo = lohi(x)
+        val = f64(V[ln, lo], V[ln, lo + 1]) if x[0] == "v" else f64(S[lo], S[lo + 1])
+        return -val if neg else val
+
+    def setd(x, ln, val):
+        lo = lohi(x)
+        b = struct.unpack("<Q", struct.pack("<d", float(val)))[0]
+        V[ln, lo], V[ln, lo + 1] = b & 0xFFFFFFFF, b >> 32
+
+    def fma(a, b, c):
+        if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+            return a * b + c
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def word_of(byte):
+        assert byte % 8 == 0 and 0 <= byte < 160 * 1024
+        return (byte // 1024) * 2 + (byte % 1024) // 8
+    pend = []        # outstanding LDS reads: sets of (lane-independent) destination registers, in issue order
+    nexec = 0
+    assert ins[pc] == ("quad_begin",)
+    pc += 1
+    while ins[pc] != ("quad_end",):
+        t = ins[pc]
+        m = t[0]
+        if m == "label":
+            pc += 1
+            continue
+        nexec += 1
+        assert nexec < max_exec, "runaway quad section"
+        if m[0] == "v" or m.startswith("ds_"):
+            used = set()
+            for x in t[1:]:
+                if isinstance(x, str):
+                    y = x.lstrip("-")
+                    if y.startswith("v["):
+                        used |= set(range(lohi(y), int(y[y.index(":") + 1:-1]) + 1))
+                    elif y[0] == "v" and y[1:].isdigit():
+                        used.add(int(y[1:]))
+            for dst in pend:
+                assert not (dst & used), ("register used before its LDS read was waited for", t)
+        if m == "s_waitcnt":
+            for part in t[1].split():
+                name, val = part[:-1].split("(")
+                if name == "lgkmcnt":
+                    del pend[:max(0, len(pend) - int(val))]
+        elif m == "s_nop":
+            pass
+        elif m == "s_mov_b32":
+            S[int(t[1][1:])] = t[2] & 0xFFFFFFFF
+        elif m == "s_mov_b64":
+            if t[2] == "exec":
+                masks[t[1]] = exec_.copy()
+            else:
+                assert t[1] == "exec"
+                exec_ = masks[t[2]].copy()
+        elif m == "s_and_b64":
+            word = S[lohi(t[2])]
+            masks[t[1]] = np.array([(word >> ln) & 1 for ln in range(4)], bool) & masks[t[3]]
+        elif m == "s_sub_i32":
+            a = S.get(int(t[2][1:]), 0) if isinstance(t[2], str) else t[2]
+            b = S.get(int(t[3][1:]), 0) if isinstance(t[3], str) else t[3]
+            S[int(t[1][1:])] = (a - b) & 0xFFFFFFFF
+        elif m in ("s_cmp_lt_i32", "s_cmp_gt_i32"):
+            sx = lambda x: (lambda w: w - (1 << 32) if w & 0x80000000 else w)(S.get(int(x[1:]), 0) if isinstance(x, str) else x & 0xFFFFFFFF)
+            scc = int(sx(t[1]) < sx(t[2])) if m == "s_cmp_lt_i32" else int(sx(t[1]) > sx(t[2]))
+        elif m == "s_cbranch_scc1":
+            if scc:
+                lab, d = t[1][:-1], t[1][-1]
+                c = labels[lab]
+                pc = min(x for x in c if x > pc) if d == "f" else max(x for x in c if x < pc)
+        elif m == "v_bfe_u32":
+            assert (t[3], t[4]) == (4, 2) and t[2] == "v1"
+            for ln in range(4):
+                if exec_[ln]:
+                    V[ln, vi(t[1])] = ln            # (lane & 3): the images are the four lanes of one quad
+        elif m == "v_mul_u32_u24":
+            for ln in range(4):
+                if exec_[ln]:
+                    V[ln, vi(t[1])] = (t[2] * int(V[ln, vi(t[3])])) & 0xFFFFFFFF
+        elif m == "v_add_u32":
+            for ln in range(4):
+                if exec_[ln]:
+                    V[ln, vi(t[1])] = (int(V[ln, vi(t[2])]) + int(V[ln, vi(t[3])])) & 0xFFFFFFFF
+        elif m == "v_mov_b32":
+            for ln in range(4):
+                if exec_[ln]:
+                    V[ln, vi(t[1])] = u32(t[2]) if isinstance(t[2], int) else V[ln, vi(t[2])]
+        elif m == "v_mov_b32_dpp":
+            mod = t[3]
+            qp = [int(c) for c in mod[mod.index("[") + 1:mod.index("]")].split(",")]
+            old = V[:, vi(t[2])].copy()
+            for ln in range(4):
+                if exec_[ln]:
+                    assert exec_[qp[ln]], "DPP read of a masked-off lane"
+                    V[ln, vi(t[1])] = old[qp[ln]]
+        elif m == "v_accvgpr_read_b32":
+            V[exec_, vi(t[1])] = A[exec_, int(t[2][1:])]
+        elif m == "v_accvgpr_write_b32":
+            A[exec_, int(t[1][1:])] = V[exec_, vi(t[2])]
+        elif m == "global_load_dwordx4":
+            lo = lohi(t[1])
+            off = int(t[4].split(":")[1])
+            assert (S[S_TAB] | (S[S_TAB + 1] << 32)) == TAB_BASE
+            for ln in range(4):
+                if exec_[ln]:
+                    byte = int(V[ln, vi(t[2])]) + off
+                    assert byte % 4 == 0 and 0 <= byte // 4 + 3 < tab.size
+                    V[ln, lo:lo + 4] = tab.ravel()[byte // 4:byte // 4 + 4]
+        elif m == "ds_read_b128":
+            lo = lohi(t[1])
+            for ln in range(4):
+                if exec_[ln]:
+                    w = word_of(int(V[ln, vi(t[2])]) + t[3])
+                    for h in range(2):
+                        b = struct.unpack("<Q", struct.pack("<d", float(lds[ln, w + h])))[0]
+                        V[ln, lo + 2 * h], V[ln, lo + 2 * h + 1] = b & 0xFFFFFFFF, b >> 32
+            pend.append(set(range(lo, lo + 4)))
+        elif m == "ds_read_b64":
+            lo = lohi(t[1])
+            for ln in range(4):
+                if exec_[ln]:
+                    w = word_of(int(V[ln, vi(t[2])]) + t[3])
+                    b = struct.unpack("<Q", struct.pack("<d", float(lds[ln, w])))[0]
+                    V[ln, lo], V[ln, lo + 1] = b & 0xFFFFFFFF, b >> 32
+            pend.append({lo, lo + 1})
+        elif m == "ds_write_b64":
+            for ln in range(4):
+                if exec_[ln]:
+                    lds[ln, word_of(int(V[ln, vi(t[1])]) + t[3])] = getd(t[2], ln)
+            pend.append(set())
+        elif m in ("v_fma_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64"):
+            for ln in range(4):
+                if not exec_[ln]:
+                    continue
+                a, b = getd(t[2], ln), getd(t[3], ln)
+                if m == "v_fma_f64":
+                    r = fma(a, b, getd(t[4], ln))
+                elif m == "v_mul_f64":
+                    r = a * b
+                elif m == "v_add_f64":
+                    r = a + b
+                else:
+                    r = max(a, b) if m == "v_max_f64" else min(a, b)
+                setd(t[1], ln, r)
+        else:
+            raise ValueError("unknown instruction in the fp64 quad section: %r" % (t,))
+        pc += 1
+    assert exec_.all() and not pend, "EXEC not restored / LDS reads outstanding at the end of the quad section"
+    return pc + 1, nexec

@@ -208,8 +208,8 @@ class BatchUprightMPC:
     def set_step_kernel(self, mode):
         """"auto" (default: the all-assembly fp32 kernel / the fp64 kernel with the assembly ADMM loop where they apply)
         or "cpp" (fp32: the C++ kernel around the assembly ADMM loop; fp64: the C++ loop): ablation and cross-checks.
-        fp32 only: "lane" / "quad" pin the form of the all-assembly stream (one lane / one lane quad per robot; "auto" takes
-        the quad form for B <= 16 384): equal up to rounding, so a run that must equal another batch size's bit for bit
+        "lane" / "quad" pin the form of the assembly path (one lane / one lane quad per robot; "auto" takes the quad form for
+        B <= 16 384 in fp32, B <= 4 096 in fp64): equal up to rounding, so a run that must equal another batch size's bit for bit
         -- a shard against the whole -- pins one."""
         self._check(self.L.umpcBatchSetStepKernel(self.h, {"auto": 0, "cpp": 1, "lane": 2, "quad": 3}[mode]))
 

@@ -44,14 +44,15 @@ int fail(hipError_t e, const char *what) {
 // one per SIMD, which is also what 512 registers per lane allow).
 // fp64: the C++ loop; LDSF (a batch of at most one wave per CU) keeps L and 1/D in LDS; LDSF + ASM64 additionally runs
 // the ADMM phase as the generated fp64 assembly (umpc_admm_asm64.h), which owns the whole 160 KiB of the CU.
-template <typename T, bool LDSF = false, bool ASM64 = false>
+template <typename T, bool LDSF = false, bool ASM64 = false, bool QUAD = false>
 __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a, int K, const T *actualT0, int skew_ticks) {
   constexpr bool kAsm = sizeof(T) == 4;
-  static_assert(!(kAsm && LDSF) && (!ASM64 || LDSF), "LDSF / ASM64 are the fp64 variants");
+  static_assert(!(kAsm && LDSF) && (!ASM64 || LDSF) && (!QUAD || ASM64), "LDSF / ASM64 / QUAD are the fp64 variants");
   __shared__ float4 lds[kAsm ? (umpcasm::LDS_BYTES_PER_LANE / 16) * kBlock
                              : ASM64 ? (umpcasm64::LDS_BYTES_PER_LANE / 16) * kBlock
                              : LDSF ? ((umpcgen::NNZL + umpcgen::NK + 1) / 2) * kBlock : 1];
-  const int b = blockIdx.x * kBlock + threadIdx.x;
+  // QUAD: 16 robots per wavefront, the four lanes of a quad own one robot (umpc::closed_loop_step)
+  const int b = QUAD ? blockIdx.x * (kBlock / 4) + (int)(threadIdx.x >> 2) : blockIdx.x * kBlock + threadIdx.x;
   if (b >= a.B) return;
   // low 32 bits of a flat LDS pointer = the LDS byte address
   const unsigned ldsaddr = (kAsm || ASM64) ? (unsigned)(size_t)(&lds[threadIdx.x]) : 0u;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_kernel(umpc::StepIO<T> a,
   }
   T *ldsw = kAsm ? reinterpret_cast<T *>(lds) + 4 * threadIdx.x : LDSF ? reinterpret_cast<T *>(lds) + 2 * threadIdx.x : nullptr;
 #pragma nounroll
-  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm || ASM64, LDSF>(a, b, ldsaddr, ldsw, k, actualT0);
+  for (int k = 0; k < K; ++k) umpc::closed_loop_step<T, kAsm || ASM64, LDSF, QUAD>(a, b, ldsaddr, ldsw, k, actualT0);
 }
 
 // The all-assembly fp32 fast path (asmstep.py -> umpc_step_asm.h): the whole K-step loop of one wavefront is ONE
@@ -466,7 +467,16 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
     if (!no_ldsf && grid <= ldsf_max_grid) {
       // ... and the ADMM phase as generated fp64 assembly (needs >= 1 iteration and 31-bit row offsets)
       const bool fits = (size_t)umpc::WS_ROWS * (size_t)h->B * 8 < ((size_t)1 << 31);
-      if (!no_asm64 && h->step_kernel == 0 && h->prm.maxIter >= 1 && fits) {
+      // ... with one robot per lane quad when that still is one round of workgroups (256 CUs x 16 robots): BASELINE
+      // config 2's 4 096 robots are then 256 waves instead of 64, each iteration ~0.55 of the one-lane loop's time
+      // (asmquad64.py). UMPC_QUAD64=0 keeps the lane form, UMPC_QUAD64=<n> moves the switch-over batch size.
+      static const int quad64_max_b = [] { const char *e_ = getenv("UMPC_QUAD64"); return e_ ? atoi(e_) : 4096; }();
+      const bool want_quad = h->step_kernel == 3 || (h->step_kernel == 0 && h->B <= quad64_max_b);
+      if (!no_asm64 && h->step_kernel != 1 && h->prm.maxIter >= 2 && fits && want_quad) {
+        hipLaunchKernelGGL((umpc_rollout_kernel<T, true, true, true>), dim3((h->B + kBlock / 4 - 1) / (kBlock / 4)), dim3(kBlock), 0,
+                           (hipStream_t)stream, a, K, (const T *)actualT0, 0);
+        h->last_kernel = "umpc_rollout_kernel<double, LDSF, ASM64, QUAD>";
+      } else if (!no_asm64 && h->step_kernel != 1 && h->prm.maxIter >= 1 && fits) {
         hipLaunchKernelGGL((umpc_rollout_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, K,
                            (const T *)actualT0, 0);
         h->last_kernel = "umpc_rollout_kernel<double, LDSF, ASM64>";
@@ -588,7 +598,7 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights) {
   return 0;
 }
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode) {
-  if (!h || mode < 0 || mode > 3 || (mode > 1 && h->dtype != UMPC_F32)) { g_err = "umpcBatchSetStepKernel: bad argument"; return -1; }
+  if (!h || mode < 0 || mode > 3) { g_err = "umpcBatchSetStepKernel: bad argument"; return -1; }
   h->step_kernel = mode;
   return 0;
 }

@@ -28,6 +28,8 @@
 #include "umpc_gen.h"
 #include "umpc_admm_asm.h"
 #include "umpc_admm_asm64.h"
+#include "umpc_admm_asm64_quad.h"   // the fp64 ADMM phase with one robot per lane quad (asmquad64.py)
+#include "umpc_quad64_tab.h"
 
 namespace umpc {
 
@@ -465,7 +467,9 @@ struct StepIO {
 // launches of one step are the same computation.
 // LDSF (fp64, small batches): the factor L and 1/D live in LDS ([word][lane], one wave per CU owns 152 kB) instead
 // of local arrays the compiler spills to scratch; same arithmetic, same results.
-template <typename T, bool ASM, bool LDSF = false>
+// QUAD (fp64 + ASM + LDSF): the four lanes of a quad were given the SAME robot b; they run every phase redundantly, each
+// on its own LDS slice, and the ADMM phase splits iterations 2..maxIter over lanes 0..2 (umpc_admm_asm64_quad.h).
+template <typename T, bool ASM, bool LDSF = false, bool QUAD = false>
 __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b, const unsigned ldsaddr, T *ldsw,
                                                  const int step, const T *actualT0) {
 // word w of this lane's LDS slot: float4-interleaved, ldsw = (T *)lds + 4 * lane
@@ -713,7 +717,12 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
   if constexpr (ASM64) {
     const unsigned voff = bb * 8u, stride = (unsigned)a.B * 8u;
     const int iters = prm.maxIter;
-    UMPC_ADMM_ASM64(voff, ldsaddr, a.ws, a.ctrl, stride, iters);
+    if constexpr (QUAD) {
+      const unsigned *tab = &umpcquad64::kTab[0][0];
+      UMPC_ADMM_ASM64_QUAD(voff, ldsaddr, a.ws, a.ctrl, tab, stride, iters);
+    } else {
+      UMPC_ADMM_ASM64(voff, ldsaddr, a.ws, a.ctrl, stride, iters);
+    }
 #ifdef UMPC_ASM64_TIMING   /* header generated with UMPC_ASM64_TIMING=1: the block's own stamps, LDS words 297..302 (the residual block reuses them) */
 #pragma unroll
     for (int k = 0; k < 6; ++k) asm64_stamps[k] = __builtin_bit_cast(long long, LDSF_W(297 + k));

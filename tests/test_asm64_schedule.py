@@ -67,6 +67,72 @@ def _case(oracle_built, g, ins, s, seq, k, iters):
     assert np.abs(dy - ref).max() <= 1e-9 * max(1e-6, np.abs(o2.get("y")).max())
 
 
+@pytest.fixture(scope="module")
+def prog_quad():
+    """the same ADMM phase with one robot per lane quad (asmquad64.py): iterations 2.. on the four lanes of a quad"""
+    from robobee3d_amd import asmgen64
+
+    class G:        # asmgen64 with simulate() bound to the program's permutation (the quad plan needs it)
+        pass
+    ins, s = asmgen64.program(quad=True)
+    g = G()
+    for k in dir(asmgen64):
+        if not k.startswith("__"):
+            setattr(g, k, getattr(asmgen64, k))
+    g.simulate = lambda ins_, ws, ctrl, iters, lds: asmgen64.simulate(ins_, ws, ctrl, iters, lds, perm=s.perm)
+    return g, ins, s
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3, 6])
+def test_generated_fp64_quad_program_matches_oracle(oracle_built, prog_quad, iters):
+    """the quad form against the same harness: iterates 1e-12 from the fp64 oracle, everything phase C reads back in the
+    lane's LDS words (x, y, z, x_prev, delta_y, the thrust-row bounds), l back in its AGPR homes for the epilogue; the
+    four lanes of the quad agree on every LDS word and thrust-row register (asserted by the interpreter's hook)."""
+    from robobee3d_amd import asmgen64
+    g, ins, s = prog_quad
+    seq = golden("seq_iter50.npz")
+    for k in (0, 11):
+        _case(oracle_built, g, ins, s, seq, k, iters)
+        assert (asmgen64.simulate.last_quad_instructions > 0) == (iters >= 2)
+
+
+def test_fp64_quad_iteration_size_and_table(prog_quad):
+    from robobee3d_amd import asmquad64
+    g, ins, s = prog_quad
+    qb, qe = ins.index(("quad_begin",)), ins.index(("quad_end",))
+    sec = ins[qb:qe]
+    l17, l18 = sec.index(("label", "17")), sec.index(("label", "18"))
+    body = sec[l17:l18]
+    f64 = sum(1 for t in body if t[0] in ("v_fma_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64"))
+    # the one-lane middle iteration: 1 483 instructions, 786 of them fp64
+    assert len(body) <= 1200 and f64 <= 330, (len(body), f64)
+    assert not any(t[0] == "s_mov_b64" and t[1] == "exec" for t in body)
+    plan = asmquad64.plan_for(s)
+    tab = asmquad64.table(plan)
+    assert tab.shape == (4, asmquad64.NTAB) and plan.ncoef <= asmquad64.NTAB and asmquad64.ATAB + plan.ncoef <= 256
+    assert (tab[3] == asmquad64.rel_addr(asmquad64.ZERO_WORD)).all()            # lane 3 of a quad idles on the zero word
+    assert (tab % 8 == 0).all() and tab.max() < 160 * 1024 // 64 * 64
+    # every entry of L is addressed exactly twice (once per solve direction), by the lane that owns its destination
+    words, counts = np.unique(tab[:3, :plan.ncoef][tab[:3, :plan.ncoef] != asmquad64.rel_addr(asmquad64.ZERO_WORD)], return_counts=True)
+    assert len(words) == len(s.L_i) and (counts == 2).all()
+
+
+def test_fp64_quad_stream_assembles(prog_quad):
+    import os, subprocess, tempfile
+    mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    g, ins, s = prog_quad
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("\n".join(g.fmt(t) for t in ins if t[0] not in g.PSEUDO) + "\n")
+    try:
+        r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[:3000]
+    finally:
+        os.unlink(f.name)
+
+
 @pytest.mark.parametrize("iters", [1, 2, 3, 6])
 def test_generated_fp64_admm_program_matches_oracle(oracle_built, prog, iters):
     g, ins, s = prog

@@ -9,14 +9,21 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 @pytest.mark.parametrize("module, fname", [("codegen", "umpc_gen.h"), ("asmgen", "umpc_admm_asm.h"),
                                            ("asmgen64", "umpc_admm_asm64.h"), ("asmstep", "umpc_step_asm.h"),
-                                           ("asmstep", "umpc_step_asm_quad.h"), ("codegen_n3", "umpc_n3_general.h")])
+                                           ("asmstep", "umpc_step_asm_quad.h"), ("codegen_n3", "umpc_n3_general.h"),
+                                           ("asmgen64", "umpc_admm_asm64_quad.h")])
 def test_committed_header_is_current(tmp_path, module, fname):
     import importlib
     from robobee3d_amd import asmgen
     assert not asmgen.generator_switches(), "generator switches must be off for this comparison"
     mod = importlib.import_module("robobee3d_amd." + module)
     out = str(tmp_path / fname)
-    mod.write(out, quad=True) if fname.endswith("_quad.h") else mod.write(out)
+    if fname == "umpc_admm_asm64_quad.h":
+        mod.write_quad(out)
+        assert open(str(tmp_path / "umpc_quad64_tab.h")).read() == open(os.path.join(CSRC, "umpc_quad64_tab.h")).read()
+    elif fname.endswith("_quad.h"):
+        mod.write(out, quad=True)
+    else:
+        mod.write(out)
     assert open(out).read() == open(os.path.join(CSRC, fname)).read(), "%s is stale: run __graft_entry__.build()" % fname
 
 

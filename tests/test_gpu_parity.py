@@ -837,3 +837,46 @@ print(" ".join("%%.9g" %% v for v in list(u) + list(a)))
     lane = np.array([float(t) for t in r.stdout.strip().splitlines()[-1].split()])
     assert abs(lane[0] - uq[0]) <= TOL_T and np.all(np.abs(lane[1:3] - uq[1:]) <= tol_tau(uq[1:]))
     assert np.abs(lane[3:] - ac).max() <= TOL_A
+
+
+def test_fp64_quad_form_on_the_gpu(torch_cuda, oracle_built, margin):
+    """Round 4: the fp64 ADMM phase with one robot per lane quad (asmquad64.py), what BASELINE config 2's 4 096 robots take.
+    (a) "auto" dispatches it for B <= 4 096; (b) against the lane form over 6 closed-loop steps: 1e-9 (summation order);
+    (c) against the fp64 oracle: the fp64 bound of the path, 1e-9; (d) a ragged batch (37 robots) and one robot alone
+    compute bit for bit what they compute among 4 096."""
+    torch = torch_cuda
+    from robobee3d_amd import _lib
+    from robobee3d_amd.batch import BatchUprightMPC, hover_initial_conditions
+    B, K = 4096, 6
+    st, ref = hover_initial_conditions(B, 20201117, np.float64)
+    res = {}
+    for form in ("auto", "lane", "quad"):
+        m = BatchUprightMPC(B, torch.float64, plant_mode=0)
+        m.set_step_kernel(form)
+        m.set_state(st, ref)
+        m.rollout(K // 2)
+        m.rollout(K - K // 2)
+        assert m.kernel_name == ("umpc_rollout_kernel<double, LDSF, ASM64>" if form == "lane" else
+                                 "umpc_rollout_kernel<double, LDSF, ASM64, QUAD>")
+        res[form] = [t.cpu().numpy() for t in (m.state, m.out, m.stats, m.ctrl, m.status)]
+    for k in range(5):
+        assert np.array_equal(res["auto"][k], res["quad"][k])
+    a, c = res["quad"], res["lane"]
+    margin("fp64 quad vs lane form, B = 4096, K = 6: |d state|", float(np.abs(a[0] - c[0]).max()), 1e-9)
+    margin("fp64 quad vs lane form: |d out| relative", float((np.abs(a[1] - c[1]) / (1e-3 + np.abs(c[1]))).max()), 1e-8)
+    margin("fp64 quad vs lane form: status words that differ", float(np.sum(a[4] != c[4])), 8)
+    perm = np.array(_lib.lib().umpcKKTPerm().contents)
+    sel = np.arange(0, B, 64)
+    s_o = np.ascontiguousarray(st[:, sel])
+    ctrl = np.zeros((127, len(sel))); ctrl[124:] = 1
+    out_o, _, _ = oracle_built.batch_rollout(s_o, ctrl, np.ascontiguousarray(ref[:, sel]), K, dtype=np.float64, perm=perm, plant_mode=0)
+    margin("fp64 quad form vs fp64 oracle (64 robots, K = 6): |d state|", float(np.abs(a[0][:, sel] - s_o).max()), 1e-9)
+    margin("fp64 quad form vs fp64 oracle: |d out| relative", float((np.abs(a[1][:, sel] - out_o) / (1e-3 + np.abs(out_o))).max()), 1e-8)
+    for n, off in ((37, 1000), (1, 4095)):
+        sub = BatchUprightMPC(n, torch.float64, plant_mode=0)
+        sub.set_state(np.ascontiguousarray(st[:, off:off + n]), np.ascontiguousarray(ref[:, off:off + n]))
+        sub.rollout(K // 2)
+        sub.rollout(K - K // 2)
+        assert sub.kernel_name == "umpc_rollout_kernel<double, LDSF, ASM64, QUAD>"
+        assert np.array_equal(sub.state.cpu().numpy(), a[0][:, off:off + n]) and np.array_equal(sub.out.cpu().numpy(), a[1][:, off:off + n])
+        assert np.array_equal(sub.ctrl.cpu().numpy(), a[3][:, off:off + n])
