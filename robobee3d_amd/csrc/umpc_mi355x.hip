@@ -102,7 +102,13 @@ __global__ __launch_bounds__(kBlock) void umpc_rollout_asm_kernel(const umpcasm:
 constexpr int kQuadMaxB = 16384;      // 1024 waves of 16 robots: one per SIMD
 __global__ __launch_bounds__(kBlock) void umpc_rollout_asm_quad_kernel(const umpcasm::StepParams prm, int B) {
   __shared__ float4 lds[(umpcasm::STEP_LDS_BYTES_PER_LANE / 16) * kBlock];
-  const int b = blockIdx.x * (kBlock / 4) + (int)(threadIdx.x >> 2);
+  // XCD-aware block -> robot-group mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and a
+  // wave of 16 robots touches 64 B of every SoA row -- half a 128-B line. Consecutive groups therefore go to workgroups
+  // of ONE XCD (ids congruent mod 8), so that the two halves of a line meet in one L2 instead of being fetched by two
+  // (measured before: 1.85 kB read per robot-step against 0.97 kB for the 64-robot waves of the lane form).
+  const unsigned nb = gridDim.x, xcd = blockIdx.x % 8u, q8 = nb / 8u, r8 = nb % 8u;
+  const unsigned grp = xcd * q8 + (xcd < r8 ? xcd : r8) + blockIdx.x / 8u;
+  const int b = (int)grp * (kBlock / 4) + (int)(threadIdx.x >> 2);
   if (b >= B) return;                 // (whole quads: the generated stream keeps EXEC as it finds it)
   const unsigned ldsaddr = (unsigned)(size_t)(&lds[threadIdx.x]);
   const unsigned voff = (unsigned)b * 4u;
