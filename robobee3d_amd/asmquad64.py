@@ -1,7 +1,7 @@
 """ONE ROBOT PER LANE QUAD, fp64: ADMM iterations 2..maxIter of the small-batch fp64 step (asmgen64.py, BASELINE config 2:
 B = 4 096) -- the fp64 counterpart of asmquad.py. 4 096 robots are 64 one-lane waves on 64 of the chip's 256 CUs; with
-four lanes per robot they are 256 waves, one per CU (the fp64 loop owns its CU's LDS), and each iteration is ~950
-instructions with 311 fp64 operations instead of 1 483 with 786.
+four lanes per robot they are 256 waves, one per CU (the fp64 loop owns its CU's LDS), and each iteration is 1 125
+instructions with 314 fp64 operations instead of 1 483 with 786 (measured: 0.295 -> 0.239 ms per step).
 
 Same idea as asmquad.py (its docstring has the reasoning): the phases around the loop run redundantly in the four lanes
 of a quad, the loop keeps a third of the unknowns in each of lanes 0..2, a triangular-solve operation runs in the lane
@@ -10,10 +10,10 @@ used unchanged). What differs for eight-byte words:
 
   * v_fma_f64 is VOP3: no DPP operand. A source that lives in another lane is fetched with two v_mov_b32_dpp (low, high
     word) into a temporary pair right before its consumer; consecutive consumers of one (register, selection) reuse it.
-  * a lane owns 121 words of VGPRs: W, x, y, 1/D and the thrust-row words (92 words) leave no room for the 189
+  * a lane owns 121 words of VGPRs: W, x, y, 1/D and the thrust-row words (92 words) leave no room for the 194
     coefficient words. They are NOT moved at all: every lane already holds the whole factor in its own LDS slice
     (phase A wrote it there for the one-lane first iteration), so instruction q reads, in lane l, the word of L that lane
-    needs -- ds_read_b64 with a PER-LANE address. The 189 addresses per lane class are a constant table
+    needs -- ds_read_b64 with a PER-LANE address. The 194 addresses per lane class are a constant table
     (`table()`, csrc/umpc_quad64_tab.h), added to the lane's LDS base once per step and parked in AGPRs; a lane with
     nothing to do in an instruction reads a word that holds 0.0. Reading 8 bytes at a per-lane word of the
     [quad][lane] layout is conflict-free (the bank is decided by the lane, not by the word).
@@ -44,7 +44,7 @@ NRING = 8
 RD_AHEAD = 6                           # coefficient reads run this many solve instructions ahead (~100+ cycles of LDS latency
                                        # for a lone wave at ~25 cycles per solve instruction); addresses one further
 STAGE = 4                              # entry staging: the (idle) W words, v4..v59 = 14 float4
-AQ, AL, ATAB = 0, 32, 56               # AGPRs: q (16 words), l (12 words), 189 coefficient addresses
+AQ, AL, ATAB = 0, 32, 56               # AGPRs: q (16 words), l (12 words), the coefficient addresses (one per solve instruction)
 NTAB = 196                             # table row length (dwords): the 194 solve instructions + padding to whole dwordx4 loads
 ZERO_WORD = 319                        # this lane's LDS word that holds 0.0
 S_L0, S_L1, S_L2, S_EXEC, S_TAB = 30, 32, 34, 36, 8
