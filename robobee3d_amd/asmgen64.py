@@ -878,8 +878,11 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds, perm=None):
             nexec += nq
             simulate.last_quad_instructions = nq
             for ln in range(1, 4):
-                assert np.array_equal(L4[ln, :asmquad64.ZERO_WORD], L4[0, :asmquad64.ZERO_WORD]), "LDS slices of the quad disagree"
-            lds[:] = L4[0]
+                # (words LW_END.. are scratch: the quad loop's per-lane address table ends there; the C++ side writes what
+                # the residual block reads from them before it runs)
+                assert np.array_equal(L4[ln, :LW_END], L4[0, :LW_END]), "LDS slices of the quad disagree"
+            lds[:LW_END] = L4[0, :LW_END]
+            lds[LW_END:] = np.nan
             keep = {0, 1, V_B1, V_B2} | set(range(V_C, V_RING))
             for r in range(256):
                 if r in keep:

@@ -1,7 +1,7 @@
 """ONE ROBOT PER LANE QUAD, fp64: ADMM iterations 2..maxIter of the small-batch fp64 step (asmgen64.py, BASELINE config 2:
 B = 4 096) -- the fp64 counterpart of asmquad.py. 4 096 robots are 64 one-lane waves on 64 of the chip's 256 CUs; with
 four lanes per robot they are 256 waves, one per CU (the fp64 loop owns its CU's LDS), and each iteration is 1 125
-instructions with 314 fp64 operations instead of 1 483 with 786 (measured: 0.295 -> 0.239 ms per step).
+instructions with 314 fp64 operations instead of 1 483 with 786 (measured: 0.295 -> 0.224 ms per step).
 
 Same idea as asmquad.py (its docstring has the reasoning): the phases around the loop run redundantly in the four lanes
 of a quad, the loop keeps a third of the unknowns in each of lanes 0..2, a triangular-solve operation runs in the lane
@@ -35,16 +35,17 @@ from .asmquad import IX_EQ, IX_T, qperm
 
 # ---- VGPR words (first register of the pair); the block may use v2..v245, v172..v201 are the one-lane thrust-row words
 QYT, QZT, QLO3, QUP3, QRHO3, QRINV3 = 118, 120, 122, 124, 126, 128
-T_ADDR = [218, 219, 220, 221, 242, 243, 244, 245]          # LDS addresses of the next coefficient reads (ring of NRING)
-T_COEF = [222, 224, 226, 228, 234, 236, 238, 240]          # coefficient words in flight (ring of NRING)
-T_SRC = [230, 232]                     # sources fetched from another lane
-T_A = [234, 236, 238, 240]             # AGPR read / update temporaries (outside the solves: the ring is idle there)
-T_X = [242, 244]
-NRING = 8
-RD_AHEAD = 6                           # coefficient reads run this many solve instructions ahead (~100+ cycles of LDS latency
-                                       # for a lone wave at ~25 cycles per solve instruction); addresses one further
+T_AQ = [218, 222, 226]                 # address quads in flight (3 x ds_read_b128 of four coefficient addresses each)
+T_COEF = [230, 232, 234, 236, 238, 240]    # coefficient words in flight (ring of NRING)
+T_SRC = [242, 244]                     # sources fetched from another lane
+T_A = [230, 232, 234, 236]             # AGPR read / update temporaries (outside the solves: the ring is idle there)
+T_X = [238, 240]
+NRING = 6
+RD_AHEAD = 5                           # coefficient reads run this many solve instructions ahead, address quads two quads ahead
+TAB_WORD = 214                         # the lane's LDS words 214..311 hold its 196 coefficient addresses during the loop (x, y
+                                       # live in registers then; the exit rewrites the words)
 STAGE = 4                              # entry staging: the (idle) W words, v4..v59 = 14 float4
-AQ, AL, ATAB = 0, 32, 56               # AGPRs: q (16 words), l (12 words), the coefficient addresses (one per solve instruction)
+AQ, AL = 0, 32                         # AGPRs: q (16 words), l (12 words)
 NTAB = 196                             # table row length (dwords): the 194 solve instructions + padding to whole dwordx4 loads
 ZERO_WORD = 319                        # this lane's LDS word that holds 0.0
 S_L0, S_L1, S_L2, S_EXEC, S_TAB = 30, 32, 34, 36, 8
@@ -139,7 +140,7 @@ def entry(e, plan, s):
     e("s_mov_b64", "exec", sp(S_EXEC))
     # ---- q, l: one-lane homes (a168..) -> the lane's AGPR words a0..a55 (zero where the entry is structurally zero)
     e("v_mov_b32", v(T_A[0]), 0)
-    for a_ in range(AQ, ATAB):
+    for a_ in range(AQ, AL + 24):
         e("v_accvgpr_write_b32", "a%d" % a_, v(T_A[0]))
     hm = g.homes(s)
     byl = {0: [], 1: [], 2: []}
@@ -183,7 +184,7 @@ def entry(e, plan, s):
                 e("v_mov_b32", v(dst), v(src))
                 e("v_mov_b32", v(dst + 1), v(src + 1))
         e("s_mov_b64", "exec", sp(S_EXEC))
-    # ---- the zero word, and the table: dword + lane LDS base -> AGPR
+    # ---- the zero word, and the table: dword + lane LDS base -> this lane's LDS words TAB_WORD.. (four addresses per float4)
     e("v_mov_b32", v(T_A[0]), 0)
     e("v_mov_b32", v(T_A[0] + 1), 0)
     b_, off, half = g.lds_addr(ZERO_WORD)
@@ -194,11 +195,11 @@ def entry(e, plan, s):
         for k in range(n):
             e("global_load_dwordx4", "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), v(tb), sp(S_TAB), "offset:%d" % (16 * (base + k)))
         e("s_waitcnt", "vmcnt(0)")
-        for k in range(4 * n):
-            q = 4 * base + k
-            if q < plan.ncoef:
-                e("v_add_u32", v(STAGE + k), v(STAGE + k), "v1")
-                e("v_accvgpr_write_b32", "a%d" % (ATAB + q), v(STAGE + k))
+        for k in range(n):
+            for h in range(4):
+                e("v_add_u32", v(STAGE + 4 * k + h), v(STAGE + 4 * k + h), "v1")
+            b_, off, _ = g.lds_addr(TAB_WORD + 2 * (base + k))
+            e("ds_write_b128", b_, "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), off)
     e("s_waitcnt", "lgkmcnt(0)")
     e("s_nop", 4)
 
@@ -227,17 +228,39 @@ def body(e, plan, s, capture):
     pos = {k: n for n, k in enumerate(opsidx)}          # sequence index -> running op number
     nops = len(opsidx)
 
-    def addr(n):
-        if n < nops:
-            e("v_accvgpr_read_b32", v(T_ADDR[n % NRING]), "a%d" % (ATAB + seq[opsidx[n]][1]))
+    from . import asmgen64 as g
+    nlds = [0]                      # LDS reads issued so far in this body (they complete in order)
+    aq_seq, co_seq = {}, {}         # address quad / coefficient read -> its issue number
+
+    def wait_for(seq):
+        e("s_waitcnt", "lgkmcnt(%d)" % min(15, nlds[0] - 1 - seq))
+
+    def aquad(gq):
+        """the four addresses of solve instructions 4 gq .. 4 gq + 3"""
+        if 4 * gq < nops:
+            b_, off, _ = g.lds_addr(TAB_WORD + 2 * gq)
+            r = T_AQ[gq % 3]
+            e("ds_read_b128", "v[%d:%d]" % (r, r + 3), b_, off)
+            aq_seq[gq] = nlds[0]
+            nlds[0] += 1
 
     def read(n):
         if n < nops:
-            e("ds_read_b64", vp(T_COEF[n % NRING]), v(T_ADDR[n % NRING]), 0)
-    for n in range(RD_AHEAD + 1):
-        addr(n)
+            q = seq[opsidx[n]][1]
+            if n % 4 == 0:
+                aquad(n // 4 + 2)                       # two quads ahead of the one about to be used
+            if aq_seq[q // 4] is not None:
+                wait_for(aq_seq[q // 4])
+                aq_seq[q // 4] = None                   # (arrived: later reads of this quad need no wait)
+            e("ds_read_b64", vp(T_COEF[n % NRING]), v(T_AQ[(q // 4) % 3] + q % 4), 0)
+            co_seq[n] = nlds[0]
+            nlds[0] += 1
+    assert all(seq[opsidx[n]][1] == n for n in range(nops))     # running op number == coefficient index
+    aquad(0)
+    aquad(1)
     for n in range(RD_AHEAD):
         read(n)
+    waited_co = [-1]
     lastw = [None, None]
     cached = [None, None]           # (sreg, perm) held by T_SRC[k]
     nsrc = 0
@@ -249,7 +272,6 @@ def body(e, plan, s, capture):
             lastw, cached = [None, None], [None, None]
             continue
         n = pos[k]
-        addr(n + RD_AHEAD + 1)
         read(n + RD_AHEAD)
         _, q, ins = it
         d, sr = QW(ins["d"]), QW(ins["s"])
@@ -270,8 +292,10 @@ def body(e, plan, s, capture):
                 e("v_mov_b32_dpp", v(T_SRC[slot] + 1), v(sr + 1), qperm(ins["perm"]))
                 cached[slot] = key
                 src = T_SRC[slot]
-        outstanding = min(RD_AHEAD, nops - 1 - n)      # coefficient reads issued behind this one
-        e("s_waitcnt", "lgkmcnt(%d)" % outstanding)
+        if n % 2 == 0 or waited_co[0] < n:          # one wait per two coefficient reads (they return in order)
+            upto = n + 1 if n + 1 in co_seq else n
+            wait_for(co_seq[upto])
+            waited_co[0] = upto
         e("v_fma_f64", vp(d), "-" + vp(T_COEF[n % NRING]), vp(src), vp(d))
         lastw = [d, lastw[0]]
         cached = [None if (c is not None and c[0] == d) else c for c in cached]     # a fetched copy of d is stale now
@@ -336,20 +360,6 @@ def exit_(e, plan, s):
             put(g.PC_DY + i, QW(IX_T), ln)
             e("v_mov_b32_dpp", v(g.V_C + 2 * k), v(QZT), qperm([ln] * 4))
             e("v_mov_b32_dpp", v(g.V_C + 2 * k + 1), v(QZT + 1), qperm([ln] * 4))
-    # l of the dynamics rows back to its one-lane AGPR homes (the table took them; the epilogue reads z = l there)
-    hm = g.homes(s)
-    for k, ((kind, idx), a_) in enumerate(sorted(hm.items(), key=lambda kv: kv[1])):
-        if kind != "l":
-            continue
-        ln, ix = plan.zhome[idx]
-        t, t2 = temps[k % len(temps)], temps[(k + 4) % len(temps)]
-        for h in range(2):
-            e("v_accvgpr_read_b32", v(t + h), "a%d" % (AL + 2 * (ix - IX_EQ) + h))
-        e("s_nop", 1)
-        for h in range(2):
-            e("v_mov_b32_dpp", v(t2 + h), v(t + h), qperm([ln] * 4))
-        for h in range(2):
-            e("v_accvgpr_write_b32", "a%d" % (a_ + h), v(t2 + h))
     e("s_waitcnt", "lgkmcnt(0)")
 
 
@@ -529,6 +539,14 @@ def simulate(ins, pc, V, A, lds, S, tab, max_exec=400000):
             for ln in range(4):
                 if exec_[ln]:
                     lds[ln, word_of(int(V[ln, vi(t[1])]) + t[3])] = getd(t[2], ln)
+            pend.append(set())
+        elif m == "ds_write_b128":
+            lo = lohi(t[2])
+            for ln in range(4):
+                if exec_[ln]:
+                    w = word_of(int(V[ln, vi(t[1])]) + t[3])
+                    for h in range(2):
+                        lds[ln, w + h] = f64(V[ln, lo + 2 * h], V[ln, lo + 2 * h + 1])
             pend.append(set())
         elif m in ("v_fma_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64"):
             for ln in range(4):

@@ -109,7 +109,7 @@ def test_fp64_quad_iteration_size_and_table(prog_quad):
     assert not any(t[0] == "s_mov_b64" and t[1] == "exec" for t in body)
     plan = asmquad64.plan_for(s)
     tab = asmquad64.table(plan)
-    assert tab.shape == (4, asmquad64.NTAB) and plan.ncoef <= asmquad64.NTAB and asmquad64.ATAB + plan.ncoef <= 256
+    assert tab.shape == (4, asmquad64.NTAB) and plan.ncoef <= asmquad64.NTAB and asmquad64.TAB_WORD + asmquad64.NTAB // 2 <= asmquad64.ZERO_WORD
     assert (tab[3] == asmquad64.rel_addr(asmquad64.ZERO_WORD)).all()            # lane 3 of a quad idles on the zero word
     assert (tab % 8 == 0).all() and tab.max() < 160 * 1024 // 64 * 64
     # every entry of L is addressed exactly twice (once per solve direction), by the lane that owns its destination
