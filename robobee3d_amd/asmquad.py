@@ -206,21 +206,27 @@ def body(e, plan, capture):
     seq = [("op", q, ins) for q, ins in enumerate(plan.fwd)]
     seq.append(("diag",))
     seq += [("op", len(plan.fwd) + q, ins) for q, ins in enumerate(plan.bwd)]
-    AH = 3
-    fetch_tmp = {}
-    nf = [0]
-
-    def fetch(k):
-        if k < len(seq) and seq[k][0] == "op" and plan.cloc[seq[k][1]][0] == "a":
-            t = QT + nf[0] % 4
-            nf[0] += 1
-            e("v_accvgpr_read_b32", v(t), "a%d" % plan.cloc[seq[k][1]][1])
-            fetch_tmp[k] = t
-    lastw = [set(), set()]
-    for k in range(AH):
-        fetch(k)
+    # coefficient words beyond the VGPR-resident ones: four per ds_read_b128 from this lane's LDS words 0.. (written there
+    # by the entry), three quads in flight in the twelve temporaries (idle during the solves)
+    ovf = [q for q in range(plan.ncoef) if plan.cloc[q][0] == "a"]
+    oidx = {q: n for n, q in enumerate(ovf)}
+    first_use = {}                  # quad -> sequence position of its first consumer
     for k, item in enumerate(seq):
-        fetch(k + AH)
+        if item[0] == "op" and item[1] in oidx:
+            first_use.setdefault(oidx[item[1]] // 4, k)
+    nquads = (len(ovf) + 3) // 4
+    AHQ = 12                        # sequence positions between a quad's read and its first consumer
+    issued, waited, nrd = [0], [0], [0]
+
+    def issue_upto(k):
+        while issued[0] < nquads and first_use[issued[0]] <= k + AHQ and issued[0] < waited[0] + 3:
+            gq = issued[0]
+            e("ds_read_b128", "v[%d:%d]" % (QT + 4 * (gq % 3), QT + 4 * (gq % 3) + 3), "v1", gq * 1024)
+            issued[0] += 1
+    lastw = [set(), set()]
+    issue_upto(0)
+    for k, item in enumerate(seq):
+        issue_upto(k)
         if item[0] == "diag":   # qdldl.c:289
             for p in range(0, 28, 2):
                 pk(e, "v_pk_mul_f32", QW + p, [_vp(QW + p), _vp(QDI + p)])
@@ -229,7 +235,16 @@ def body(e, plan, capture):
             lastw = [set(), set()]
             continue
         _, q, ins = item
-        c = fetch_tmp.pop(k) if k in fetch_tmp else plan.cloc[q][1]
+        if q in oidx:
+            gq = oidx[q] // 4
+            if gq >= waited[0]:         # first consumer of this quad: reads return in order
+                assert gq < issued[0]
+                e("s_waitcnt", "lgkmcnt(%d)" % (issued[0] - 1 - gq))
+                waited[0] = gq + 1
+                issue_upto(k)
+            c = QT + 4 * (gq % 3) + oidx[q] % 4
+        else:
+            c = plan.cloc[q][1]
         d, sr = QW + ins["d"], QW + ins["s"]
         if ins["perm"] == [0, 1, 2, 3]:
             e("v_fmac_f32", v(d), v(sr), v(c))
@@ -398,6 +413,16 @@ def entry(e, plan):
                 else:
                     e("v_accvgpr_write_b32", "a%d" % loc[1], v(src))
     e("s_mov_b64", "exec", sp_(S_EXEC))
+    # the composed AGPR words move to this lane's LDS words 0.. (the factor there has been consumed): four per float4,
+    # read back with one ds_read_b128 per four coefficients in every iteration instead of one v_accvgpr_read each
+    ovf = [r for kind, r in plan.cloc if kind == "a"]
+    for base in range(0, len(ovf), 4):
+        t = QT + 4 * ((base // 4) % 3)
+        for k in range(4):
+            if base + k < len(ovf):
+                e("v_accvgpr_read_b32", v(t + k), "a%d" % ovf[base + k])
+        e("ds_write_b128", "v1", "v[%d:%d]" % (t, t + 3), (base // 4) * 1024)
+    e("s_waitcnt", "lgkmcnt(0)")
     e("s_nop", 4)
 
 
@@ -504,6 +529,17 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
                 raise AssertionError("DPP read of a masked-off lane: %r" % (mod,))
         return asf(V[qp, reg])
     nexec = 0
+    pend = []           # outstanding LDS operations in issue order: the registers a read will write (writes: empty)
+    import re as _re
+
+    def regs_of(x):
+        if not isinstance(x, str):
+            return set()
+        x = x.lstrip("-")
+        mm = _re.fullmatch(r"v\[(\d+):(\d+)\]", x)
+        if mm:
+            return set(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        return {int(x[1:])} if _re.fullmatch(r"v\d+", x) else set()
     assert ins[pc] == ("quad_begin",)
     pc += 1
     with np.errstate(all="ignore"):
@@ -515,7 +551,19 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
                 continue
             nexec += 1
             assert nexec < max_exec, "runaway quad section"
-            if m in ("s_waitcnt", "s_nop"):
+            if m[0] == "v" or m.startswith("ds_"):
+                used = set().union(*[regs_of(x) for x in t[1:]])
+                for dst in pend:
+                    assert not (dst & used), ("register used before its LDS read was waited for", t)
+                if m.startswith("ds_read"):
+                    pend.append(regs_of(t[1]))
+                elif m.startswith("ds_write"):
+                    pend.append(set())
+            if m == "s_waitcnt":
+                for part in t[1].split():
+                    if part.startswith("lgkmcnt("):
+                        del pend[:max(0, len(pend) - int(part[8:-1]))]
+            elif m == "s_nop":
                 pass
             elif m == "s_mov_b32":
                 S[int(t[1][1:])] = t[2] & 0xFFFFFFFF if isinstance(t[2], int) else S.get(int(t[2][1:]), 0)
@@ -549,6 +597,12 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
                 for ln in range(4):
                     if exec_[ln]:
                         V[ln, lo:lo + 4] = lds[ln, w0:w0 + 4]
+            elif m == "ds_write_b128":
+                lo = int(t[2][2:t[2].index(":")])
+                w0 = t[3] // 1024 * 4
+                for ln in range(4):
+                    if exec_[ln]:
+                        lds[ln, w0:w0 + 4] = V[ln, lo:lo + 4]
             elif m == "v_accvgpr_read_b32":
                 V[exec_, vi(t[1])] = A[exec_, int(t[2][1:])]
             elif m == "v_accvgpr_write_b32":
@@ -603,5 +657,5 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
             else:
                 raise ValueError("unknown instruction in the quad section: %r" % (t,))
             pc += 1
-    assert exec_.all(), "EXEC not restored at the end of the quad section"
+    assert exec_.all() and not pend, "EXEC not restored / LDS operations outstanding at the end of the quad section"
     return pc + 1, nexec

@@ -61,9 +61,11 @@ def test_stream_size_and_exec_discipline(programs):
     assert len(labs) == 2
     body = [t for t in sec[labs[0]:labs[1]] if t[0] != "label"]
     # one quad iteration against the one-lane body (804 instructions): VERDICT r3 item 1
-    assert len(body) <= 360, len(body)
+    assert len(body) <= 330, len(body)
     assert not any(t[0] == "s_mov_b64" and t[1] == "exec" for t in body), "EXEC must stay full inside the iterations (DPP)"
-    assert not any(t[0].startswith("ds_") or t[0].startswith("global_") for t in body), "no memory instruction in the iteration"
+    # the only memory instructions of an iteration: the ~20 float4 reads of the coefficient words that found no VGPR home
+    assert not any(t[0].startswith("global_") or t[0].startswith("ds_write") for t in body)
+    assert sum(1 for t in body if t[0] == "ds_read_b128") <= 20 and not any(t[0] == "v_accvgpr_read_b32" for t in body)
     # EXEC masks only around plain moves: no DPP instruction between a mask switch and the restore
     masked = False
     for t in sec:
@@ -122,7 +124,7 @@ def test_quad_form_matches_the_oracle_and_the_lane_form(programs, oracle_built, 
         n4 = asmstep.simulate(ins4, a4, dict(K=K, maxIter=50, nsub=25, plant=1), fl)
         nq = asmstep.simulate.last_quad_instructions
         # per step: one-lane 57 k instructions, quad form <= 39 k, of which <= 19.5 k inside the quad section
-        assert n4 < 0.68 * n1 and 30000 < nq < 39000, (n1, n4, nq)
+        assert n4 < 0.66 * n1 and 30000 < nq < 37000, (n1, n4, nq)
         for a, key in ((a1, 1), (a4, 4)):
             assert np.abs(a["state"][0:3] - s64[0:3, b]).max() < 1e-4 and np.abs(a["state"][3:] - s64[3:, b]).max() < 3e-5
             assert abs(a["out"][0] - out_o[0, b]) < 3e-5
