@@ -20,9 +20,9 @@ keeps a third of the unknowns in each of lanes 0..2 (lane 3 idles on zeros):
     ~270 operand fetches).
   * every element-wise phase (right-hand side, 1/D, x / y updates) is 15 + 12 registers wide instead of 45 + 39 + 39,
     packed two registers per instruction; q, l, 1/D and 116 coefficient words are VGPR-resident (a lane owns a third of
-    the 561-word working set), the remaining 78 coefficient words are read from AGPRs a few instructions ahead of use.
+    the 561-word working set), the remaining 78 coefficient words come four per ds_read_b128 from the lane's LDS words.
 
-~344 instructions per iteration instead of 804. Entry (after the first iteration, which runs in the one-lane form on
+318 instructions per iteration instead of 804. Entry (after the first iteration, which runs in the one-lane form on
 the one-lane homes phase A filled): each lane copies ITS third of x, y, z, q, l, 1/D and L into the quad registers with
 plain moves under a lane-class mask (~1 000 instructions, two iterations' worth). Exit: every word of x, y, z, delta_x,
 delta_y is broadcast to the four lanes' one-lane homes with one v_mov_b32_dpp each (171), and phase C goes on as ever.
