@@ -695,6 +695,22 @@ def write_quad(path=None, N=3, perm=None):
         out.append('  "%s\\n" \\' % fmt(t))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{s[4:5]}"(ws), "{s[6:7]}"(ctrl), "{s[8:9]}"(tab), "{s10}"(stride), "{s11}"(iters) \\')
     out.append("  : " + ", ".join(clob) + ")")
+    # the Ruiz passes on the quad
+    rins, _ = asmquad64.ruiz_program(N, perm)
+    rins = [t for t in rins if t[0] not in PSEUDO]
+    r27 = [k for k, t_ in enumerate(rins) if t_ == ("label", "27")][0]
+    rend = [k for k, t_ in enumerate(rins) if t_[0] == "s_cbranch_scc1"][-1]
+    rclob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
+            ['"s%d"' % i for i in [S_CNT] + list(range(30, 42))]
+    out += ["// The Ruiz passes of the fp64 step on the lane quad (asmquad64.ruiz_program): %d instructions, %d per pass (one-lane"
+            % (len(rins), rend - r27),
+            "// block: 2 546 per pass). LDS words in and out as UMPC_RUIZ_ASM64; every lane's slice ends with the whole result.",
+            "// inputs: v1 = lane LDS address (16*lane), s11 = passes >= 1",
+            "#define UMPC_RUIZ_ASM64_QUAD(ldsaddr, passes) asm volatile( \\"]
+    for t_ in rins:
+        out.append('  "%s\\n" \\' % fmt(t_))
+    out.append('  : : "{v1}"(ldsaddr), "{s11}"(passes) \\')
+    out.append("  : " + ", ".join(rclob) + ")")
     txt = "\n".join(out) + "\n"
     if not os.path.exists(path) or open(path).read() != txt:
         with open(path, "w") as fh:

@@ -392,6 +392,7 @@ def simulate(ins, pc, V, A, lds, S, tab, max_exec=400000):
     from fractions import Fraction
     u32 = np.uint32
     exec_ = np.ones(4, bool)
+    vcc = np.zeros(4, bool)
     masks, labels, scc = {}, {}, 0
     for k, t in enumerate(ins):
         if t[0] == "label":
@@ -410,6 +411,8 @@ def simulate(ins, pc, V, A, lds, S, tab, max_exec=400000):
         neg = x.startswith("-")
         if neg:
             x = x[1:]
+        if x.startswith("|"):
+            return (-1.0 if neg else 1.0) * abs(getd(x[1:-1], ln))
         lo = lohi(x)
         val = f64(V[ln, lo], V[ln, lo + 1]) if x[0] == "v" else f64(S[lo], S[lo + 1])
         return -val if neg else val
@@ -458,7 +461,24 @@ def simulate(ins, pc, V, A, lds, S, tab, max_exec=400000):
         elif m == "s_nop":
             pass
         elif m == "s_mov_b32":
-            S[int(t[1][1:])] = t[2] & 0xFFFFFFFF
+            S[int(t[1][1:])] = (t[2] & 0xFFFFFFFF) if isinstance(t[2], int) else S.get(int(t[2][1:]), 0)
+        elif m == "v_cmp_nlt_f64":
+            assert t[1] == "vcc"
+            for ln in range(4):
+                if exec_[ln]:
+                    vcc[ln] = not (getd(t[2], ln) < getd(t[3], ln))
+        elif m == "v_cndmask_b32":
+            assert t[4] == "vcc"
+            for ln in range(4):
+                if exec_[ln]:
+                    a = u32(t[2]) if isinstance(t[2], int) else V[ln, vi(t[2])]
+                    V[ln, vi(t[1])] = V[ln, vi(t[3])] if vcc[ln] else a
+        elif m in ("v_rsq_f64", "v_rcp_f64"):
+            for ln in range(4):
+                if exec_[ln]:
+                    a = getd(t[2], ln)
+                    with np.errstate(all="ignore"):
+                        setd(t[1], ln, (1.0 / np.sqrt(a)) if m == "v_rsq_f64" else (np.float64(1.0) / np.float64(a)))
         elif m == "s_mov_b64":
             if t[2] == "exec":
                 masks[t[1]] = exec_.copy()
@@ -492,7 +512,8 @@ def simulate(ins, pc, V, A, lds, S, tab, max_exec=400000):
         elif m == "v_add_u32":
             for ln in range(4):
                 if exec_[ln]:
-                    V[ln, vi(t[1])] = (int(V[ln, vi(t[2])]) + int(V[ln, vi(t[3])])) & 0xFFFFFFFF
+                    a = t[2] if isinstance(t[2], int) else int(V[ln, vi(t[2])])
+                    V[ln, vi(t[1])] = (a + int(V[ln, vi(t[3])])) & 0xFFFFFFFF
         elif m == "v_mov_b32":
             for ln in range(4):
                 if exec_[ln]:
@@ -567,3 +588,255 @@ def simulate(ins, pc, V, A, lds, S, tab, max_exec=400000):
         pc += 1
     assert exec_.all() and not pend, "EXEC not restored / LDS reads outstanding at the end of the quad section"
     return pc + 1, nexec
+
+
+# =====================================================================================================================
+# The ten Ruiz passes of the fp64 step on the lane quad (the quad counterpart of asmgen64.ruiz_program)
+# =====================================================================================================================
+# The one-lane block spends 2 546 instructions per pass, most of them the 84 refined 1/sqrt and limit_scaling sequences --
+# one per row and per column. On the quad a register holds the x / y / z members of a triple (or the three horizon steps of
+# an input), so the same sequences run on 13 row registers and 15 column registers: a third of the work, and nothing
+# crosses lanes except the nine input columns (thrust and the two moments of the three steps), whose entries sit in the
+# lanes of their ROWS: their column norms are reduced over the quad with DPP moves and their scalings are fetched from the
+# lane of the step. Every lane reads ITS entries of P, q and A straight from its own LDS slice (masked reads: all four
+# slices hold the whole problem) and the scaled data go back to every slice at the end.
+#   LDS words on entry and exit: as asmgen64.ruiz_program (RZ_P, RZ_Q, RZ_A; RZ_C on exit).
+RQ_T = 4                   # 10 temporaries (words) v4..v23
+RQ_C = 24                  # c (accumulated cost scaling)
+RQ_ONEHI = 26              # high word of 1.0
+RQ_ET = 28                 # 13 words: row scalings of this pass
+RQ_P = 54                  # 15 words
+RQ_Q = 84                  # 15 words
+RQ_A = 114                 # the entry slots (<= 66 words to v245)
+S_RMINS, S_RMAXS = 30, 32
+S_RL0, S_RL1, S_RL2, S_REXEC = 34, 36, 38, 40
+ROT1, ROT2 = [1, 2, 0, 3], [2, 0, 1, 3]
+
+
+class RuizQuadPlan:
+    def __init__(self, s, plan):
+        self.s, self.plan = s, plan
+        self.slots = {}          # (row register 0..12, column register 0..14) -> {row lane: entry}
+        collane = {}             # slot -> {row lane: lane of the entry's column}
+        for j in range(s.nx):
+            lc, C = plan.xhome[j]
+            for p in range(s.A_p[j], s.A_p[j + 1]):
+                lr, R = plan.zhome[s.A_i[p]]
+                key = (R - IX_EQ, C)
+                d = self.slots.setdefault(key, {})
+                assert lr not in d
+                d[lr] = p
+                collane.setdefault(key, {})[lr] = lc
+        # "own": every entry's column lives in the entry's own lane; otherwise ONE lane k holds the column of every entry
+        # of the slot (an input of horizon step k against the three members of a row triple of that step)
+        self.kind = {}
+        for key, cl in collane.items():
+            if all(lc == lr for lr, lc in cl.items()):
+                self.kind[key] = "own"
+            else:
+                ks = set(cl.values())
+                assert len(ks) == 1, (key, cl)
+                self.kind[key] = ks.pop()
+        self.order = sorted(self.slots)
+        self.reg = {key: RQ_A + 2 * n for n, key in enumerate(self.order)}
+        assert RQ_A + 2 * len(self.order) <= 246, len(self.order)
+        assert all((kd == "own") or C >= 12 for (R, C), kd in self.kind.items())
+
+
+def ruiz_program(N=3, perm=None):
+    """s11 = number of passes (>= 1); v1 = lane LDS address. Standalone block: the whole list runs on the quad."""
+    from . import asmgen64 as g
+    from .asmgen64 import RZ_A, RZ_C, RZ_P, RZ_Q, f64bits
+    s = symbolic.analyse(N, perm)
+    plan = plan_for(s)
+    rp = RuizQuadPlan(s, plan)
+    nx, nc = s.nx, s.nc
+    e = g.Emit()
+    v = lambda n: "v%d" % n
+    T = lambda q: RQ_T + 2 * q
+    ET = lambda R: RQ_ET + 2 * R
+    P = lambda C: RQ_P + 2 * C
+    Q = lambda C: RQ_Q + 2 * C
+    sMIN, sMAX = sp(S_RMINS), sp(S_RMAXS)
+    ab = lambda r: "|" + vp(r) + "|"
+    masks = (S_RL0, S_RL1, S_RL2)
+
+    def setc(reg, val):
+        b = f64bits(val)
+        e("s_mov_b32", "s%d" % reg, b & 0xFFFFFFFF)
+        e("s_mov_b32", "s%d" % (reg + 1), b >> 32)
+
+    def limit(t, t2):
+        e("v_cmp_nlt_f64", "vcc", vp(t), sMIN)
+        e("v_min_f64", vp(t2), vp(t), sMAX)
+        e("v_cndmask_b32", v(t), 0, v(t2), "vcc")
+        e("v_cndmask_b32", v(t + 1), v(RQ_ONEHI), v(t2 + 1), "vcc")
+
+    def rsqrt(y, t, a_, h_):
+        e("v_rsq_f64", vp(y), vp(t))
+        e("s_nop", 0)
+        for _ in range(2):
+            e("v_mul_f64", vp(a_), vp(t), vp(y))
+            e("v_fma_f64", vp(a_), "-" + vp(a_), vp(y), 1.0)
+            e("v_mul_f64", vp(h_), 0.5, vp(y))
+            e("v_fma_f64", vp(y), vp(h_), vp(a_), vp(y))
+
+    def recip(y, t, a_):
+        e("v_rcp_f64", vp(y), vp(t))
+        e("s_nop", 0)
+        for _ in range(2):
+            e("v_fma_f64", vp(a_), "-" + vp(t), vp(y), 1.0)
+            e("v_fma_f64", vp(y), vp(y), vp(a_), vp(y))
+
+    def fetch(dst, src, perm):
+        """dst <- src of the lanes `perm` selects (two 32-bit DPP moves)"""
+        e("v_mov_b32_dpp", v(dst), v(src), qperm(perm))
+        e("v_mov_b32_dpp", v(dst + 1), v(src + 1), qperm(perm))
+
+    # ---- prologue: constants, masks, zero, then every lane's own entries from its LDS slice
+    e("quad_begin",)
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    setc(S_RMINS, 1e-4)
+    setc(S_RMAXS, 1e4)
+    e("v_add_u32", v(g.V_B1), 0x10000, "v1")
+    e("v_add_u32", v(g.V_B2), 0x20000, "v1")
+    e("s_mov_b64", sp(S_REXEC), "exec")
+    for ln, m in enumerate(masks):
+        e("s_mov_b32", "s%d" % m, 0x11111111 << ln)
+        e("s_mov_b32", "s%d" % (m + 1), 0x11111111 << ln)
+        e("s_and_b64", sp(m), sp(m), sp(S_REXEC))
+    words = [P(C) for C in range(15)] + [Q(C) for C in range(15)] + [rp.reg[k] for k in rp.order]
+    for r in words:
+        e("v_mov_b32", v(r), 0)
+        e("v_mov_b32", v(r + 1), 0)
+    b1 = f64bits(1.0)
+    e("v_mov_b32", v(RQ_C), b1 & 0xFFFFFFFF)
+    e("v_mov_b32", v(RQ_C + 1), b1 >> 32)
+    e("v_mov_b32", v(RQ_ONEHI), b1 >> 32)
+    loads = {0: [], 1: [], 2: []}
+    for j in range(nx):
+        ln, C = plan.xhome[j]
+        loads[ln].append((P(C), RZ_P + j))
+        loads[ln].append((Q(C), RZ_Q + j))
+    for key in rp.order:
+        for ln, p in rp.slots[key].items():
+            loads[ln].append((rp.reg[key], RZ_A + p))
+    for ln in range(3):
+        e("s_mov_b64", "exec", sp(masks[ln]))
+        for k, (dst, word) in enumerate(loads[ln]):
+            b_, off, half = g.lds_addr(word)
+            e("ds_read_b64", vp(dst), b_, off + 8 * half)
+            if k % 12 == 11:
+                e("s_waitcnt", "lgkmcnt(0)")
+        e("s_waitcnt", "lgkmcnt(0)")
+    e("s_mov_b64", "exec", sp(S_REXEC))
+    e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
+    e("label", "27")
+    # ---- row scalings
+    byrow = {}
+    for key in rp.order:
+        byrow.setdefault(key[0], []).append(rp.reg[key])
+    for R in range(13):
+        t, regs = T(0), byrow[R]
+        if len(regs) == 1:
+            e("v_max_f64", vp(t), ab(regs[0]), ab(regs[0]))
+        else:
+            e("v_max_f64", vp(t), ab(regs[0]), ab(regs[1]))
+            for r in regs[2:]:
+                e("v_max_f64", vp(t), vp(t), ab(r))
+        limit(t, T(1))
+        rsqrt(ET(R), t, T(2), T(3))
+    # ---- columns
+    for r in (T(4), T(5)):
+        e("v_mov_b32", v(r), 0)
+        e("v_mov_b32", v(r + 1), 0)
+    bycol = {}
+    for key in rp.order:
+        bycol.setdefault(key[1], []).append(key)
+    for C in range(15):
+        t, dt, pn = T(0), T(1), T(6)
+        own = [k for k in bycol.get(C, []) if rp.kind[k] == "own"]
+        far = [k for k in bycol.get(C, []) if rp.kind[k] != "own"]
+        e("v_mul_f64", vp(pn), vp(P(C)), vp(RQ_C))            # the norms see c * P_j (the cost scaling is carried as a scalar)
+        first = True
+        for k in own:
+            e("v_max_f64", vp(t), ab(pn if first else t), ab(rp.reg[k]))
+            first = False
+        if first:
+            e("v_max_f64", vp(t), ab(pn), ab(pn))
+        for k in far:          # the column of step rp.kind[k]: its entries sit in the three ROW lanes of slot k
+            r = rp.reg[k]
+            fetch(T(7), r, ROT1)
+            fetch(T(8), r, ROT2)
+            e("v_max_f64", vp(T(7)), ab(T(7)), ab(T(8)))
+            e("v_max_f64", vp(T(7)), vp(T(7)), ab(r))          # max over lanes 0..2, in each of them
+            e("s_mov_b64", "exec", sp(masks[rp.kind[k]]))
+            e("v_max_f64", vp(t), vp(t), vp(T(7)))
+            e("s_mov_b64", "exec", sp(S_REXEC))
+        limit(t, dt)
+        rsqrt(dt, t, T(2), T(3))
+        e("v_mul_f64", vp(P(C)), vp(P(C)), vp(dt))
+        e("v_mul_f64", vp(P(C)), vp(P(C)), vp(dt))
+        e("v_add_f64", vp(T(4)), vp(T(4)), ab(P(C)))
+        for k in own:
+            e("v_mul_f64", vp(rp.reg[k]), vp(rp.reg[k]), vp(ET(k[0])))
+            e("v_mul_f64", vp(rp.reg[k]), vp(rp.reg[k]), vp(dt))
+        for k in far:
+            e("s_nop", 1)
+            fetch(T(7), dt, [rp.kind[k]] * 4)
+            e("v_mul_f64", vp(rp.reg[k]), vp(rp.reg[k]), vp(ET(k[0])))
+            e("v_mul_f64", vp(rp.reg[k]), vp(rp.reg[k]), vp(T(7)))
+        e("v_mul_f64", vp(Q(C)), vp(Q(C)), vp(dt))
+        e("v_max_f64", vp(T(5)), vp(T(5)), ab(Q(C)))
+    # ---- sum |P_j| and max |q_j| over the quad: a butterfly, so that ALL FOUR lanes end with the same value (lane 3 owns
+    # nothing but runs the phases around this block like the others and must read the same c)
+    e("s_nop", 1)
+    for perm_ in ([1, 0, 3, 2], [2, 3, 0, 1]):
+        fetch(T(7), T(4), perm_)
+        fetch(T(8), T(5), perm_)
+        e("v_add_f64", vp(T(4)), vp(T(4)), vp(T(7)))
+        e("v_max_f64", vp(T(5)), vp(T(5)), vp(T(8)))
+        e("s_nop", 1)
+    # ---- cost scaling: ct = 1 / limit(max(pmean / nx, limit(qn))), as the one-lane block
+    b = f64bits(float(nx))
+    e("v_mov_b32", v(T(0)), b & 0xFFFFFFFF)
+    e("v_mov_b32", v(T(0) + 1), b >> 32)
+    recip(T(1), T(0), T(2))
+    e("v_mul_f64", vp(T(4)), vp(T(4)), vp(RQ_C))
+    e("v_mul_f64", vp(T(5)), vp(T(5)), vp(RQ_C))
+    e("v_mul_f64", vp(T(2)), vp(T(4)), vp(T(1)))
+    e("v_fma_f64", vp(T(3)), "-" + vp(T(0)), vp(T(2)), vp(T(4)))
+    e("v_fma_f64", vp(T(4)), vp(T(3)), vp(T(1)), vp(T(2)))
+    limit(T(5), T(0))
+    e("v_max_f64", vp(T(4)), vp(T(4)), vp(T(5)))
+    limit(T(4), T(0))
+    recip(T(5), T(4), T(0))
+    e("v_mul_f64", vp(RQ_C), vp(RQ_C), vp(T(5)))
+    e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
+    e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
+    e("s_cbranch_scc1", "27b")
+    # ---- epilogue: c once into P and q; every word back to every lane's slice
+    for C in range(15):
+        e("v_mul_f64", vp(P(C)), vp(P(C)), vp(RQ_C))
+        e("v_mul_f64", vp(Q(C)), vp(Q(C)), vp(RQ_C))
+    e("s_nop", 1)
+    cnt = [0]
+
+    def put(word, src, ln):
+        t = T(cnt[0] % 10)
+        cnt[0] += 1
+        fetch(t, src, [ln] * 4)
+        b_, off, half = g.lds_addr(word)
+        e("ds_write_b64", b_, vp(t), off + 8 * half)
+    for j in range(nx):
+        ln, C = plan.xhome[j]
+        put(RZ_P + j, P(C), ln)
+        put(RZ_Q + j, Q(C), ln)
+    for key in rp.order:
+        for ln, p in rp.slots[key].items():
+            put(RZ_A + p, rp.reg[key], ln)
+    b_, off, half = g.lds_addr(RZ_C)
+    e("ds_write_b64", b_, vp(RQ_C), off + 8 * half)
+    e("s_waitcnt", "lgkmcnt(0)")
+    e("quad_end",)
+    return e.ins, s

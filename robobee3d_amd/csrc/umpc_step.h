@@ -611,7 +611,11 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
 #pragma unroll
       for (int j = 0; j < NX; ++j) LDSF_W(umpcasm64::RZ_P + j) = P[j];
       UMPC_PHASE_FENCE();
-      UMPC_RUIZ_ASM64(ldsaddr, UMPC_SCALING_ITERS);
+      if constexpr (QUAD) {
+        UMPC_RUIZ_ASM64_QUAD(ldsaddr, UMPC_SCALING_ITERS);      // the passes on the lane quad (asmquad64.ruiz_program)
+      } else {
+        UMPC_RUIZ_ASM64(ldsaddr, UMPC_SCALING_ITERS);
+      }
       UMPC_PHASE_FENCE();
 #pragma unroll
       for (int j = 0; j < NX; ++j) P[j] = LDSF_W(umpcasm64::RZ_P + j);

@@ -342,3 +342,47 @@ def test_fp64_residual_stream_assembles_and_fits():
         assert r.returncode == 0, r.stderr[:3000]
     finally:
         os.unlink(f.name)
+
+
+@pytest.mark.parametrize("passes", [1, 10])
+def test_generated_fp64_quad_ruiz_block_matches_numpy(passes):
+    """the Ruiz passes on the lane quad (asmquad64.ruiz_program): every lane reads its own third of P, q, A from its LDS
+    slice, the nine input columns are reduced / scaled across lanes, and all four slices end with the whole equilibrated
+    problem -- equal to the numpy statement of scaling.c:44-156 to 1e-13 (the sum of |P_j| is associated per lane)."""
+    from robobee3d_amd import asmgen64 as g, asmquad64 as q4
+    ins, s = q4.ruiz_program()
+    rng = np.random.default_rng(passes)
+    nx, nnz = s.nx, len(s.A_i)
+    for scale in (1.0, 1e-6, 3e5):
+        P = np.abs(rng.normal(size=nx)) * 10 * scale + 1e-3 * scale
+        A = rng.normal(size=nnz) * scale
+        A[rng.random(nnz) < 0.3] = 1.0
+        q = rng.normal(size=nx) * scale
+        lds = np.zeros((4, 320))
+        lds[:, g.RZ_P:g.RZ_P + nx], lds[:, g.RZ_Q:g.RZ_Q + nx], lds[:, g.RZ_A:g.RZ_A + nnz] = P, q, A
+        V, A4 = np.zeros((4, 256), np.uint32), np.zeros((4, 256), np.uint32)
+        from robobee3d_amd.asmgen import S_ITERS
+        _, n = q4.simulate(ins, 0, V, A4, lds, {S_ITERS: passes}, None)
+        Pr, Ar, qr, cr = _ruiz_numpy(s, P, A, q, passes)
+        for ln in range(4):
+            for got, ref in ((lds[ln, g.RZ_P:g.RZ_P + nx], Pr), (lds[ln, g.RZ_A:g.RZ_A + nnz], Ar), (lds[ln, g.RZ_Q:g.RZ_Q + nx], qr)):
+                assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (passes, scale, ln)
+            assert abs(lds[ln, g.RZ_C] - cr) <= 1e-13 * cr
+        assert n < 400 + 640 + passes * 800
+
+
+def test_fp64_quad_ruiz_stream_assembles():
+    import os, subprocess, tempfile
+    from robobee3d_amd import asmgen64 as g, asmquad64 as q4
+    mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("llvm-mc not available")
+    ins, s = q4.ruiz_program()
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("\n".join(g.fmt(t) for t in ins if t[0] not in g.PSEUDO) + "\n")
+    try:
+        r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", os.devnull, f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[:3000]
+    finally:
+        os.unlink(f.name)
