@@ -1,7 +1,7 @@
 """ONE ROBOT PER LANE QUAD, fp64: ADMM iterations 2..maxIter of the small-batch fp64 step (asmgen64.py, BASELINE config 2:
 B = 4 096) -- the fp64 counterpart of asmquad.py. 4 096 robots are 64 one-lane waves on 64 of the chip's 256 CUs; with
 four lanes per robot they are 256 waves, one per CU (the fp64 loop owns its CU's LDS), and each iteration is 1 125
-instructions with 314 fp64 operations instead of 1 483 with 786 (measured: 0.295 -> 0.224 ms per step).
+instructions with 314 fp64 operations instead of 1 483 with 786 (measured: 0.295 -> 0.224 ms per step; 0.185 with the Ruiz passes on the quad too, ruiz_program below).
 
 Same idea as asmquad.py (its docstring has the reasoning): the phases around the loop run redundantly in the four lanes
 of a quad, the loop keeps a third of the unknowns in each of lanes 0..2, a triangular-solve operation runs in the lane
