@@ -509,7 +509,12 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
         neg = x.startswith("-")
         if neg:
             x = x[1:]
+        ab = x.startswith("|")
+        if ab:
+            x = x[1:-1]
         val = asf(V[:, vi(x)]) if x[0] == "v" else np.full(4, sval(x), f32)
+        if ab:
+            val = np.abs(val)
         return -val if neg else val
 
     def setv(x, val):
@@ -523,11 +528,22 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
         return np.full(4, np.float64(asf(u32(S.get(lo + sel, 0)))))
 
     def dpp_src(reg, mod):
+        """reg: a register number, or an operand string with modifiers ("|v12|")"""
+        neg = ab = False
+        if isinstance(reg, str):
+            neg = reg.startswith("-")
+            reg = reg[1:] if neg else reg
+            ab = reg.startswith("|")
+            reg = vi(reg[1:-1] if ab else reg)
         qp = [int(c) for c in mod[mod.index("[") + 1:mod.index("]")].split(",")]
         for ln in range(4):
             if exec_[ln] and not exec_[qp[ln]]:
                 raise AssertionError("DPP read of a masked-off lane: %r" % (mod,))
-        return asf(V[qp, reg])
+        val = asf(V[qp, reg])
+        if ab:
+            val = np.abs(val)
+        return -val if neg else val
+    vcc = np.zeros(4, bool)
     nexec = 0
     pend = []           # outstanding LDS operations in issue order: the registers a read will write (writes: empty)
     import re as _re
@@ -540,10 +556,10 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
         if mm:
             return set(range(int(mm.group(1)), int(mm.group(2)) + 1))
         return {int(x[1:])} if _re.fullmatch(r"v\d+", x) else set()
-    assert ins[pc] == ("quad_begin",)
+    assert ins[pc][0] == "quad_begin"
     pc += 1
     with np.errstate(all="ignore"):
-        while ins[pc] != ("quad_end",):
+        while ins[pc][0] != "quad_end":
             t = ins[pc]
             m = t[0]
             if m in ("label", "kill"):
@@ -566,7 +582,7 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
             elif m == "s_nop":
                 pass
             elif m == "s_mov_b32":
-                S[int(t[1][1:])] = t[2] & 0xFFFFFFFF if isinstance(t[2], int) else S.get(int(t[2][1:]), 0)
+                S[int(t[1][1:])] = (t[2] & 0xFFFFFFFF) if isinstance(t[2], int) else S.get(int(t[2][1:]), 0)
             elif m == "s_mov_b64":
                 if t[2] == "exec":
                     masks[t[1]] = exec_.copy()
@@ -627,10 +643,30 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
                 setv(t[1], fsrc(t[2]) + fsrc(t[3]))
             elif m == "v_sub_f32":
                 setv(t[1], fsrc(t[2]) - fsrc(t[3]))
-            elif m in ("v_max_f32", "v_min_f32"):
-                a, b = fsrc(t[2]), fsrc(t[3])
-                r = np.where(b != b, a, np.where(a != a, b, np.maximum(a, b) if m == "v_max_f32" else np.minimum(a, b)))
+            elif m in ("v_max_f32", "v_min_f32", "v_max_f32_dpp"):
+                a, b = (dpp_src(t[2], t[4]) if m.endswith("_dpp") else fsrc(t[2])), fsrc(t[3])
+                r = np.where(b != b, a, np.where(a != a, b, np.minimum(a, b) if m == "v_min_f32" else np.maximum(a, b)))
                 setv(t[1], r)
+            elif m == "v_max3_f32":
+                a, b, c = fsrc(t[2]), fsrc(t[3]), fsrc(t[4])
+                setv(t[1], np.fmax(np.fmax(a, b), c))
+            elif m == "v_and_b32":
+                assert t[2] == 0x7fffffff
+                V[exec_, vi(t[1])] = (V[:, vi(t[3])] & u32(0x7fffffff))[exec_]
+            elif m in ("v_mul_f32_dpp", "v_add_f32_dpp"):
+                a, b = dpp_src(t[2], t[4]), fsrc(t[3])
+                setv(t[1], a * b if m == "v_mul_f32_dpp" else a + b)
+            elif m == "v_cmp_lt_f32":
+                assert t[1] == "vcc"
+                vcc[exec_] = (fsrc(t[2]) < fsrc(t[3]))[exec_]
+            elif m == "v_cndmask_b32":
+                assert t[4] == "vcc"
+                a, b = fsrc(t[2]), fsrc(t[3])
+                setv(t[1], np.where(vcc, b, a))
+            elif m == "v_rsq_f32":
+                setv(t[1], (1.0 / np.sqrt(fsrc(t[2]).astype(np.float64))).astype(f32))
+            elif m == "v_rcp_f32":
+                setv(t[1], f32(1.0) / fsrc(t[2]))
             elif m == "v_pk_mov_b32":
                 d = t[-1]
                 lo = int(t[1][2:t[1].index(":")])

@@ -617,7 +617,7 @@ class StepGen:
         pool.free(*RF)
         pool.free(*WV.values())
         pool.free_range(LS, 20)
-        self.ruiz()
+        self.ruiz_quad() if self.quad else self.ruiz()
         self.recover_and_bounds()
         self.factor()
 
@@ -795,6 +795,169 @@ class StepGen:
         e("s_sub_i32", sg(S_RUIZ), sg(S_RUIZ), 1)
         e("s_cmp_gt_i32", sg(S_RUIZ), 0)
         e("s_cbranch_scc1", top + "b")
+
+
+    # ---- Ruiz equilibration on the lane QUAD (the quad form of the stream, asmquad.py) ---------------------------------
+    def ruiz_quad(self):
+        """The ten passes with a third of the matrix per lane. Every lane of the quad holds the whole raw problem in the
+        one-lane registers (the phases before ran redundantly), so nothing is allocated: the register of the lane-0 member
+        of every entry slot / column triple HOSTS the slot -- lanes 1 and 2 move their member in under a lane mask -- and the
+        other members' registers serve as temporaries. A register then holds the x / y / z members of a row / column triple
+        (or the three horizon steps of an input): 13 row norms + 15 column norms per pass instead of 39 + 45, and nothing
+        crosses lanes but the nine input columns (their entries sit in the lanes of their ROWS: norms reduced by DPP,
+        scalings fetched from the lane of the step) and the cost normalisation's sum / maximum (a four-lane butterfly; lane
+        3 duplicates lane 0 up to there and is zeroed out of it). At the end every word goes back to its one-lane home in
+        all four lanes. Same operations per value as ruiz(); the sum of P_jj is associated per lane (rounding only)."""
+        from . import asmquad, asmquad64
+        e, pool, st, s = self.e, self.pool, self.st, self.s
+        nx, nc = s.nx, s.nc
+        RP, RA, RQ = self.RP, self.RA, self.RQ
+        VE = pool.getn(nc + 1)
+        self.VE = VE
+        self.RE = lambda i: VE + st.zs[i]
+        cs = pool.get()
+        self.cs = cs
+        e("v_mov_b32", v(cs), 1.0)
+        e("v_mov_b32", v(VE + nc), 0)
+        qp = asmquad.QuadPlan(st)
+        rp = asmquad64.RuizQuadPlan(s, qp)
+        # hosts and the registers they free
+        hostA = {key: RA(d[min(d)]) for key, d in rp.slots.items()}
+        colmem = {}                       # column register -> {lane: x index}
+        for j in range(nx):
+            ln, C = qp.xhome[j]
+            colmem.setdefault(C, {})[ln] = j
+        hostP = {C: RP(m[min(m)]) for C, m in colmem.items()}
+        hostQ = {C: RQ(min(jj for jj in m.values() if jj in st.qslot)) for C, m in colmem.items() if any(jj in st.qslot for jj in m.values())}
+        # (q is structurally zero on the other columns)
+        for C, m in colmem.items():
+            if C in hostQ:
+                assert all(jj in st.qslot for jj in m.values())
+        dead = [RA(p) for key, d in rp.slots.items() for ln, p in d.items() if RA(p) != hostA[key]] + \
+               [RP(j) for C, m in colmem.items() for j in m.values() if RP(j) != hostP[C]]
+        dead = sorted(set(dead))
+        ET = [dead.pop() for _ in range(13)]
+        DT = [dead.pop() for _ in range(15)]
+        t, m7, acc, qn, ct, tt = (dead.pop() for _ in range(6))
+        masks = (asmquad.S_L0, asmquad.S_L1, asmquad.S_L2)
+        S_L3 = 98
+        keep = sorted(set(range(self.VP, self.VP + nx + 1)) | set(range(self.VQ, self.VQ + st.nq + st.nq % 2)) |
+                      set(range(self.VA, self.VA + st.na + st.na % 2)) | {cs, VE + nc})
+        e("quad_begin", "ruiz")
+        e("s_mov_b64", sp(asmquad.S_EXEC), "exec")
+        for ln, m in enumerate(masks + (S_L3,)):
+            e("s_mov_b32", sg(m), 0x11111111 << ln)
+            e("s_mov_b32", sg(m + 1), 0x11111111 << ln)
+            e("s_and_b64", sp(m), sp(m), sp(asmquad.S_EXEC))
+        # ---- entry: lanes 1 and 2 bring their members into the hosts
+        for ln in (1, 2):
+            e("s_mov_b64", "exec", sp(masks[ln]))
+            for key, d in rp.slots.items():
+                if ln in d and RA(d[ln]) != hostA[key]:
+                    e("v_mov_b32", v(hostA[key]), v(RA(d[ln])))
+                elif ln not in d:
+                    e("v_mov_b32", v(hostA[key]), 0)
+            for C, m in colmem.items():
+                if ln in m:
+                    if RP(m[ln]) != hostP[C]:
+                        e("v_mov_b32", v(hostP[C]), v(RP(m[ln])))
+                    if C in hostQ and RQ(m[ln]) != hostQ[C]:
+                        e("v_mov_b32", v(hostQ[C]), v(RQ(m[ln])))
+        # (a slot without a lane-0 member: lane 0 and its duplicate, lane 3, hold another lane's entry there -- zero)
+        for key, d in rp.slots.items():
+            if 0 not in d:
+                e("s_mov_b64", "exec", sp(masks[0]))
+                e("v_mov_b32", v(hostA[key]), 0)
+                e("s_mov_b64", "exec", sp(S_L3))
+                e("v_mov_b32", v(hostA[key]), 0)
+        e("s_mov_b64", "exec", sp(asmquad.S_EXEC))
+        e("s_nop", 4)
+        e("s_mov_b32", sg(S_RUIZ), 10)
+        top = self.label()
+        e("label", top)
+        # (a) row norms -> Et
+        byrow, bycol = {}, {}
+        for key in sorted(rp.slots):
+            byrow.setdefault(key[0], []).append(key)
+            bycol.setdefault(key[1], []).append(key)
+        for R in range(13):
+            self.maxabs(ET[R], [hostA[k] for k in byrow[R]])
+        self.limit(ET, rsq=True)
+        # (b) column norms from the untouched columns -> Dt
+        for C in range(15):
+            own = [k for k in bycol.get(C, []) if rp.kind[k] == "own"]
+            self.maxabs(DT[C], [hostP[C]] + [hostA[k] for k in own])
+            for k in [k for k in bycol.get(C, []) if rp.kind[k] != "own"]:
+                r = hostA[k]
+                e("v_max_f32_dpp", v(m7), "|%s|" % v(r), "|%s|" % v(r), asmquad.qperm(asmquad64.ROT1))
+                e("v_max_f32_dpp", v(m7), "|%s|" % v(r), v(m7), asmquad.qperm(asmquad64.ROT2))       # max over lanes 0..2
+                e("s_mov_b64", "exec", sp(masks[rp.kind[k]]))
+                e("v_max_f32", v(DT[C]), v(DT[C]), v(m7))
+                e("s_mov_b64", "exec", sp(asmquad.S_EXEC))
+                e("s_nop", 4)
+        self.limit(DT, rsq=True)
+        # apply: A <- diag(Et) A diag(Dt), P <- Dt P Dt, q <- Dt q
+        for C in range(15):
+            for k in bycol.get(C, []):
+                r = hostA[k]
+                e("v_mul_f32", v(r), v(r), v(ET[k[0]]))
+                if rp.kind[k] == "own":
+                    e("v_mul_f32", v(r), v(r), v(DT[C]))
+                else:
+                    kk = rp.kind[k]
+                    e("v_mul_f32_dpp", v(r), v(DT[C]), v(r), asmquad.qperm([kk] * 4))
+            e("v_mul_f32", v(hostP[C]), v(hostP[C]), v(DT[C]))
+            e("v_mul_f32", v(hostP[C]), v(hostP[C]), v(DT[C]))
+            if C in hostQ:
+                e("v_mul_f32", v(hostQ[C]), v(hostQ[C]), v(DT[C]))
+        # (c) cost normalisation: c_t = 1 / limit(max(mean_j P_jj, limit(|q|_inf)))
+        e("v_add_f32", v(acc), v(hostP[0]), v(hostP[1]))
+        for C in range(2, 15):
+            e("v_add_f32", v(acc), v(acc), v(hostP[C]))
+        self.maxabs(qn, [hostQ[C] for C in sorted(hostQ)])
+        e("s_mov_b64", "exec", sp(S_L3))
+        e("v_mov_b32", v(acc), 0)
+        e("v_mov_b32", v(qn), 0)
+        e("s_mov_b64", "exec", sp(asmquad.S_EXEC))
+        e("s_nop", 4)
+        for perm_ in ([1, 0, 3, 2], [2, 3, 0, 1]):
+            e("v_add_f32_dpp", v(acc), v(acc), v(acc), asmquad.qperm(perm_))
+            e("v_max_f32_dpp", v(qn), v(qn), v(qn), asmquad.qperm(perm_))
+            e("s_nop", 1)
+        e("v_mul_f32", v(acc), sg(S_C["c45"]), v(acc))
+        self.limit([qn], rsq=False)
+        e("v_max_f32", v(acc), v(acc), v(qn))
+        self.limit([acc], rsq=False)
+        self.rcp_nr(ct, acc, tt)
+        for C in range(15):
+            e("v_mul_f32", v(hostP[C]), v(hostP[C]), v(ct))
+            if C in hostQ:
+                e("v_mul_f32", v(hostQ[C]), v(hostQ[C]), v(ct))
+        e("v_mul_f32", v(cs), v(cs), v(ct))
+        e("s_sub_i32", sg(S_RUIZ), sg(S_RUIZ), 1)
+        e("s_cmp_gt_i32", sg(S_RUIZ), 0)
+        e("s_cbranch_scc1", top + "b")
+        # ---- exit: every word back to its one-lane home in all four lanes (the hosts last: they are sources until then)
+        e("s_nop", 1)
+
+        def bcast(dst, src, ln):
+            e("v_mov_b32_dpp", v(dst), v(src), asmquad.qperm([ln] * 4))
+        for key, d in rp.slots.items():
+            for ln in sorted(d, reverse=True):
+                bcast(RA(d[ln]), hostA[key], ln)
+        for C, m in colmem.items():
+            for ln in sorted(m, reverse=True):
+                bcast(RP(m[ln]), hostP[C], ln)
+            if C in hostQ:
+                for ln in sorted(m, reverse=True):
+                    bcast(RQ(m[ln]), hostQ[C], ln)
+        e("v_mov_b32", v(self.VP + nx), 0)
+        if st.nq % 2:
+            e("v_mov_b32", v(self.VQ + st.nq), 0)
+        if st.na % 2:
+            e("v_mov_b32", v(self.VA + st.na), 0)
+        e("s_nop", 1)
+        e("quad_end", tuple(keep))
 
     # ---- D, E recovery, scaled bounds, q / bounds -> loop homes ---------------------------------------------------
     def recover_and_bounds(self):
@@ -2061,8 +2224,10 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
             "eq": lambda a, b: a == b, "u": lambda a, b: (a != a) or (b != b)}
     pc = nexec = 0
     nquad = [0]
+    sections = {}
     self_neq = 2 * 3 * symbolic.NY
     simulate.last_quad_instructions = 0
+    simulate.last_quad_sections = sections
     with np.errstate(all="ignore"):
         while pc < len(ins):
             t = ins[pc]
@@ -2084,6 +2249,14 @@ def simulate(ins, arrays, ints, floats, max_exec=3000000, ptr_xform=None):
                 pc, nq = asmquad.simulate(ins, pc, V4, A4, L4, S)
                 nexec += nq
                 nquad[0] += nq
+                sections[t[1] if len(t) > 1 else "admm"] = sections.get(t[1] if len(t) > 1 else "admm", 0) + nq
+                endm = ins[pc - 1]
+                if len(endm) > 1:           # a section that names what it hands back (the Ruiz passes): everything else is as before
+                    for r in endm[1]:
+                        assert (V4[1:4, r] == V4[0, r]).all(), "lanes of the quad disagree on v%d after the %s section" % (r, t[1])
+                        V[r] = V4[0, r]
+                    assert (A4[1:4] == A4[0]).all()
+                    continue
                 keep = set([0, 1]) | set(range(V_W, V_Z)) | set(range(V_Z + self_neq, V_Z + 40))
                 for r in range(256):
                     if r in keep:

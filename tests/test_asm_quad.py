@@ -21,9 +21,10 @@ def programs():
     return g1, g1.program(), g4, g4.program()
 
 
-def _section(ins):
-    qb = ins.index(("quad_begin",))
-    qe = ins.index(("quad_end",))
+def _section(ins, name=None):
+    """the ADMM section (name None) or a named one ("ruiz")"""
+    qb = ins.index(("quad_begin",) if name is None else ("quad_begin", name))
+    qe = next(k for k in range(qb, len(ins)) if ins[k][0] == "quad_end")
     return ins[qb + 1:qe]
 
 
@@ -74,6 +75,16 @@ def test_stream_size_and_exec_discipline(programs):
         assert not (masked and t[0].endswith("_dpp")), t
     real4 = [t for t in ins4 if t[0] not in asmstep.PSEUDO and t[0] != "label"]
     assert len(real4) < 12000
+    # the Ruiz section: one pass <= 460 instructions (one-lane: 730), EXEC masks only around plain moves / maxima
+    rz = _section(ins4, "ruiz")
+    lab = [k for k, t in enumerate(rz) if t[0] == "label"][0]
+    loop_end = [k for k, t in enumerate(rz) if t[0] == "s_cbranch_scc1"][-1]
+    assert loop_end - lab <= 460, loop_end - lab
+    masked = False
+    for t in rz:
+        if t[0] == "s_mov_b64" and t[1] == "exec":
+            masked = t[2] != "s[%d:%d]" % (asmquad.S_EXEC, asmquad.S_EXEC + 1)
+        assert not (masked and t[0].endswith("_dpp")), t
 
 
 def test_quad_stream_assembles_for_gfx950(programs, tmp_path):
@@ -122,9 +133,10 @@ def test_quad_form_matches_the_oracle_and_the_lane_form(programs, oracle_built, 
         a1, a4 = _arrays(st, ref, b), _arrays(st, ref, b)
         n1 = asmstep.simulate(ins1, a1, dict(K=K, maxIter=50, nsub=25, plant=1), fl)
         n4 = asmstep.simulate(ins4, a4, dict(K=K, maxIter=50, nsub=25, plant=1), fl)
-        nq = asmstep.simulate.last_quad_instructions
-        # per step: one-lane 57 k instructions, quad form <= 39 k, of which <= 19.5 k inside the quad section
-        assert n4 < 0.66 * n1 and 30000 < nq < 37000, (n1, n4, nq)
+        sec = asmstep.simulate.last_quad_sections
+        # per step: one-lane 57 k instructions, quad form <= 34 k: <= 18.5 k in the ADMM section (entry, 48 + 1 iterations,
+        # exit), <= 4.4 k in the ten Ruiz passes (one-lane: 7.3 k)
+        assert n4 < 0.59 * n1 and 30000 < sec["admm"] < 37000 and 6000 < sec["ruiz"] < 8800, (n1, n4, sec)
         for a, key in ((a1, 1), (a4, 4)):
             assert np.abs(a["state"][0:3] - s64[0:3, b]).max() < 1e-4 and np.abs(a["state"][3:] - s64[3:, b]).max() < 3e-5
             assert abs(a["out"][0] - out_o[0, b]) < 3e-5
@@ -153,7 +165,7 @@ def test_iteration_counts_that_take_different_paths(programs, oracle_built, iter
     a4 = _arrays(st, ref, 0, aT0=np.array([0.0123, -1.0]))
     asmstep.simulate(ins1, a1, dict(K=1, maxIter=iters, nsub=0, plant=1), asmstep.host_floats())
     asmstep.simulate(ins4, a4, dict(K=1, maxIter=iters, nsub=0, plant=1), asmstep.host_floats())
-    assert (asmstep.simulate.last_quad_instructions == 0) == (iters == 1)
+    assert (asmstep.simulate.last_quad_sections.get("admm", 0) == 0) == (iters == 1)
     if iters == 1:
         for k in ("out", "ctrl", "info", "status"):
             assert np.array_equal(a1[k], a4[k]), k
@@ -168,3 +180,25 @@ def test_iteration_counts_that_take_different_paths(programs, oracle_built, iter
     sc = 1e-3 + np.abs(a1["ctrl"][:123]).max()
     assert np.abs(a1["ctrl"][:123] - a4["ctrl"][:123]).max() / sc < 2e-5
     assert int(a1["status"][0]) == int(a4["status"][0])
+
+
+def test_quad_ruiz_limit_scaling_exact_path_and_per_robot_weights(programs, oracle_built):
+    """the Ruiz passes on the quad with weights far outside [1e-4, 1e4] (the exact limit_scaling branch, scaling.c:7-14)
+    handed over as a per-robot weights row (the gain-sweep option of the stream), against the fp64 oracle"""
+    _, _, g4, ins4 = programs
+    st, ref = hover_initial_conditions(1, 3, np.float32)
+    kw = dict(wvf=5e5, wmom=2e-5)
+    base = dict(ws=1e1, wds=1e3, wpr=1.0, wpf=5.0, wvr=1e3, wvf=2e3, wthrust=1e-1, wmom=1e-2)
+    base.update(kw)
+    W = np.array([[base[n]] for n in ("ws", "wds", "wpr", "wpf", "wvr", "wvf", "wthrust", "wmom")], np.float32)
+    for weights in (None, W):
+        a = _arrays(st, ref, 0, weights=weights)
+        fl = asmstep.host_floats(**kw) if weights is None else asmstep.host_floats()
+        asmstep.simulate(ins4, a, dict(K=1, maxIter=50, nsub=0, plant=1), fl)
+        o = oracle_built.Oracle(np.float64, perm=g4.s.perm, **kw)
+        o.set_canonical(True)
+        R = st[3:12, 0].reshape(3, 3).T
+        uq, ac = o.update(st[0:3, 0], R, st[12:18, 0], ref[0:3, 0], ref[3:6, 0], ref[6:9, 0], -1.0)
+        assert abs(a["out"][0] - uq[0]) < 1e-4 and np.abs(a["out"][3:] - ac).max() < 1e-4
+        assert np.all(np.abs(a["out"][1:3] - uq[1:]) <= np.maximum(5e-2, 2e-3 * np.abs(uq[1:])))
+        np.testing.assert_allclose(a["ctrl"][124:], np.asarray(o.get("E"))[36:39], rtol=1e-4)
