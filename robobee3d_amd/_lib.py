@@ -128,7 +128,9 @@ def build(force=False, verbose=False):
     One object per translation unit (recompiled only when it or its headers changed), then one link."""
     from . import asmgen, asmgen64, asmstep, codegen, codegen_n3, codegen_qp
     sw = asmgen.generator_switches()
-    if sw:
+    # (a scratch COPY of the tree may be built under switches for A/B experiments: UMPC_VARIANT_ROOT must name exactly the
+    # root being built, so the variable cannot unlock the tree it was not meant for; tools/build_qp_variant.sh)
+    if sw and os.environ.get("UMPC_VARIANT_ROOT") != ROOT:
         # build() REWRITES the tracked generated headers and the shipped .so: a stray A/B switch in a test, bench or
         # profile shell must not change the kernels silently (one of them, UMPC_ASM_LIMIT_FAST, changes the numerics).
         # Variants are built by tools/build_variant.py into robobee3d_amd/variants/ and selected with UMPC_LIB.

@@ -2063,6 +2063,10 @@ def res_program(s, eq_rows, ap, res):
         pass
     pl = P_()
     pl.V_RING, pl.V_LAND, pl.V_AT, pl.n_land = R.V_RING, R.V_LAND, R.V_AT, R.n_land
+    # (diagnostics: fewer landing registers in use -> fewer stream loads in flight; if the block's time follows 1 / this,
+    # it is bound by the latency of its landing stream)
+    pl.NLAND = int(os.environ.get("UMPC_QP_RES_NLAND", str(NLAND)))
+    assert 8 <= pl.NLAND <= NLAND
     sc = Sched(e, pl, 0)
     # the landing stream starts at item it_rows: pointer and block bookkeeping relative to it
     e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, res.it_rows * 256)
