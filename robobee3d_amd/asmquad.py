@@ -594,6 +594,8 @@ def simulate(ins, pc, V, A, lds, S, max_exec=400000):
                 lo = int(t[2][2:t[2].index(":")])
                 word = S[lo]
                 masks[t[1]] = np.array([(word >> ln) & 1 for ln in range(4)], bool) & masks[t[3]]
+            elif m == "s_or_b64":
+                masks[t[1]] = masks[t[2]] | masks[t[3]]
             elif m in ("s_sub_i32", "s_add_i32"):
                 a = S.get(int(t[2][1:]), 0) if isinstance(t[2], str) else t[2]
                 b = S.get(int(t[3][1:]), 0) if isinstance(t[3], str) else t[3]

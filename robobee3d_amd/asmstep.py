@@ -1918,6 +1918,9 @@ class StepGen:
         e("s_branch", lab_done + "f")
         # ---- mode 1: classical RK4 on the same vector field (build-defined)
         e("label", lab_rk4)
+        if self.quad:
+            self._rk4_quad(Y0, YS, KK, AC, Th, u1, u2, einc, Ib, Ibi, serr, seff, a, b, two)
+            e("s_branch", lab_done + "f")
         e("s_mov_b32", sg(S_SUB), sg(S_INT["nsub"]))
         top = self.label()
         e("label", top)
@@ -1954,6 +1957,110 @@ class StepGen:
         for base in (Y0, YS, KK, AC):
             pool.free_range(base, 18)
         e("label", lab_end)
+
+
+    def _rk4_quad(self, Y0, YS, KK, AC, Th, u1, u2, einc, Ib, Ibi, serr, seff, a, b, two):
+        """The RK4 substeps on the lane quad (the quad form of the stream): lane r integrates ROW r of the state -- p_r, v_r and
+        row r of R, whose derivative R skew(w) needs nothing but that row and w -- and every lane carries w (its 13-instruction
+        vector field runs replicated). 8 words per lane instead of 18: 123 instructions per substep instead of 230. Every
+        element goes through the one-lane sequence of operations, so the result equals the lane form's bit for bit; the
+        position-error sum takes the three p from the lanes in the one-lane order."""
+        from . import asmquad
+        e = self.e
+        SF = lambda n: sg(S_F[n])
+        masks = (asmquad.S_L0, asmquad.S_L1, asmquad.S_L2)
+        S_L3, S_L03 = 98, 36                       # lane 3 alone (scratch), lanes 0 and 3 (lane 3 mirrors lane 0: finite, unused)
+        S_EX = 62                                  # s[62:63]: the entry EXEC (S_MBAD is dead here)
+        Q0, QS, QK, QA = YS, KK, AC, KK + 8         # 8-word vectors: [p_r, v_r, R_r0, R_r1, R_r2, wx, wy, wz]
+        G, PA = AC + 8, AC + 10                     # g in lane 2 only; the three p of the robot (AC + 10 .. + 12)
+        keep = sorted(set(range(Y0, Y0 + 18)) | {serr, seff})
+        e("quad_begin", "plant")
+        e("s_mov_b64", sp(S_EX), "exec")
+        for ln, m in enumerate(masks + (S_L3,)):
+            e("s_mov_b32", sg(m), 0x11111111 << ln)
+            e("s_mov_b32", sg(m + 1), 0x11111111 << ln)
+            e("s_and_b64", sp(m), sp(m), sp(S_EX))
+        e("s_or_b64", sp(S_L03), sp(masks[0]), sp(S_L3))
+        e("v_mov_b32", v(G), 0)
+        for r, m in ((0, S_L03), (1, masks[1]), (2, masks[2])):
+            e("s_mov_b64", "exec", sp(m))
+            e("v_mov_b32", v(Q0), v(Y0 + r))
+            e("v_mov_b32", v(Q0 + 1), v(Y0 + 12 + r))
+            for c in range(3):
+                e("v_mov_b32", v(Q0 + 2 + c), v(Y0 + 3 + r + 3 * c))
+            if r == 2:
+                e("v_mov_b32", v(G), SF("gpl"))
+        e("s_mov_b64", "exec", sp(S_EX))
+        for i in range(3):
+            e("v_mov_b32", v(Q0 + 5 + i), v(Y0 + 15 + i))
+        e("s_nop", 4)
+
+        def vf(src, dst):
+            p_, v_, r0, r1, r2, wx, wy, wz = (src + k for k in range(8))
+            e("v_mov_b32", v(dst), v(v_))
+            e("v_mul_f32", v(dst + 1), v(Th), v(r2))
+            e("v_sub_f32", v(dst + 1), v(dst + 1), v(G))
+            e("v_mul_f32", v(a), v(r2), v(wy))
+            e("v_fma_f32", v(dst + 2), v(r1), v(wz), "-" + v(a))
+            e("v_mul_f32", v(b), v(r0), v(wz))
+            e("v_fma_f32", v(dst + 3), v(r2), v(wx), "-" + v(b))
+            e("v_mul_f32", v(a), v(r1), v(wx))
+            e("v_fma_f32", v(dst + 4), v(r0), v(wy), "-" + v(a))
+            hx, hy, hz = dst + 5, dst + 6, dst + 7
+            e("v_mul_f32", v(hx), v(Ib[0]), v(wx))
+            e("v_mul_f32", v(hy), v(Ib[1]), v(wy))
+            e("v_mul_f32", v(hz), v(Ib[2]), v(wz))
+            e("v_mul_f32", v(a), v(wz), v(hy))
+            e("v_fma_f32", v(a), v(wy), v(hz), "-" + v(a))
+            e("v_mul_f32", v(b), v(wx), v(hz))
+            e("v_fma_f32", v(b), v(wz), v(hx), "-" + v(b))
+            e("v_mul_f32", v(hz), v(wy), v(hx))
+            e("v_fma_f32", v(hz), v(wx), v(hy), "-" + v(hz))
+            e("v_sub_f32", v(a), v(u1), v(a))
+            e("v_mul_f32", v(dst + 5), v(a), v(Ibi[0]))
+            e("v_sub_f32", v(b), v(u2), v(b))
+            e("v_mul_f32", v(dst + 6), v(b), v(Ibi[1]))
+            e("v_mul_f32", v(dst + 7), "-" + v(hz), v(Ibi[2]))
+        e("s_mov_b32", sg(S_SUB), sg(S_INT["nsub"]))
+        top = self.label()
+        e("label", top)
+        vf(Q0, QA)
+        for k in range(0, 8, 2):
+            pk(e, "v_pk_fma_f32", QS + k, [PS(S_F["hh"]), P2(QA + k), P2(Q0 + k)])
+        vf(QS, QK)
+        for k in range(0, 8, 2):
+            pk(e, "v_pk_fma_f32", QA + k, [PB(two), P2(QK + k), P2(QA + k)])
+            pk(e, "v_pk_fma_f32", QS + k, [PS(S_F["hh"]), P2(QK + k), P2(Q0 + k)])
+        vf(QS, QK)
+        for k in range(0, 8, 2):
+            pk(e, "v_pk_fma_f32", QA + k, [PB(two), P2(QK + k), P2(QA + k)])
+            pk(e, "v_pk_fma_f32", QS + k, [PS(S_F["h"]), P2(QK + k), P2(Q0 + k)])
+        vf(QS, QK)
+        for k in range(0, 8, 2):
+            pk(e, "v_pk_add_f32", QA + k, [P2(QA + k), P2(QK + k)])
+        for k in range(0, 8, 2):
+            pk(e, "v_pk_fma_f32", Q0 + k, [PS(S_F["h6"]), P2(QA + k), P2(Q0 + k)])
+        e("s_nop", 1)
+        for r in range(3):
+            e("v_mov_b32_dpp", v(PA + r), v(Q0), asmquad.qperm([r] * 4))
+        e("s_nop", 1)
+        for r in range(3):
+            e("v_fmac_f32", v(serr), v(PA + r), v(PA + r))
+        e("v_add_f32", v(seff), v(seff), v(einc))
+        e("s_sub_i32", sg(S_SUB), sg(S_SUB), 1)
+        e("s_cmp_gt_i32", sg(S_SUB), 0)
+        e("s_cbranch_scc1", top + "b")
+        # back to the one-lane state vector, in all four lanes
+        e("s_nop", 1)
+        for r in range(3):
+            e("v_mov_b32_dpp", v(Y0 + r), v(Q0), asmquad.qperm([r] * 4))
+            e("v_mov_b32_dpp", v(Y0 + 12 + r), v(Q0 + 1), asmquad.qperm([r] * 4))
+            for c in range(3):
+                e("v_mov_b32_dpp", v(Y0 + 3 + r + 3 * c), v(Q0 + 2 + c), asmquad.qperm([r] * 4))
+        for i in range(3):
+            e("v_mov_b32", v(Y0 + 15 + i), v(Q0 + 5 + i))
+        e("s_nop", 1)
+        e("quad_end", tuple(keep))
 
     # ---- the whole kernel body --------------------------------------------------------------------------------
     def program(self):
