@@ -35,7 +35,7 @@ Reference mapping: template/uprightmpc2/osqp.c:354-370, auxil.c:164-228, qdldl.c
 """
 import numpy as np
 
-from . import asmgen, symbolic
+from . import symbolic
 from .asmgen import (A_D, A_L, A_LO, A_M, A_Q, NLDS, S_ALPHA, S_CNT, S_ITERS, S_OMA, S_RINV, S_SIGMA, V_W, V_WZ, V_X,
                      V_Y, V_Z, _sb, _vp, pk)
 
@@ -216,7 +216,7 @@ def body(e, plan, capture):
             first_use.setdefault(oidx[item[1]] // 4, k)
     nquads = (len(ovf) + 3) // 4
     AHQ = 12                        # sequence positions between a quad's read and its first consumer
-    issued, waited, nrd = [0], [0], [0]
+    issued, waited = [0], [0]
 
     def issue_upto(k):
         while issued[0] < nquads and first_use[issued[0]] <= k + AHQ and issued[0] < waited[0] + 3:

@@ -30,7 +30,7 @@ import struct
 import numpy as np
 
 from . import asmquad, symbolic
-from .asmgen import S_ALPHA, S_CNT, S_ITERS, S_OMA, S_RHO, S_RINV, S_SIGMA
+from .asmgen import S_ALPHA, S_CNT, S_ITERS, S_OMA, S_RINV, S_SIGMA
 from .asmquad import IX_EQ, IX_T, qperm
 
 # ---- VGPR words (first register of the pair); the block may use v2..v245, v172..v201 are the one-lane thrust-row words
