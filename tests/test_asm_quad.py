@@ -202,3 +202,22 @@ def test_quad_ruiz_limit_scaling_exact_path_and_per_robot_weights(programs, orac
         assert abs(a["out"][0] - uq[0]) < 1e-4 and np.abs(a["out"][3:] - ac).max() < 1e-4
         assert np.all(np.abs(a["out"][1:3] - uq[1:]) <= np.maximum(5e-2, 2e-3 * np.abs(uq[1:])))
         np.testing.assert_allclose(a["ctrl"][124:], np.asarray(o.get("E"))[36:39], rtol=1e-4)
+
+
+def test_ruiz_and_plant_sections_reproduce_the_lane_stream_bit_for_bit(programs):
+    """With ONE ADMM iteration the quad stream has no quad ADMM section: what differs from the lane stream is the Ruiz passes
+    and the RK4 substeps on the quad. Both go through the one-lane sequence of operations per element (the cost
+    normalisation's sum of P_jj is the exception, and is exact on these weights), so 3 closed-loop steps of 2 robots, plant
+    and statistics included, come out BIT-identical -- registers, lane masks, DPP selections and the write-back of every
+    word of both sections checked at once."""
+    _, ins1, _, ins4 = programs
+    st, ref = hover_initial_conditions(2, 11, np.float32)
+    fl = asmstep.host_floats()
+    for b in range(2):
+        a1, a4 = _arrays(st, ref, b), _arrays(st, ref, b)
+        asmstep.simulate(ins1, a1, dict(K=3, maxIter=1, nsub=25, plant=1), fl)
+        asmstep.simulate(ins4, a4, dict(K=3, maxIter=1, nsub=25, plant=1), fl)
+        sec = asmstep.simulate.last_quad_sections
+        assert sec.get("admm", 0) == 0 and sec["ruiz"] > 0 and sec["plant"] > 0
+        for k in ("state", "out", "ctrl", "stats", "info", "status", "ws"):
+            assert np.array_equal(a1[k], a4[k], equal_nan=True), (b, k)
