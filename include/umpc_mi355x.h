@@ -374,6 +374,9 @@ int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src,
  * (Ad[4][3], Ad[5][3], Bd[4], Bd[5], Bd[6]); mode 1 additionally applies the reference's plant tick
  * y <- y + (Ad y + Bd u) dt (:176). y [7][B], u [B]; lin may be NULL in mode 1. */
 int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, void *lin, void *stream);
+/* The same with ONE nominal input for the whole batch, as the reference's loop has it (unom = 15 sin(2 pi 170 t) is a
+ * scalar, planar/mpc_osqp_p5f.py:157): no [B] array to fill per tick. */
+int umpcP5fStepU(int B, int dtype, int mode, double dt, double u, void *y, void *lin, void *stream);
 /* UprightMPC2 at any horizon N (template/template_controllers.py:170-258; N = 3 is Parts 1-2's specialised path):
  * assembly (updateConstraint :65-125, updateObjective :127-143 = uprightmpc2.c:121-207) and extraction (update2 /
  * getAccDes :232-250 = uprightmpc2.c:253-269) around umpcQPSolve on the structure of initConstraint (:28-63).

@@ -1311,7 +1311,56 @@ def uni_scalar_operand(v, sign_extend_bug=False):
     return (hi << 32) | lo
 
 
-def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_agpr=False, base_xform=None, count=None):
+def simulate(*args, **kw):
+    """One wave: runs _simulate to the end (an s_barrier of a lone wave is a no-op). See _simulate for the arguments."""
+    g = _simulate(*args, **kw)
+    while True:
+        try:
+            next(g)
+        except StopIteration as stop:
+            return stop.value
+
+
+def simulate_group(ins, nw, W, S, iters, consts, wave_sgpr, **kw):
+    """nw waves of one workgroup run `ins` on the same LDS slots and the same global arrays (wave w gets SGPR `wave_sgpr` = w),
+    each up to its next s_barrier in turn. Checks that every wave meets every barrier, and that between two barriers no LDS
+    word is written by one wave and read or written by another (the data races a barrier-phased schedule can have). Returns
+    the shared LDS words and the per-wave executed instruction counts."""
+    lds = np.zeros(640, np.float32)
+    if kw.get("lds0") is not None:
+        lds[:len(kw["lds0"])] = kw.pop("lds0")
+    logs = [dict(r=set(), w=set()) for _ in range(nw)]
+    counts = [[] for _ in range(nw)]
+    gens = []
+    for w in range(nw):
+        sg = dict(kw.get("sgpr") or {})
+        sg[wave_sgpr] = w
+        gens.append(_simulate(ins, W, S, iters, consts, **dict(kw, sgpr=sg, lds_shared=lds, access_log=logs[w], count=counts[w])))
+    live = [True] * nw
+    nbar = 0
+    while any(live):
+        for w in range(nw):
+            if live[w]:
+                try:
+                    next(gens[w])
+                except StopIteration:
+                    live[w] = False
+        assert all(live) or not any(live), ("the waves disagree about barrier %d" % nbar, live)
+        for a_ in range(nw):
+            for b_ in range(nw):
+                if a_ != b_:
+                    clash = logs[a_]["w"] & (logs[b_]["r"] | logs[b_]["w"])
+                    assert not clash, ("LDS race before barrier %d: words written by wave %d and touched by wave %d" % (nbar, a_, b_),
+                                       sorted(clash)[:8])
+        for lg in logs:
+            lg["r"].clear()
+            lg["w"].clear()
+        nbar += 1
+    return lds, [c[0] for c in counts], nbar - 1
+
+
+def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_agpr=False, base_xform=None, count=None,
+              lds_shared=None, access_log=None):
     """W: float32[rows] row workspace (one robot), S: float32[items] stream block (one lane); consts = (alpha, sigma, rinv_eq).
     Runs the program and returns the lane's LDS words (x, y, z, x_prev, delta_y are left there).
     Addresses are formed as the ISA does for global_* with an SGPR base: SGPR pair (64 bits) + zero-extended 32-bit VGPR
@@ -1320,10 +1369,13 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
     f32 = np.float32
     V = np.zeros(256, np.uint32)
     A = np.zeros(256, np.uint32)
-    lds = np.zeros(640, f32)
+    lds = np.zeros(640, f32) if lds_shared is None else lds_shared
     SG = {}
     scc = 0
     labels = {}
+    log_r = access_log["r"] if access_log is not None else set()
+    log_w = access_log["w"] if access_log is not None else set()
+    src_word = {}
     for k, t in enumerate(ins):
         if t[0] == "label":
             labels.setdefault(t[1], []).append(k)
@@ -1428,6 +1480,10 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
         elif m[0] == "v" or m.startswith("ds_") or m.startswith("global_"):
             used = set().union(*[regs_of(x) for x in t[1:]])
             check(used)
+            if m != "ds_read_b128":           # (a word fetched from LDS counts as READ when its register is consumed: a
+                for r_ in used:               # quad may carry a neighbour's words that this wave never looks at)
+                    if r_ in src_word:
+                        log_r.add(src_word[r_])
             if m == "ds_read_b128":
                 pend["lgkmcnt"].append(regs_of(t[1]))
             elif m.startswith("ds_write"):
@@ -1438,6 +1494,9 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
                 pend["vmcnt"].append(set())
         if m in ("label", "s_waitcnt", "s_nop"):
             pass
+        elif m == "s_barrier":
+            assert not pend["lgkmcnt"], ("s_barrier with LDS operations in flight: another wave may not see them", pc)
+            yield pc
         elif m == "v_mov_b32":
             V[int(t[1][1:])] = (t[2] if isinstance(t[2], int) else f32bits(t[2]) if isinstance(t[2], float)
                                 else SG[int(t[2][1:])] if t[2][0] == "s" else V[int(t[2][1:])])
@@ -1529,17 +1588,21 @@ def simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_a
             w = ldsword(t[2], t[3])
             for h in range(4):
                 V[lo + h] = f32bits(float(lds[w + h]))
+                src_word[("v", lo + h)] = w + h
         elif m == "ds_write_b128":
             lo = int(t[2][2:t[2].index(":")])
             w = ldsword(t[1], t[3])
             for h in range(4):
                 lds[w + h] = bits2f(V[lo + h])
+            log_w.update(range(w, w + 4))
         elif m == "ds_write_b32":
             lds[ldsword(t[1], t[3])] = bits2f(V[int(t[2][1:])])
+            log_w.add(ldsword(t[1], t[3]))
         elif m == "ds_write_b64":
             lo = int(t[2][2:t[2].index(":")])
             w = ldsword(t[1], t[3])
             lds[w], lds[w + 1] = bits2f(V[lo]), bits2f(V[lo + 1])
+            log_w.update((w, w + 1))
         elif m in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
             d = t[-1]
             srcs = t[2:-1]
@@ -1728,16 +1791,77 @@ class ResPlan:
         self.end = idx + 1
 
 
+class RuizSplit:
+    """The Ruiz passes of ONE group of 64 robots shared by the NW wavefronts of a workgroup (round 4): a batch of 16 384 robots
+    is 256 wavefronts, one per CU, and three of a CU's four SIMDs idle while a lone wave issues the 4.1 k instructions of a
+    pass. The columns of A are cut into NW contiguous stretches of the chain (a column's place = its first row), wave w owns
+    stretch w: its entries of A, P, q, D, its rows' E. All waves address the SAME LDS slots (lane = robot); per pass they
+    exchange, through LDS words that are free during the passes (the homes P and q get in the epilogue), (1) the partial
+    norms of the few rows whose entries lie in two stretches (max: exact and order-free), (2) the new P entries, which every
+    wave sums in the reference's order (the cost normalisation's mean column norm: the same sequence of additions as one
+    wave), and max |q| per wave -- two s_barrier per pass. Every word comes out BIT-identical to ruiz_program(s, res)."""
+
+    def __init__(self, p, nw):
+        n, m = p.n, p.m
+        self.nw = nw
+        ent = {j: list(range(p.A_p[j], p.A_p[j + 1])) for j in range(n)}
+        key = {j: (min(p.A_i[q] for q in ent[j]) if ent[j] else 0, j) for j in range(n)}
+        order = sorted(range(n), key=lambda j: key[j])
+        wt = {j: 8 + 5 * len(ent[j]) + (6 if p.pidx[j] >= 0 else 0) for j in range(n)}
+        total, acc = float(sum(wt.values())), 0.0
+        self.colw = {}
+        for j in order:
+            self.colw[j] = min(nw - 1, int(acc * nw / total))
+            acc += wt[j]
+        touch = {i: set() for i in range(m)}
+        cnt = {i: {} for i in range(m)}
+        for j in range(n):
+            for q in ent[j]:
+                i = p.A_i[q]
+                touch[i].add(self.colw[j])
+                cnt[i][self.colw[j]] = cnt[i].get(self.colw[j], 0) + 1
+        assert all(touch[i] for i in range(m))
+        self.touch = touch
+        self.roww = {i: max(sorted(cnt[i]), key=lambda w: cnt[i][w]) for i in range(m)}
+        self.shared = [i for i in range(m) if len(touch[i]) > 1]
+        # exchange words, from the home of P upward (free until the epilogue)
+        w0 = p.LW_P + (-p.LW_P) % 4
+        self.X = {}
+        for i in self.shared:
+            for w in sorted(touch[i]):
+                self.X[(i, w)] = w0
+                w0 += 1
+        w0 += (-w0) % 4
+        self.PX = {k: w0 + k for k in range(p.nnzP)}
+        w0 += p.nnzP + (-p.nnzP) % 4
+        self.QN = {w: w0 + w for w in range(nw)}
+        w0 += nw
+        assert w0 <= p.LW_END, (w0, p.LW_END)
+
+
+S_RWAVE = 26                       # ruiz_group_program: s26 = the wave's index in its workgroup
 S_AV, S_PV, S_QV = 4, 6, 8          # s[4:5] Av rows, s[6:7] Pv rows, s[8:9] q rows (the block's inputs, [k][B] floats)
 S_RSB, V_RLANE = 24, 210           # Ruiz block with a residual stream: s[24:25] = the wave's stream block, v210 = 4*lane
 S_RMIN, S_RMAX = 20, 21            # 1e-4, 1e4 (float bits, set by the block)
+RUIZ_STAMPS = os.environ.get("UMPC_QP_RUIZ_STAMPS") == "1"     # (diagnostics: see ruiz_program)
+STAMP_ITEM0 = 2040                 # spare items at the end of a wave's stream block (codegen_qp.ASM_STREAM_ITEMS = 2048)
 
 
-def ruiz_program(s, res=None):
+def ruiz_program(s, res=None, split=None, wave=0):
     """s11 = number of passes (>= 1). Inputs as above, v0 = 4*robot, v1 = lane LDS address, s10 = 4*B.
-    res: a ResPlan -> the epilogue also writes the equilibrated A, E, D, q, P and c to the wave's residual stream."""
+    res: a ResPlan -> the epilogue also writes the equilibrated A, E, D, q, P and c to the wave's residual stream.
+    split (a RuizSplit), wave: the program of wave `wave` of a workgroup that shares the passes (see RuizSplit)."""
     p = RuizPlan(s)
     n, m = p.n, p.m
+    sp = split
+    own_col = (lambda j: True) if sp is None else (lambda j: sp.colw[j] == wave)
+    own_row = (lambda i: True) if sp is None else (lambda i: sp.roww[i] == wave)
+    cols = [j for j in range(n) if own_col(j)]
+    rows_own = [i for i in range(m) if own_row(i)]
+    aq = [q for j in cols for q in range(p.A_p[j], p.A_p[j + 1])]                 # own entries of A, increasing
+    aq_set = set(aq)
+    pk = [p.pidx[j] for j in cols if p.pidx[j] >= 0]                              # own entries of P, increasing
+    assert aq == sorted(aq) and pk == sorted(pk)
     e = Emit()
     v = lambda r: "v%d" % r
     T = lambda q: p.V_TT + q
@@ -1750,6 +1874,17 @@ def ruiz_program(s, res=None):
         e("s_mul_hi_u32", "s%d" % (S_P + 1), "s%d" % S_STRIDE, row)
         e("s_add_u32", "s%d" % S_P, "s%d" % S_P, "s%d" % base)
         e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_P + 1), "s%d" % (base + 1))
+
+    def load_rows(base, rows, dst):
+        """global rows `rows` (increasing) of the [row][B] array at s[base:base+1] -> the registers dst(position)"""
+        last = None
+        for q_, r_ in enumerate(rows):
+            if last is None or r_ != last + 1:
+                rowptr(base, r_)
+            else:
+                _adv(e, S_P)
+            last = r_
+            e("global_load_dword", dst(q_), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
 
     def limit(t, t2):
         """t <- limit_scaling(t) (umpc_bqp_common.h): t < 1e-4 ? 1 : min(t, 1e4)"""
@@ -1769,35 +1904,47 @@ def ruiz_program(s, res=None):
         e("v_fma_f32", v(a_), "-" + v(t), v(y), 1.0)
         e("v_fma_f32", v(y), v(y), v(a_), v(y))
 
+    # (diagnostics, UMPC_QP_RUIZ_STAMPS=1 on a block with a residual stream: 100 MHz stamps -> five intervals in the spare
+    # items STAMP_ITEM0.. of the stream -- prologue, sum of the norm phases, sum of the apply phases, P / q / c -> LDS,
+    # stream stores; the glue block adds its own and the residual block copies all six over the info rows)
+    RST = RUIZ_STAMPS and res is not None and wave == 0
+    ST = 60
+
+    def stamp(k):
+        if RST:
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("s_memrealtime", "s[%d:%d]" % (ST + 2 * k, ST + 2 * k + 1))
+            e("s_waitcnt", "lgkmcnt(0)")
+
+    def stamp_acc(k_from, k_to, acc):
+        if RST:
+            e("s_sub_u32", "s%d" % (ST + 2 * k_from), "s%d" % (ST + 2 * k_to), "s%d" % (ST + 2 * k_from))
+            e("s_add_u32", "s%d" % acc, "s%d" % acc, "s%d" % (ST + 2 * k_from))
     # ---- prologue: A rows -> LDS through the Et registers (landing zone), P and q -> AGPRs, D = E = 1 in LDS, c = 1
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    stamp(0)
+    if RST:
+        e("s_mov_b32", "s80", 0)
+        e("s_mov_b32", "s81", 0)
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
     e("s_mov_b32", sMIN, f32bits(RZ_MIN))
     e("s_mov_b32", sMAX, f32bits(RZ_MAX))
-    rowptr(S_PV, 0)
-    for k in range(p.nnzP):
-        e("global_load_dword", "a%d" % (p.A_P + k), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
-        _adv(e, S_P)
-    rowptr(S_QV, 0)
-    for j in range(n):
-        e("global_load_dword", "a%d" % (p.A_Q + j), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
-        _adv(e, S_P)
-    rowptr(S_AV, 0)
-    for g in range(0, p.nnzA, m):
-        cnt = min(m, p.nnzA - g)
-        for q in range(cnt):
-            e("global_load_dword", v(p.V_ET + q), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
-            _adv(e, S_P)
+    load_rows(S_PV, pk, lambda q_: "a%d" % (p.A_P + pk[q_]))
+    load_rows(S_QV, cols, lambda q_: "a%d" % (p.A_Q + cols[q_]))
+    for g in range(0, len(aq), m):
+        chunk = aq[g:g + m]
+        load_rows(S_AV, chunk, lambda q_: v(p.V_ET + q_))
         e("s_waitcnt", "vmcnt(0)")
-        for q in range(cnt):
-            base, off = lds_addr(p.LW_A + g + q)
-            e("ds_write_b32", base, v(p.V_ET + q), off)
+        for q_, k in enumerate(chunk):
+            base, off = lds_addr(p.LW_A + k)
+            e("ds_write_b32", base, v(p.V_ET + q_), off)
     e("v_mov_b32", v(T(13)), 1.0)                                  # c
-    for w in range(p.LW_D, p.LW_C):
+    for w in [p.LW_D + j for j in cols] + [p.LW_EV + i for i in rows_own]:
         base, off = lds_addr(w)
         e("ds_write_b32", base, v(T(13)), off)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    stamp(1)
     e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
     e("label", "7")
     sc = Sched(e, p, 0)
@@ -1805,15 +1952,21 @@ def ruiz_program(s, res=None):
 
     def op(srcs, fn):
         ops.append(dict(srcs=srcs, emit=fn))
+
+    def barrier():
+        """every LDS write of this wave has landed, then all waves of the workgroup meet; nothing fetched before is reused"""
+        op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
+        ops.append(dict(flush=True))
+    op([], lambda g: stamp(2))
     # ---- norms: columns in order; the row norms accumulate in the Et registers
     touched = set()
-    for j in range(n):
-        cols = list(range(p.A_p[j], p.A_p[j + 1]))
+    for j in cols:
+        ents = list(range(p.A_p[j], p.A_p[j + 1]))
         if p.pidx[j] >= 0:
             op([("A", p.A_P + p.pidx[j])], lambda g: e("v_max_f32", v(T(0)), ab(v(g[0])), ab(v(g[0]))))
         else:
             op([], lambda g: e("v_mov_b32", v(T(0)), 0))
-        for q in cols:
+        for q in ents:
             i = p.A_i[q]
 
             def f(g, i=i, first=i not in touched):
@@ -1827,23 +1980,39 @@ def ruiz_program(s, res=None):
             rsqrt(T(1), T(0), T(2))
             e("v_accvgpr_write_b32", "a%d" % (p.A_DT + j), v(T(1)))
         op([], fin)
-    assert len(touched) == m
-    for i in range(m):
+    if sp is None:
+        assert len(touched) == m
+    else:
+        assert touched == set(i for i in range(m) if wave in sp.touch[i])
+        # rows with entries in two stretches: the partial norms change hands (max: exact, order-free)
+        mine = [i for i in sp.shared if wave in sp.touch[i]]
+        for i in mine:
+            op([], lambda g, i=i: sc.lds_write(sp.X[(i, wave)], p.V_ET + i))
+        barrier()
+        for i in mine:
+            for w2 in sorted(sp.touch[i] - {wave}):
+                op([("L", sp.X[(i, w2)])], lambda g, i=i: e("v_max_f32", ET(i), ET(i), v(g[0])))
+    for i in sorted(touched):
         def fe(g, i=i):
             limit(p.V_ET + i, T(1))
             e("v_rsq_f32", ET(i), ET(i))        # in place; the next VALU instruction (the next row's compare, or the
         op([], fe)                               # csum initialisation) does not read it: no trans-use wait state needed
     # ---- apply; csum in T(4), qn in T(5), dt of the column in T(7)
     wqa, wqd, wqe = (QuadWriter(sc, p.V_WQ + 4 * z) for z in range(3))
+    op([], lambda g: stamp(3))
     op([], lambda g: (e("v_mov_b32", v(T(4)), 0), e("v_mov_b32", v(T(5)), 0)))
-    for j in range(n):
+    for j in cols:
         op([("A", p.A_DT + j)], lambda g: e("v_mov_b32", v(T(7)), v(g[0])))
         if p.pidx[j] >= 0:
             def fp(g, k=p.pidx[j]):
-                e("v_mul_f32", v(T(6)), v(g[0]), v(T(7)))
-                e("v_mul_f32", v(T(6)), v(T(6)), v(T(7)))
-                e("v_accvgpr_write_b32", "a%d" % (p.A_P + k), v(T(6)))
-                e("v_add_f32", v(T(4)), v(T(4)), ab(v(T(6))))
+                t = T(6) if sp is None else T(8 + k % 4)
+                e("v_mul_f32", v(t), v(g[0]), v(T(7)))
+                e("v_mul_f32", v(t), v(t), v(T(7)))
+                e("v_accvgpr_write_b32", "a%d" % (p.A_P + k), v(t))
+                if sp is None:
+                    e("v_add_f32", v(T(4)), v(T(4)), ab(v(t)))
+                else:
+                    sc.lds_write(sp.PX[k], t)       # (every wave sums all of them in the reference's order below)
             op([("A", p.A_P + p.pidx[j])], fp)
         for q in range(p.A_p[j], p.A_p[j + 1]):
             def fa(g, q=q, i=p.A_i[q]):
@@ -1851,7 +2020,7 @@ def ruiz_program(s, res=None):
                 e("v_mul_f32", v(t), v(g[0]), ET(i))
                 e("v_mul_f32", v(t), v(t), v(T(7)))
                 if p.WQ:
-                    wqa.done(p.LW_A + q, q == p.nnzA - 1)
+                    wqa.done(p.LW_A + q, q + 1 not in aq_set)
                 else:
                     sc.lds_write(p.LW_A + q, t)
             op([("L", p.LW_A + q)], fa)
@@ -1863,19 +2032,28 @@ def ruiz_program(s, res=None):
             t = wqd.reg(p.LW_D + j) if p.WQ else T(12)
             e("v_mul_f32", v(t), v(T(7)), v(g[1]))
             if p.WQ:
-                wqd.done(p.LW_D + j, j == n - 1)
+                wqd.done(p.LW_D + j, not (j + 1 < n and own_col(j + 1)))
             else:
                 sc.lds_write(p.LW_D + j, T(12))
         op([("A", p.A_Q + j), ("L", p.LW_D + j)], fq)
-    for i in range(m):
+    for i in rows_own:
         def fv(g, i=i):
             t = wqe.reg(p.LW_EV + i) if p.WQ else T(8 + i % 4)
             e("v_mul_f32", v(t), ET(i), v(g[0]))
             if p.WQ:
-                wqe.done(p.LW_EV + i, i == m - 1)
+                wqe.done(p.LW_EV + i, not (i + 1 < m and own_row(i + 1)))
             else:
                 sc.lds_write(p.LW_EV + i, t)
         op([("L", p.LW_EV + i)], fv)
+    if sp is not None:
+        # the cost normalisation needs the sum of |P_jj| over ALL columns in the reference's order and max |q_j|
+        op([], lambda g: sc.lds_write(sp.QN[wave], T(5)))
+        barrier()
+        for k in range(p.nnzP):
+            op([("L", sp.PX[k])], lambda g: e("v_add_f32", v(T(4)), v(T(4)), ab(v(g[0]))))
+        for w2 in range(sp.nw):
+            if w2 != wave:
+                op([("L", sp.QN[w2])], lambda g: e("v_max_f32", v(T(5)), v(T(5)), v(g[0])))
 
     # ---- cost scaling: ct = 1 / limit(max(csum / n, limit(qn)))
     def cost(g):
@@ -1890,7 +2068,7 @@ def ruiz_program(s, res=None):
         recip(T(5), T(4), T(0))                                        # ct
         e("v_mul_f32", v(T(13)), v(T(13)), v(T(5)))
     op([], cost)
-    for k in range(p.nnzP + n):
+    for k in pk + [p.nnzP + j for j in cols]:
         def fs(g, k=k):
             t = T(8 + k % 4)
             e("v_mul_f32", v(t), v(g[0]), v(T(5)))
@@ -1898,13 +2076,20 @@ def ruiz_program(s, res=None):
         op([("A", p.A_P + k)], fs)
     sc.run(ops)
     e("s_waitcnt", "lgkmcnt(0)")
+    stamp(4)
+    stamp_acc(2, 3, 80)
+    stamp_acc(3, 4, 81)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
+    stamp(5)
+    if sp is not None:
+        e("s_barrier")            # (the exchange words are the homes of P and q: every wave has read them)
     # ---- epilogue: c, P, q -> LDS
-    base, off = lds_addr(p.LW_C)
-    e("ds_write_b32", base, v(T(13)), off)
-    for k in range(p.nnzP + n):
+    if wave == 0:
+        base, off = lds_addr(p.LW_C)
+        e("ds_write_b32", base, v(T(13)), off)
+    for k in pk + [p.nnzP + j for j in cols]:
         t = T(k % 8)
         e("v_accvgpr_read_b32", v(t), "a%d" % (p.A_P + k))
         base, off = lds_addr(p.LW_P + k)
@@ -1912,6 +2097,7 @@ def ruiz_program(s, res=None):
     if res is not None:
         assert V_RLANE >= p.V_TT + p.NT
         e("s_waitcnt", "lgkmcnt(0)")
+        stamp(6)
 
         rs_blk = [None]
 
@@ -1922,8 +2108,8 @@ def ruiz_program(s, res=None):
                 e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_RSB + 1), 0)
             e("global_store_dword", "v%d" % V_RLANE, v(reg), "s[%d:%d]" % (S_P, S_P + 1), (item % BLOCK) * 256)
         # LDS words (A, D, E) through the ring registers, a group of quads at a time
-        words = [(p.LW_A + k, res.it_A + k) for k in range(p.nnzA)] + [(p.LW_D + j, res.it_d[j]) for j in range(n)] + \
-                [(p.LW_EV + i, res.it_ev[i]) for i in range(m)]
+        words = [(p.LW_A + k, res.it_A + k) for k in aq] + [(p.LW_D + j, res.it_d[j]) for j in cols] + \
+                [(p.LW_EV + i, res.it_ev[i]) for i in rows_own]
         item_of = dict(words)
         quads = sorted(set(w >> 2 for w, _ in words))
         for g in range(0, len(quads), NRING):
@@ -1936,7 +2122,7 @@ def ruiz_program(s, res=None):
                 for h in range(4):
                     if 4 * qd + h in item_of:
                         put(item_of[4 * qd + h], p.V_RING + 4 * q + h)
-        for j in range(n):
+        for j in cols:
             t_ = T(j % 8)
             e("v_accvgpr_read_b32", v(t_), "a%d" % (p.A_Q + j))
             put(res.it_q[j], t_)
@@ -1944,9 +2130,41 @@ def ruiz_program(s, res=None):
                 t2 = T(8 + j % 4)
                 e("v_accvgpr_read_b32", v(t2), "a%d" % (p.A_P + p.pidx[j]))
                 put(res.it_p[j], t2)
-        put(res.it_c, T(13))
+        if wave == 0:
+            put(res.it_c, T(13))
+    if RST:
+        e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+        stamp(7)
+        # intervals: 0 prologue (t1 - t0), 1 sum norms (s80), 2 sum apply (s81), 3 P / q / c -> LDS (t6 - t5), 4 stream (t7 - t6)
+        e("s_sub_u32", "s%d" % (ST + 0), "s%d" % (ST + 2), "s%d" % (ST + 0))
+        e("s_sub_u32", "s%d" % (ST + 14), "s%d" % (ST + 14), "s%d" % (ST + 12))
+        e("s_sub_u32", "s%d" % (ST + 12), "s%d" % (ST + 12), "s%d" % (ST + 10))
+        for k, sreg in enumerate((ST + 0, 80, 81, ST + 12, ST + 14)):
+            e("v_cvt_f32_u32", v(T(k)), "s%d" % sreg)
+            put(STAMP_ITEM0 + k, T(k))
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    if sp is not None:
+        e("s_barrier")            # everything the block leaves (LDS, stream) is there for whichever wave reads it next
     return e.ins, p
+
+
+def ruiz_group_program(s, res=None, nw=4):
+    """The Ruiz block for a workgroup of nw wavefronts that share 64 robots (RuizSplit): s26 = the wave's index; the other
+    inputs as ruiz_program. Every wave executes the same number of s_barrier."""
+    p = RuizPlan(s)
+    sp = RuizSplit(p, nw)
+    e = Emit()
+    for w in range(nw):
+        if w < nw - 1:
+            e("s_cmp_lg_u32", "s%d" % S_RWAVE, w)
+            e("s_cbranch_scc1", "8f")
+        ins, _ = ruiz_program(s, res, sp, w)
+        e.ins.extend(ins)
+        if w < nw - 1:
+            e("s_branch", "9f")
+            e("label", "8")
+    e("label", "9")
+    return e.ins, p, sp
 
 
 # ---------------------------------------------------------------------------
@@ -2041,7 +2259,19 @@ def res_program(s, eq_rows, ap, res):
         e("v_fma_f32", v(a_), "-" + v(t), v(y), 1.0)
         e("v_fma_f32", v(y), v(y), v(a_), v(y))
 
+    # (diagnostics, UMPC_QP_RES_STAMPS=1: 100 MHz stamps at the block's internal boundaries; the six intervals replace the
+    # info rows -- A loads, pass 1, rows, y -> accumulators, columns, termination test)
+    STAMPS = os.environ.get("UMPC_QP_RES_STAMPS") == "1"
+    S_STAMP = 60
+
+    def stamp(k):
+        if STAMPS:
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("s_memrealtime", "s[%d:%d]" % (S_STAMP + 2 * k, S_STAMP + 2 * k + 1))
+            e("s_waitcnt", "lgkmcnt(0)")
+
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    stamp(0)
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
     # A -> AGPRs (direct loads), c
@@ -2058,6 +2288,7 @@ def res_program(s, eq_rows, ap, res):
     recip(CINV, C, T(9))
     for r in (PRI, NZ, NAX, DUA, NQ, NATY, NPX):
         e("v_mov_b32", v(r), 0)
+    stamp(1)
 
     class P_:               # what Sched needs
         pass
@@ -2107,6 +2338,7 @@ def res_program(s, eq_rows, ap, res):
             op([("A", q), ("L", ap.LW_X + j)], f)
             touched.add(i)
     assert len(touched) == m
+    op([], lambda g: stamp(2))
     # rows: residual entries, E y / c, stores of y, z
     for i in range(m):
         zsrc = SI(res.it_ls[i]) if i in res.eq else ("L", ap.LW_Z + ap.zpos[i])
@@ -2133,9 +2365,11 @@ def res_program(s, eq_rows, ap, res):
             store("ep", ev)
         op(srcs, f)
     op([], lambda g: e("v_max_f32", v(NZ), v(NZ), v(NAX)))            # prim_rel; NAX is a temporary from here on
+    op([], lambda g: stamp(3))
     # ---- pass 2: y into the accumulator registers, then columns: A' y, P x, q
     for i in range(m):
         op([("L", ap.LW_Y + i)], lambda g, i=i: e("v_mov_b32", ACC(i), v(g[0])))
+    op([], lambda g: stamp(4))
     for j in range(n):
         cols = list(range(res.A_p[j], res.A_p[j + 1]))
         for qn, q in enumerate(cols):
@@ -2171,6 +2405,7 @@ def res_program(s, eq_rows, ap, res):
                 e("v_max_f32", v(NPX), v(NPX), ab(v(T(11))))
         op(srcs, f)
     sc.run(ops)
+    stamp(5)
     # ---- termination test at the strict tolerances (osqp.c:524-573), flag, status and info rows
     e("v_mul_f32", v(DUA), v(CINV), v(DUA))
     e("v_max_f32", v(NQ), v(NQ), v(NATY))
@@ -2189,7 +2424,24 @@ def res_program(s, eq_rows, ap, res):
     e("global_store_dword", "v0", v(T(9)), "s[%d:%d]" % (S_ST, S_ST + 1), 0)
     e("v_cvt_f32_i32", v(NAX), "s%d" % S_MAXIT)
     e("v_mov_b32", v(NATY), 0)
-    for reg in (PRI, DUA, C, NATY, NAX, NATY):                         # info rows: pri, dua, c, 0 (no zero pivot), max_iter, 0
+    if RUIZ_STAMPS and not STAMPS:
+        e("s_waitcnt", "vmcnt(0)")
+        e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (STAMP_ITEM0 // BLOCK) * BLOCK * 256)
+        e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        for k in range(6):
+            e("global_load_dword", v(T(k)), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), ((STAMP_ITEM0 + k) % BLOCK) * 256)
+        e("s_waitcnt", "vmcnt(0)")
+        for k in range(6):
+            store("in", T(k))
+    if STAMPS:
+        e("s_waitcnt", "vmcnt(0)")
+        stamp(6)
+        for k in range(6):
+            e("s_sub_u32", "s%d" % (S_STAMP + 2 * k), "s%d" % (S_STAMP + 2 * k + 2), "s%d" % (S_STAMP + 2 * k))
+            e("v_cvt_f32_u32", v(T(9)), "s%d" % (S_STAMP + 2 * k))
+            store("in", T(9))
+            e("s_nop", 1)
+    for reg in (() if STAMPS or RUIZ_STAMPS else (PRI, DUA, C, NATY, NAX, NATY)):     # info rows: pri, dua, c, 0 (no zero pivot), max_iter, 0
         store("in", reg)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
     return e.ins, R
@@ -2326,6 +2578,9 @@ def glue_program(s, eq_rows, p, res, rp):
     assert NSET >= 2
     F, TOL = _f32_strict_bounds()
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    if RUIZ_STAMPS:
+        e("s_memrealtime", "s[60:61]")
+        e("s_waitcnt", "lgkmcnt(0)")
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
     for reg, val in ((V_RMIN, np.float32(QP_RHO_MIN)), (V_RIMIN, np.float32(1.0 / QP_RHO_MIN)), (V_F, F), (V_NF, -F), (V_TOL, TOL)):
@@ -2419,6 +2674,13 @@ def glue_program(s, eq_rows, p, res, rp):
     base, off = lds_addr(LOOSE_FLAG)
     e("ds_write_b32", base, v(V_LFLAG), off)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    if RUIZ_STAMPS:
+        e("s_memrealtime", "s[62:63]")
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_sub_u32", "s60", "s62", "s60")
+        e("v_cvt_f32_u32", v(V_T), "s60")
+        put(STAMP_ITEM0 + 5, V_T)
+        e("s_waitcnt", "vmcnt(0)")
     written = sorted(q for lst in pos.values() for q in lst)
     assert written == list(range(p.n_stream + len(p.extra)))
     return e.ins

@@ -198,11 +198,7 @@ class PlanarP5fMPC:
 
     def linearise(self, u):
         """getLin at (u, sigma = y[0], phi = y[3]) -> lin [5, B] and the assembled A values."""
-        self.u_nom.copy_(u) if torch.is_tensor(u) else self.u_nom.fill_(float(u))
-        stream = C.c_void_p(torch.cuda.current_stream(self.qp.device).cuda_stream)
-        rc = self.L.umpcP5fStep(self.B, _DT[self.dtype], 0, self.dt, _ptr(self.u_nom), _ptr(self.y), _ptr(self.lin), stream)
-        if rc != 0:
-            raise RuntimeError(self.L.umpcLastError().decode())
+        self._p5f_step(0, u, self.lin)
         self.qp.gather(self.cst, self.src, self.lin, self.Av)
         return self.lin
 
@@ -212,11 +208,22 @@ class PlanarP5fMPC:
         self.linearise(unom)
         if solve:
             self.qp.solve(self.Pv, self.Av, self.q, self.l, self.u)
+        self._p5f_step(1, unom, None)
+        return self.y
+
+    def _p5f_step(self, mode, u, lin):
+        """umpcP5fStep with a per-robot input tensor, umpcP5fStepU with the reference's scalar (no [B] array filled per tick)"""
         stream = C.c_void_p(torch.cuda.current_stream(self.qp.device).cuda_stream)
-        rc = self.L.umpcP5fStep(self.B, _DT[self.dtype], 1, self.dt, _ptr(self.u_nom), _ptr(self.y), None, stream)
+        if torch.is_tensor(u):
+            self.u_nom.copy_(u)
+            rc = self.L.umpcP5fStep(self.B, _DT[self.dtype], mode, self.dt, _ptr(self.u_nom), _ptr(self.y),
+                                    _ptr(lin) if lin is not None else None, stream)
+        else:
+            self.u_nom_scalar = float(u)
+            rc = self.L.umpcP5fStepU(self.B, _DT[self.dtype], mode, self.dt, float(u), _ptr(self.y),
+                                     _ptr(lin) if lin is not None else None, stream)
         if rc != 0:
             raise RuntimeError(self.L.umpcLastError().decode())
-        return self.y
 
 
 # ---------------------------------------------------------------------------------------------------------

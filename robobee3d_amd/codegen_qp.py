@@ -40,6 +40,7 @@ ASM_STRUCTURES = {"p5f10": list(range(77))}   # structure -> rows assumed to be 
 ASM_STREAM_ROW = 1024                          # the hand-off rows of an assembly specialisation stay below this row
 ASM_STREAM_ITEMS = 2048                        # items of a wave's stream block: the loop's stream, then the residual stream
 ASM_RES_ITEM0 = 600                            # first item of the residual stream (asmqp.ResPlan)
+ASM_GROUP_WAVES = 4                            # wavefronts per workgroup of an assembly specialisation (asmqp.RuizSplit)
 
 
 def emit_structure(name, s, asm=None):
@@ -54,7 +55,9 @@ def emit_structure(name, s, asm=None):
     E = o.append
     E("template <typename T>")
     if asm:
-        E("__device__ __forceinline__ void bqp_fixed_%s_asm(const QPArgs<T> &a, const int b, const int wave, const unsigned ldsaddr, const float *ldsf) {" % name)
+        E("// wave = this group of 64 robots (its stream block), lane = the robot's lane, wv = which of the workgroup's %d wavefronts runs" % ASM_GROUP_WAVES)
+        E("// (all of them own the SAME 64 robots and LDS slots: asmqp.RuizSplit; only wavefront 0 goes past the Ruiz block)")
+        E("__device__ __forceinline__ void bqp_fixed_%s_asm(const QPArgs<T> &a, const int b, const int wave, const unsigned lane, const unsigned wv, const unsigned ldsaddr, const float *ldsf) {" % name)
     else:
         E("__device__ __forceinline__ void bqp_fixed_%s(const QPArgs<T> &a, const int b) {" % name)
     E("  const size_t B = (size_t)a.B;")
@@ -84,7 +87,7 @@ def emit_structure(name, s, asm=None):
         E("  const unsigned voff = (unsigned)b * 4u, s_stride = __builtin_amdgcn_readfirstlane((unsigned)a.B * 4u);")
         E("  T *const sblk = a.S + (size_t)wave * %d;   // this wave's stream block ([item][lane]); wave-uniform (SGPR) base" % (ASM_STREAM_ITEMS * 64))
         E("  const unsigned long long ssp = a.asm_ok ? uni((unsigned long long)sblk) : 0ull;")
-        E("  const unsigned lane4 = (unsigned)threadIdx.x * 4u;")
+        E("  const unsigned lane4 = lane * 4u;")
         emit_fast_route(E, name, s, asm, TIMING, mark)
         if not TIMING:
             # (leave here: hipcc computes and spills ~700 row addresses of the routes below in their common dominator, which
@@ -170,7 +173,7 @@ def emit_structure(name, s, asm=None):
         E("#undef LDSQ")
         E("  if (a.asm_ok) {   // z of the equality rows (= their scaled bound) for the residual block")
         for i in sorted(asm.res.it_ls):
-            E("    sblk[%d + threadIdx.x] = ls[%d];" % (asm.res.it_ls[i] * 64, i))
+            E("    sblk[%d + lane] = ls[%d];" % (asm.res.it_ls[i] * 64, i))
         E("  }")
     else:
         for i in range(m):
@@ -269,7 +272,7 @@ def emit_structure(name, s, asm=None):
         nst = P.n_stream + len(P.extra)
         src = {"rinv": "rinv[%d]", "l": "ls[%d]", "u": "us[%d]", "rho": "rho[%d]", "q": "qs[%d]"}
         for q, (what, i) in enumerate(P.stream + P.extra):
-            E("    sblk[%d + threadIdx.x] = %s;" % (q * 64, src[what] % i))
+            E("    sblk[%d + lane] = %s;" % (q * 64, src[what] % i))
         mark(4)
         E("    {")
 
@@ -407,11 +410,14 @@ def emit_structure(name, s, asm=None):
     E("#undef IN")
     E("}")
     if asm:
-        E("__global__ void __launch_bounds__(64) bqp_fixed_%s_asm_kernel(const QPArgs<float> a) {" % name)
+        E("__global__ void __launch_bounds__(%d) bqp_fixed_%s_asm_kernel(const QPArgs<float> a) {" % (64 * ASM_GROUP_WAVES, name))
         E("  __shared__ float4 lds[160 * 64];   // the whole CU: 640 words per lane (asmqp.py)")
-        E("  const int b = blockIdx.x * 64 + threadIdx.x;")
-        E("  if (b >= a.B) return;")
-        E("  bqp_fixed_%s_asm<float>(a, b, (int)blockIdx.x, (unsigned)(size_t)(&lds[threadIdx.x]), reinterpret_cast<const float *>(lds) + 4 * threadIdx.x);" % name)
+        E("  // %d wavefronts (one per SIMD of the CU) share the 64 robots of the workgroup: lane l of EVERY wavefront is robot" % ASM_GROUP_WAVES)
+        E("  // 64 * blockIdx.x + l and addresses the same LDS slot")
+        E("  const unsigned lane = threadIdx.x & 63u, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+        E("  const int b = blockIdx.x * 64 + (int)lane;")
+        E("  if (b >= a.B) return;              // (the same lanes in every wavefront: none of them is left without a lane)")
+        E("  bqp_fixed_%s_asm<float>(a, b, (int)blockIdx.x, lane, wv, (unsigned)(size_t)(&lds[lane]), reinterpret_cast<const float *>(lds) + 4 * lane);" % name)
         E("}")
         return "\n".join(o) + "\n"
     E("template <typename T>")
@@ -442,11 +448,14 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("  int mode = 0, fail = 0;")
     E("  T c = T(1.0), cinv = T(1.0);")
     E("  bool resdone = false;")
+    E("  if (!(a.asm_ok && a.scaling >= 1) && wv != 0u) return;   // (the other routes are one wavefront's)")
     E("  if (a.asm_ok && a.scaling >= 1) {")
     mark(0)
     E("    const unsigned s_pass = __builtin_amdgcn_readfirstlane((unsigned)a.scaling);")
-    E("    BQP_%s_RUIZ_RS_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.Av), uni((unsigned long long)a.Pv), "
-      "uni((unsigned long long)a.q), ssp, s_stride, s_pass);" % U)
+    E("    // the passes shared by the workgroup's wavefronts (asmqp.ruiz_group_program); ends behind a barrier")
+    E("    BQP_%s_RUIZ_RS4_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.Av), uni((unsigned long long)a.Pv), "
+      "uni((unsigned long long)a.q), ssp, s_stride, s_pass, wv);" % U)
+    E("    if (wv != 0u) return;")
     E("    BQP_%s_GLUE_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.l), ssp, uni((unsigned long long)a.u), s_stride, "
       "uni((unsigned long long)a.Eprev), uni((unsigned long long)a.z), a.rho, T(1. / (double)a.rho), rho_eq, T(1. / (double)rho_eq));" % U)
     mark(1)
@@ -490,7 +499,7 @@ def emit_fast_route_reload(E, name, s, P):
     for q, it in enumerate(P.stream + P.extra):
         pos.setdefault(it, q)
     E("  if (mode == 1) {")
-    E("#define SB(item) sblk[(item) * 64 + threadIdx.x]")
+    E("#define SB(item) sblk[(item) * 64 + lane]")
     for k in range(s.nnzA):
         E("    As[%d] = SB(%d);" % (k, res.it_A + k))
     for j in range(n):
@@ -519,9 +528,15 @@ def emit_fast_route_reload(E, name, s, P):
     E("  }")
 
 
+def _stamp_clobbers():
+    """(diagnostic builds, UMPC_QP_RES_STAMPS / UMPC_QP_RUIZ_STAMPS: the blocks keep 100 MHz stamps in s60..s81)"""
+    on = os.environ.get("UMPC_QP_RES_STAMPS") == "1" or os.environ.get("UMPC_QP_RUIZ_STAMPS") == "1"
+    return ['"s%d"' % i for i in range(60, 82)] if on else []
+
+
 def glue_macro(name, ins):
     from . import asmqp
-    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(9, asmqp.V_END))] + \
+    clob = ['"memory"', '"scc"', '"vcc"'] + _stamp_clobbers() + ['"v%d"' % i for i in [2, 3] + list(range(9, asmqp.V_END))] + \
            ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1)] + ['"s%d"' % (q + h) for q in asmqp.GLUE_PTRS for h in (0, 1)]
     out = ["// Glue between the Ruiz block and the loop (asmqp.glue_program): rho classification, scaled bounds, the loop's stream,",
            "// LDS word %d = 1 iff the wave may take the all-assembly route. %d instructions." % (asmqp.GLUE_FLAG, len(ins)),
@@ -571,7 +586,7 @@ def asm_macro(name, ins, plan, loose=False):
 
 def res_macro(name, ins):
     from . import asmqp
-    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
+    clob = ['"memory"', '"scc"', '"vcc"'] + _stamp_clobbers() + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in [asmqp.S_SP, asmqp.S_SP + 1] + list(range(42, 54)) + [56, 57]]
     out = ["// Residuals, strict termination test and solution stores after the loop (asmqp.res_program): %d instructions." % len(ins),
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[6:7] = the wave's stream block, s10 = 4*B,",
@@ -587,9 +602,28 @@ def res_macro(name, ins):
     return "\n".join(out) + "\n"
 
 
-def ruiz_macro(name, ins, rp, rs=False):
+def ruiz_macro(name, ins, rp, rs=False, group=False):
     from . import asmqp
-    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, asmqp.V_END) if not (rs and i == asmqp.V_RLANE)] + \
+    if group:
+        clob = ['"memory"', '"scc"', '"vcc"'] + _stamp_clobbers() + ['"v%d"' % i for i in range(2, asmqp.V_END) if i != asmqp.V_RLANE] + \
+               ['"a%d"' % i for i in range(256)] + \
+               ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_RMIN, asmqp.S_RMAX)]
+        nbar = sum(t_[0] == "s_barrier" for t_ in ins)
+        out = ["// The passes and the residual stream as above, SHARED by the %d wavefronts of a workgroup that own the same 64 robots"
+               % ASM_GROUP_WAVES,
+               "// (asmqp.ruiz_group_program / RuizSplit: each wavefront takes a stretch of the columns; two s_barrier per pass; s26 = the",
+               "// wavefront's index). %d instructions in %d sections; every word left in LDS and in the stream is bit-identical to the"
+               % (len(ins), ASM_GROUP_WAVES),
+               "// one-wavefront block's. Ends behind a barrier: whichever wavefront continues sees all of it.",
+               "#define BQP_%s_RUIZ_RS4_ASM(voff, ldsaddr, lane4, av, pv, qv, sblk, stride, passes, wave) asm volatile( \\" % name.upper()]
+        assert nbar % ASM_GROUP_WAVES == 0
+        for t_ in ins:
+            out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+        out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v%d}"(lane4), "{s[4:5]}"(av), "{s[6:7]}"(pv), "{s[8:9]}"(qv), '
+                   '"{s[24:25]}"(sblk), "{s10}"(stride), "{s11}"(passes), "{s%d}"(wave) \\' % (asmqp.V_RLANE, asmqp.S_RWAVE))
+        out.append("  : " + ", ".join(clob) + ")")
+        return "\n".join(out) + "\n"
+    clob = ['"memory"', '"scc"', '"vcc"'] + _stamp_clobbers() + ['"v%d"' % i for i in range(2, asmqp.V_END) if not (rs and i == asmqp.V_RLANE)] + \
            ['"a%d"' % i for i in range(256)] + \
            ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_RMIN, asmqp.S_RMAX)]
     if rs:
@@ -647,6 +681,7 @@ def generate():
             assert plan.res.end <= ASM_STREAM_ITEMS
             rins, plan.ruiz = asmqp.ruiz_program(s)
             rsins, _ = asmqp.ruiz_program(s, plan.res)
+            rs4ins, _, _ = asmqp.ruiz_group_program(s, plan.res, ASM_GROUP_WAVES)
             resins, _ = asmqp.res_program(s, ASM_STRUCTURES[name], plan, plan.res)
             glins = asmqp.glue_program(s, ASM_STRUCTURES[name], plan, plan.res, plan.ruiz)
             asm_body = emit_structure(name, s, asm=plan)
@@ -654,7 +689,8 @@ def generate():
             assert plan.ruiz.LW_END <= asmqp.LW_FLAGS
             files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + asm_macro(name, ins_loose, plan, loose=True) + \
                 ruiz_macro(name, rins, plan.ruiz) + \
-                ruiz_macro(name, rsins, plan.ruiz, rs=True) + res_macro(name, resins) + glue_macro(name, glins) + \
+                ruiz_macro(name, rsins, plan.ruiz, rs=True) + ruiz_macro(name, rs4ins, plan.ruiz, rs=True, group=True) + \
+                res_macro(name, resins) + glue_macro(name, glins) + \
                 loader_macro(name, "XYZ", [(s.n, 0), (s.m, s.n), (s.m, s.n + s.m)]) + \
                 loader_macro(name, "LUE", [(s.m, 0), (s.m, s.m), (s.m, 2 * s.m)])
         for tag, ctype in DTYPES:
@@ -669,7 +705,7 @@ def generate():
                    % (name, tag, ctype)] + ([
                    "  // middle iterations as generated assembly (asmqp.py) when the host found room for the stream buffer",
                    "  if (a.asm_ok && a.max_iter >= 3) {",
-                   "    hipLaunchKernelGGL(bqp_fixed_%s_asm_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a);" % name,
+                   "    hipLaunchKernelGGL(bqp_fixed_%s_asm_kernel, dim3((a.B + 63) / 64), dim3(%d), 0, s, a);" % (name, 64 * ASM_GROUP_WAVES),
                    "    return;",
                    "  }"] if with_asm else []) + [
                    "  hipLaunchKernelGGL(bqp_fixed_%s_kernel<%s>, dim3((a.B + 63) / 64), dim3(64), 0, s, a);" % (name, ctype),

@@ -660,12 +660,20 @@ __global__ void __launch_bounds__(64) bqp_wave_kernel(const QPArgs<T> a) {
 
 // Av[k] = cst[k] if src[k] < 0 else par[src[k]][b] * cst[k]: assembles any per-robot value vector (A, P, q, l, u)
 // whose entries are constants or scaled copies of a few per-robot parameters.
+// One thread per (robot, kGatherRows entries): the grid covers B x nnz, so a small batch still fills the chip (round 4: one
+// thread per robot walking all nnz entries kept 64 of the 256 CUs busy for 25 us per p5f tick; src / cst are wave-uniform
+// scalar loads either way).
+constexpr int kGatherRows = 4;
 template <typename T>
 __global__ void bqp_gather_kernel(int B, int nnz, const T *__restrict__ cst, const int32_t *__restrict__ src,
                                   const T *__restrict__ par, T *__restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int k = 0; k < nnz; ++k) {
+  const int k0 = blockIdx.y * kGatherRows;
+#pragma unroll
+  for (int r = 0; r < kGatherRows; ++r) {
+    const int k = k0 + r;
+    if (k >= nnz) break;
     const int s = src[k];
     const T cv = cst[k];
     out[(size_t)k * B + b] = s < 0 ? cv : par[(size_t)s * B + b] * cv;
@@ -696,13 +704,13 @@ __device__ __forceinline__ void p5f_getlin(T u, T sigma, T phi, T o[5]) {
 // mode 0: lin[5][B] <- getLin(u[b], y[0][b], y[3][b]) (the reference linearises about the PREVIOUS state, :165-167)
 // mode 1: the same, then the reference's plant tick y += (Ad y + Bd u) dt (:176)
 template <typename T>
-__global__ void p5f_kernel(int B, int mode, T dt, const T *__restrict__ u, T *__restrict__ y, T *__restrict__ lin) {
+__global__ void p5f_kernel(int B, int mode, T dt, const T *__restrict__ u, T u_all, T *__restrict__ y, T *__restrict__ lin) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const size_t Bz = (size_t)B;
   T yy[7], o[5];
   for (int i = 0; i < 7; ++i) yy[i] = y[i * Bz + b];
-  const T ub = u[b];
+  const T ub = u ? u[b] : u_all;   // (umpcP5fStepU: the reference's unom is ONE number for all robots, mpc_osqp_p5f.py:157)
   p5f_getlin(ub, yy[0], yy[3], o);
   if (lin) for (int i = 0; i < 5; ++i) lin[i * Bz + b] = o[i];
   if (mode == 1) {
@@ -1074,11 +1082,11 @@ int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src,
   if (B <= 0 || nnz <= 0 || !cst || !src || !out) { umpc_set_error("umpcQPGather: bad argument"); return -1; }
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UMPC_F32)
-    hipLaunchKernelGGL(bqp_gather_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, s, B, nnz, (const float *)cst, src,
-                       (const float *)par, (float *)out);
+    hipLaunchKernelGGL(bqp_gather_kernel<float>, dim3((B + 255) / 256, (nnz + kGatherRows - 1) / kGatherRows), dim3(256), 0, s,
+                       B, nnz, (const float *)cst, src, (const float *)par, (float *)out);
   else
-    hipLaunchKernelGGL(bqp_gather_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, nnz, (const double *)cst,
-                       src, (const double *)par, (double *)out);
+    hipLaunchKernelGGL(bqp_gather_kernel<double>, dim3((B + 255) / 256, (nnz + kGatherRows - 1) / kGatherRows), dim3(256), 0, s,
+                       B, nnz, (const double *)cst, src, (const double *)par, (double *)out);
   return check_launch("umpcQPGather");
 }
 
@@ -1089,12 +1097,27 @@ int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, v
   }
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UMPC_F32)
-    hipLaunchKernelGGL(p5f_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, (float)dt, (const float *)u,
+    hipLaunchKernelGGL(p5f_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, (float)dt, (const float *)u, 0.f,
                        (float *)y, (float *)lin);
   else
-    hipLaunchKernelGGL(p5f_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, dt, (const double *)u,
+    hipLaunchKernelGGL(p5f_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, dt, (const double *)u, 0.0,
                        (double *)y, (double *)lin);
   return check_launch("umpcP5fStep");
+}
+
+int umpcP5fStepU(int B, int dtype, int mode, double dt, double u, void *y, void *lin, void *stream) {
+  if (B <= 0 || !y || (mode != 0 && mode != 1) || (mode == 0 && !lin)) {
+    umpc_set_error("umpcP5fStepU: bad argument");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL(p5f_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, (float)dt, (const float *)nullptr,
+                       (float)u, (float *)y, (float *)lin);
+  else
+    hipLaunchKernelGGL(p5f_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, dt, (const double *)nullptr, u,
+                       (double *)y, (double *)lin);
+  return check_launch("umpcP5fStepU");
 }
 
 int umpcNAssemble(int B, int dtype, int N, const umpcNParams *p, const void *state, const void *ref, void *T0,

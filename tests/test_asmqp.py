@@ -530,3 +530,34 @@ def test_lds_write_combiners():
     for w in (0, 1, 2, 3, 4, 5):                       # ... and a run that ends in the middle of one
         qw.done(w, w == 5)
     assert sc.log == [("b128", 0, 100), ("b64", 4, 100)]
+
+
+@pytest.mark.parametrize("passes", [1, 3, 10])
+def test_ruiz_block_shared_by_four_waves_is_bit_identical_to_one_wave(passes):
+    """asmqp.ruiz_group_program: the four wavefronts of a workgroup split the columns of the SAME 64 robots (RuizSplit) and meet
+    at two barriers per pass. The interpreter runs the four programs barrier phase by barrier phase on one LDS image, rejects
+    a word written by one wave and touched by another between two barriers, and a wave that misses a barrier; every LDS word
+    the block leaves and every item of the residual stream must equal the one-wave block's BIT for bit."""
+    asmqp, s, eq, ap, res = _p5f()
+    one, p = asmqp.ruiz_program(s, res)
+    grp, _, sp = asmqp.ruiz_group_program(s, res, 4)
+    assert sorted(set(sp.colw.values())) == [0, 1, 2, 3] and 0 < len(sp.shared) <= 40
+    rng = np.random.default_rng(40 + passes)
+    f = lambda a: a.astype(np.float32)
+    for scale in (1.0, 1e-6, 3e5):
+        P = f(np.abs(rng.normal(size=p.nnzP)) * 10 * scale + 1e-3 * scale)
+        A = f(rng.normal(size=p.nnzA) * scale)
+        A[rng.random(p.nnzA) < 0.3] = 1.0
+        q = f(rng.normal(size=p.n) * scale)
+        S1, S4 = np.full(res.end, np.nan, np.float32), np.full(res.end, np.nan, np.float32)
+        kw = dict(regions=[(asmqp.S_AV, A), (asmqp.S_PV, P), (asmqp.S_QV, q)], sgpr={asmqp.S_RSB: "S"})
+        lds1 = asmqp.simulate(one, np.zeros(1, np.float32), S1, passes, (1.6, 1e-6, 0.01), **kw)
+        lds4, counts, nbar = asmqp.simulate_group(grp, 4, np.zeros(1, np.float32), S4, passes, (1.6, 1e-6, 0.01), asmqp.S_RWAVE, **kw)
+        assert nbar == 2 * passes + 2
+        keep = list(range(p.LW_A, p.LW_END))
+        assert np.array_equal(lds1[keep], lds4[keep]), scale
+        assert np.array_equal(S1, S4, equal_nan=True), scale
+    # the point of it: the longest of the four programs executes about a third of the one-wave block's instructions
+    n1 = []
+    asmqp.simulate(one, np.zeros(1, np.float32), S1, passes, (1.6, 1e-6, 0.01), count=n1, **kw)
+    assert max(counts) < 0.42 * n1[0], (counts, n1)

@@ -303,6 +303,34 @@ def test_gpu_p5f_getlin_and_plant_match_reference_fixture():
 
 
 @pytest.mark.gpu
+def test_gpu_p5f_scalar_input_entry_and_wide_gather_agree_with_the_array_entry():
+    """umpcP5fStepU (ONE nominal input for the batch, as the reference's loop has it: planar/mpc_osqp_p5f.py:157) against
+    umpcP5fStep with a filled [B] array: bit-identical lin, A values and plant tick over three ticks of a ragged batch (the
+    gather kernel's grid covers B x nnz: 300 robots leave a partial block in both directions)."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    B = 300
+    for tdt in (torch.float32, torch.float64):
+        a, b = PlanarP5fMPC(B, tdt), PlanarP5fMPC(B, tdt)
+        y0 = torch.as_tensor(np.random.default_rng(5).normal(size=(7, B)) * 0.1).to(a.y)
+        a.y.copy_(y0)
+        b.y.copy_(y0)
+        for ti in range(2, 5):
+            unom = 15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti)
+            a.linearise(unom)                                               # scalar entry
+            b.linearise(torch.full((B,), unom, dtype=torch.float64).to(b.y))    # array entry
+            assert torch.equal(a.lin, b.lin) and torch.equal(a.Av, b.Av), (tdt, ti)
+            a._p5f_step(1, unom, None)
+            b._p5f_step(1, torch.full((B,), unom, dtype=torch.float64).to(b.y), None)
+            assert torch.equal(a.y, b.y), (tdt, ti)
+        # every entry of the value array: constants where src < 0, cst * lin[src] elsewhere
+        Av, lin = a.Av.cpu().numpy(), a.lin.cpu().numpy()
+        cst, src = a.cst.cpu().numpy(), a.src.cpu().numpy()
+        want = np.where(src[:, None] < 0, cst[:, None], cst[:, None] * lin[np.maximum(src, 0)])
+        assert np.array_equal(Av, want.astype(Av.dtype)), tdt
+
+
+@pytest.mark.gpu
 def test_gpu_p5f_loop_matches_oracle():
     """Config 4 path: per tick getLin -> A -> one 50-iteration QP step -> plant; fp64 GPU vs the table oracle fed with
     the GPU's own A values (so the comparison isolates the solver), warm-started tick to tick."""
