@@ -1327,8 +1327,9 @@ def simulate_group(ins, nw, W, S, iters, consts, wave_sgpr, **kw):
     word is written by one wave and read or written by another (the data races a barrier-phased schedule can have). Returns
     the shared LDS words and the per-wave executed instruction counts."""
     lds = np.zeros(640, np.float32)
-    if kw.get("lds0") is not None:
-        lds[:len(kw["lds0"])] = kw.pop("lds0")
+    lds0 = kw.pop("lds0", None)
+    if lds0 is not None:
+        lds[:len(lds0)] = lds0
     logs = [dict(r=set(), w=set()) for _ in range(nw)]
     counts = [[] for _ in range(nw)]
     gens = []
@@ -1349,12 +1350,13 @@ def simulate_group(ins, nw, W, S, iters, consts, wave_sgpr, **kw):
         for a_ in range(nw):
             for b_ in range(nw):
                 if a_ != b_:
-                    clash = logs[a_]["w"] & (logs[b_]["r"] | logs[b_]["w"])
+                    clash = (logs[a_]["w"] & (logs[b_]["r"] | logs[b_]["w"] | logs[b_].get("a", set()))) | \
+                            (logs[a_].get("a", set()) & logs[b_]["r"])
                     assert not clash, ("LDS race before barrier %d: words written by wave %d and touched by wave %d" % (nbar, a_, b_),
                                        sorted(clash)[:8])
         for lg in logs:
-            lg["r"].clear()
-            lg["w"].clear()
+            for st_ in lg.values():
+                st_.clear()
         nbar += 1
     return lds, [c[0] for c in counts], nbar - 1
 
@@ -1375,6 +1377,7 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
     labels = {}
     log_r = access_log["r"] if access_log is not None else set()
     log_w = access_log["w"] if access_log is not None else set()
+    log_a = access_log.setdefault("a", set()) if access_log is not None else set()
     src_word = {}
     for k, t in enumerate(ins):
         if t[0] == "label":
@@ -1486,7 +1489,7 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
                         log_r.add(src_word[r_])
             if m == "ds_read_b128":
                 pend["lgkmcnt"].append(regs_of(t[1]))
-            elif m.startswith("ds_write"):
+            elif m.startswith("ds_write") or m == "ds_min_f32":
                 pend["lgkmcnt"].append(set())
             elif m == "global_load_dword":
                 pend["vmcnt"].append(regs_of(t[1]))
@@ -1598,6 +1601,10 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
         elif m == "ds_write_b32":
             lds[ldsword(t[1], t[3])] = bits2f(V[int(t[2][1:])])
             log_w.add(ldsword(t[1], t[3]))
+        elif m == "ds_min_f32":               # LDS float-min atomic (no return): other waves may do the same to the word
+            w = ldsword(t[1], t[3])
+            lds[w] = min(lds[w], bits2f(V[int(t[2][1:])]))
+            log_a.add(w)
         elif m == "ds_write_b64":
             lo = int(t[2][2:t[2].index(":")])
             w = ldsword(t[1], t[3])
@@ -2554,9 +2561,18 @@ def _f32_strict_bounds():
     return float(F), float(TOL)
 
 
-def glue_program(s, eq_rows, p, res, rp):
-    """p: Plan (stream positions), res: ResPlan (z of the equality rows), rp: RuizPlan (where E and q are in LDS)"""
+S_GWAVE = 28                       # glue_group_program: s28 = the wave's index in its workgroup
+
+
+def glue_program(s, eq_rows, p, res, rp, split=None):
+    """p: Plan (stream positions), res: ResPlan (z of the equality rows), rp: RuizPlan (where E and q are in LDS).
+    split = (wave, nw): the program of one of nw wavefronts that share the block (each a quarter of the rows and of q; the two
+    flags are combined with LDS float-min atomics between two barriers). Returns the instructions (and, with split, the set of
+    stream items this wave writes)."""
     n, m = s.n, s.m
+    wave, nw = split if split is not None else (0, 1)
+    my_rows = [i for i in range(m) if i * nw // m == wave]
+    my_cols = [j for j in range(n) if j * nw // n == wave]
     eq = set(int(i) for i in eq_rows)
     pos = {}
     for q, it in enumerate(p.stream + p.extra):
@@ -2578,7 +2594,7 @@ def glue_program(s, eq_rows, p, res, rp):
     assert NSET >= 2
     F, TOL = _f32_strict_bounds()
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
-    if RUIZ_STAMPS:
+    if RUIZ_STAMPS and wave == 0:
         e("s_memrealtime", "s[60:61]")
         e("s_waitcnt", "lgkmcnt(0)")
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
@@ -2587,6 +2603,13 @@ def glue_program(s, eq_rows, p, res, rp):
         e("v_mov_b32", v(reg), f32bits(float(val)))
     e("v_mov_b32", v(V_FLAG), 1.0)
     e("v_mov_b32", v(V_LFLAG), 1.0)
+    if split is not None:
+        if wave == 0:             # the flag words start at 1; every wave then folds its own verdict in (float min, atomic)
+            for word in (GLUE_FLAG, LOOSE_FLAG):
+                base, off = lds_addr(word)
+                e("ds_write_b32", base, v(V_FLAG), off)
+            e("s_waitcnt", "lgkmcnt(0)")
+        e("s_barrier")
     # a row's items go to three regions of the stream (1/rho list, per-row items, the residual stream): four block
     # pointers are kept, least recently used replaced
     ptrs = [[sreg, None, 0] for sreg in GLUE_PTRS]          # [SGPR pair, block, last use]
@@ -2604,14 +2627,18 @@ def glue_program(s, eq_rows, p, res, rp):
             e("s_add_u32", "s%d" % q[0], "s%d" % S_S, blk * BLOCK * 256)
             e("s_addc_u32", "s%d" % (q[0] + 1), "s%d" % (S_S + 1), 0)
         q[2] = tick[0]
+        put_items.append(item)
         e("global_store_dword", "v%d" % V_LANE, v(reg), "s[%d:%d]" % (q[0], q[0] + 1), (item % BLOCK) * 256)
 
     def check(a_, b_):
         e("v_cmp_eq_f32", "vcc", v(a_), v(b_))
         e("v_cndmask_b32", v(V_FLAG), 0, v(V_FLAG), "vcc")
     nrow = 0
-    for c0 in range(0, m, R):
-        rows = list(range(c0, min(m, c0 + R)))
+    put_items = []
+    for c00 in range(0, len(my_rows), R):
+        rows = my_rows[c00:c00 + R]
+        c0 = rows[0]
+        assert rows == list(range(c0, c0 + len(rows)))
         for base_s, v0_, sel in ((S_LR, V_L, rows), (S_UR, V_U, rows), (S_ER, V_E, rows), (S_ZR, V_Z, [i for i in rows if i in eq])):
             last = None
             for i in sel:
@@ -2663,18 +2690,19 @@ def glue_program(s, eq_rows, p, res, rp):
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")        # the landing registers are loaded again by the next chunk
     sc = Sched(e, pl, 0)
     ops = []
-    for j in range(n):
+    for j in my_cols:
         def fq(g, j=j):
             for q in pos[("q", j)]:
                 put(q, g[0])
         ops.append(dict(srcs=[("L", rp.LW_Q + j)], emit=fq))
     sc.run(ops)
-    base, off = lds_addr(GLUE_FLAG)
-    e("ds_write_b32", base, v(V_FLAG), off)
-    base, off = lds_addr(LOOSE_FLAG)
-    e("ds_write_b32", base, v(V_LFLAG), off)
+    for word, reg in ((GLUE_FLAG, V_FLAG), (LOOSE_FLAG, V_LFLAG)):
+        base, off = lds_addr(word)
+        e("ds_min_f32" if split is not None else "ds_write_b32", base, v(reg), off)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
-    if RUIZ_STAMPS:
+    if split is not None:
+        e("s_barrier")
+    if RUIZ_STAMPS and wave == 0:
         e("s_memrealtime", "s[62:63]")
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_sub_u32", "s60", "s62", "s60")
@@ -2683,4 +2711,27 @@ def glue_program(s, eq_rows, p, res, rp):
         e("s_waitcnt", "vmcnt(0)")
     written = sorted(q for lst in pos.values() for q in lst)
     assert written == list(range(p.n_stream + len(p.extra)))
+    if split is not None:
+        return e.ins, put_items
+    assert sorted(q for q in put_items if q < res.rs0) == written
+    return e.ins
+
+
+def glue_group_program(s, eq_rows, p, res, rp, nw=4):
+    """The glue block for a workgroup of nw wavefronts that share 64 robots: s28 = the wave's index, the other inputs as
+    glue_program. Every wave meets the same two barriers."""
+    e = Emit()
+    items = []
+    for w in range(nw):
+        if w < nw - 1:
+            e("s_cmp_lg_u32", "s%d" % S_GWAVE, w)
+            e("s_cbranch_scc1", "8f")
+        ins, put_w = glue_program(s, eq_rows, p, res, rp, (w, nw))
+        items += put_w
+        e.ins.extend(ins)
+        if w < nw - 1:
+            e("s_branch", "9f")
+            e("label", "8")
+    e("label", "9")
+    assert sorted(q for q in items if q < res.rs0) == list(range(p.n_stream + len(p.extra))), "every stream item exactly once"
     return e.ins

@@ -455,9 +455,9 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("    // the passes shared by the workgroup's wavefronts (asmqp.ruiz_group_program); ends behind a barrier")
     E("    BQP_%s_RUIZ_RS4_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.Av), uni((unsigned long long)a.Pv), "
       "uni((unsigned long long)a.q), ssp, s_stride, s_pass, wv);" % U)
+    E("    BQP_%s_GLUE4_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.l), ssp, uni((unsigned long long)a.u), s_stride, "
+      "uni((unsigned long long)a.Eprev), uni((unsigned long long)a.z), a.rho, T(1. / (double)a.rho), rho_eq, T(1. / (double)rho_eq), wv);" % U)
     E("    if (wv != 0u) return;")
-    E("    BQP_%s_GLUE_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.l), ssp, uni((unsigned long long)a.u), s_stride, "
-      "uni((unsigned long long)a.Eprev), uni((unsigned long long)a.z), a.rho, T(1. / (double)a.rho), rho_eq, T(1. / (double)rho_eq));" % U)
     mark(1)
     if TIMING:
         E("    tmark[2] = tmark[3] = tmark[4] = tmark[1];")
@@ -534,7 +534,7 @@ def _stamp_clobbers():
     return ['"s%d"' % i for i in range(60, 82)] if on else []
 
 
-def glue_macro(name, ins):
+def glue_macro(name, ins, group=False):
     from . import asmqp
     clob = ['"memory"', '"scc"', '"vcc"'] + _stamp_clobbers() + ['"v%d"' % i for i in [2, 3] + list(range(9, asmqp.V_END))] + \
            ['"s%d"' % i for i in (asmqp.S_P, asmqp.S_P + 1)] + ['"s%d"' % (q + h) for q in asmqp.GLUE_PTRS for h in (0, 1)]
@@ -543,10 +543,17 @@ def glue_macro(name, ins):
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[4:5] / s[8:9] / s[24:25] / s[26:27] = l, u, Eprev, z rows,",
            "// s[6:7] = the wave's stream block, s10 = 4*B, v5..v8 = rho, 1/rho, rho_eq, 1/rho_eq (floats)",
            "#define BQP_%s_GLUE_ASM(voff, ldsaddr, lane4, lp, sblk, up, stride, ep, zp, rho0, rinv0, rhoeq, rinveq) asm volatile( \\" % name.upper()]
+    if group:
+        out = ["// The glue block SHARED by the %d wavefronts of a workgroup (asmqp.glue_group_program): each a quarter of the rows and of q,"
+               % ASM_GROUP_WAVES,
+               "// the two flag words combined with LDS float-min atomics between two barriers; s%d = the wavefront's index. %d instructions."
+               % (asmqp.S_GWAVE, len(ins)),
+               "#define BQP_%s_GLUE4_ASM(voff, ldsaddr, lane4, lp, sblk, up, stride, ep, zp, rho0, rinv0, rhoeq, rinveq, wave) asm volatile( \\" % name.upper()]
     for t_ in ins:
         out.append('  "%s\\n" \\' % asmqp.fmt(t_))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(lp), "{s[6:7]}"(sblk), "{s[8:9]}"(up), "{s10}"(stride), '
-               '"{s[24:25]}"(ep), "{s[26:27]}"(zp), "{v5}"(rho0), "{v6}"(rinv0), "{v7}"(rhoeq), "{v8}"(rinveq) \\')
+               '"{s[24:25]}"(ep), "{s[26:27]}"(zp), "{v5}"(rho0), "{v6}"(rinv0), "{v7}"(rhoeq), "{v8}"(rinveq)%s \\'
+               % (', "{s%d}"(wave)' % asmqp.S_GWAVE if group else ""))
     out.append("  : " + ", ".join(clob) + ")")
     return "\n".join(out) + "\n"
 
@@ -684,13 +691,14 @@ def generate():
             rs4ins, _, _ = asmqp.ruiz_group_program(s, plan.res, ASM_GROUP_WAVES)
             resins, _ = asmqp.res_program(s, ASM_STRUCTURES[name], plan, plan.res)
             glins = asmqp.glue_program(s, ASM_STRUCTURES[name], plan, plan.res, plan.ruiz)
+            gl4ins = asmqp.glue_group_program(s, ASM_STRUCTURES[name], plan, plan.res, plan.ruiz, ASM_GROUP_WAVES)
             asm_body = emit_structure(name, s, asm=plan)
             asm_hdr = "bqp_%s_asm.h" % name
             assert plan.ruiz.LW_END <= asmqp.LW_FLAGS
             files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + asm_macro(name, ins_loose, plan, loose=True) + \
                 ruiz_macro(name, rins, plan.ruiz) + \
                 ruiz_macro(name, rsins, plan.ruiz, rs=True) + ruiz_macro(name, rs4ins, plan.ruiz, rs=True, group=True) + \
-                res_macro(name, resins) + glue_macro(name, glins) + \
+                res_macro(name, resins) + glue_macro(name, glins) + glue_macro(name, gl4ins, group=True) + \
                 loader_macro(name, "XYZ", [(s.n, 0), (s.m, s.n), (s.m, s.n + s.m)]) + \
                 loader_macro(name, "LUE", [(s.m, 0), (s.m, s.m), (s.m, 2 * s.m)])
         for tag, ctype in DTYPES:

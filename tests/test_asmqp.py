@@ -379,6 +379,13 @@ def test_glue_block_classifies_and_writes_the_stream(prog):
         its = sorted(res.it_ls.values())
         assert np.array_equal(S[its], Sx[its]), case
         assert lds[asmqp.GLUE_FLAG] == (1.0 if case == "ok" else 0.0), case
+        # the block shared by four wavefronts (glue_group_program): the same stream, the same flags, no LDS race, two barriers
+        S4 = np.full(res.end, np.nan, f32)
+        lds4, _, nbar = asmqp.simulate_group(pre + asmqp.glue_group_program(s, eq, p, res, rp, 4), 4, np.zeros(1, f32), S4, 0,
+                                             (1.6, 1e-6, 0.01), asmqp.S_GWAVE, lds0=lds0,
+                                             regions=[(asmqp.S_LR, l), (asmqp.S_UR, u), (asmqp.S_ER, ep), (asmqp.S_ZR, z)])
+        assert nbar == 2 and np.array_equal(S, S4, equal_nan=True), case
+        assert lds4[asmqp.GLUE_FLAG] == lds[asmqp.GLUE_FLAG] and lds4[asmqp.LOOSE_FLAG] == lds[asmqp.LOOSE_FLAG], case
         assert (rho == f32(1e-6)).sum() == len(loose) and (rho == f32(100.0)).sum() == len(eq) - (case == "noteq")
 
 
