@@ -250,6 +250,60 @@ NT_ITEMS = int(os.environ.get("UMPC_QP_NT", "0"))
 RING_AHEAD = int(os.environ.get("UMPC_QP_RING_AHEAD", "20"))   # ops of look-ahead for the LDS ring reads
 
 
+class Own:
+    """Which variables, rows and KKT unknowns a wavefront's copy of the loop block works on (LoopSplit); ALL = one wave, all."""
+
+    def __init__(self, varw=None, roww=None, kw=None, wave=0):
+        self.varw, self.roww, self.kw, self.wave = varw, roww, kw, wave
+        self.all = varw is None
+
+    def var(self, j):
+        return self.all or self.varw[j] == self.wave
+
+    def row(self, i):
+        return self.all or self.roww[i] == self.wave
+
+    def k(self, k):
+        return self.all or self.kw[k] == self.wave
+
+    def item(self, item):
+        what, idx = item
+        return self.var(idx) if what == "q" else self.row(idx)
+
+
+ALL = Own()
+
+
+class LoopSplit:
+    """A QP whose constraint graph falls into several connected components (qpstruct.qp_components) is several independent
+    QPs: right-hand sides, LDL' factor, triangular solves, row and x updates of one component never touch another's words.
+    The loose loop block gives the largest component to wavefront 0 of the workgroup and the others to wavefront 1 (planar
+    p5f: 41 + 46 of 87 variables, 113 + 138 of 251 unknowns); both run their 50 iterations side by side on disjoint LDS words
+    of the SAME layout (Plan), without a barrier inside the loop. Words come out bit-identical to the one-wave block."""
+
+    def __init__(self, p, nw=4):
+        from . import qpstruct
+        s = p.s
+        vc, rc = qpstruct.qp_components(s.n, s.m, list(s.tables["A_p"]), list(s.tables["A_i"]))
+        self.nw = nw
+        self.active = 2 if max(vc) > 0 else 1
+        self.varw = [0 if c == 0 else 1 for c in vc]
+        self.roww = [0 if c == 0 else 1 for c in rc]
+        self.kw = [0] * s.nk
+        for j in range(s.n):
+            self.kw[p.pinv[j]] = self.varw[j]
+        for i in range(s.m):
+            self.kw[p.pinv[s.n + i]] = self.roww[i]
+        for r in p.rows:
+            if r["leaf"]:
+                assert self.kw[r["r"]] == self.roww[r["i"]]
+        for (r_, c, j) in p.solve_entries:
+            assert self.kw[r_] == self.kw[c]
+
+    def own(self, wave):
+        return Own(self.varw, self.roww, self.kw, wave)
+
+
 class Sched:
     """Emits a list of ops with their operand fetches: LDS quads through a ring (prefetched `ahead` ops before first use),
     AGPR words two ops ahead, stream items through the landing registers. op = dict(srcs=[...], emit=fn(regs)),
@@ -423,14 +477,14 @@ class Sched:
             op["emit"](regs)
 
 
-def preloads(e, p, homes=()):
+def preloads(e, p, homes=(), own=ALL):
     """the tail of the stream: q -> W_x, l of the non-leaf equality rows -> their W registers (in place operands);
     homes: items that live in LDS in this variant (y0) and are not loaded"""
     idx = p.n_land - 1
     blk = None
     for (what, q) in p.stream[p.n_land:]:
         idx += 1
-        if (what, q) in homes:
+        if (what, q) in homes or not own.item((what, q)):
             continue
         if idx // BLOCK != blk:
             # pointer = this wave's block + (idx // BLOCK) * 4096
@@ -456,7 +510,7 @@ def couples(words):
 PAIR_QUADS = os.environ.get("UMPC_QP_PAIR_QUADS", "1") == "1"
 
 
-def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
+def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=ALL, group=False):
     """capture: the LAST iteration -- x_prev and delta_y go to rows R_XP / R_DY (auxil.c:362-512 consumes them)
     loose: every inequality row is a loose row (see S_RIMIN above)
     rhs / fuse (y0 bodies): fuse -- the row and x updates leave the NEXT iteration's right-hand side in the W registers (the new
@@ -469,7 +523,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
     T = lambda q: p.V_TT + q
     assert loose or not y0
     homes = p.y0_home if y0 else {}
-    pre_items = [it for it in p.stream[p.n_land:] if it not in homes]
+    pre_items = [it for it in p.stream[p.n_land:] if it not in homes and own.item(it)]
     npre = len(pre_items)
     sc = Sched(e, p, npre)
     e("s_mov_b64", "s[%d:%d]" % (S_SP, S_SP + 1), "s[%d:%d]" % (S_S, S_S + 1))
@@ -489,11 +543,11 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
     VP = lambda r_: ("v[%d:%d]" % (r_, r_ + 1), 0, 1)
     SB = lambda sreg, h: ("s[%d:%d]" % (sreg - sreg % 2, sreg - sreg % 2 + 1), h, h)
     xpair = lambda j: pack and j + 1 < n and (p.LW_X + j) % 2 == 0 and p.wreg[p.pinv[j]] % 2 == 0 and \
-        p.wreg[p.pinv[j + 1]] == p.wreg[p.pinv[j]] + 1
+        p.wreg[p.pinv[j + 1]] == p.wreg[p.pinv[j]] + 1 and own.var(j) and own.var(j + 1)
     jskip = set()
     for j in range(n):
         k = p.pinv[j]
-        if j in jskip:
+        if j in jskip or not own.var(j):
             continue
         qh = homes.get(("q", j))
         if isinstance(qh, tuple):
@@ -537,11 +591,14 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
     # them out that way). The capturing iteration keeps the scalar form (delta_y words are not pair-aligned).
     VP = lambda r_: ("v[%d:%d]" % (r_, r_ + 1), 0, 1)
     SB = lambda sreg, h: ("s[%d:%d]" % (sreg - sreg % 2, sreg - sreg % 2 + 1), h, h)
-    eqfirst = {a_ for (a_, b_) in p.eqpairs if p.wreg[p.rows[a_]["k"]] % 2 == 0 and p.wreg[p.rows[b_]["k"]] == p.wreg[p.rows[a_]["k"]] + 1}
+    eqfirst = {a_ for (a_, b_) in p.eqpairs if p.wreg[p.rows[a_]["k"]] % 2 == 0 and p.wreg[p.rows[b_]["k"]] == p.wreg[p.rows[a_]["k"]] + 1
+               and own.row(a_) and own.row(b_)}
     eqskip = set()
     paired = {}
     if loose and not capture and PACK_LOOSE:
         for a_, b_ in p.pairs:
+            if not (own.row(a_["i"]) and own.row(b_["i"])):
+                continue                  # (a pair across two waves' components: each wave takes its row alone)
             assert (p.LW_Y + a_["i"]) % 2 == 0 and (p.LW_Z + p.zpos[a_["i"]]) % 2 == 0 and p.zpos[b_["i"]] == p.zpos[a_["i"]] + 1
             assert p.lpos[a_["j"]] % 2 == 0 and p.lpos[b_["j"]] == p.lpos[a_["j"]] + 1
             paired[a_["i"]] = b_
@@ -551,6 +608,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
     assert not paired or p.NLAND >= 32
     for r in p.rows:
         i, k = r["i"], r["k"]
+        if not own.row(i):
+            continue
         if i in paired:
             if paired[i] is None:
                 continue
@@ -626,10 +685,11 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
         del ops[rhs_ops_start:]
     # ---- solves over the non-leaf unknowns (qdldl.c:250-293)
     for (r_, c, j) in p.solve_entries:
-        op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
-    kof = {reg: k for k, reg in p.wreg.items()}
+        if own.k(c):
+            op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
+    kof = {reg: k for k, reg in p.wreg.items() if own.k(k)}
     kdone = set()
-    for reg in sorted(kof) if pack else [p.wreg[k] for k in p.nonleaf]:      # (by register when pairing: a pair is visited once)
+    for reg in sorted(kof) if pack else [p.wreg[k] for k in p.nonleaf if own.k(k)]:      # (by register when pairing: a pair is visited once)
         k = kof[reg]
         if k in kdone:
             continue
@@ -640,7 +700,11 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
         else:
             op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
     for (r_, c, j) in reversed(p.solve_entries):
-        op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+        if own.k(c):
+            op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+    if capture and group:
+        # x_prev and delta_y are written over the L words, ANY wave's: nobody writes them before everybody's last solve is done
+        op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
     ops.append(dict(flush=True))
     sptr = "s[%d:%d]" % (S_P, S_P + 1)
 
@@ -697,6 +761,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
         xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j) and j not in fused_x])
     for r in p.rows:
         i, k = r["i"], r["k"]
+        if not own.row(i):
+            continue
         yw = p.LW_Y + i
         if i in fused_rows:
             if paired[i] is None:
@@ -926,10 +992,15 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
     # ---- x <- alpha x~ + (1 - alpha) x
     if fuse:
         ops.extend(B_EQ + B_OTHER + B_PAIR)
+    if capture and group:
+        # x_prev goes over the leaf block of L, which ANY wave's row updates above still read: meet once more
+        assert not fuse
+        op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
+        ops.append(dict(flush=True))
     jskip = set(fused_x)
     for j in range(n):
         k = p.pinv[j]
-        if j in jskip:
+        if j in jskip or not own.var(j):
             continue
         if "3" in PACK_PARTS and xpair(j) and j + 1 not in fused_x:
             jskip.add(j + 1)
@@ -969,7 +1040,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False):
         ops.extend(B_PUSH)
     sc.run(ops)
     if not capture:
-        preloads(e, p, homes)
+        preloads(e, p, homes, own)
 
 
 def _row_ptr(e, sreg, row, base=S_W):
@@ -1016,10 +1087,10 @@ def prologue(e, p):
     prologue_tail(e, p)
 
 
-def y0_fill(e, p):
+def y0_fill(e, p, own=ALL):
     """y0 variant: the items that have an LDS home (Plan.y0_home) are fetched from the stream ONCE, through the W registers"""
     items = p.stream + p.extra
-    todo = sorted(p.y0_home.items(), key=lambda kv: items.index(kv[0]))
+    todo = sorted((kv for kv in p.y0_home.items() if own.item(kv[0])), key=lambda kv: items.index(kv[0]))
     assert len(todo) <= len(p.nonleaf)
     blk = None
     for q, (item, word) in enumerate(todo):
@@ -1039,9 +1110,9 @@ def y0_fill(e, p):
     e("s_waitcnt", "lgkmcnt(0)")
 
 
-def y0_restore(e, p):
+def y0_restore(e, p, own=ALL):
     """y0 variant, after the last iteration: the y words that held q are the multipliers again (zero)"""
-    words = sorted(w for (what, _), w in p.y0_home.items() if what == "q" and not isinstance(w, tuple))
+    words = sorted(w for (what, j_), w in p.y0_home.items() if what == "q" and not isinstance(w, tuple) and own.var(j_))
     z4 = p.V_TT
     for r in range(4):
         e("v_mov_b32", "v%d" % (z4 + r), 0)
@@ -1057,12 +1128,12 @@ def y0_restore(e, p):
             k += 1
 
 
-def prologue_tail(e, p, loose=False, homes=()):
+def prologue_tail(e, p, loose=False, homes=(), own=ALL):
     """once-only stream items (l of the leaf equality rows) -> their registers; the first iteration's preloads"""
     idx = p.n_stream
     assert len(p.extra) <= len(p.nonleaf)
     blk = None
-    skip = (lambda item: loose and item[0] == "rinv")          # (the loose loop takes 1/rho of those rows from an SGPR)
+    skip = (lambda item: (loose and item[0] == "rinv") or not own.item(item))   # (the loose loop takes 1/rho of those rows from an SGPR)
     for q, item in enumerate(p.extra):
         if skip(item):
             continue
@@ -1084,7 +1155,7 @@ def prologue_tail(e, p, loose=False, homes=()):
         e("v_mov_b32", "v%d" % p.V_RHO0, "s%d" % S_RHO0)
         e("v_mov_b32", "v%d" % p.V_RHOEQ, "s%d" % S_RHOEQ)
         e("v_mov_b32", "v%d" % p.V_RHOMIN, f32bits(float(np.float32(RHO_MIN_F32))))
-    preloads(e, p, homes)
+    preloads(e, p, homes, own)
 
 
 def epilogue(e, p):
@@ -1097,7 +1168,7 @@ S_FAST, S_XI, S_YI, S_ZI = 30, 24, 26, 28    # fast start: flag, the caller's x,
 FAC_MIN = 638                                # LDS word: min |d_k| of the factorisation (0 = a zero pivot)
 
 
-def prologue_fast(e, p, res, loose=False, y0check=False):
+def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     """KKT fill + LDL' inside the block (factor_emit): the equilibrated A and P come from the wave's residual stream (written
     by the Ruiz block), 1/rho of the inequality rows from the loop's stream, the warm start straight from the caller's rows.
     -L lands in the loop's LDS words, 1/D in its AGPRs: no hand-off rows at all."""
@@ -1116,8 +1187,10 @@ def prologue_fast(e, p, res, loose=False, y0check=False):
     # A -> LDS words LW_X.. (the x, y, z words: the warm start arrives after the factorisation)
     assert p.LW_X + s.nnzA <= 640
     G = V_END - V_W - (1 if y0check else 0)      # landing registers V_W ..; y0check keeps the last one as its accumulator
-    for g in range(0, s.nnzA, G):
-        ks = list(range(g, min(s.nnzA, g + G)))
+    A_p_ = list(s.tables["A_p"])
+    own_a = [k for j in range(s.n) if own.var(j) for k in range(A_p_[j], A_p_[j + 1])]
+    for g in range(0, len(own_a), G):
+        ks = own_a[g:g + G]
         for q, k in enumerate(ks):
             sload(V_W + q, res.it_A + k)
         e("s_waitcnt", "vmcnt(0)")
@@ -1131,7 +1204,8 @@ def prologue_fast(e, p, res, loose=False, y0check=False):
     pool0 = v_rinv + len(gen)
     assert pool0 + 30 <= p.V_RING
     for j in sorted(res.it_p):
-        sload(v_p + res.pidx[j], res.it_p[j])
+        if own.var(j):
+            sload(v_p + res.pidx[j], res.it_p[j])
     items = p.stream + p.extra
     for q, i in enumerate(gen):
         if loose:
@@ -1142,13 +1216,23 @@ def prologue_fast(e, p, res, loose=False, y0check=False):
     e("v_mov_b32", "v%d" % v_fmin, 1.0)
     e("s_waitcnt", "vmcnt(0)")
     factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING)),
-                list(range(p.V_LAND, p.V_LAND + p.NLAND)), v_fmin)
+                list(range(p.V_LAND, p.V_LAND + p.NLAND)), v_fmin, own)
     base, off = lds_addr(FAC_MIN)
-    e("ds_write_b32", base, "v%d" % v_fmin, off)
+    if group:
+        # several waves: the A words above are the other waves' x, y words -- nobody loads its warm start before everybody
+        # has factorised; the smallest pivot is folded into the flag word wave 0 set to 1 (float min, atomic)
+        if own.wave == 0:
+            e("v_mov_b32", "v%d" % (p.V_TT), 1.0)
+            e("ds_write_b32", base, "v%d" % (p.V_TT), off)
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_barrier")
+        e("ds_min_f32", base, "v%d" % v_fmin, off)
+    else:
+        e("ds_write_b32", base, "v%d" % v_fmin, off)
     e("s_waitcnt", "lgkmcnt(0)")
     # the warm start: x, y, z of the inequality rows -> LDS
-    rows = [(S_XI, j, p.LW_X + j) for j in range(p.n)] + [(S_YI, i, p.LW_Y + i) for i in range(p.m)] + \
-           [(S_ZI, i, p.LW_Z + p.zpos[i]) for i in gen]
+    rows = [(S_XI, j, p.LW_X + j) for j in range(p.n) if own.var(j)] + [(S_YI, i, p.LW_Y + i) for i in range(p.m) if own.row(i)] + \
+           [(S_ZI, i, p.LW_Z + p.zpos[i]) for i in gen if own.row(i)]
     v_or = V_END - 1             # y0check: OR of the multipliers' bits over the inequality rows
     if y0check:
         e("v_mov_b32", "v%d" % v_or, 0)
@@ -1171,49 +1255,53 @@ def prologue_fast(e, p, res, loose=False, y0check=False):
         e("s_waitcnt", "lgkmcnt(0)")
     if y0check:
         return v_or
-    prologue_tail(e, p, loose)
+    prologue_tail(e, p, loose, own=own)
 
 
-def program(s, eq_rows, res=None, loose=False):
+def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
     """s11 = number of non-capturing iterations (>= 0); one capturing iteration follows them.
-    res: a ResPlan -> the block also holds the fast start (prologue_fast), taken when s30 != 0"""
+    res: a ResPlan -> the block also holds the fast start (prologue_fast), taken when s30 != 0
+    own, group (loose only): the copy of the block that one wavefront of a workgroup runs on its components (LoopSplit); it
+    meets the other wavefronts at two barriers (after the factorisation, at the end)"""
     p = Plan(s, eq_rows)
     e = Emit()
+    assert loose or (own.all and not group)
 
     def loop(**kw):
         e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
         e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
         e("s_cbranch_scc1", "8f")
         e("label", "7")
-        body(e, p, loose=loose, **kw)
+        body(e, p, loose=loose, own=own, **kw)
         e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
         e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
         e("s_cbranch_scc1", "7b")
         e("label", "8")
-        body(e, p, capture=True, loose=loose, **kw)
+        body(e, p, capture=True, loose=loose, own=own, group=group, **kw)
     if loose:
         # the loose variant exists for the all-assembly route only: always the fast start (the caller passes s30 != 0)
         assert res is not None
         e("s_mov_b32", "s%d" % S_RIMIN, f32bits(float(np.float32(1.0 / QP_RHO_MIN))))
         e("s_mov_b32", "s%d" % S_RHOMIN, f32bits(float(np.float32(QP_RHO_MIN))))
         if not Y0_VARIANT:
-            prologue_fast(e, p, res, loose=True)
+            prologue_fast(e, p, res, loose=True, own=own, group=group)
         else:
             # y0: a loose row's multiplier moves by rho (t - z_new) with z_new = t + y / rho unclipped, so a multiplier that
             # starts at exactly 0 stays exactly 0 (z_new = t, delta_y = rho * 0) -- in the reference as here. When the warm start
             # has y == 0 on every inequality row of the wave (a cold start, or any earlier result of this loop), the iterations
             # below drop those 87 words and their operations (same values: bit-identical), and q / l move into the freed LDS
             # words instead of being loaded from the stream every iteration. Any other warm start takes the loop after label 20.
-            v_or = prologue_fast(e, p, res, loose=True, y0check=True)
+            v_or = prologue_fast(e, p, res, loose=True, y0check=True, own=own, group=group)
             e("v_and_b32", "v%d" % v_or, 0x7FFFFFFF, "v%d" % v_or)
             e("v_cmp_ne_u32", "vcc", 0, "v%d" % v_or)
             e("s_cbranch_vccnz", "20f")
-            if Y0_DLEAF and p.y0_dleaf:
-                e("v_accvgpr_read_b32", "v%d" % v_or, "a%d" % p.y0_dleaf[0])
+            dleaf = [k for k in p.y0_dleaf if own.k(k)]
+            if Y0_DLEAF and dleaf:
+                e("v_accvgpr_read_b32", "v%d" % v_or, "a%d" % dleaf[0])
                 e("s_nop", 0)
                 e("v_readfirstlane_b32", "s%d" % S_DLEAF, "v%d" % v_or)
-            y0_fill(e, p)
-            prologue_tail(e, p, True, p.y0_home)
+            y0_fill(e, p, own)
+            prologue_tail(e, p, True, p.y0_home, own)
             if not Y0_FUSE:
                 loop(y0=True)
             else:
@@ -1222,28 +1310,30 @@ def program(s, eq_rows, res=None, loose=False):
                 e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
                 e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
                 e("s_cbranch_scc1", "30f")
-                body(e, p, loose=True, y0=True, rhs=True, fuse=True)
+                body(e, p, loose=True, y0=True, rhs=True, fuse=True, own=own)
                 e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
                 e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
                 e("s_cbranch_scc1", "8f")
                 e("label", "7")
-                body(e, p, loose=True, y0=True, rhs=False, fuse=True)
+                body(e, p, loose=True, y0=True, rhs=False, fuse=True, own=own)
                 e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
                 e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
                 e("s_cbranch_scc1", "7b")
                 e("label", "8")
-                body(e, p, capture=True, loose=True, y0=True, rhs=False)
+                body(e, p, capture=True, loose=True, y0=True, rhs=False, own=own, group=group)
                 e("s_branch", "31f")
                 e("label", "30")
-                body(e, p, capture=True, loose=True, y0=True)
+                body(e, p, capture=True, loose=True, y0=True, own=own, group=group)
                 e("label", "31")
-            y0_restore(e, p)
+            y0_restore(e, p, own)
             e("s_branch", "29f")
             e("label", "20")
-            prologue_tail(e, p, True)
+            prologue_tail(e, p, True, own=own)
             loop()
             e("label", "29")
             epilogue(e, p)
+            if group:
+                e("s_barrier")        # every wave's x, y, z, x_prev, delta_y words are in LDS for whoever reads them next
             return e.ins, p
     else:
         if res is not None:
@@ -1267,6 +1357,33 @@ def program(s, eq_rows, res=None, loose=False):
     body(e, p, capture=True, loose=loose)
     epilogue(e, p)
     return e.ins, p
+
+
+def loop_group_program(s, eq_rows, res, nw=4):
+    """The loose loop block for a workgroup of nw wavefronts that own the same 64 robots: wavefronts 0 and 1 take the
+    components LoopSplit gives them, the others only keep the barriers company. s33 = the wave's index; the other inputs as
+    program(..., loose=True). Returns (instructions, plan, split)."""
+    p = Plan(s, eq_rows)
+    sp = LoopSplit(p, nw)
+    e = Emit()
+    for w in range(nw):
+        if w < nw - 1:
+            e("s_cmp_lg_u32", "s%d" % S_LWAVE, w)
+            e("s_cbranch_scc1", "48f")
+        if w < sp.active:
+            ins, _ = program(s, eq_rows, res, loose=True, own=sp.own(w), group=True)
+            e.ins.extend(ins)
+        else:
+            for _ in range(4):        # after the factorisation, twice in the capturing iteration (its stores over L), at the end
+                e("s_barrier")
+        if w < nw - 1:
+            e("s_branch", "49f")
+            e("label", "48")
+    e("label", "49")
+    return e.ins, p, sp
+
+
+S_LWAVE = 33                       # loop_group_program: s33 = the wave's index in its workgroup
 
 
 def fmt(t):
@@ -1353,7 +1470,7 @@ def simulate_group(ins, nw, W, S, iters, consts, wave_sgpr, **kw):
                     clash = (logs[a_]["w"] & (logs[b_]["r"] | logs[b_]["w"] | logs[b_].get("a", set()))) | \
                             (logs[a_].get("a", set()) & logs[b_]["r"])
                     assert not clash, ("LDS race before barrier %d: words written by wave %d and touched by wave %d" % (nbar, a_, b_),
-                                       sorted(clash)[:8])
+                                       sorted(clash)[:8], {k_: sorted(clash & v_)[:4] for k_, v_ in logs[b_].items() if k_ != "watch"})
         for lg in logs:
             for st_ in lg.values():
                 st_.clear()
@@ -1484,7 +1601,10 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
             used = set().union(*[regs_of(x) for x in t[1:]])
             check(used)
             if m != "ds_read_b128":           # (a word fetched from LDS counts as READ when its register is consumed: a
-                for r_ in used:               # quad may carry a neighbour's words that this wave never looks at)
+                wr_only = regs_of(t[1]) if m in ("global_load_dword", "v_mov_b32", "v_accvgpr_read_b32") else set()
+                for r_ in wr_only:            # quad may carry a neighbour's words that this wave never looks at; a register
+                    src_word.pop(r_, None)    # that is overwritten no longer stands for the word)
+                for r_ in used - wr_only:
                     if r_ in src_word:
                         log_r.add(src_word[r_])
             if m == "ds_read_b128":
@@ -2457,7 +2577,7 @@ def res_program(s, eq_rows, ap, res):
 # ---------------------------------------------------------------------------
 # KKT fill + LDL' (kkt.c:184-222, qdldl.c:86-247) of a build-time-known structure, fp32, into the loop's homes
 # ---------------------------------------------------------------------------
-def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, v_pin, v_fmax):
+def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, v_pin, v_fmax, own=ALL):
     """Emits the up-looking factorisation recorded in s.factor_ops: -L goes to the loop's LDS words (p.lpos), 1/D to the
     loop's AGPRs (a[k], permuted index k); v_fmax accumulates min |d_k| (0 = a zero pivot, qdldl.c:221-224).
     lw_a: LDS word of A entry 0 (the equilibrated A, CSC order); v_p: first VGPR of P (nnzP); v_rinv: first VGPR of 1/rho of
@@ -2467,7 +2587,8 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
     t = s.tables
     pidx = list(t["pidx"])
     v = lambda r: "v%d" % r
-    reused = sorted({j for op_ in s.factor_ops for (_, upd, _) in op_["elim"] for (j, _) in upd})
+    fops = [op_ for op_ in s.factor_ops if own.k(op_["k"])]      # (components factorise independently: LoopSplit)
+    reused = sorted({j for op_ in fops for (_, upd, _) in op_["elim"] for (j, _) in upd})
     assert len(reused) <= len(v_pin), (len(reused), len(v_pin))
     pin = {j: v_pin[q] for q, j in enumerate(reused)}
 
@@ -2482,7 +2603,7 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
 
     def op(srcs, fn):
         ops.append(dict(srcs=srcs, emit=fn))
-    for op_ in s.factor_ops:
+    for op_ in fops:
         k = op_["k"]
         yv = {}
         for (bb, pk) in op_["init"]:

@@ -132,11 +132,43 @@ class BatchQP:
 # ---------------------------------------------------------------------------------------------------------
 # planar/mpc_osqp_p5f.py
 # ---------------------------------------------------------------------------------------------------------
-def p5f_structure(N=10):
+qp_components = qpstruct.qp_components
+
+
+def p5f_structure(N=10, grouped=False):
     """The QP of planar/mpc_osqp_p5f.py:87-147: x = (y(0..N) [7 each], u(0..N-1)); rows = (N+1)*7 dynamics
     equalities + identity box rows. Returns dict(n, m, A_p, A_i, P_cols, cst, src, Pv, q, l, u) where
     A[k] = cst[k] (src < 0) or cst[k] * lin[src[k]] with lin = (Ad43, Ad53, Bd4, Bd5, Bd6) (getLin :45-85).
-    Structural pattern of (Ad, Bd): the entries the symbolic expressions of getLin can make non-zero."""
+    Structural pattern of (Ad, Bd): the entries the symbolic expressions of getLin can make non-zero.
+    grouped: the SAME problem with variables and rows relabelled so that each connected component (qp_components: the
+    script's Ad has no diagonal, so the horizon falls apart into two interleaved chains and five one- or two-variable
+    pieces) is a contiguous stretch -- variables by component, the dynamics rows by component, the box row of variable j
+    still row neq + j. var_order / row_order give the script's index of every relabelled variable / row. This is the order
+    PlanarP5fMPC hands to the solver (whose build-time specialisation gives each wavefront of a workgroup whole components)."""
+    if grouped:
+        st = p5f_structure(N)
+        n, m = st["n"], st["m"]
+        neq = m - n
+        vc, rc = qp_components(n, m, st["A_p"], st["A_i"])
+        var_order = sorted(range(n), key=lambda j: (vc[j], j))
+        row_order = sorted(range(neq), key=lambda i: (rc[i], i)) + [neq + j for j in var_order]
+        vnew = {j: t for t, j in enumerate(var_order)}
+        rnew = {i: t for t, i in enumerate(row_order)}
+        A_p, A_i, cst, src = [0], [], [], []
+        for j in var_order:
+            col = sorted((rnew[st["A_i"][q]], q) for q in range(st["A_p"][j], st["A_p"][j + 1]))
+            for i, q in col:
+                A_i.append(i)
+                cst.append(st["cst"][q])
+                src.append(st["src"][q])
+            A_p.append(len(A_i))
+        Pfull = np.zeros(n)
+        Pfull[st["P_cols"]] = st["Pv"]
+        Pfull = Pfull[var_order]
+        P_cols = [j for j in range(n) if Pfull[j] != 0.0]
+        return dict(N=N, n=n, m=m, A_p=A_p, A_i=A_i, P_cols=P_cols, cst=np.array(cst), src=np.array(src, np.int32),
+                    Pv=Pfull[P_cols], q=st["q"][var_order], l=st["l"][row_order], u=st["u"][row_order],
+                    var_order=np.array(var_order), row_order=np.array(row_order))
     nx, nu = 7, 1
     n = (N + 1) * nx + N * nu
     neq = (N + 1) * nx
@@ -179,7 +211,7 @@ class PlanarP5fMPC:
     reference's plant tick y += (Ad y + Bd unom) dt."""
 
     def __init__(self, B, dtype=torch.float32, device="cuda", N=10, dt=0.002, **settings):
-        st = p5f_structure(N)
+        st = p5f_structure(N, grouped=True)
         self.st, self.B, self.dt, self.dtype = st, int(B), float(dt), dtype
         self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, **settings)
         if not os.environ.get("UMPC_QP_KERNEL") and dtype != torch.float32:
@@ -210,6 +242,13 @@ class PlanarP5fMPC:
             self.qp.solve(self.Pv, self.Av, self.q, self.l, self.u)
         self._p5f_step(1, unom, None)
         return self.y
+
+    def solution(self):
+        """sol_x [n, B] of the last solve in the SCRIPT's variable order (the solver works on the relabelled problem of
+        p5f_structure(grouped=True))"""
+        out = torch.empty_like(self.qp.sol_x)
+        out[torch.as_tensor(self.st["var_order"]).to(out.device)] = self.qp.sol_x
+        return out
 
     def _p5f_step(self, mode, u, lin):
         """umpcP5fStep with a per-robot input tensor, umpcP5fStepU with the reference's scalar (no [B] array filled per tick)"""

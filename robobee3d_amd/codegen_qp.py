@@ -27,7 +27,7 @@ def fnv1a(words):
 
 def builtin_structures():
     out = []
-    st = batchqp.p5f_structure(10)
+    st = batchqp.p5f_structure(10, grouped=True)       # (the order PlanarP5fMPC uses: components contiguous)
     out.append(("p5f10", qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])))
     st = batchqp.v1_structure(3)
     out.append(("v1n3", qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])))
@@ -457,7 +457,6 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
       "uni((unsigned long long)a.q), ssp, s_stride, s_pass, wv);" % U)
     E("    BQP_%s_GLUE4_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.l), ssp, uni((unsigned long long)a.u), s_stride, "
       "uni((unsigned long long)a.Eprev), uni((unsigned long long)a.z), a.rho, T(1. / (double)a.rho), rho_eq, T(1. / (double)rho_eq), wv);" % U)
-    E("    if (wv != 0u) return;")
     mark(1)
     if TIMING:
         E("    tmark[2] = tmark[3] = tmark[4] = tmark[1];")
@@ -468,12 +467,14 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("      const unsigned s_rinveq = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.rinv_eq));")
     E("      const unsigned s_iters = __builtin_amdgcn_readfirstlane((unsigned)(a.max_iter - 1));")
     E("      // every inequality row of the wave a loose row (planar p5f: all 87 are): the loop variant that streams nothing per row")
+    E("      // (the flags are LDS words of the 64 robots every wavefront of the workgroup owns: all of them decide alike)")
     E("      if (__all(LDSQ(%d) == T(1.0)))" % asmqp.LOOSE_FLAG)
-    E("        BQP_%s_ASM_LOOSE(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
-      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s);" % (U, RHO_ARGS))
-    E("      else")
+    E("        BQP_%s_ASM_LOOSE4(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
+      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s, wv);" % (U, RHO_ARGS))
+    E("      else if (wv == 0u)")
     E("      BQP_%s_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
       "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s);" % (U, RHO_ARGS))
+    E("      if (wv != 0u) return;")
     mark(5)
     E("      fail = (LDSQ(%d) == T(0.0)) ? 1 : 0;   // a zero pivot of the block's factorisation (qdldl.c:221-224)" % asmqp.FAC_MIN)
     E("      if (a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
@@ -487,6 +488,7 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("      }")
     E("      mode = resdone ? 2 : 1;")
     E("    }")
+    E("    if (wv != 0u) return;   // (a workgroup that does not take the all-assembly route: wavefront 0 alone goes on)")
     E("  }")
 
 
@@ -558,10 +560,32 @@ def glue_macro(name, ins, group=False):
     return "\n".join(out) + "\n"
 
 
-def asm_macro(name, ins, plan, loose=False):
+def asm_macro(name, ins, plan, loose=False, group=None):
     """csrc/gen/bqp_<name>_asm.h: the instruction stream of asmqp.program as one asm volatile statement
-    (loose: the variant for waves whose inequality rows are all loose rows, asmqp.S_RIMIN; same interface, fast start only)"""
+    (loose: the variant for waves whose inequality rows are all loose rows, asmqp.S_RIMIN; same interface, fast start only;
+    group: an asmqp.LoopSplit -- the loose variant shared by the workgroup's wavefronts, asmqp.loop_group_program)"""
     from . import asmqp
+    if group is not None:
+        used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1, asmqp.S_RIMIN, asmqp.S_RHOMIN, asmqp.S_DLEAF]
+        clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
+               ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
+        nv = [sum(1 for w_ in group.varw if w_ == w) for w in range(group.active)]
+        nk_ = [sum(1 for w_ in group.kw if w_ == w) for w in range(group.active)]
+        out = ["// The LOOSE variant SHARED by the workgroup's wavefronts (asmqp.loop_group_program / LoopSplit): the QP's connected",
+               "// components are independent QPs -- wavefront 0 iterates on the largest (%d of %d variables, %d of %d KKT unknowns),"
+               % (nv[0], len(group.varw), nk_[0], len(group.kw)),
+               "// wavefront 1 on the others, the rest only keep the %d barriers company; same LDS layout, disjoint words, bit-identical"
+               % (sum(t_[0] == "s_barrier" for t_ in ins) // group.nw),
+               "// words. s%d = the wavefront's index; the other inputs as BQP_%s_ASM_LOOSE. %d instructions."
+               % (asmqp.S_LWAVE, name.upper(), len(ins)),
+               "#define BQP_%s_ASM_LOOSE4(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast, rho0, rinv0, rhoeq, wave) asm volatile( \\" % name.upper()]
+        for t_ in ins:
+            out.append('  "%s\\n" \\' % asmqp.fmt(t_))
+        out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(ws), "{s[6:7]}"(sblk), "{s10}"(stride), '
+                   '"{s11}"(iters), "{s20}"(alpha), "{s21}"(oma), "{s22}"(sigma), "{s23}"(rinveq), "{s[24:25]}"(xi), "{s[26:27]}"(yi), '
+                   '"{s[28:29]}"(zi), "{s30}"(fast), "{s31}"(rho0), "{s34}"(rinv0), "{s35}"(rhoeq), "{s%d}"(wave) \\' % asmqp.S_LWAVE)
+        out.append("  : " + ", ".join(clob) + ")")
+        return "\n".join(out) + "\n"
     used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1] + ([asmqp.S_RIMIN, asmqp.S_RHOMIN, asmqp.S_DLEAF] if loose else [])
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
            ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
@@ -683,6 +707,7 @@ def generate():
             res = asmqp.ResPlan(s, ASM_STRUCTURES[name], ASM_RES_ITEM0)
             ins, plan = asmqp.program(s, ASM_STRUCTURES[name], res)
             ins_loose, _ = asmqp.program(s, ASM_STRUCTURES[name], res, loose=True)
+            ins_loose4, _, lsplit = asmqp.loop_group_program(s, ASM_STRUCTURES[name], res, ASM_GROUP_WAVES)
             assert plan.n_stream + len(plan.extra) <= ASM_RES_ITEM0
             plan.res = res
             assert plan.res.end <= ASM_STREAM_ITEMS
@@ -696,6 +721,7 @@ def generate():
             asm_hdr = "bqp_%s_asm.h" % name
             assert plan.ruiz.LW_END <= asmqp.LW_FLAGS
             files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + asm_macro(name, ins_loose, plan, loose=True) + \
+                asm_macro(name, ins_loose4, plan, loose=True, group=lsplit) + \
                 ruiz_macro(name, rins, plan.ruiz) + \
                 ruiz_macro(name, rsins, plan.ruiz, rs=True) + ruiz_macro(name, rs4ins, plan.ruiz, rs=True, group=True) + \
                 res_macro(name, resins) + glue_macro(name, glins) + glue_macro(name, gl4ins, group=True) + \

@@ -255,3 +255,33 @@ def csc_pattern(dense_mask):
         A_i += [int(i) for i in np.nonzero(dense_mask[:, j])[0]]
         A_p.append(len(A_i))
     return A_p, A_i
+
+
+def qp_components(n, m, A_p, A_i):
+    """Connected components of a QP with DIAGONAL P: variables that share a constraint row belong together. Returns
+    (component of each variable, component of each row), components numbered by decreasing number of variables (ties: by
+    first variable). A QP with several components is several independent QPs solved side by side -- ADMM, the Ruiz
+    equilibration's row / column norms and the LDL' factorisation never couple them."""
+    par = list(range(n + m))
+
+    def find(a):
+        while par[a] != a:
+            par[a] = par[par[a]]
+            a = par[a]
+        return a
+    for j in range(n):
+        for q in range(A_p[j], A_p[j + 1]):
+            ra, rb = find(j), find(n + A_i[q])
+            if ra != rb:
+                par[ra] = rb
+    members = {}
+    for j in range(n):
+        members.setdefault(find(j), []).append(j)
+    order = sorted(members, key=lambda r: (-len(members[r]), members[r][0]))
+    num = {r: c for c, r in enumerate(order)}
+    rows = []
+    for i in range(m):
+        r = find(n + i)
+        assert r in num, "a constraint row without a variable"
+        rows.append(num[r])
+    return [num[find(j)] for j in range(n)], rows

@@ -111,6 +111,26 @@ def test_p5f_structure_reproduces_the_kron_construction():
                 A[st["A_i"][p], j] = vals[p]
         assert np.array_equal(A, p5f_dense_A(10, Ad, Bd))
     assert st["P_cols"] == [j for j in range(87) if (j < 77 and j % 7 in (1, 2, 3)) or j >= 77]
+    # grouped=True: the same problem relabelled so that its connected components are contiguous (what PlanarP5fMPC solves)
+    from robobee3d_amd.batchqp import qp_components
+    sg = p5f_structure(10, grouped=True)
+    vo, ro = sg["var_order"], sg["row_order"]
+    assert sorted(vo) == list(range(87)) and sorted(ro) == list(range(164)) and list(ro[77:]) == [77 + j for j in vo]
+    vc, rc = qp_components(sg["n"], sg["m"], sg["A_p"], sg["A_i"])
+    assert vc == sorted(vc) and rc[:77] == sorted(rc[:77]) and [vc.count(c) for c in range(max(vc) + 1)] == [41, 39, 2, 2, 1, 1, 1]
+    Ad, Bd = g["lin_Ad"][5], g["lin_Bd"][5]
+    lin = np.array([Ad[4, 3], Ad[5, 3], Bd[4], Bd[5], Bd[6]])
+    vals = np.where(sg["src"] < 0, sg["cst"], sg["cst"] * lin[np.maximum(sg["src"], 0)])
+    A = np.zeros((164, 87))
+    for j in range(87):
+        for p in range(sg["A_p"][j], sg["A_p"][j + 1]):
+            A[ro[sg["A_i"][p]], vo[j]] = vals[p]
+    assert np.array_equal(A, p5f_dense_A(10, Ad, Bd))
+    for key, order in (("q", vo), ("l", ro), ("u", ro)):
+        assert np.array_equal(sg[key], st[key][order])
+    Pc, Pg = np.zeros(87), np.zeros(87)
+    Pc[st["P_cols"]], Pg[sg["P_cols"]] = st["Pv"], sg["Pv"]
+    assert np.array_equal(Pg, Pc[vo])
 
 
 def test_p5f_qp_data_is_the_reference_scripts(structure):
@@ -291,7 +311,7 @@ def test_gpu_p5f_getlin_and_plant_match_reference_fixture():
             A = np.zeros((st["m"], st["n"]))
             for j in range(st["n"]):
                 for p in range(st["A_p"][j], st["A_p"][j + 1]):
-                    A[st["A_i"][p], j] = Av[p, k]
+                    A[st["row_order"][st["A_i"][p]], st["var_order"][j]] = Av[p, k]      # (back to the script's labels)
             assert np.allclose(A, p5f_dense_A(10, g["lin_Ad"][k], g["lin_Bd"][k]), rtol=tol * 50, atol=tol)
         # plant tick y += (Ad y + Bd u) dt, planar/mpc_osqp_p5f.py:176
         mpc.L.umpcP5fStep(B, 0 if tdt == torch.float32 else 1, 1, 0.002, u.data_ptr(), mpc.y.data_ptr(), None, None)
