@@ -277,18 +277,26 @@ ALL = Own()
 class LoopSplit:
     """A QP whose constraint graph falls into several connected components (qpstruct.qp_components) is several independent
     QPs: right-hand sides, LDL' factor, triangular solves, row and x updates of one component never touch another's words.
-    The loose loop block gives the largest component to wavefront 0 of the workgroup and the others to wavefront 1 (planar
-    p5f: 41 + 46 of 87 variables, 113 + 138 of 251 unknowns); both run their 50 iterations side by side on disjoint LDS words
-    of the SAME layout (Plan), without a barrier inside the loop. Words come out bit-identical to the one-wave block."""
+    The loose loop block deals the components out to the wavefronts of the workgroup, largest first, each to the least loaded
+    (planar p5f: 118 + 112 + 8 + 7 of 251 unknowns on four wavefronts); they run their 50 iterations side by side on disjoint
+    LDS words of the SAME layout (Plan), without a barrier inside the loop. Words come out bit-identical to the one-wave block."""
 
     def __init__(self, p, nw=4):
         from . import qpstruct
         s = p.s
         vc, rc = qpstruct.qp_components(s.n, s.m, list(s.tables["A_p"]), list(s.tables["A_i"]))
         self.nw = nw
-        self.active = 2 if max(vc) > 0 else 1
-        self.varw = [0 if c == 0 else 1 for c in vc]
-        self.roww = [0 if c == 0 else 1 for c in rc]
+        ncomp = max(vc) + 1
+        # components (numbered by decreasing size) -> wavefronts: each to the least loaded so far (weight = KKT unknowns)
+        load, cw = [0] * min(nw, ncomp), {}
+        for c in range(ncomp):
+            w = min(range(len(load)), key=lambda w_: (load[w_], w_))
+            cw[c] = w
+            load[w] += sum(1 for x in vc if x == c) + sum(1 for x in rc if x == c)
+        self.active = len(load)
+        self.load = load
+        self.varw = [cw[c] for c in vc]
+        self.roww = [cw[c] for c in rc]
         self.kw = [0] * s.nk
         for j in range(s.n):
             self.kw[p.pinv[j]] = self.varw[j]
@@ -357,12 +365,13 @@ class Sched:
 
     def issue_stream(self, idx):
         e, p = self.e, self.p
-        while idx // BLOCK > self.sp_block:
-            e("s_add_u32", "s%d" % S_SP, "s%d" % S_SP, BLOCK * 256)
+        item = p.land_map[idx] if getattr(p, "land_map", None) is not None else idx     # (a wave that lands a subset of the items)
+        if item // BLOCK > self.sp_block:
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_SP, (item // BLOCK - self.sp_block) * BLOCK * 256)
             e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_SP + 1), 0)
-            self.sp_block += 1
+            self.sp_block = item // BLOCK
         e("global_load_dword", "v%d" % (p.V_LAND + idx % self.nland), "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1),
-          (idx % BLOCK) * 256, *(["nt"] if idx < NT_ITEMS else []))
+          (item % BLOCK) * 256, *(["nt"] if idx < NT_ITEMS else []))
         self.vmpos[idx] = self.nvm
         self.vm_at[self.nvm] = len(e.ins)
         self.nvm += 1
@@ -2367,12 +2376,21 @@ class _ResRegs:
         self.n_land = 0
 
 
-def res_program(s, eq_rows, ap, res):
+def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
     """ap: the loop's Plan (LDS words of x, y, z), res: the ResPlan. v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane,
-    s[6:7] = the wave's stream block, s10 = 4*B"""
+    s[6:7] = the wave's stream block, s10 = 4*B.
+    own, nw: the copy of the block one of nw wavefronts runs on ITS components (LoopSplit: A x of a row and A' y of a column
+    involve one component only, so every accumulation is the one-wave block's); the six partial norms (max: exact) meet in
+    LDS between two barriers and wavefront 0 does the termination test."""
     n, m = s.n, s.m
     R = _ResRegs(m)
-    R.n_land = res.it_c + 1 - res.it_rows          # the landing stream: items it_rows .. it_c
+    A_p_ = res.A_p
+    own_a = [k for j in range(n) if own.var(j) for k in range(A_p_[j], A_p_[j + 1])]
+    land = [it for it in range(res.it_rows, res.it_c + 1)
+            if any(it == res.it_ev[i] or it == res.it_ls.get(i) for i in range(m) if own.row(i)) or
+            any(it in (res.it_d[j], res.it_q[j], res.it_p.get(j)) for j in range(n) if own.var(j))]
+    lidx = {it: q for q, it in enumerate(land)}
+    R.n_land = len(land)                           # the landing stream: the own items among it_rows .. it_c, in stream order
     e = Emit()
     v = lambda r: "v%d" % r
     T = lambda q: R.V_TT + q
@@ -2388,7 +2406,7 @@ def res_program(s, eq_rows, ap, res):
 
     # (diagnostics, UMPC_QP_RES_STAMPS=1: 100 MHz stamps at the block's internal boundaries; the six intervals replace the
     # info rows -- A loads, pass 1, rows, y -> accumulators, columns, termination test)
-    STAMPS = os.environ.get("UMPC_QP_RES_STAMPS") == "1"
+    STAMPS = os.environ.get("UMPC_QP_RES_STAMPS") == "1" and own.wave == 0
     S_STAMP = 60
 
     def stamp(k):
@@ -2402,10 +2420,12 @@ def res_program(s, eq_rows, ap, res):
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
     # A -> AGPRs (direct loads), c
-    for k in range(s.nnzA):
+    blk_a = None
+    for k in own_a:
         it = res.it_A + k
-        if k == 0 or it % BLOCK == 0:
-            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (it // BLOCK) * BLOCK * 256)
+        if it // BLOCK != blk_a:
+            blk_a = it // BLOCK
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, blk_a * BLOCK * 256)
             e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
         e("global_load_dword", "a%d" % k, "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (it % BLOCK) * 256)
     e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (res.it_c // BLOCK) * BLOCK * 256)
@@ -2421,6 +2441,7 @@ def res_program(s, eq_rows, ap, res):
         pass
     pl = P_()
     pl.V_RING, pl.V_LAND, pl.V_AT, pl.n_land = R.V_RING, R.V_LAND, R.V_AT, R.n_land
+    pl.land_map = None if own.all else [it - res.it_rows for it in land]
     # (diagnostics: fewer landing registers in use -> fewer stream loads in flight; if the block's time follows 1 / this,
     # it is bound by the latency of its landing stream)
     pl.NLAND = int(os.environ.get("UMPC_QP_RES_NLAND", str(NLAND)))
@@ -2429,7 +2450,7 @@ def res_program(s, eq_rows, ap, res):
     # the landing stream starts at item it_rows: pointer and block bookkeeping relative to it
     e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, res.it_rows * 256)
     e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
-    SI = lambda item: ("S", item - res.it_rows)
+    SI = lambda item: ("S", lidx[item])
     ops = []
 
     def op(srcs, fn):
@@ -2439,8 +2460,18 @@ def res_program(s, eq_rows, ap, res):
     for name, src in (("x", S_XO), ("y", S_YO), ("z", S_ZO), ("sx", S_SX), ("sy", S_SY), ("in", S_IN), ("ep", S_EP)):
         e("s_mov_b64", "s[%d:%d]" % (PTR[name], PTR[name] + 1), "s[%d:%d]" % (src, src + 1))
 
-    def store(which, reg):
+    cur_row = {}
+
+    def store(which, reg, row=None):
         b = PTR[which]
+        if row is not None and row != cur_row.get(which, 0):        # (a wave that stores a subset of the rows: skip ahead)
+            d_ = row - cur_row.get(which, 0)
+            assert d_ > 0
+            e("s_mul_i32", "s58", "s%d" % S_STRIDE, d_)
+            e("s_mul_hi_u32", "s59", "s%d" % S_STRIDE, d_)
+            e("s_add_u32", "s%d" % b, "s%d" % b, "s58")
+            e("s_addc_u32", "s%d" % (b + 1), "s%d" % (b + 1), "s59")
+        cur_row[which] = (row if row is not None else cur_row.get(which, 0)) + 1
         # Stores count in vmcnt like loads, in issue order: the scheduler must know about them, or its `vmcnt(N)` before a
         # landing item (N = the LOADS issued since) also drains every store issued since -- an exposed HBM write latency per
         # row (round 2: 82 us for this 7.7 k-instruction block). Registered as VMEM operations nobody waits for.
@@ -2454,8 +2485,11 @@ def res_program(s, eq_rows, ap, res):
     # ---- pass 1: A x by columns into the row accumulators
     touched = set()
     for j in range(n):
+        if not own.var(j):
+            continue
         for q in range(res.A_p[j], res.A_p[j + 1]):
             i = res.A_i[q]
+            assert own.row(i)
 
             def f(g, i=i, first=i not in touched):
                 if first:
@@ -2464,10 +2498,10 @@ def res_program(s, eq_rows, ap, res):
                     e("v_fmac_f32", ACC(i), v(g[0]), v(g[1]))
             op([("A", q), ("L", ap.LW_X + j)], f)
             touched.add(i)
-    assert len(touched) == m
+    assert touched == set(i for i in range(m) if own.row(i))
     op([], lambda g: stamp(2))
     # rows: residual entries, E y / c, stores of y, z
-    for i in range(m):
+    for i in sorted(touched):
         zsrc = SI(res.it_ls[i]) if i in res.eq else ("L", ap.LW_Z + ap.zpos[i])
         srcs = [SI(res.it_ev[i]), ("L", ap.LW_Y + i), zsrc]
         if i in res.eq:           # stream items must be named in consumption order
@@ -2486,18 +2520,20 @@ def res_program(s, eq_rows, ap, res):
             e("v_max_f32", v(NAX), v(NAX), ab(v(T(10))))
             e("v_mul_f32", v(T(11)), v(y), v(ev))
             e("v_mul_f32", v(T(11)), v(T(11)), v(CINV))              # sol_y = (y E) / c
-            store("y", y)
-            store("z", z)
-            store("sy", T(11))
-            store("ep", ev)
+            store("y", y, i)
+            store("z", z, i)
+            store("sy", T(11), i)
+            store("ep", ev, i)
         op(srcs, f)
     op([], lambda g: e("v_max_f32", v(NZ), v(NZ), v(NAX)))            # prim_rel; NAX is a temporary from here on
     op([], lambda g: stamp(3))
     # ---- pass 2: y into the accumulator registers, then columns: A' y, P x, q
-    for i in range(m):
+    for i in sorted(touched):
         op([("L", ap.LW_Y + i)], lambda g, i=i: e("v_mov_b32", ACC(i), v(g[0])))
     op([], lambda g: stamp(4))
     for j in range(n):
+        if not own.var(j):
+            continue
         cols = list(range(res.A_p[j], res.A_p[j + 1]))
         for qn, q in enumerate(cols):
             op([("A", q)], lambda g, q=q, qn=qn: e("v_mul_f32" if qn == 0 else "v_fmac_f32", v(T(9)), v(g[0]), ACC(res.A_i[q])))
@@ -2506,7 +2542,7 @@ def res_program(s, eq_rows, ap, res):
         has_p = j in res.it_p
         srcs = [SI(res.it_d[j]), SI(res.it_q[j])] + ([SI(res.it_p[j])] if has_p else []) + [("L", ap.LW_X + j)]
 
-        def f(g, has_p=has_p):
+        def f(g, has_p=has_p, j=j):
             d, qv, x = g[0], g[1], g[-1]
             if has_p:
                 e("v_mul_f32", v(T(10)), v(g[2]), v(x))              # px
@@ -2517,8 +2553,8 @@ def res_program(s, eq_rows, ap, res):
                 scratch = T(10)
             e("v_add_f32", v(T(11)), v(T(11)), v(T(9)))               # (q + P x) + A' y     [T(9) = A' y]
             e("v_mul_f32", v(NAX), v(x), v(d))                        # sol_x = x D
-            store("x", x)
-            store("sx", NAX)
+            store("x", x, j)
+            store("sx", NAX, j)
             e("v_rcp_f32", v(NAX), v(d))                              # 1 / D_j (likewise)
             e("s_nop", 0)
             e("v_mul_f32", v(T(11)), v(NAX), v(T(11)))
@@ -2533,6 +2569,27 @@ def res_program(s, eq_rows, ap, res):
         op(srcs, f)
     sc.run(ops)
     stamp(5)
+    if nw > 1:
+        # the partial norms of every wave -> LDS (words that only the loop used), barrier, wavefront 0 folds them (max)
+        e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+        xw = lambda w: RES_XCHG + 8 * w
+        assert PRI % 2 == 0 and (PRI, NZ, NAX, DUA, NQ, NATY, NPX, CINV) == tuple(range(PRI, PRI + 8)) and xw(nw) <= LW_FLAGS
+        for h in (0, 4):
+            base, off = lds_addr(xw(own.wave) + h)
+            e("ds_write_b128", base, "v[%d:%d]" % (PRI + h, PRI + h + 3), off)
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_barrier")
+        if own.wave != 0:
+            e("s_barrier")
+            return e.ins, R
+        for w in range(1, nw):
+            for h in (0, 4):
+                base, off = lds_addr(xw(w) + h)
+                e("ds_read_b128", "v[%d:%d]" % (R.V_RING + h, R.V_RING + h + 3), base, off)
+            e("s_waitcnt", "lgkmcnt(0)")
+            for q, reg in enumerate((PRI, NZ, None, DUA, NQ, NATY, NPX)):
+                if reg is not None:
+                    e("v_max_f32", v(reg), v(reg), v(R.V_RING + q))
     # ---- termination test at the strict tolerances (osqp.c:524-573), flag, status and info rows
     e("v_mul_f32", v(DUA), v(CINV), v(DUA))
     e("v_max_f32", v(NQ), v(NQ), v(NATY))
@@ -2571,7 +2628,35 @@ def res_program(s, eq_rows, ap, res):
     for reg in (() if STAMPS or RUIZ_STAMPS else (PRI, DUA, C, NATY, NAX, NATY)):     # info rows: pri, dua, c, 0 (no zero pivot), max_iter, 0
         store("in", reg)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    if nw > 1:
+        e("s_barrier")              # RES_FLAG is there for every wavefront
     return e.ins, R
+
+
+def res_group_program(s, eq_rows, ap, res, nw=4):
+    """The residual block for a workgroup of nw wavefronts that own the same 64 robots, each on the components LoopSplit
+    gives it; s41 = the wavefront's index, the other inputs as res_program. Two barriers."""
+    sp = LoopSplit(ap, nw)
+    e = Emit()
+    for w in range(nw):
+        if w < nw - 1:
+            e("s_cmp_lg_u32", "s%d" % S_XWAVE, w)
+            e("s_cbranch_scc1", "48f")
+        if w < sp.active:
+            ins, R = res_program(s, eq_rows, ap, res, sp.own(w), nw)
+            e.ins.extend(ins)
+        else:
+            e("s_barrier")
+            e("s_barrier")
+        if w < nw - 1:
+            e("s_branch", "49f")
+            e("label", "48")
+    e("label", "49")
+    return e.ins, R
+
+
+S_XWAVE = 41                       # res_group_program: s41 = the wave's index in its workgroup
+RES_XCHG = 604                     # LDS words 604..635: the waves' partial norms (8 per wave; only the loop used these words)
 
 
 # ---------------------------------------------------------------------------

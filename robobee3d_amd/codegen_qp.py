@@ -471,19 +471,21 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("      if (__all(LDSQ(%d) == T(1.0)))" % asmqp.LOOSE_FLAG)
     E("        BQP_%s_ASM_LOOSE4(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
       "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s, wv);" % (U, RHO_ARGS))
-    E("      else if (wv == 0u)")
-    E("      BQP_%s_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
+    E("      else {")
+    E("        if (wv == 0u)")
+    E("        BQP_%s_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
       "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s);" % (U, RHO_ARGS))
-    E("      if (wv != 0u) return;")
+    E("        __syncthreads();   // (the shared blocks end behind a barrier themselves)")
+    E("      }")
     mark(5)
     E("      fail = (LDSQ(%d) == T(0.0)) ? 1 : 0;   // a zero pivot of the block's factorisation (qdldl.c:221-224)" % asmqp.FAC_MIN)
     E("      if (a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
     E("        const unsigned s_epsa = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.eps_abs));")
     E("        const unsigned s_epsr = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a.eps_rel));")
     E("        const unsigned s_maxit = __builtin_amdgcn_readfirstlane((unsigned)a.max_iter);")
-    E("        BQP_%s_RES_ASM(voff, ldsaddr, lane4, ssp, s_stride, uni((unsigned long long)a.x), uni((unsigned long long)a.y), "
+    E("        BQP_%s_RES4_ASM(voff, ldsaddr, lane4, ssp, s_stride, uni((unsigned long long)a.x), uni((unsigned long long)a.y), "
       "uni((unsigned long long)a.z), uni((unsigned long long)a.sol_x), uni((unsigned long long)a.sol_y), "
-      "uni((unsigned long long)a.status), uni((unsigned long long)a.info), s_epsa, s_epsr, s_maxit, uni((unsigned long long)a.Eprev));" % U)
+      "uni((unsigned long long)a.status), uni((unsigned long long)a.info), s_epsa, s_epsr, s_maxit, uni((unsigned long long)a.Eprev), wv);" % U)
     E("        resdone = __all(LDSQ(%d) == T(1.0));" % asmqp.RES_FLAG)
     E("      }")
     E("      mode = resdone ? 2 : 1;")
@@ -572,9 +574,9 @@ def asm_macro(name, ins, plan, loose=False, group=None):
         nv = [sum(1 for w_ in group.varw if w_ == w) for w in range(group.active)]
         nk_ = [sum(1 for w_ in group.kw if w_ == w) for w in range(group.active)]
         out = ["// The LOOSE variant SHARED by the workgroup's wavefronts (asmqp.loop_group_program / LoopSplit): the QP's connected",
-               "// components are independent QPs -- wavefront 0 iterates on the largest (%d of %d variables, %d of %d KKT unknowns),"
-               % (nv[0], len(group.varw), nk_[0], len(group.kw)),
-               "// wavefront 1 on the others, the rest only keep the %d barriers company; same LDS layout, disjoint words, bit-identical"
+               "// components are independent QPs, dealt out to the wavefronts (%s of %d variables, %s of %d KKT unknowns); they meet at"
+               % (" + ".join(map(str, nv)), len(group.varw), " + ".join(map(str, nk_)), len(group.kw)),
+               "// %d barriers, none inside the loop; same LDS layout, disjoint words, bit-identical"
                % (sum(t_[0] == "s_barrier" for t_ in ins) // group.nw),
                "// words. s%d = the wavefront's index; the other inputs as BQP_%s_ASM_LOOSE. %d instructions."
                % (asmqp.S_LWAVE, name.upper(), len(ins)),
@@ -615,20 +617,25 @@ def asm_macro(name, ins, plan, loose=False, group=None):
     return "\n".join(out) + "\n"
 
 
-def res_macro(name, ins):
+def res_macro(name, ins, group=False):
     from . import asmqp
     clob = ['"memory"', '"scc"', '"vcc"'] + _stamp_clobbers() + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
-           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in [asmqp.S_SP, asmqp.S_SP + 1] + list(range(42, 54)) + [56, 57]]
+           ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in [asmqp.S_SP, asmqp.S_SP + 1] + list(range(42, 54)) + [56, 57, 58, 59]]
     out = ["// Residuals, strict termination test and solution stores after the loop (asmqp.res_program): %d instructions." % len(ins),
            "// inputs: v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane, s[6:7] = the wave's stream block, s10 = 4*B,",
            "// s[24:25] .. s[36:37] = x, y, z, sol_x, sol_y, status, info rows, s38 / s39 = eps_abs / eps_rel (float bits), s40 = max_iter,",
            "// s[54:55] = Eprev rows (E of this solve is stored there)",
            "#define BQP_%s_RES_ASM(voff, ldsaddr, lane4, sblk, stride, xo, yo, zo, sxo, syo, sto, ino, epsa, epsr, maxit, epo) asm volatile( \\" % name.upper()]
+    if group:
+        out = ["// The residual block SHARED by the workgroup's wavefronts (asmqp.res_group_program): each on the components LoopSplit gives",
+               "// it (A x of a row, A' y of a column stay inside a component: the same accumulations as one wavefront), the partial norms",
+               "// folded by wavefront 0 between two barriers; s%d = the wavefront's index. %d instructions." % (asmqp.S_XWAVE, len(ins)),
+               "#define BQP_%s_RES4_ASM(voff, ldsaddr, lane4, sblk, stride, xo, yo, zo, sxo, syo, sto, ino, epsa, epsr, maxit, epo, wave) asm volatile( \\" % name.upper()]
     for t_ in ins:
         out.append('  "%s\\n" \\' % asmqp.fmt(t_))
     out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[6:7]}"(sblk), "{s10}"(stride), "{s[24:25]}"(xo), '
                '"{s[26:27]}"(yo), "{s[28:29]}"(zo), "{s[30:31]}"(sxo), "{s[32:33]}"(syo), "{s[34:35]}"(sto), "{s[36:37]}"(ino), '
-               '"{s38}"(epsa), "{s39}"(epsr), "{s40}"(maxit), "{s[54:55]}"(epo) \\')
+               '"{s38}"(epsa), "{s39}"(epsr), "{s40}"(maxit), "{s[54:55]}"(epo)%s \\' % (', "{s%d}"(wave)' % asmqp.S_XWAVE if group else ""))
     out.append("  : " + ", ".join(clob) + ")")
     return "\n".join(out) + "\n"
 
@@ -715,6 +722,7 @@ def generate():
             rsins, _ = asmqp.ruiz_program(s, plan.res)
             rs4ins, _, _ = asmqp.ruiz_group_program(s, plan.res, ASM_GROUP_WAVES)
             resins, _ = asmqp.res_program(s, ASM_STRUCTURES[name], plan, plan.res)
+            res4ins, _ = asmqp.res_group_program(s, ASM_STRUCTURES[name], plan, plan.res, ASM_GROUP_WAVES)
             glins = asmqp.glue_program(s, ASM_STRUCTURES[name], plan, plan.res, plan.ruiz)
             gl4ins = asmqp.glue_group_program(s, ASM_STRUCTURES[name], plan, plan.res, plan.ruiz, ASM_GROUP_WAVES)
             asm_body = emit_structure(name, s, asm=plan)
@@ -724,7 +732,7 @@ def generate():
                 asm_macro(name, ins_loose4, plan, loose=True, group=lsplit) + \
                 ruiz_macro(name, rins, plan.ruiz) + \
                 ruiz_macro(name, rsins, plan.ruiz, rs=True) + ruiz_macro(name, rs4ins, plan.ruiz, rs=True, group=True) + \
-                res_macro(name, resins) + glue_macro(name, glins) + glue_macro(name, gl4ins, group=True) + \
+                res_macro(name, resins) + res_macro(name, res4ins, group=True) + glue_macro(name, glins) + glue_macro(name, gl4ins, group=True) + \
                 loader_macro(name, "XYZ", [(s.n, 0), (s.m, s.n), (s.m, s.n + s.m)]) + \
                 loader_macro(name, "LUE", [(s.m, 0), (s.m, s.m), (s.m, 2 * s.m)])
         for tag, ctype in DTYPES:

@@ -314,6 +314,24 @@ def test_residual_block_matches_numpy(eps, expect):
     assert abs(info[0] - pri) <= 2e-6 * pri and abs(info[1] - dua) <= 2e-6 * dua and info[2] == c and info[3] == 0 and info[4] == 50
     assert np.array_equal(xo, x) and np.array_equal(yo, y) and np.array_equal(zo, z)
     assert np.abs(sx - x * D).max() <= 1e-6 * np.abs(x * D).max() and np.abs(sy - y * Ev / c).max() <= 1e-6 * np.abs(y * Ev / c).max()
+    # the block shared by the workgroup's four wavefronts (res_group_program: each on its components): every store, the info
+    # rows, the status word and the flag bit for bit the one-wave block's; two barriers, no LDS race
+    grp, _ = asmqp.res_group_program(s, eq, ap, res, 4)
+    out4 = [np.full(k, np.nan, np.float32) for k in (n, m, m, n, m)]
+    stt4, info4, epo4 = np.zeros(1, np.float32), np.zeros(6, np.float32), np.full(m, np.nan, np.float32)
+    n1 = []
+    asmqp.simulate(ins, np.zeros(1, np.float32), S, 1, (1.6, 1e-6, 0.01), count=n1,
+                   regions=[(asmqp.S_XO, xo.copy()), (asmqp.S_YO, yo.copy()), (asmqp.S_ZO, zo.copy()), (asmqp.S_SX, sx.copy()),
+                            (asmqp.S_SY, sy.copy()), (asmqp.S_ST, stt.copy()), (asmqp.S_IN, info.copy()), (asmqp.S_EP, epo.copy())],
+                   sgpr=sg, lds0=lds0)
+    lds4, counts, nbar = asmqp.simulate_group(grp, 4, np.zeros(1, np.float32), S, 1, (1.6, 1e-6, 0.01), asmqp.S_XWAVE,
+                                              regions=[(asmqp.S_XO, out4[0]), (asmqp.S_YO, out4[1]), (asmqp.S_ZO, out4[2]),
+                                                       (asmqp.S_SX, out4[3]), (asmqp.S_SY, out4[4]), (asmqp.S_ST, stt4),
+                                                       (asmqp.S_IN, info4), (asmqp.S_EP, epo4)], sgpr=sg, lds0=lds0)
+    assert nbar == 2 and lds4[asmqp.RES_FLAG] == lds[asmqp.RES_FLAG]
+    for got, ref in zip(out4 + [stt4, info4, epo4], [xo, yo, zo, sx, sy, stt, info, epo]):
+        assert np.array_equal(got, ref)
+    assert max(counts) < 0.6 * n1[0], (counts, n1)
 
 
 def _glue_expected(p, res, eq, l, u, ep, ev, q, rho0):
@@ -573,11 +591,11 @@ def test_ruiz_block_shared_by_four_waves_is_bit_identical_to_one_wave(passes):
 @pytest.mark.parametrize("iters,zero_y", [(0, True), (1, True), (3, True), (3, False)])
 def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, iters, zero_y):
     """asmqp.loop_group_program: the QP's connected components (two chains of the horizon and five small pieces for planar
-    p5f) are independent QPs; wavefront 0 runs the loose loop block on the largest, wavefront 1 on the others, side by side
-    on disjoint words of the same LDS layout, meeting only after the factorisation and at the end. The interpreter runs the
-    four wavefronts barrier phase by barrier phase with its LDS race check; x, y, z, x_prev, delta_y and the pivot flag must
-    equal the one-wave loose program's bit for bit, and the longer of the two working wavefronts must execute little more
-    than half the one-wave block's instructions."""
+    p5f) are independent QPs; the wavefronts of the workgroup run the loose loop block each on its own components, side by
+    side on disjoint words of the same LDS layout, meeting after the factorisation, twice in the capturing iteration (its
+    stores reuse the L words) and at the end. The interpreter runs the four wavefronts barrier phase by barrier phase with
+    its LDS race check; x, y, z, x_prev, delta_y and the pivot flag must equal the one-wave loose program's bit for bit, and
+    the longest wavefront must execute little more than half the one-wave block's instructions."""
     from robobee3d_amd import codegen_qp
     asmqp, _, p = prog
     s = p.s
@@ -585,7 +603,7 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
     res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
     one, _ = asmqp.program(s, eq, res, loose=True)
     grp, pg, sp = asmqp.loop_group_program(s, eq, res, 4)
-    assert sp.active == 2 and 0.4 < sum(sp.varw) / p.n < 0.6
+    assert sp.active == 4 and sp.load == [118, 112, 12, 9]          # KKT unknowns per wavefront: two chains, small pieces
     f = lambda a: a.astype(np.float32).astype(np.float64)
     gen = [i for i in range(p.m) if i not in set(eq)]
     rng = np.random.default_rng(3)
@@ -615,4 +633,4 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
                                               regions=regs(), sgpr={asmqp.S_FAST: 1})
     assert nbar == 4
     assert np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
-    assert max(counts) < 0.62 * n1[0] and counts[2] < 20 and counts[3] < 20, (counts, n1)
+    assert max(counts) < 0.56 * n1[0] and counts[2] < 0.2 * n1[0] and counts[3] < 0.2 * n1[0], (counts, n1)
