@@ -370,6 +370,10 @@ int umpcQPSolve(void *h, const void *Pv, const void *Av, const void *q, const vo
  * planar/mpc_osqp_p5f.py:168-170. cst, src are device arrays of length nnz. */
 int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src, const void *par, void *out,
                  void *stream);
+/* The same for the entries with src[k] >= 0 only: `out` already holds the constant entries from an earlier umpcQPGather
+ * with the same cst / src (the reference rewrites only the Ad / Bd blocks of its A every tick, mpc_osqp_p5f.py:168-170). */
+int umpcQPGatherUpdate(int B, int dtype, int nnz, const void *cst, const int32_t *src, const void *par, void *out,
+                       void *stream);
 /* planar/mpc_osqp_p5f.py: getLin (:45-85) at (u[b], sigma = y[0][b], phi = y[3][b]) -> lin [5][B] =
  * (Ad[4][3], Ad[5][3], Bd[4], Bd[5], Bd[6]); mode 1 additionally applies the reference's plant tick
  * y <- y + (Ad y + Bd u) dt (:176). y [7][B], u [B]; lin may be NULL in mode 1. */

@@ -26,7 +26,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease", "
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchSetStepKernel", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "umpcBatchKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
-           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather",
+           "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather", "umpcQPGatherUpdate",
            "umpcP5fStep", "umpcP5fStepU", "umpcNAssemble", "umpcNExtract"]
 
 
@@ -250,6 +250,7 @@ def lib():
         L.umpcQPKernelName.restype = C.c_char_p
         L.umpcQPSolve.argtypes = [C.c_void_p] * 15
         L.umpcQPGather.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.umpcQPGatherUpdate.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcP5fStep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4
         L.umpcP5fStepU.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 3
         L.umpcNAssemble.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(NParams)] + [C.c_void_p] * 10

@@ -119,11 +119,12 @@ class BatchQP:
             raise RuntimeError(self.L.umpcLastError().decode())
         return self.sol_x, self.sol_y, self.status
 
-    def gather(self, cst, src, par, out):
-        """out[k] = cst[k] if src[k] < 0 else cst[k] * par[src[k]] (umpcQPGather)."""
+    def gather(self, cst, src, par, out, update=False):
+        """out[k] = cst[k] if src[k] < 0 else cst[k] * par[src[k]] (umpcQPGather); update: only the entries with
+        src[k] >= 0 -- `out` holds the constants from an earlier full gather (umpcQPGatherUpdate)."""
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self.L.umpcQPGather(self.B, _DT[self.dtype], int(cst.numel()), _ptr(cst), _ptr(src), _ptr(par), _ptr(out),
-                                 stream)
+        fn = self.L.umpcQPGatherUpdate if update else self.L.umpcQPGather
+        rc = fn(self.B, _DT[self.dtype], int(cst.numel()), _ptr(cst), _ptr(src), _ptr(par), _ptr(out), stream)
         if rc != 0:
             raise RuntimeError(self.L.umpcLastError().decode())
         return out
@@ -226,12 +227,14 @@ class PlanarP5fMPC:
         self.lin = torch.zeros((5, B), dtype=dtype, device=dev)
         self.y = torch.zeros((7, B), dtype=dtype, device=dev)
         self.u_nom = torch.zeros(B, dtype=dtype, device=dev)
+        self._av_constants_written = False
         self.L = self.qp.L
 
     def linearise(self, u):
         """getLin at (u, sigma = y[0], phi = y[3]) -> lin [5, B] and the assembled A values."""
         self._p5f_step(0, u, self.lin)
-        self.qp.gather(self.cst, self.src, self.lin, self.Av)
+        self.qp.gather(self.cst, self.src, self.lin, self.Av, update=self._av_constants_written)
+        self._av_constants_written = True      # (Av is this object's: nobody else writes its constant entries)
         return self.lin
 
     def tick(self, t, solve=True):

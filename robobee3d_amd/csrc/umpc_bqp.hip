@@ -664,7 +664,8 @@ __global__ void __launch_bounds__(64) bqp_wave_kernel(const QPArgs<T> a) {
 // thread per robot walking all nnz entries kept 64 of the 256 CUs busy for 25 us per p5f tick; src / cst are wave-uniform
 // scalar loads either way).
 constexpr int kGatherRows = 4;
-template <typename T>
+// DYN_ONLY (umpcQPGatherUpdate): the constant entries (src < 0) were written by an earlier umpcQPGather and are left alone.
+template <typename T, bool DYN_ONLY>
 __global__ void bqp_gather_kernel(int B, int nnz, const T *__restrict__ cst, const int32_t *__restrict__ src,
                                   const T *__restrict__ par, T *__restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -675,6 +676,7 @@ __global__ void bqp_gather_kernel(int B, int nnz, const T *__restrict__ cst, con
     const int k = k0 + r;
     if (k >= nnz) break;
     const int s = src[k];
+    if (DYN_ONLY && s < 0) continue;
     const T cv = cst[k];
     out[(size_t)k * B + b] = s < 0 ? cv : par[(size_t)s * B + b] * cv;
   }
@@ -1081,13 +1083,28 @@ int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src,
                  void *stream) {
   if (B <= 0 || nnz <= 0 || !cst || !src || !out) { umpc_set_error("umpcQPGather: bad argument"); return -1; }
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((B + 255) / 256, (nnz + kGatherRows - 1) / kGatherRows);
   if (dtype == UMPC_F32)
-    hipLaunchKernelGGL(bqp_gather_kernel<float>, dim3((B + 255) / 256, (nnz + kGatherRows - 1) / kGatherRows), dim3(256), 0, s,
-                       B, nnz, (const float *)cst, src, (const float *)par, (float *)out);
+    hipLaunchKernelGGL((bqp_gather_kernel<float, false>), grid, dim3(256), 0, s, B, nnz, (const float *)cst, src,
+                       (const float *)par, (float *)out);
   else
-    hipLaunchKernelGGL(bqp_gather_kernel<double>, dim3((B + 255) / 256, (nnz + kGatherRows - 1) / kGatherRows), dim3(256), 0, s,
-                       B, nnz, (const double *)cst, src, (const double *)par, (double *)out);
+    hipLaunchKernelGGL((bqp_gather_kernel<double, false>), grid, dim3(256), 0, s, B, nnz, (const double *)cst, src,
+                       (const double *)par, (double *)out);
   return check_launch("umpcQPGather");
+}
+
+int umpcQPGatherUpdate(int B, int dtype, int nnz, const void *cst, const int32_t *src, const void *par, void *out,
+                       void *stream) {
+  if (B <= 0 || nnz <= 0 || !cst || !src || !par || !out) { umpc_set_error("umpcQPGatherUpdate: bad argument"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((B + 255) / 256, (nnz + kGatherRows - 1) / kGatherRows);
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL((bqp_gather_kernel<float, true>), grid, dim3(256), 0, s, B, nnz, (const float *)cst, src,
+                       (const float *)par, (float *)out);
+  else
+    hipLaunchKernelGGL((bqp_gather_kernel<double, true>), grid, dim3(256), 0, s, B, nnz, (const double *)cst, src,
+                       (const double *)par, (double *)out);
+  return check_launch("umpcQPGatherUpdate");
 }
 
 int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, void *lin, void *stream) {
