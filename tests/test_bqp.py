@@ -965,3 +965,42 @@ def test_gpu_p5f_loose_loop_y0_variant_and_its_fallback_agree(margin):
     worst = max(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) for a, b in zip(res[0][:5], res[1][:5]))
     margin("y0 body vs general loose body, 3 ticks, B = 200: iterates / solution, |d| / max(1, |ref|)", worst, 1e-12)
     assert np.array_equal(res[0][5], res[1][5]) and np.all(res[0][5] == 1)
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_relabelled_problem_is_the_scripts_problem():
+    """PlanarP5fMPC solves p5f_structure(grouped=True) -- the script's QP with variables and rows relabelled so that its connected
+    components are contiguous. The same ticks on the script's own labelling (a BatchQP on p5f_structure(), data un-permuted)
+    must give the same solution: fp64, both through the general kernels, to 1e-9; solution() undoes the relabelling."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC, BatchQP, p5f_structure
+    B = 70
+    mpc = PlanarP5fMPC(B, torch.float64)
+    sc = p5f_structure(10)
+    st = mpc.st
+    vo, ro = torch.as_tensor(st["var_order"]).cuda(), torch.as_tensor(st["row_order"]).cuda()
+    col = lambda v: torch.as_tensor(np.repeat(np.asarray(v, np.float64)[:, None], B, 1)).cuda().contiguous()
+    Pv, q, l, u = col(sc["Pv"]), col(sc["q"]), col(sc["l"]), col(sc["u"])
+    cst, src = torch.as_tensor(sc["cst"]).cuda(), torch.as_tensor(sc["src"]).cuda()
+    Av = torch.zeros((len(sc["A_i"]), B), dtype=torch.float64, device="cuda")
+    mpc.y.copy_(torch.as_tensor(np.random.default_rng(8).normal(size=(7, B)) * 0.05).to(mpc.y))
+    for ti in range(2, 6):
+        mpc.tick(0.002 * ti)
+    # the same four warm-started solves, step by step, on both labellings
+    qp2 = BatchQP(sc["n"], sc["m"], sc["A_p"], sc["A_i"], sc["P_cols"], B, torch.float64)
+    qp2.set_kernel("wave")
+    mpc2 = PlanarP5fMPC(B, torch.float64)
+    mpc2.y.copy_(torch.as_tensor(np.random.default_rng(8).normal(size=(7, B)) * 0.05).to(mpc2.y))
+    for ti in range(2, 6):
+        unom = 15.0 * np.sin(2 * np.pi * 170 * 0.002 * ti)
+        mpc2.linearise(unom)
+        qp2.gather(cst, src, mpc2.lin, Av)
+        sx, sy, status = qp2.solve(Pv, Av, q, l, u)
+        mpc2.qp.solve(mpc2.Pv, mpc2.Av, mpc2.q, mpc2.l, mpc2.u)
+        mpc2._p5f_step(1, unom, None)
+    got = mpc2.solution()
+    assert torch.equal(got[vo], mpc2.qp.sol_x)
+    scale = max(1.0, float(sx.abs().max()))
+    assert float((got - sx).abs().max()) <= 1e-9 * scale
+    assert float((mpc2.qp.sol_y - sy[ro]).abs().max()) <= 1e-9 * max(1.0, float(sy.abs().max()))
+    assert float((mpc2.qp.sol_x - mpc.qp.sol_x).abs().max()) <= 1e-12 * scale     # (and the tick() path is that sequence)
