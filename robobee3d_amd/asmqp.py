@@ -1174,6 +1174,14 @@ def epilogue(e, p):
 
 
 S_FAST, S_XI, S_YI, S_ZI = 30, 24, 26, 28    # fast start: flag, the caller's x, y, z rows ([row][B] floats)
+
+
+def _lstamp(e, own, k):
+    """(diagnostics, UMPC_QP_LOOP_STAMPS=1: 100 MHz stamp k of wavefront 0's loose loop block in s[60+2k:61+2k])"""
+    if LOOP_STAMPS and (own.all or own.wave == 0):
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_memrealtime", "s[%d:%d]" % (60 + 2 * k, 61 + 2 * k))
+        e("s_waitcnt", "lgkmcnt(0)")
 FAC_MIN = 638                                # LDS word: min |d_k| of the factorisation (0 = a zero pivot)
 
 
@@ -1183,6 +1191,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     -L lands in the loop's LDS words, 1/D in its AGPRs: no hand-off rows at all."""
     s = p.s
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+    _lstamp(e, own, 0)
     e("v_add_u32", "v%d" % V_B1, 0x10000, "v1")
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
     cur = [None]
@@ -1207,6 +1216,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
             base, off = lds_addr(p.LW_X + k)
             e("ds_write_b32", base, "v%d" % (V_W + q), off)
         e("s_waitcnt", "lgkmcnt(0)")
+    _lstamp(e, own, 1)
     # P, 1/rho of the inequality rows -> registers for the whole factorisation
     v_p, v_rinv = V_W, V_W + s.nnzP
     gen = sorted(p.zpos, key=lambda i: p.zpos[i])
@@ -1226,6 +1236,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     e("s_waitcnt", "vmcnt(0)")
     factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING)),
                 list(range(p.V_LAND, p.V_LAND + p.NLAND)), v_fmin, own)
+    _lstamp(e, own, 2)
     base, off = lds_addr(FAC_MIN)
     if group:
         # several waves: the A words above are the other waves' x, y words -- nobody loads its warm start before everybody
@@ -1239,6 +1250,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     else:
         e("ds_write_b32", base, "v%d" % v_fmin, off)
     e("s_waitcnt", "lgkmcnt(0)")
+    _lstamp(e, own, 3)
     # the warm start: x, y, z of the inequality rows -> LDS
     rows = [(S_XI, j, p.LW_X + j) for j in range(p.n) if own.var(j)] + [(S_YI, i, p.LW_Y + i) for i in range(p.m) if own.row(i)] + \
            [(S_ZI, i, p.LW_Z + p.zpos[i]) for i in gen if own.row(i)]
@@ -1262,6 +1274,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
             if y0check and sb == S_YI and row in p.zpos:
                 e("v_or_b32", "v%d" % v_or, "v%d" % v_or, "v%d" % (V_W + q))
         e("s_waitcnt", "lgkmcnt(0)")
+    _lstamp(e, own, 4)
     if y0check:
         return v_or
     prologue_tail(e, p, loose, own=own)
@@ -1311,6 +1324,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
                 e("v_readfirstlane_b32", "s%d" % S_DLEAF, "v%d" % v_or)
             y0_fill(e, p, own)
             prologue_tail(e, p, True, p.y0_home, own)
+            _lstamp(e, own, 5)
             if not Y0_FUSE:
                 loop(y0=True)
             else:
@@ -1338,9 +1352,20 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
             e("s_branch", "29f")
             e("label", "20")
             prologue_tail(e, p, True, own=own)
+            _lstamp(e, own, 5)
             loop()
             e("label", "29")
             epilogue(e, p)
+            if LOOP_STAMPS and (own.all or own.wave == 0):
+                _lstamp(e, own, 6)
+                # intervals: A -> LDS, factorisation, barrier, warm start, y0 fill + preloads, the iterations -> stream items
+                e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (STAMP_ITEM0 // BLOCK) * BLOCK * 256)
+                e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+                for k in range(6):
+                    e("s_sub_u32", "s%d" % (60 + 2 * k), "s%d" % (62 + 2 * k), "s%d" % (60 + 2 * k))
+                    e("v_cvt_f32_u32", "v%d" % (p.V_TT + k), "s%d" % (60 + 2 * k))
+                    e("global_store_dword", "v%d" % V_LANE, "v%d" % (p.V_TT + k), "s[%d:%d]" % (S_SP, S_SP + 1), ((STAMP_ITEM0 + k) % BLOCK) * 256)
+                e("s_waitcnt", "vmcnt(0)")
             if group:
                 e("s_barrier")        # every wave's x, y, z, x_prev, delta_y words are in LDS for whoever reads them next
             return e.ins, p
@@ -1980,6 +2005,7 @@ S_AV, S_PV, S_QV = 4, 6, 8          # s[4:5] Av rows, s[6:7] Pv rows, s[8:9] q r
 S_RSB, V_RLANE = 24, 210           # Ruiz block with a residual stream: s[24:25] = the wave's stream block, v210 = 4*lane
 S_RMIN, S_RMAX = 20, 21            # 1e-4, 1e4 (float bits, set by the block)
 RUIZ_STAMPS = os.environ.get("UMPC_QP_RUIZ_STAMPS") == "1"     # (diagnostics: see ruiz_program)
+LOOP_STAMPS = os.environ.get("UMPC_QP_LOOP_STAMPS") == "1"     # (diagnostics: see program(); the residual block copies the items)
 STAMP_ITEM0 = 2040                 # spare items at the end of a wave's stream block (codegen_qp.ASM_STREAM_ITEMS = 2048)
 
 
@@ -2608,7 +2634,7 @@ def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
     e("global_store_dword", "v0", v(T(9)), "s[%d:%d]" % (S_ST, S_ST + 1), 0)
     e("v_cvt_f32_i32", v(NAX), "s%d" % S_MAXIT)
     e("v_mov_b32", v(NATY), 0)
-    if RUIZ_STAMPS and not STAMPS:
+    if (RUIZ_STAMPS or LOOP_STAMPS) and not STAMPS:
         e("s_waitcnt", "vmcnt(0)")
         e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, (STAMP_ITEM0 // BLOCK) * BLOCK * 256)
         e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
@@ -2625,7 +2651,7 @@ def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
             e("v_cvt_f32_u32", v(T(9)), "s%d" % (S_STAMP + 2 * k))
             store("in", T(9))
             e("s_nop", 1)
-    for reg in (() if STAMPS or RUIZ_STAMPS else (PRI, DUA, C, NATY, NAX, NATY)):     # info rows: pri, dua, c, 0 (no zero pivot), max_iter, 0
+    for reg in (() if STAMPS or RUIZ_STAMPS or LOOP_STAMPS else (PRI, DUA, C, NATY, NAX, NATY)):     # info rows: pri, dua, c, 0 (no zero pivot), max_iter, 0
         store("in", reg)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
     if nw > 1:

@@ -534,7 +534,7 @@ def emit_fast_route_reload(E, name, s, P):
 
 def _stamp_clobbers():
     """(diagnostic builds, UMPC_QP_RES_STAMPS / UMPC_QP_RUIZ_STAMPS: the blocks keep 100 MHz stamps in s60..s81)"""
-    on = os.environ.get("UMPC_QP_RES_STAMPS") == "1" or os.environ.get("UMPC_QP_RUIZ_STAMPS") == "1"
+    on = any(os.environ.get("UMPC_QP_%s_STAMPS" % k_) == "1" for k_ in ("RES", "RUIZ", "LOOP"))
     return ['"s%d"' % i for i in range(60, 82)] if on else []
 
 
@@ -569,7 +569,7 @@ def asm_macro(name, ins, plan, loose=False, group=None):
     from . import asmqp
     if group is not None:
         used_s = [asmqp.S_P, asmqp.S_P + 1, asmqp.S_CNT, asmqp.S_SP, asmqp.S_SP + 1, asmqp.S_RIMIN, asmqp.S_RHOMIN, asmqp.S_DLEAF]
-        clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
+        clob = ['"memory"', '"scc"', '"vcc"'] + _stamp_clobbers() + ['"v%d"' % i for i in [2, 3] + list(range(5, asmqp.V_END))] + \
                ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
         nv = [sum(1 for w_ in group.varw if w_ == w) for w in range(group.active)]
         nk_ = [sum(1 for w_ in group.kw if w_ == w) for w in range(group.active)]
