@@ -28,7 +28,13 @@ device, taking the C++ loop for a wave where it does not hold.
 Arithmetic vs the C++ statement: fused multiply-adds in the solves, leaf contributions applied before the other
 columns, the equality-row shortcut: rounding only. `simulate()` interprets the stream on numpy float32 (tests/test_asmqp.py).
 Reference mapping: osqp 0.6.0 auxil.c:164-228, qdldl.c:250-293, proj.c:4-14 (planar/mpc_osqp_p5f.py never calls
-solve(); the iteration is the build's)."""
+solve(); the iteration is the build's).
+
+Round 4: the kernel's workgroup is FOUR wavefronts (one per SIMD of the CU) that own the same 64 robots and LDS slots and
+divide every block's instructions -- RuizSplit / ruiz_group_program (stretches of columns), glue_group_program (rows),
+LoopSplit / loop_group_program and res_group_program (the QP's connected components: independent QPs, no barrier inside the
+loop). Same layouts, every word bit-identical to the one-wavefront blocks; simulate_group() runs the wavefronts barrier phase
+by barrier phase on one LDS image and rejects a word written by one and touched by another between two barriers."""
 import os
 import struct
 
@@ -1504,7 +1510,7 @@ def simulate_group(ins, nw, W, S, iters, consts, wave_sgpr, **kw):
                     clash = (logs[a_]["w"] & (logs[b_]["r"] | logs[b_]["w"] | logs[b_].get("a", set()))) | \
                             (logs[a_].get("a", set()) & logs[b_]["r"])
                     assert not clash, ("LDS race before barrier %d: words written by wave %d and touched by wave %d" % (nbar, a_, b_),
-                                       sorted(clash)[:8], {k_: sorted(clash & v_)[:4] for k_, v_ in logs[b_].items() if k_ != "watch"})
+                                       sorted(clash)[:8], {k_: sorted(clash & v_)[:4] for k_, v_ in logs[b_].items()})
         for lg in logs:
             for st_ in lg.values():
                 st_.clear()
