@@ -381,6 +381,11 @@ int umpcP5fStep(int B, int dtype, int mode, double dt, const void *u, void *y, v
 /* The same with ONE nominal input for the whole batch, as the reference's loop has it (unom = 15 sin(2 pi 170 t) is a
  * scalar, planar/mpc_osqp_p5f.py:157): no [B] array to fill per tick. */
 int umpcP5fStepU(int B, int dtype, int mode, double dt, double u, void *y, void *lin, void *stream);
+/* getLin and the A update of one tick (mpc_osqp_p5f.py:165-170) in ONE launch: umpcP5fStep[U] mode 0 followed by
+ * umpcQPGather (update = 0) or umpcQPGatherUpdate (update != 0) with par = lin; the entries of the structure refer to lin
+ * rows (src[k] in 0..4). u [B] or NULL (then u_all is every robot's input); lin [5][B], Av [nnz][B] as above. */
+int umpcP5fLinearise(int B, int dtype, const void *u, double u_all, const void *y, void *lin, int nnz, const void *cst,
+                     const int32_t *src, void *Av, int update, void *stream);
 /* UprightMPC2 at any horizon N (template/template_controllers.py:170-258; N = 3 is Parts 1-2's specialised path):
  * assembly (updateConstraint :65-125, updateObjective :127-143 = uprightmpc2.c:121-207) and extraction (update2 /
  * getAccDes :232-250 = uprightmpc2.c:253-269) around umpcQPSolve on the structure of initConstraint (:28-63).

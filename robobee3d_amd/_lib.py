@@ -27,7 +27,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease", "
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchSetStepKernel", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "umpcBatchKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather", "umpcQPGatherUpdate",
-           "umpcP5fStep", "umpcP5fStepU", "umpcNAssemble", "umpcNExtract"]
+           "umpcP5fStep", "umpcP5fStepU", "umpcP5fLinearise", "umpcNAssemble", "umpcNExtract"]
 
 
 class NParams(C.Structure):
@@ -253,6 +253,8 @@ def lib():
         L.umpcQPGatherUpdate.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.umpcP5fStep.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4
         L.umpcP5fStepU.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 3
+        L.umpcP5fLinearise.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.umpcNAssemble.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(NParams)] + [C.c_void_p] * 10
         L.umpcNExtract.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 5
         L.umpcLastStatus.restype = C.c_int

@@ -232,8 +232,15 @@ class PlanarP5fMPC:
 
     def linearise(self, u):
         """getLin at (u, sigma = y[0], phi = y[3]) -> lin [5, B] and the assembled A values."""
-        self._p5f_step(0, u, self.lin)
-        self.qp.gather(self.cst, self.src, self.lin, self.Av, update=self._av_constants_written)
+        stream = C.c_void_p(torch.cuda.current_stream(self.qp.device).cuda_stream)
+        if torch.is_tensor(u):
+            self.u_nom.copy_(u)
+        # one launch: getLin -> lin and the entries of A (after the first tick only the state-dependent ones)
+        rc = self.L.umpcP5fLinearise(self.B, _DT[self.dtype], _ptr(self.u_nom) if torch.is_tensor(u) else None,
+                                     0.0 if torch.is_tensor(u) else float(u), _ptr(self.y), _ptr(self.lin), int(self.cst.numel()),
+                                     _ptr(self.cst), _ptr(self.src), _ptr(self.Av), 1 if self._av_constants_written else 0, stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
         self._av_constants_written = True      # (Av is this object's: nobody else writes its constant entries)
         return self.lin
 

@@ -722,6 +722,39 @@ __global__ void p5f_kernel(int B, int mode, T dt, const T *__restrict__ u, T u_a
   }
 }
 
+// getLin and the A update of one tick in ONE launch (umpcP5fLinearise = umpcP5fStep mode 0 + umpcQPGather[Update] with
+// par = lin): blockIdx.y == 0 writes lin, the other block rows each kGatherRows entries of A, recomputing getLin from
+// the same inputs (the same function of the same numbers: the values are the ones the two launches produce).
+template <typename T>
+__global__ void p5f_linearise_kernel(int B, const T *__restrict__ u, T u_all, const T *__restrict__ y, T *__restrict__ lin,
+                                     int nnz, const T *__restrict__ cst, const int32_t *__restrict__ src, T *__restrict__ out,
+                                     int update) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const size_t Bz = (size_t)B;
+  const int k0 = ((int)blockIdx.y - 1) * kGatherRows;
+  if (blockIdx.y > 0) {           // (wave-uniform: a block row without a state-dependent entry has nothing to compute)
+    bool any = false;
+    for (int r = 0; r < kGatherRows; ++r) any = any || (k0 + r < nnz && (src[k0 + r] >= 0 || !update));
+    if (!any) return;
+  }
+  T o[5];
+  p5f_getlin(u ? u[b] : u_all, y[b], y[3 * Bz + b], o);
+  if (blockIdx.y == 0) {
+    for (int i = 0; i < 5; ++i) lin[i * Bz + b] = o[i];
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < kGatherRows; ++r) {
+    const int k = k0 + r;
+    if (k >= nnz) break;
+    const int s = src[k];
+    if (update && s < 0) continue;
+    const T cv = cst[k];
+    out[(size_t)k * Bz + b] = s < 0 ? cv : o[s] * cv;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // uprightmpc2 at any horizon N: the assembly (template/template_controllers.py:65-143 = uprightmpc2.c:121-207)
 // and the extraction (template_controllers.py:232-250 = uprightmpc2.c:253-269) around umpcQPSolve. Row layout
@@ -1135,6 +1168,20 @@ int umpcP5fStepU(int B, int dtype, int mode, double dt, double u, void *y, void 
     hipLaunchKernelGGL(p5f_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, s, B, mode, dt, (const double *)nullptr, u,
                        (double *)y, (double *)lin);
   return check_launch("umpcP5fStepU");
+}
+
+int umpcP5fLinearise(int B, int dtype, const void *u, double u_all, const void *y, void *lin, int nnz, const void *cst,
+                     const int32_t *src, void *Av, int update, void *stream) {
+  if (B <= 0 || nnz <= 0 || !y || !lin || !cst || !src || !Av) { umpc_set_error("umpcP5fLinearise: bad argument"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((B + 255) / 256, 1 + (nnz + kGatherRows - 1) / kGatherRows);
+  if (dtype == UMPC_F32)
+    hipLaunchKernelGGL(p5f_linearise_kernel<float>, grid, dim3(256), 0, s, B, (const float *)u, (float)u_all, (const float *)y,
+                       (float *)lin, nnz, (const float *)cst, src, (float *)Av, update);
+  else
+    hipLaunchKernelGGL(p5f_linearise_kernel<double>, grid, dim3(256), 0, s, B, (const double *)u, u_all, (const double *)y,
+                       (double *)lin, nnz, (const double *)cst, src, (double *)Av, update);
+  return check_launch("umpcP5fLinearise");
 }
 
 int umpcNAssemble(int B, int dtype, int N, const umpcNParams *p, const void *state, const void *ref, void *T0,
