@@ -323,8 +323,11 @@ class Sched:
     AGPR words two ops ahead, stream items through the landing registers. op = dict(srcs=[...], emit=fn(regs)),
     src = ('L', lds word) | ('A', agpr) | ('S', stream item) | ('V', vgpr). emit may call lds_write()."""
 
-    def __init__(self, e, plan, vm_outstanding, la=3):
+    def __init__(self, e, plan, vm_outstanding, la=3, land_map=None):
         self.e, self.p, self.la = e, plan, la    # la: ops of look-ahead for AGPR reads (0: right before use)
+        # land_map: this wave lands a SUBSET of the stream's landing items (positions in the stream, increasing)
+        self.land_map = land_map if land_map is not None else getattr(plan, "land_map", None)
+        self.n_land = len(self.land_map) if self.land_map is not None else getattr(plan, "n_land", 0)
         self.nlds = 0                       # LDS instructions issued so far (reads and writes complete in order)
         self.nvm = vm_outstanding           # VMEM loads issued so far; the first `vm_outstanding` are the preloads
         self.vmpos = {}                     # stream item -> its load's issue index
@@ -371,7 +374,7 @@ class Sched:
 
     def issue_stream(self, idx):
         e, p = self.e, self.p
-        item = p.land_map[idx] if getattr(p, "land_map", None) is not None else idx     # (a wave that lands a subset of the items)
+        item = self.land_map[idx] if self.land_map is not None else idx     # (a wave that lands a subset of the items)
         if item // BLOCK > self.sp_block:
             e("s_add_u32", "s%d" % S_SP, "s%d" % S_SP, (item // BLOCK - self.sp_block) * BLOCK * 256)
             e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_SP + 1), 0)
@@ -447,7 +450,7 @@ class Sched:
             # stream: keep the landing registers full ahead of the consumer
             nxt = next((f for f in first_item[i:] if f is not None), None)
             if nxt is not None:
-                while self.s_issued < p.n_land and self.s_issued < nxt + self.nland - 4:
+                while self.s_issued < self.n_land and self.s_issued < nxt + self.nland - 4:
                     self.issue_stream(self.s_issued)
                     self.s_issued += 1
             while next_inst < len(insts):
@@ -540,7 +543,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     homes = p.y0_home if y0 else {}
     pre_items = [it for it in p.stream[p.n_land:] if it not in homes and own.item(it)]
     npre = len(pre_items)
-    sc = Sched(e, p, npre)
+    own_land = None if own.all else [q for q, it in enumerate(p.stream[:p.n_land]) if own.item(it)]
+    sc = Sched(e, p, npre, land_map=own_land)
     e("s_mov_b64", "s[%d:%d]" % (S_SP, S_SP + 1), "s[%d:%d]" % (S_S, S_S + 1))
     ops = []
 
@@ -598,7 +602,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
         """a constant word: its on-chip home (Plan.once) or the next landing item"""
         if item in p.once:
             return p.once[item]
-        assert p.stream[land[0]] == item, (item, land[0])
+        assert p.stream[land[0] if own_land is None else own_land[land[0]]] == item, (item, land[0])
         land[0] += 1
         return ("S", land[0] - 1)
     # ---- the loose variant's middle iterations take the leaf inequality rows (p5f: the 87 box rows) TWO per packed
@@ -1003,7 +1007,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             sc.lds_write(zw, T(4))
             sc.lds_write(yw, T(5))
         op(srcs, f)
-    assert land[0] == (0 if loose else p.n_land)
+    assert land[0] == (0 if loose else p.n_land if own_land is None else len(own_land))
     # ---- x <- alpha x~ + (1 - alpha) x
     if fuse:
         ops.extend(B_EQ + B_OTHER + B_PAIR)
@@ -1293,7 +1297,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
     meets the other wavefronts at two barriers (after the factorisation, at the end)"""
     p = Plan(s, eq_rows)
     e = Emit()
-    assert loose or (own.all and not group)
+    assert res is not None or (own.all and not group)
 
     def loop(**kw):
         e("s_mov_b32", "s%d" % S_CNT, "s%d" % S_ITERS)
@@ -1375,6 +1379,8 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
             if group:
                 e("s_barrier")        # every wave's x, y, z, x_prev, delta_y words are in LDS for whoever reads them next
             return e.ins, p
+    elif group:
+        prologue_fast(e, p, res, own=own, group=True)          # (a shared block always factorises itself: the fast start)
     else:
         if res is not None:
             e("s_cmp_lg_u32", "s%d" % S_FAST, 0)
@@ -1389,20 +1395,22 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
     e("s_cmp_lt_i32", "s%d" % S_CNT, 1)
     e("s_cbranch_scc1", "8f")
     e("label", "7")
-    body(e, p, loose=loose)
+    body(e, p, loose=loose, own=own)
     e("s_sub_i32", "s%d" % S_CNT, "s%d" % S_CNT, 1)
     e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
     e("s_cbranch_scc1", "7b")
     e("label", "8")
-    body(e, p, capture=True, loose=loose)
+    body(e, p, capture=True, loose=loose, own=own, group=group)
     epilogue(e, p)
+    if group:
+        e("s_barrier")
     return e.ins, p
 
 
-def loop_group_program(s, eq_rows, res, nw=4):
-    """The loose loop block for a workgroup of nw wavefronts that own the same 64 robots: wavefronts 0 and 1 take the
-    components LoopSplit gives them, the others only keep the barriers company. s33 = the wave's index; the other inputs as
-    program(..., loose=True). Returns (instructions, plan, split)."""
+def loop_group_program(s, eq_rows, res, nw=4, loose=True):
+    """The loop block (loose or general variant) for a workgroup of nw wavefronts that own the same 64 robots: each takes the
+    components LoopSplit gives it (a wavefront without one only keeps the barriers company). s33 = the wave's index; the
+    other inputs as program(...) with the fast start. Returns (instructions, plan, split)."""
     p = Plan(s, eq_rows)
     sp = LoopSplit(p, nw)
     e = Emit()
@@ -1411,7 +1419,7 @@ def loop_group_program(s, eq_rows, res, nw=4):
             e("s_cmp_lg_u32", "s%d" % S_LWAVE, w)
             e("s_cbranch_scc1", "48f")
         if w < sp.active:
-            ins, _ = program(s, eq_rows, res, loose=True, own=sp.own(w), group=True)
+            ins, _ = program(s, eq_rows, res, loose=loose, own=sp.own(w), group=True)
             e.ins.extend(ins)
         else:
             for _ in range(4):        # after the factorisation, twice in the capturing iteration (its stores over L), at the end

@@ -471,12 +471,9 @@ def emit_fast_route(E, name, s, P, TIMING, mark):
     E("      if (__all(LDSQ(%d) == T(1.0)))" % asmqp.LOOSE_FLAG)
     E("        BQP_%s_ASM_LOOSE4(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
       "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s, wv);" % (U, RHO_ARGS))
-    E("      else {")
-    E("        if (wv == 0u)")
-    E("        BQP_%s_ASM(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
-      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s);" % (U, RHO_ARGS))
-    E("        __syncthreads();   // (the shared blocks end behind a barrier themselves)")
-    E("      }")
+    E("      else")
+    E("        BQP_%s_ASM4(voff, ldsaddr, lane4, uni((unsigned long long)a.W), ssp, s_stride, s_iters, s_alpha, s_oma, s_sigma, s_rinveq, "
+      "uni((unsigned long long)a.x), uni((unsigned long long)a.y), uni((unsigned long long)a.z), 1u%s, wv);" % (U, RHO_ARGS))
     mark(5)
     E("      fail = (LDSQ(%d) == T(0.0)) ? 1 : 0;   // a zero pivot of the block's factorisation (qdldl.c:221-224)" % asmqp.FAC_MIN)
     E("      if (a.sol_x && a.sol_y && a.status && a.info && __all(fail == 0)) {")
@@ -573,14 +570,14 @@ def asm_macro(name, ins, plan, loose=False, group=None):
                ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in used_s]
         nv = [sum(1 for w_ in group.varw if w_ == w) for w in range(group.active)]
         nk_ = [sum(1 for w_ in group.kw if w_ == w) for w in range(group.active)]
-        out = ["// The LOOSE variant SHARED by the workgroup's wavefronts (asmqp.loop_group_program / LoopSplit): the QP's connected",
+        out = ["// The %s variant SHARED by the workgroup's wavefronts (asmqp.loop_group_program / LoopSplit): the QP's connected" % ("LOOSE" if loose else "GENERAL"),
                "// components are independent QPs, dealt out to the wavefronts (%s of %d variables, %s of %d KKT unknowns); they meet at"
                % (" + ".join(map(str, nv)), len(group.varw), " + ".join(map(str, nk_)), len(group.kw)),
                "// %d barriers, none inside the loop; same LDS layout, disjoint words, bit-identical"
                % (sum(t_[0] == "s_barrier" for t_ in ins) // group.nw),
                "// words. s%d = the wavefront's index; the other inputs as BQP_%s_ASM_LOOSE. %d instructions."
                % (asmqp.S_LWAVE, name.upper(), len(ins)),
-               "#define BQP_%s_ASM_LOOSE4(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast, rho0, rinv0, rhoeq, wave) asm volatile( \\" % name.upper()]
+               "#define BQP_%s_ASM%s4(voff, ldsaddr, lane4, ws, sblk, stride, iters, alpha, oma, sigma, rinveq, xi, yi, zi, fast, rho0, rinv0, rhoeq, wave) asm volatile( \\" % (name.upper(), "_LOOSE" if loose else "")]
         for t_ in ins:
             out.append('  "%s\\n" \\' % asmqp.fmt(t_))
         out.append('  : : "{v0}"(voff), "{v1}"(ldsaddr), "{v4}"(lane4), "{s[4:5]}"(ws), "{s[6:7]}"(sblk), "{s10}"(stride), '
@@ -715,6 +712,7 @@ def generate():
             ins, plan = asmqp.program(s, ASM_STRUCTURES[name], res)
             ins_loose, _ = asmqp.program(s, ASM_STRUCTURES[name], res, loose=True)
             ins_loose4, _, lsplit = asmqp.loop_group_program(s, ASM_STRUCTURES[name], res, ASM_GROUP_WAVES)
+            ins_gen4, _, _ = asmqp.loop_group_program(s, ASM_STRUCTURES[name], res, ASM_GROUP_WAVES, loose=False)
             assert plan.n_stream + len(plan.extra) <= ASM_RES_ITEM0
             plan.res = res
             assert plan.res.end <= ASM_STREAM_ITEMS
@@ -729,7 +727,7 @@ def generate():
             asm_hdr = "bqp_%s_asm.h" % name
             assert plan.ruiz.LW_END <= asmqp.LW_FLAGS
             files["gen/" + asm_hdr] = asm_macro(name, ins, plan) + asm_macro(name, ins_loose, plan, loose=True) + \
-                asm_macro(name, ins_loose4, plan, loose=True, group=lsplit) + \
+                asm_macro(name, ins_loose4, plan, loose=True, group=lsplit) + asm_macro(name, ins_gen4, plan, loose=False, group=lsplit) + \
                 ruiz_macro(name, rins, plan.ruiz) + \
                 ruiz_macro(name, rsins, plan.ruiz, rs=True) + ruiz_macro(name, rs4ins, plan.ruiz, rs=True, group=True) + \
                 res_macro(name, resins) + res_macro(name, res4ins, group=True) + glue_macro(name, glins) + glue_macro(name, gl4ins, group=True) + \

@@ -634,3 +634,40 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
     assert nbar == 4
     assert np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
     assert max(counts) < 0.56 * n1[0] and counts[2] < 0.2 * n1[0] and counts[3] < 0.2 * n1[0], (counts, n1)
+
+
+@pytest.mark.parametrize("iters", [0, 2])
+def test_general_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, iters):
+    """loop_group_program(loose=False): the GENERAL variant of the loop block (finite bounds: l, u, 1/rho, rho of every inequality
+    row streamed, clipping) split by the QP's components over the wavefronts like the loose one -- every wavefront lands its own
+    items of the stream (a landing map in the scheduler). Bit-identical LDS words, no race, the same four barriers."""
+    from robobee3d_amd import codegen_qp
+    asmqp, one, p = prog
+    s = p.s
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
+    grp, _, sp = asmqp.loop_group_program(s, eq, res, 4, loose=False)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(21)
+    d = _data(p, 2, eq)
+    gen = [i for i in range(p.m) if i not in set(eq)]
+    A = f(rng.normal(size=s.nnzA))
+    Pv = f(np.abs(rng.normal(size=s.nnzP)) + 0.5)
+    S = np.zeros(res.end, np.float32)
+    for q, (what, i) in enumerate(p.stream + p.extra):
+        S[q] = {"rinv": d["rinv"], "l": d["l"], "u": d["u"], "rho": d["rho"], "q": d["q"]}[what][i]
+    S[res.it_A:res.it_A + s.nnzA] = A
+    for j, it in res.it_p.items():
+        S[it] = Pv[res.pidx[j]]
+    arrs = [d[k].astype(np.float32) for k in ("x", "y", "z")]
+    consts = (1.6, 0.5, float(np.float32(0.01)))
+    regs = lambda: [(asmqp.S_XI, arrs[0].copy()), (asmqp.S_YI, arrs[1].copy()), (asmqp.S_ZI, arrs[2].copy())]
+    words = lambda lds: np.concatenate([lds[p.LW_X:p.LW_X + p.n], lds[p.LW_Y:p.LW_Y + p.m], lds[p.LW_Z:p.LW_Z + len(gen)],
+                                        lds[p.LW_XP:p.LW_XP + p.n], lds[p.LW_DY:p.LW_DY + p.m], lds[asmqp.FAC_MIN:asmqp.FAC_MIN + 1]])
+    n1 = []
+    lds1 = asmqp.simulate(one, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, regions=regs(),
+                          sgpr={asmqp.S_FAST: 1}, count=n1)
+    lds4, counts, nbar = asmqp.simulate_group(grp, 4, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, asmqp.S_LWAVE,
+                                              regions=regs(), sgpr={asmqp.S_FAST: 1})
+    assert nbar == 4 and np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
+    assert max(counts) < 0.6 * n1[0], (counts, n1)

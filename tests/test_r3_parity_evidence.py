@@ -50,8 +50,12 @@ def test_p5f_fp32_assembly_route_against_the_table_oracle(torch_cuda, margin, ul
     mpc.y.copy_(torch.as_tensor(y0).cuda())
     st, perm = mpc.st, mpc.qp.s.perm
     if ulim is not None:
-        mpc.l[-10:] = -ulim          # the last N rows of the identity block: umin <= u_k <= umax
-        mpc.u[-10:] = ulim
+        # the box rows of the N inputs: umin <= u_k <= umax (the solver's labelling groups the QP's components: the box row of
+        # the script's variable j is row 77 + its place in st["var_order"])
+        rows = [77 + t for t, j in enumerate(st["var_order"]) if j >= 77]
+        assert len(rows) == 10
+        mpc.l[rows] = -ulim
+        mpc.u[rows] = ulim
     f = lambda t: t.cpu().numpy()
     z32 = lambda r: np.zeros((r, B), np.float32)
     x, y, z, E = z32(87), z32(164), z32(164), np.ones((164, B), np.float32)
