@@ -588,7 +588,7 @@ def test_ruiz_block_shared_by_four_waves_is_bit_identical_to_one_wave(passes):
     assert max(counts) < 0.42 * n1[0], (counts, n1)
 
 
-@pytest.mark.parametrize("iters,zero_y", [(0, True), (1, True), (3, True), (3, False)])
+@pytest.mark.parametrize("iters,zero_y", [(0, True), (1, True), (3, True), (3, False), (2, "mixed")])
 def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, iters, zero_y):
     """asmqp.loop_group_program: the QP's connected components (two chains of the horizon and five small pieces for planar
     p5f) are independent QPs; the wavefronts of the workgroup run the loose loop block each on its own components, side by
@@ -621,19 +621,29 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
         S[it] = Pv[res.pidx[j]]
     if zero_y:
         d["y"][gen] = 0.0
+    if zero_y == "mixed":
+        # multipliers of wavefront 1's loose rows only: wavefront 1 takes the general-loose bodies, the others their y0 bodies --
+        # every path through the block meets the same four barriers
+        for i in gen:
+            if sp.roww[i] == 1:
+                d["y"][i] = 0.25
     arrs = [d[k].astype(np.float32) for k in ("x", "y", "z")]
     consts = (1.6, 0.5, float(np.float32(0.01)))
     words = lambda lds: np.concatenate([lds[p.LW_X:p.LW_X + p.n], lds[p.LW_Y:p.LW_Y + p.m], lds[p.LW_Z:p.LW_Z + len(gen)],
                                         lds[p.LW_XP:p.LW_XP + p.n], lds[p.LW_DY:p.LW_DY + p.m], lds[asmqp.FAC_MIN:asmqp.FAC_MIN + 1]])
     n1 = []
     regs = lambda: [(asmqp.S_XI, arrs[0].copy()), (asmqp.S_YI, arrs[1].copy()), (asmqp.S_ZI, arrs[2].copy())]
+    if zero_y == "mixed":
+        # (the one-wave block decides for all rows at once: with any multiplier set it runs the general-loose bodies, whose words
+        # are the y0 bodies' bit for bit -- test_loose_loop_variant_is_bit_identical_to_the_general_loop)
+        pass
     lds1 = asmqp.simulate(one, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, regions=regs(),
                           sgpr={asmqp.S_FAST: 1}, count=n1)
     lds4, counts, nbar = asmqp.simulate_group(grp, 4, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, asmqp.S_LWAVE,
                                               regions=regs(), sgpr={asmqp.S_FAST: 1})
     assert nbar == 4
     assert np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
-    assert max(counts) < 0.56 * n1[0] and counts[2] < 0.2 * n1[0] and counts[3] < 0.2 * n1[0], (counts, n1)
+    assert max(counts) < 0.6 * n1[0] and counts[2] < 0.2 * n1[0] and counts[3] < 0.2 * n1[0], (counts, n1)
 
 
 @pytest.mark.parametrize("iters", [0, 2])
