@@ -259,9 +259,10 @@ RING_AHEAD = int(os.environ.get("UMPC_QP_RING_AHEAD", "20"))   # ops of look-ahe
 class Own:
     """Which variables, rows and KKT unknowns a wavefront's copy of the loop block works on (LoopSplit); ALL = one wave, all."""
 
-    def __init__(self, varw=None, roww=None, kw=None, wave=0):
+    def __init__(self, varw=None, roww=None, kw=None, wave=0, lhome=None):
         self.varw, self.roww, self.kw, self.wave = varw, roww, kw, wave
         self.all = varw is None
+        self.lhome = lhome or {}          # L entry (CSC index) -> VGPR that holds -L during the iterations (LoopSplit.own)
 
     def var(self, j):
         return self.all or self.varw[j] == self.wave
@@ -278,6 +279,7 @@ class Own:
 
 
 ALL = Own()
+L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
 
 
 class LoopSplit:
@@ -290,6 +292,7 @@ class LoopSplit:
     def __init__(self, p, nw=4):
         from . import qpstruct
         s = p.s
+        self.p = p
         vc, rc = qpstruct.qp_components(s.n, s.m, list(s.tables["A_p"]), list(s.tables["A_i"]))
         self.nw = nw
         ncomp = max(vc) + 1
@@ -315,7 +318,14 @@ class LoopSplit:
             assert self.kw[r_] == self.kw[c]
 
     def own(self, wave):
-        return Own(self.varw, self.roww, self.kw, wave)
+        """... and the W registers of the OTHER wavefronts' unknowns, which this wavefront's copy of the block never touches, hold
+        its solve entries of L during the iterations: each is used twice per iteration (forward, backward solve), and an LDS
+        instruction costs a lone wave ~6 ns whatever its width"""
+        p = self.p
+        pool = sorted(p.wreg[k] for k in p.nonleaf if self.kw[k] != wave)
+        mine = [j for (r_, c, j) in p.solve_entries if self.kw[c] == wave]
+        lhome = dict(zip(mine, pool)) if L_HOMES else {}
+        return Own(self.varw, self.roww, self.kw, wave, lhome)
 
 
 class Sched:
@@ -703,9 +713,10 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     if not rhs:                  # (the definitions above are needed below; the operations are not)
         del ops[rhs_ops_start:]
     # ---- solves over the non-leaf unknowns (qdldl.c:250-293)
+    lsrc_ = lambda j: ("V", own.lhome[j]) if j in own.lhome else ("L", p.lpos[j])
     for (r_, c, j) in p.solve_entries:
         if own.k(c):
-            op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
+            op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
     kof = {reg: k for k, reg in p.wreg.items() if own.k(k)}
     kdone = set()
     for reg in sorted(kof) if pack else [p.wreg[k] for k in p.nonleaf if own.k(k)]:      # (by register when pairing: a pair is visited once)
@@ -720,7 +731,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
     for (r_, c, j) in reversed(p.solve_entries):
         if own.k(c):
-            op([("L", p.lpos[j])], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+            op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
     if capture and group:
         # x_prev and delta_y are written over the L words, ANY wave's: nobody writes them before everybody's last solve is done
         op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
@@ -1290,6 +1301,25 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     prologue_tail(e, p, loose, own=own)
 
 
+def l_homes_fill(e, p, own):
+    """-L of the wave's solve entries: LDS (where the factorisation left them) -> their VGPR homes, once per block"""
+    if not own.lhome:
+        return
+    quads = sorted(set(p.lpos[j] >> 2 for j in own.lhome))
+    byword = {p.lpos[j]: reg for j, reg in own.lhome.items()}
+    e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")         # (the preloads into W registers have landed: the ring registers are free)
+    for g in range(0, len(quads), NRING):
+        grp = quads[g:g + NRING]
+        for q, qd in enumerate(grp):
+            base, off = lds_addr(4 * qd)
+            e("ds_read_b128", "v[%d:%d]" % (p.V_RING + 4 * q, p.V_RING + 4 * q + 3), base, off)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for q, qd in enumerate(grp):
+            for h in range(4):
+                if 4 * qd + h in byword:
+                    e("v_mov_b32", "v%d" % byword[4 * qd + h], "v%d" % (p.V_RING + 4 * q + h))
+
+
 def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
     """s11 = number of non-capturing iterations (>= 0); one capturing iteration follows them.
     res: a ResPlan -> the block also holds the fast start (prologue_fast), taken when s30 != 0
@@ -1334,6 +1364,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
                 e("v_readfirstlane_b32", "s%d" % S_DLEAF, "v%d" % v_or)
             y0_fill(e, p, own)
             prologue_tail(e, p, True, p.y0_home, own)
+            l_homes_fill(e, p, own)
             _lstamp(e, own, 5)
             if not Y0_FUSE:
                 loop(y0=True)
@@ -1362,6 +1393,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
             e("s_branch", "29f")
             e("label", "20")
             prologue_tail(e, p, True, own=own)
+            l_homes_fill(e, p, own)
             _lstamp(e, own, 5)
             loop()
             e("label", "29")
@@ -1381,6 +1413,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
             return e.ins, p
     elif group:
         prologue_fast(e, p, res, own=own, group=True)          # (a shared block always factorises itself: the fast start)
+        l_homes_fill(e, p, own)
     else:
         if res is not None:
             e("s_cmp_lg_u32", "s%d" % S_FAST, 0)
