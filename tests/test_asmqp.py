@@ -633,10 +633,8 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
                                         lds[p.LW_XP:p.LW_XP + p.n], lds[p.LW_DY:p.LW_DY + p.m], lds[asmqp.FAC_MIN:asmqp.FAC_MIN + 1]])
     n1 = []
     regs = lambda: [(asmqp.S_XI, arrs[0].copy()), (asmqp.S_YI, arrs[1].copy()), (asmqp.S_ZI, arrs[2].copy())]
-    if zero_y == "mixed":
-        # (the one-wave block decides for all rows at once: with any multiplier set it runs the general-loose bodies, whose words
-        # are the y0 bodies' bit for bit -- test_loose_loop_variant_is_bit_identical_to_the_general_loop)
-        pass
+    # ("mixed": the one-wave block decides for all rows at once -- with any multiplier set it runs the general-loose bodies, whose
+    # words are the y0 bodies' bit for bit: test_loose_loop_variant_is_bit_identical_to_the_general_loop)
     lds1 = asmqp.simulate(one, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, regions=regs(),
                           sgpr={asmqp.S_FAST: 1}, count=n1)
     lds4, counts, nbar = asmqp.simulate_group(grp, 4, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, asmqp.S_LWAVE,
