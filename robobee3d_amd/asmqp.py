@@ -1037,12 +1037,12 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
 
             def fx2(g, j=j):
                 xw = p.LW_X + j
-                t = TPK(j // 4, 4) if xw in xc1 else TPK(j // 4, 6) if xw in xc2 else TPK(j // 2, 6)
+                t = TPK(xw // 4, 4) if xw in xc1 else TPK(xw // 4, 6) if xw in xc2 else TPK(j // 2, 6)     # (a couple = one float4 of x words)
                 wr = p.wreg[p.pinv[j]]
                 _pk(e, "v_pk_mul_f32", t, [SB(S_OMA, S_OMA % 2), VP(g[0])])
                 _pk(e, "v_pk_fma_f32", t, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(t)])
                 if xw in xc2:
-                    sc.lds_write4(xw - 2, TPK(j // 4, 4))
+                    sc.lds_write4(xw - 2, TPK(xw // 4, 4))
                 elif xw not in xc1:
                     sc.lds_write2(xw, t)
                 if fuse:          # next rhs: sigma x_new - q
@@ -1255,8 +1255,11 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     v_fmin = p.V_TT + N_TT - 1
     e("v_mov_b32", "v%d" % v_fmin, 1.0)
     e("s_waitcnt", "vmcnt(0)")
-    factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING)),
-                list(range(p.V_LAND, p.V_LAND + p.NLAND)), v_fmin, own)
+    # (temporaries: the factorisation keeps <= 8 partial rows alive; the rest of the pool pins L entries that a later row
+    # multiplies again)
+    assert p.V_RING - pool0 >= 30
+    factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING - 12)),
+                list(range(p.V_LAND, p.V_LAND + p.NLAND)) + list(range(p.V_RING - 12, p.V_RING)), v_fmin, own)
     _lstamp(e, own, 2)
     base, off = lds_addr(FAC_MIN)
     if group:
@@ -1681,14 +1684,14 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
         elif m[0] == "v" or m.startswith("ds_") or m.startswith("global_"):
             used = set().union(*[regs_of(x) for x in t[1:]])
             check(used)
-            if m != "ds_read_b128":           # (a word fetched from LDS counts as READ when its register is consumed: a
+            if m not in ("ds_read_b128", "ds_read_b32"):   # (a word fetched from LDS counts as READ when its register is consumed: a
                 wr_only = regs_of(t[1]) if m in ("global_load_dword", "v_mov_b32", "v_accvgpr_read_b32") else set()
                 for r_ in wr_only:            # quad may carry a neighbour's words that this wave never looks at; a register
                     src_word.pop(r_, None)    # that is overwritten no longer stands for the word)
                 for r_ in used - wr_only:
                     if r_ in src_word:
                         log_r.add(src_word[r_])
-            if m == "ds_read_b128":
+            if m in ("ds_read_b128", "ds_read_b32"):
                 pend["lgkmcnt"].append(regs_of(t[1]))
             elif m.startswith("ds_write") or m == "ds_min_f32":
                 pend["lgkmcnt"].append(set())
@@ -1793,6 +1796,10 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
             for h in range(4):
                 V[lo + h] = f32bits(float(lds[w + h]))
                 src_word[("v", lo + h)] = w + h
+        elif m == "ds_read_b32":
+            w = ldsword(t[2], t[3])
+            V[int(t[1][1:])] = f32bits(float(lds[w]))
+            src_word[("v", int(t[1][1:]))] = w
         elif m == "ds_write_b128":
             lo = int(t[2][2:t[2].index(":")])
             w = ldsword(t[1], t[3])
@@ -2644,25 +2651,28 @@ def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
     stamp(5)
     if nw > 1:
         # the partial norms of every wave -> LDS (words that only the loop used), barrier, wavefront 0 folds them (max)
+        # (exchange words: what nothing uses after the loop -- the tail of the L block behind delta_y and the words behind z,
+        # which held constants of the loop)
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
-        xw = lambda w: RES_XCHG + 8 * w
-        assert PRI % 2 == 0 and (PRI, NZ, NAX, DUA, NQ, NATY, NPX, CINV) == tuple(range(PRI, PRI + 8)) and xw(nw) <= LW_FLAGS
-        for h in (0, 4):
-            base, off = lds_addr(xw(own.wave) + h)
-            e("ds_write_b128", base, "v[%d:%d]" % (PRI + h, PRI + h + 3), off)
+        parts = (PRI, NZ, DUA, NQ, NATY, NPX)
+        free_w = list(range(ap.LW_DY + m, ap.LW_X)) + list(range(ap.LW_END, LW_FLAGS))
+        assert len(free_w) >= len(parts) * nw, (len(free_w), ap.LW_DY + m, ap.LW_X, ap.LW_END)
+        xw = lambda w: free_w[len(parts) * w:len(parts) * (w + 1)]
+        for q, reg in enumerate(parts):
+            base, off = lds_addr(xw(own.wave)[q])
+            e("ds_write_b32", base, v(reg), off)
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_barrier")
         if own.wave != 0:
             e("s_barrier")
             return e.ins, R
         for w in range(1, nw):
-            for h in (0, 4):
-                base, off = lds_addr(xw(w) + h)
-                e("ds_read_b128", "v[%d:%d]" % (R.V_RING + h, R.V_RING + h + 3), base, off)
+            for q, reg in enumerate(parts):
+                base, off = lds_addr(xw(w)[q])
+                e("ds_read_b32", v(R.V_RING + q), base, off)
             e("s_waitcnt", "lgkmcnt(0)")
-            for q, reg in enumerate((PRI, NZ, None, DUA, NQ, NATY, NPX)):
-                if reg is not None:
-                    e("v_max_f32", v(reg), v(reg), v(R.V_RING + q))
+            for q, reg in enumerate(parts):
+                e("v_max_f32", v(reg), v(reg), v(R.V_RING + q))
     # ---- termination test at the strict tolerances (osqp.c:524-573), flag, status and info rows
     e("v_mul_f32", v(DUA), v(CINV), v(DUA))
     e("v_max_f32", v(NQ), v(NQ), v(NATY))
@@ -2729,7 +2739,6 @@ def res_group_program(s, eq_rows, ap, res, nw=4):
 
 
 S_XWAVE = 41                       # res_group_program: s41 = the wave's index in its workgroup
-RES_XCHG = 604                     # LDS words 604..635: the waves' partial norms (8 per wave; only the loop used these words)
 
 
 # ---------------------------------------------------------------------------

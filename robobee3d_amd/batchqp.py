@@ -136,6 +136,13 @@ class BatchQP:
 qp_components = qpstruct.qp_components
 
 
+def p5f_analysis(N=10):
+    """(p5f_structure(N, grouped=True), its qpstruct.analyse_qp): what PlanarP5fMPC and the build-time specialisation
+    (codegen_qp) both use"""
+    st = p5f_structure(N, grouped=True)
+    return st, qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+
+
 def p5f_structure(N=10, grouped=False):
     """The QP of planar/mpc_osqp_p5f.py:87-147: x = (y(0..N) [7 each], u(0..N-1)); rows = (N+1)*7 dynamics
     equalities + identity box rows. Returns dict(n, m, A_p, A_i, P_cols, cst, src, Pv, q, l, u) where

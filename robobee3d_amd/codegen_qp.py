@@ -27,8 +27,7 @@ def fnv1a(words):
 
 def builtin_structures():
     out = []
-    st = batchqp.p5f_structure(10, grouped=True)       # (the order PlanarP5fMPC uses: components contiguous)
-    out.append(("p5f10", qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])))
+    out.append(("p5f10", batchqp.p5f_analysis(10)[1]))   # (the labelling and elimination order PlanarP5fMPC uses)
     st = batchqp.v1_structure(3)
     out.append(("v1n3", qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])))
     st = batchqp.uprightmpc2_structure(5)

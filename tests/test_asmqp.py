@@ -9,8 +9,7 @@ import pytest
 @pytest.fixture(scope="module")
 def prog():
     from robobee3d_amd import asmqp, batchqp, codegen_qp, qpstruct
-    st = batchqp.p5f_structure(10, grouped=True)
-    s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    st, s = batchqp.p5f_analysis(10)
     eq = codegen_qp.ASM_STRUCTURES["p5f10"]
     # (the block codegen_qp emits: both starts -- hand-off rows, s30 == 0, and the in-block factorisation, s30 != 0)
     ins, p = asmqp.program(s, eq, asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0))
@@ -216,8 +215,7 @@ def _ruiz_numpy(p, P, A, q, passes):
 @pytest.mark.parametrize("passes", [1, 10])
 def test_generated_p5f_ruiz_block_matches_numpy(passes):
     from robobee3d_amd import asmqp, batchqp, qpstruct
-    st = batchqp.p5f_structure(10, grouped=True)
-    s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    st, s = batchqp.p5f_analysis(10)
     ins, p = asmqp.ruiz_program(s)
     rng = np.random.default_rng(passes)
     f = lambda a: a.astype(np.float32)
@@ -238,8 +236,7 @@ def test_generated_p5f_ruiz_block_matches_numpy(passes):
 
 def _p5f():
     from robobee3d_amd import asmqp, batchqp, codegen_qp, qpstruct
-    st = batchqp.p5f_structure(10, grouped=True)
-    s = qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    st, s = batchqp.p5f_analysis(10)
     eq = codegen_qp.ASM_STRUCTURES["p5f10"]
     return asmqp, s, eq, asmqp.Plan(s, eq), asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
 
