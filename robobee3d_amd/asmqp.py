@@ -2459,13 +2459,14 @@ class _ResRegs:
 def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
     """ap: the loop's Plan (LDS words of x, y, z), res: the ResPlan. v0 = 4*robot, v1 = lane LDS address, v4 = 4*lane,
     s[6:7] = the wave's stream block, s10 = 4*B.
-    own, nw: the copy of the block one of nw wavefronts runs on ITS components (LoopSplit: A x of a row and A' y of a column
-    involve one component only, so every accumulation is the one-wave block's); the six partial norms (max: exact) meet in
-    LDS between two barriers and wavefront 0 does the termination test."""
+    own, nw: the copy of the block one of nw wavefronts runs on ITS rows (pass 1: A x of a row, accumulated over the columns in
+    the one-wave block's order) and ITS columns (pass 2: A' y of a column, likewise) -- any rows, any columns: x and y are
+    in LDS for everybody, so the split is an even one (own.row / own.var: ResSplit); the six partial norms (max: exact)
+    meet in LDS between two barriers and wavefront 0 does the termination test."""
     n, m = s.n, s.m
     R = _ResRegs(m)
     A_p_ = res.A_p
-    own_a = [k for j in range(n) if own.var(j) for k in range(A_p_[j], A_p_[j + 1])]
+    own_a = [k for j in range(n) for k in range(A_p_[j], A_p_[j + 1]) if own.var(j) or own.row(res.A_i[k])]
     land = [it for it in range(res.it_rows, res.it_c + 1)
             if any(it == res.it_ev[i] or it == res.it_ls.get(i) for i in range(m) if own.row(i)) or
             any(it in (res.it_d[j], res.it_q[j], res.it_p.get(j)) for j in range(n) if own.var(j))]
@@ -2565,11 +2566,10 @@ def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
     # ---- pass 1: A x by columns into the row accumulators
     touched = set()
     for j in range(n):
-        if not own.var(j):
-            continue
         for q in range(res.A_p[j], res.A_p[j + 1]):
             i = res.A_i[q]
-            assert own.row(i)
+            if not own.row(i):
+                continue
 
             def f(g, i=i, first=i not in touched):
                 if first:
@@ -2608,7 +2608,8 @@ def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
     op([], lambda g: e("v_max_f32", v(NZ), v(NZ), v(NAX)))            # prim_rel; NAX is a temporary from here on
     op([], lambda g: stamp(3))
     # ---- pass 2: y into the accumulator registers, then columns: A' y, P x, q
-    for i in sorted(touched):
+    yrows = sorted(set(res.A_i[q] for j in range(n) if own.var(j) for q in range(res.A_p[j], res.A_p[j + 1])))
+    for i in yrows:
         op([("L", ap.LW_Y + i)], lambda g, i=i: e("v_mov_b32", ACC(i), v(g[0])))
     op([], lambda g: stamp(4))
     for j in range(n):
@@ -2717,20 +2718,17 @@ def res_program(s, eq_rows, ap, res, own=ALL, nw=1):
 
 
 def res_group_program(s, eq_rows, ap, res, nw=4):
-    """The residual block for a workgroup of nw wavefronts that own the same 64 robots, each on the components LoopSplit
-    gives it; s41 = the wavefront's index, the other inputs as res_program. Two barriers."""
-    sp = LoopSplit(ap, nw)
+    """The residual block for a workgroup of nw wavefronts that own the same 64 robots, each a quarter of the rows and a
+    quarter of the columns; s41 = the wavefront's index, the other inputs as res_program. Two barriers."""
     e = Emit()
     for w in range(nw):
         if w < nw - 1:
             e("s_cmp_lg_u32", "s%d" % S_XWAVE, w)
             e("s_cbranch_scc1", "48f")
-        if w < sp.active:
-            ins, R = res_program(s, eq_rows, ap, res, sp.own(w), nw)
-            e.ins.extend(ins)
-        else:
-            e("s_barrier")
-            e("s_barrier")
+        # an even split: rows i * nw // m == w for pass 1 and the row phase, columns j * nw // n == w for pass 2
+        own = Own([j * nw // s.n for j in range(s.n)], [i * nw // s.m for i in range(s.m)], None, w)
+        ins, R = res_program(s, eq_rows, ap, res, own, nw)
+        e.ins.extend(ins)
         if w < nw - 1:
             e("s_branch", "49f")
             e("label", "48")

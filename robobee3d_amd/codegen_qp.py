@@ -623,9 +623,9 @@ def res_macro(name, ins, group=False):
            "// s[54:55] = Eprev rows (E of this solve is stored there)",
            "#define BQP_%s_RES_ASM(voff, ldsaddr, lane4, sblk, stride, xo, yo, zo, sxo, syo, sto, ino, epsa, epsr, maxit, epo) asm volatile( \\" % name.upper()]
     if group:
-        out = ["// The residual block SHARED by the workgroup's wavefronts (asmqp.res_group_program): each on the components LoopSplit gives",
-               "// it (A x of a row, A' y of a column stay inside a component: the same accumulations as one wavefront), the partial norms",
-               "// folded by wavefront 0 between two barriers; s%d = the wavefront's index. %d instructions." % (asmqp.S_XWAVE, len(ins)),
+        out = ["// The residual block SHARED by the workgroup's wavefronts (asmqp.res_group_program): each a quarter of the rows (A x, the row",
+               "// norms) and a quarter of the columns (A' y, P x, q) -- every accumulation in the one-wavefront block's order --, the partial",
+               "// norms folded by wavefront 0 between two barriers; s%d = the wavefront's index. %d instructions." % (asmqp.S_XWAVE, len(ins)),
                "#define BQP_%s_RES4_ASM(voff, ldsaddr, lane4, sblk, stride, xo, yo, zo, sxo, syo, sto, ino, epsa, epsr, maxit, epo, wave) asm volatile( \\" % name.upper()]
     for t_ in ins:
         out.append('  "%s\\n" \\' % asmqp.fmt(t_))
