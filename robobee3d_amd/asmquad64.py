@@ -49,6 +49,15 @@ AQ, AL = 0, 32                         # AGPRs: q (16 words), l (12 words)
 NTAB = 196                             # table row length (dwords): the 194 solve instructions + padding to whole dwordx4 loads
 ZERO_WORD = 319                        # this lane's LDS word that holds 0.0
 S_L0, S_L1, S_L2, S_EXEC, S_TAB = 30, 32, 34, 36, 8
+# Coefficients of the first NAC solve instructions live in AGPRs during the loop instead of being fetched from LDS every
+# iteration: a56..a167 hold nothing while the section runs (the one-lane block's 1/D copies, dead after the first iteration;
+# q and l took a0..a55, the right-hand-side homes a168.. stay), and a register is per-lane storage by nature -- lane l's
+# a[AC0 + 2 n] is ITS coefficient of instruction n, no per-lane address needed. Two v_accvgpr_read instead of a per-lane
+# ds_read_b64 plus a quarter of an address quad (an LDS instruction costs a lone wave ~6 ns).
+import os as _os
+NAC = int(_os.environ.get("UMPC_ASM64_QUAD_NAC", "56"))
+AC0 = 56
+assert NAC % 4 == 0 and AC0 + 2 * NAC <= 168
 
 
 def QW(ix):
@@ -202,6 +211,23 @@ def entry(e, plan, s):
             e("ds_write_b128", b_, "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), off)
     e("s_waitcnt", "lgkmcnt(0)")
     e("s_nop", 4)
+    # ---- the coefficients of solve instructions 0 .. NAC-1 -> AGPRs (through the idle W words: four address quads at a time)
+    for g0 in range(0, NAC // 4, 4):
+        gqs = list(range(g0, min(NAC // 4, g0 + 4)))
+        for k, gq in enumerate(gqs):
+            b_, off, _ = g.lds_addr(TAB_WORD + 2 * gq)
+            e("ds_read_b128", "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), b_, off)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for k, gq in enumerate(gqs):
+            for h in range(4):
+                e("ds_read_b64", vp(STAGE + 16 + 8 * k + 2 * h), v(STAGE + 4 * k + h), 0)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for k, gq in enumerate(gqs):
+            for h in range(4):
+                n_ = 4 * gq + h
+                e("v_accvgpr_write_b32", "a%d" % (AC0 + 2 * n_), v(STAGE + 16 + 8 * k + 2 * h))
+                e("v_accvgpr_write_b32", "a%d" % (AC0 + 2 * n_ + 1), v(STAGE + 16 + 8 * k + 2 * h + 1))
+    e("s_nop", 1)
 
 
 def body(e, plan, s, capture):
@@ -237,6 +263,8 @@ def body(e, plan, s, capture):
 
     def aquad(gq):
         """the four addresses of solve instructions 4 gq .. 4 gq + 3"""
+        if 4 * gq + 3 < NAC:
+            return                                      # (their coefficients are in AGPRs)
         if 4 * gq < nops:
             b_, off, _ = g.lds_addr(TAB_WORD + 2 * gq)
             r = T_AQ[gq % 3]
@@ -249,6 +277,10 @@ def body(e, plan, s, capture):
             q = seq[opsidx[n]][1]
             if n % 4 == 0:
                 aquad(n // 4 + 2)                       # two quads ahead of the one about to be used
+            if q < NAC:
+                e("v_accvgpr_read_b32", v(T_COEF[n % NRING]), "a%d" % (AC0 + 2 * q))
+                e("v_accvgpr_read_b32", v(T_COEF[n % NRING] + 1), "a%d" % (AC0 + 2 * q + 1))
+                return
             if aq_seq[q // 4] is not None:
                 wait_for(aq_seq[q // 4])
                 aq_seq[q // 4] = None                   # (arrived: later reads of this quad need no wait)
@@ -292,7 +324,7 @@ def body(e, plan, s, capture):
                 e("v_mov_b32_dpp", v(T_SRC[slot] + 1), v(sr + 1), qperm(ins["perm"]))
                 cached[slot] = key
                 src = T_SRC[slot]
-        if n % 2 == 0 or waited_co[0] < n:          # one wait per two coefficient reads (they return in order)
+        if n in co_seq and (n % 2 == 0 or waited_co[0] < n):    # one wait per two coefficient reads (they return in order)
             upto = n + 1 if n + 1 in co_seq else n
             wait_for(co_seq[upto])
             waited_co[0] = upto
