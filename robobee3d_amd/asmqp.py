@@ -2059,6 +2059,7 @@ S_AV, S_PV, S_QV = 4, 6, 8          # s[4:5] Av rows, s[6:7] Pv rows, s[8:9] q r
 S_RSB, V_RLANE = 24, 210           # Ruiz block with a residual stream: s[24:25] = the wave's stream block, v210 = 4*lane
 S_RMIN, S_RMAX = 20, 21            # 1e-4, 1e4 (float bits, set by the block)
 RUIZ_STAMPS = os.environ.get("UMPC_QP_RUIZ_STAMPS") == "1"     # (diagnostics: see ruiz_program)
+RUIZ_HOMES = os.environ.get("UMPC_QP_RUIZ_HOMES", "1") == "1"   # (A/B switch: ruiz_program, shared blocks)
 LOOP_STAMPS = os.environ.get("UMPC_QP_LOOP_STAMPS") == "1"     # (diagnostics: see program(); the residual block copies the items)
 STAMP_ITEM0 = 2040                 # spare items at the end of a wave's stream block (codegen_qp.ASM_STREAM_ITEMS = 2048)
 
@@ -2078,6 +2079,16 @@ def ruiz_program(s, res=None, split=None, wave=0):
     aq_set = set(aq)
     pk = [p.pidx[j] for j in cols if p.pidx[j] >= 0]                              # own entries of P, increasing
     assert aq == sorted(aq) and pk == sorted(pk)
+    # A wavefront of a shared block touches a quarter of the rows: the Et registers of the others hold ITS entries of A and of
+    # D across the passes (RA, RD) -- no LDS round trip per pass for them (an LDS instruction costs a lone wave ~6 ns), and
+    # none at all: nothing downstream of a shared block reads A or D from LDS (the factorisation and the residual block take
+    # them from the residual stream). RUIZ_HOMES=0: the LDS form (A/B switch).
+    RA, RD = {}, {}
+    if sp is not None and res is not None and RUIZ_HOMES:
+        idle = [p.V_ET + i for i in range(m) if wave not in sp.touch[i]]
+        assert len(idle) >= len(aq) + len(cols), (len(idle), len(aq), len(cols))
+        RA = dict(zip(aq, idle))
+        RD = dict(zip(cols, idle[len(aq):]))
     e = Emit()
     v = lambda r: "v%d" % r
     T = lambda q: p.V_TT + q
@@ -2148,15 +2159,20 @@ def ruiz_program(s, res=None, split=None, wave=0):
     e("s_mov_b32", sMAX, f32bits(RZ_MAX))
     load_rows(S_PV, pk, lambda q_: "a%d" % (p.A_P + pk[q_]))
     load_rows(S_QV, cols, lambda q_: "a%d" % (p.A_Q + cols[q_]))
-    for g in range(0, len(aq), m):
-        chunk = aq[g:g + m]
-        load_rows(S_AV, chunk, lambda q_: v(p.V_ET + q_))
-        e("s_waitcnt", "vmcnt(0)")
-        for q_, k in enumerate(chunk):
-            base, off = lds_addr(p.LW_A + k)
-            e("ds_write_b32", base, v(p.V_ET + q_), off)
+    if RA:
+        load_rows(S_AV, aq, lambda q_: v(RA[aq[q_]]))
+    else:
+        for g in range(0, len(aq), m):
+            chunk = aq[g:g + m]
+            load_rows(S_AV, chunk, lambda q_: v(p.V_ET + q_))
+            e("s_waitcnt", "vmcnt(0)")
+            for q_, k in enumerate(chunk):
+                base, off = lds_addr(p.LW_A + k)
+                e("ds_write_b32", base, v(p.V_ET + q_), off)
     e("v_mov_b32", v(T(13)), 1.0)                                  # c
-    for w in [p.LW_D + j for j in cols] + [p.LW_EV + i for i in rows_own]:
+    for j in RD:
+        e("v_mov_b32", v(RD[j]), 1.0)
+    for w in [p.LW_D + j for j in cols if j not in RD] + [p.LW_EV + i for i in rows_own]:
         base, off = lds_addr(w)
         e("ds_write_b32", base, v(T(13)), off)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
@@ -2188,7 +2204,7 @@ def ruiz_program(s, res=None, split=None, wave=0):
             def f(g, i=i, first=i not in touched):
                 e("v_max_f32", v(T(0)), v(T(0)), ab(v(g[0])))
                 e("v_max_f32", ET(i), ab(v(g[0])) if first else ET(i), ab(v(g[0])))
-            op([("L", p.LW_A + q)], f)
+            op([("V", RA[q]) if q in RA else ("L", p.LW_A + q)], f)
             touched.add(i)
 
         def fin(g, j=j):
@@ -2232,6 +2248,10 @@ def ruiz_program(s, res=None, split=None, wave=0):
             op([("A", p.A_P + p.pidx[j])], fp)
         for q in range(p.A_p[j], p.A_p[j + 1]):
             def fa(g, q=q, i=p.A_i[q]):
+                if q in RA:                   # in place, in its register home
+                    e("v_mul_f32", v(RA[q]), v(RA[q]), ET(i))
+                    e("v_mul_f32", v(RA[q]), v(RA[q]), v(T(7)))
+                    return
                 t = wqa.reg(p.LW_A + q) if p.WQ else T(8 + q % 4)
                 e("v_mul_f32", v(t), v(g[0]), ET(i))
                 e("v_mul_f32", v(t), v(t), v(T(7)))
@@ -2239,19 +2259,22 @@ def ruiz_program(s, res=None, split=None, wave=0):
                     wqa.done(p.LW_A + q, q + 1 not in aq_set)
                 else:
                     sc.lds_write(p.LW_A + q, t)
-            op([("L", p.LW_A + q)], fa)
+            op([("V", RA[q]) if q in RA else ("L", p.LW_A + q)], fa)
 
         def fq(g, j=j):
             e("v_mul_f32", v(T(6)), v(g[0]), v(T(7)))
             e("v_accvgpr_write_b32", "a%d" % (p.A_Q + j), v(T(6)))
             e("v_max_f32", v(T(5)), ab(v(T(6))), v(T(5)))
+            if j in RD:
+                e("v_mul_f32", v(RD[j]), v(T(7)), v(RD[j]))
+                return
             t = wqd.reg(p.LW_D + j) if p.WQ else T(12)
             e("v_mul_f32", v(t), v(T(7)), v(g[1]))
             if p.WQ:
                 wqd.done(p.LW_D + j, not (j + 1 < n and own_col(j + 1)))
             else:
                 sc.lds_write(p.LW_D + j, T(12))
-        op([("A", p.A_Q + j), ("L", p.LW_D + j)], fq)
+        op([("A", p.A_Q + j), ("V", RD[j]) if j in RD else ("L", p.LW_D + j)], fq)
     for i in rows_own:
         def fv(g, i=i):
             t = wqe.reg(p.LW_EV + i) if p.WQ else T(8 + i % 4)
@@ -2324,7 +2347,13 @@ def ruiz_program(s, res=None, split=None, wave=0):
                 e("s_addc_u32", "s%d" % (S_P + 1), "s%d" % (S_RSB + 1), 0)
             e("global_store_dword", "v%d" % V_RLANE, v(reg), "s[%d:%d]" % (S_P, S_P + 1), (item % BLOCK) * 256)
         # LDS words (A, D, E) through the ring registers, a group of quads at a time
-        words = [(p.LW_A + k, res.it_A + k) for k in aq] + [(p.LW_D + j, res.it_d[j]) for j in cols] + \
+        for k in aq:
+            if k in RA:
+                put(res.it_A + k, RA[k])
+        for j in cols:
+            if j in RD:
+                put(res.it_d[j], RD[j])
+        words = [(p.LW_A + k, res.it_A + k) for k in aq if k not in RA] + [(p.LW_D + j, res.it_d[j]) for j in cols if j not in RD] + \
                 [(p.LW_EV + i, res.it_ev[i]) for i in rows_own]
         item_of = dict(words)
         quads = sorted(set(w >> 2 for w, _ in words))
