@@ -2083,12 +2083,32 @@ def ruiz_program(s, res=None, split=None, wave=0):
     # D across the passes (RA, RD) -- no LDS round trip per pass for them (an LDS instruction costs a lone wave ~6 ns), and
     # none at all: nothing downstream of a shared block reads A or D from LDS (the factorisation and the residual block take
     # them from the residual stream). RUIZ_HOMES=0: the LDS form (A/B switch).
-    RA, RD = {}, {}
+    RA, RD, HV = {}, {}, {}
+
+    def asrc(a_):
+        return ("V", HV[a_]) if a_ in HV else ("A", a_)
+
+    def awrite(a_, t):
+        if a_ in HV:
+            if HV[a_] != t:
+                e("v_mov_b32", v(HV[a_]), v(t))
+        else:
+            e("v_accvgpr_write_b32", "a%d" % a_, v(t))
+
+    def adst(a_):
+        return v(HV[a_]) if a_ in HV else "a%d" % a_
     if sp is not None and res is not None and RUIZ_HOMES:
         idle = [p.V_ET + i for i in range(m) if wave not in sp.touch[i]]
         assert len(idle) >= len(aq) + len(cols), (len(idle), len(aq), len(cols))
         RA = dict(zip(aq, idle))
         RD = dict(zip(cols, idle[len(aq):]))
+        # ... and what is left of them, the two write-combining quads A and D no longer need and the registers behind the
+        # quads are the homes of the wave's Dt, q and P words, which the one-wave block keeps in AGPRs (a v_accvgpr_read /
+        # write costs a lone wave 3.7 ns, a VGPR operand nothing)
+        pool = idle[len(aq) + len(cols):] + list(range(p.V_WQ, p.V_WQ + 8)) + list(range(p.V_WQ + 12, V_END))
+        for a_ in [p.A_DT + j for j in cols] + [p.A_Q + j for j in cols] + [p.A_P + k for k in pk]:
+            if pool:
+                HV[a_] = pool.pop(0)
     e = Emit()
     v = lambda r: "v%d" % r
     T = lambda q: p.V_TT + q
@@ -2157,8 +2177,8 @@ def ruiz_program(s, res=None, split=None, wave=0):
     e("v_add_u32", "v%d" % V_B2, 0x20000, "v1")
     e("s_mov_b32", sMIN, f32bits(RZ_MIN))
     e("s_mov_b32", sMAX, f32bits(RZ_MAX))
-    load_rows(S_PV, pk, lambda q_: "a%d" % (p.A_P + pk[q_]))
-    load_rows(S_QV, cols, lambda q_: "a%d" % (p.A_Q + cols[q_]))
+    load_rows(S_PV, pk, lambda q_: adst(p.A_P + pk[q_]))
+    load_rows(S_QV, cols, lambda q_: adst(p.A_Q + cols[q_]))
     if RA:
         load_rows(S_AV, aq, lambda q_: v(RA[aq[q_]]))
     else:
@@ -2195,7 +2215,7 @@ def ruiz_program(s, res=None, split=None, wave=0):
     for j in cols:
         ents = list(range(p.A_p[j], p.A_p[j + 1]))
         if p.pidx[j] >= 0:
-            op([("A", p.A_P + p.pidx[j])], lambda g: e("v_max_f32", v(T(0)), ab(v(g[0])), ab(v(g[0]))))
+            op([asrc(p.A_P + p.pidx[j])], lambda g: e("v_max_f32", v(T(0)), ab(v(g[0])), ab(v(g[0]))))
         else:
             op([], lambda g: e("v_mov_b32", v(T(0)), 0))
         for q in ents:
@@ -2210,7 +2230,7 @@ def ruiz_program(s, res=None, split=None, wave=0):
         def fin(g, j=j):
             limit(T(0), T(1))
             rsqrt(T(1), T(0), T(2))
-            e("v_accvgpr_write_b32", "a%d" % (p.A_DT + j), v(T(1)))
+            awrite(p.A_DT + j, T(1))
         op([], fin)
     if sp is None:
         assert len(touched) == m
@@ -2234,18 +2254,18 @@ def ruiz_program(s, res=None, split=None, wave=0):
     op([], lambda g: stamp(3))
     op([], lambda g: (e("v_mov_b32", v(T(4)), 0), e("v_mov_b32", v(T(5)), 0)))
     for j in cols:
-        op([("A", p.A_DT + j)], lambda g: e("v_mov_b32", v(T(7)), v(g[0])))
+        op([asrc(p.A_DT + j)], lambda g: e("v_mov_b32", v(T(7)), v(g[0])))
         if p.pidx[j] >= 0:
             def fp(g, k=p.pidx[j]):
                 t = T(6) if sp is None else T(8 + k % 4)
                 e("v_mul_f32", v(t), v(g[0]), v(T(7)))
                 e("v_mul_f32", v(t), v(t), v(T(7)))
-                e("v_accvgpr_write_b32", "a%d" % (p.A_P + k), v(t))
+                awrite(p.A_P + k, t)
                 if sp is None:
                     e("v_add_f32", v(T(4)), v(T(4)), ab(v(t)))
                 else:
                     sc.lds_write(sp.PX[k], t)       # (every wave sums all of them in the reference's order below)
-            op([("A", p.A_P + p.pidx[j])], fp)
+            op([asrc(p.A_P + p.pidx[j])], fp)
         for q in range(p.A_p[j], p.A_p[j + 1]):
             def fa(g, q=q, i=p.A_i[q]):
                 if q in RA:                   # in place, in its register home
@@ -2263,7 +2283,7 @@ def ruiz_program(s, res=None, split=None, wave=0):
 
         def fq(g, j=j):
             e("v_mul_f32", v(T(6)), v(g[0]), v(T(7)))
-            e("v_accvgpr_write_b32", "a%d" % (p.A_Q + j), v(T(6)))
+            awrite(p.A_Q + j, T(6))
             e("v_max_f32", v(T(5)), ab(v(T(6))), v(T(5)))
             if j in RD:
                 e("v_mul_f32", v(RD[j]), v(T(7)), v(RD[j]))
@@ -2274,7 +2294,7 @@ def ruiz_program(s, res=None, split=None, wave=0):
                 wqd.done(p.LW_D + j, not (j + 1 < n and own_col(j + 1)))
             else:
                 sc.lds_write(p.LW_D + j, T(12))
-        op([("A", p.A_Q + j), ("V", RD[j]) if j in RD else ("L", p.LW_D + j)], fq)
+        op([asrc(p.A_Q + j), ("V", RD[j]) if j in RD else ("L", p.LW_D + j)], fq)
     for i in rows_own:
         def fv(g, i=i):
             t = wqe.reg(p.LW_EV + i) if p.WQ else T(8 + i % 4)
@@ -2310,9 +2330,12 @@ def ruiz_program(s, res=None, split=None, wave=0):
     for k in pk + [p.nnzP + j for j in cols]:
         def fs(g, k=k):
             t = T(8 + k % 4)
+            if p.A_P + k in HV:
+                e("v_mul_f32", v(HV[p.A_P + k]), v(g[0]), v(T(5)))     # in place, in its register home
+                return
             e("v_mul_f32", v(t), v(g[0]), v(T(5)))
             e("v_accvgpr_write_b32", "a%d" % (p.A_P + k), v(t))        # (q follows P in the AGPRs)
-        op([("A", p.A_P + k)], fs)
+        op([asrc(p.A_P + k)], fs)
     sc.run(ops)
     e("s_waitcnt", "lgkmcnt(0)")
     stamp(4)
@@ -2330,7 +2353,10 @@ def ruiz_program(s, res=None, split=None, wave=0):
         e("ds_write_b32", base, v(T(13)), off)
     for k in pk + [p.nnzP + j for j in cols]:
         t = T(k % 8)
-        e("v_accvgpr_read_b32", v(t), "a%d" % (p.A_P + k))
+        if p.A_P + k in HV:
+            t = HV[p.A_P + k]
+        else:
+            e("v_accvgpr_read_b32", v(t), "a%d" % (p.A_P + k))
         base, off = lds_addr(p.LW_P + k)
         e("ds_write_b32", base, v(t), off)
     if res is not None:
@@ -2369,11 +2395,17 @@ def ruiz_program(s, res=None, split=None, wave=0):
                         put(item_of[4 * qd + h], p.V_RING + 4 * q + h)
         for j in cols:
             t_ = T(j % 8)
-            e("v_accvgpr_read_b32", v(t_), "a%d" % (p.A_Q + j))
+            if p.A_Q + j in HV:
+                t_ = HV[p.A_Q + j]
+            else:
+                e("v_accvgpr_read_b32", v(t_), "a%d" % (p.A_Q + j))
             put(res.it_q[j], t_)
             if p.pidx[j] >= 0:
                 t2 = T(8 + j % 4)
-                e("v_accvgpr_read_b32", v(t2), "a%d" % (p.A_P + p.pidx[j]))
+                if p.A_P + p.pidx[j] in HV:
+                    t2 = HV[p.A_P + p.pidx[j]]
+                else:
+                    e("v_accvgpr_read_b32", v(t2), "a%d" % (p.A_P + p.pidx[j]))
                 put(res.it_p[j], t2)
         if wave == 0:
             put(res.it_c, T(13))
