@@ -1010,3 +1010,25 @@ def test_gpu_p5f_relabelled_problem_is_the_scripts_problem():
     assert float((got - sx).abs().max()) <= 1e-9 * scale
     assert float((mpc2.qp.sol_y - sy[ro]).abs().max()) <= 1e-9 * max(1.0, float(sy.abs().max()))
     assert float((mpc2.qp.sol_x - mpc.qp.sol_x).abs().max()) <= 1e-12 * scale     # (and the tick() path is that sequence)
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_entries_reject_bad_arguments():
+    """the C entries of the p5f tick report misuse instead of launching: -1 and a message naming the entry"""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC, _ptr
+    mpc = PlanarP5fMPC(8, torch.float32)
+    L = mpc.L
+    nnz = int(mpc.cst.numel())
+    assert L.umpcP5fLinearise(8, 0, None, 1.0, _ptr(mpc.y), _ptr(mpc.lin), 0, _ptr(mpc.cst), _ptr(mpc.src), _ptr(mpc.Av), 0, None) == -1
+    assert b"umpcP5fLinearise" in L.umpcLastError()
+    assert L.umpcP5fLinearise(8, 0, None, 1.0, None, _ptr(mpc.lin), nnz, _ptr(mpc.cst), _ptr(mpc.src), _ptr(mpc.Av), 0, None) == -1
+    assert L.umpcQPGatherUpdate(8, 0, nnz, _ptr(mpc.cst), _ptr(mpc.src), None, _ptr(mpc.Av), None) == -1
+    assert b"umpcQPGatherUpdate" in L.umpcLastError()
+    assert L.umpcP5fStepU(8, 0, 2, 0.002, 1.0, _ptr(mpc.y), None, None) == -1
+    assert b"umpcP5fStepU" in L.umpcLastError()
+    assert L.umpcP5fStepU(8, 0, 0, 0.002, 1.0, _ptr(mpc.y), None, None) == -1          # mode 0 needs lin
+    # and the good calls still go through afterwards
+    assert L.umpcP5fLinearise(8, 0, None, 1.0, _ptr(mpc.y), _ptr(mpc.lin), nnz, _ptr(mpc.cst), _ptr(mpc.src), _ptr(mpc.Av), 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(mpc.Av).all() and torch.isfinite(mpc.lin).all()
