@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 def profile_json(name):
     """A committed rocprofv3 summary under profiles/ (PMC counters cannot be read live from inside the process)."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(path):
             try:
@@ -107,13 +107,13 @@ def reference_anchor():
         return {"error": repr(ex)[:200]}
 
 
-def valu_issue(valu_per_wave_step, B, spl, kern_ms, src):
+def valu_issue(valu_per_wave_step, B, spl, kern_ms, src, robots_per_wave=64):
     """Vector-instruction issue rate of the step kernel against BOTH peaks: the hardware's (MI355X_MICROARCH.md constants
     table: a wave64 VALU op occupies a SIMD-32 for 2 cycles, reached with >= 2 waves per SIMD) and the lone-wave rate
     (one wave per SIMD issues a VALU op every 4 cycles; this kernel's 512-register waves run one per SIMD by design)."""
-    ach = valu_per_wave_step * (B / 64) * spl / (kern_ms * 1e-3) / 1e9
+    ach = valu_per_wave_step * (B / robots_per_wave) * spl / (kern_ms * 1e-3) / 1e9
     p2, p4 = 1024 * 2.4 / 2, 1024 * 2.4 / 4
-    return {"valu_instr_per_wave_step": valu_per_wave_step, "achieved": ach, "unit": "G wave-instr/s",
+    return {"valu_instr_per_wave_step": valu_per_wave_step, "robots_per_wave": robots_per_wave, "achieved": ach, "unit": "G wave-instr/s",
             "peak": p2, "frac": ach / p2, "peak_simd32": p2, "frac_simd32": ach / p2,
             "peak_lone_wave": p4, "frac_lone_wave": ach / p4, "source": src,
             "note": "VALU instructions only (SQ_INSTS_VALU per wave-step, profile-derived). peak / frac = the SIMD-32 issue "
@@ -505,7 +505,10 @@ def main():
     else:
         # inputs are generated ON the device from the counter hash: no host-side pass over the batch per rank
         from robobee3d_amd.batch import hover_initial_conditions_device, monte_carlo_draws_device
-        mpc = BatchUprightMPC(B, tdt, device=dev, plant_mode=plant_mode, maxIter=args.max_iter, nsub=args.nsub)
+        # global_batch: the lane / quad form of the step kernel is chosen from the size of the WHOLE job, so a shard runs
+        # the instruction stream the undivided batch would (results are partition-invariant)
+        mpc = BatchUprightMPC(B, tdt, device=dev, global_batch=world * B, plant_mode=plant_mode, maxIter=args.max_iter,
+                              nsub=args.nsub)
         st, ref, _ = hover_initial_conditions_device(B, 20201118, tdt, index_offset=lo, device=dev)
         mpc.set_state(st, ref)
     if args.monte_carlo:  # Ib = Ib0 (1 + d), d ~ U(-0.2, 0.2)^3, thrust gain 1 + U(-0.2, 0.2)
@@ -552,10 +555,17 @@ def main():
         if cuda:
             torch.cuda.synchronize(dev)
         local = time.perf_counter() - t0          # this rank's K steps, start barrier -> local completion
-        barrier()
-        return (local, shard.max_over_ranks(local, device=dev), shard.gather_scalars(local, device=dev),
-                float(np.mean([a.elapsed_time(b) for a, b in evs])) if cuda else local / nlaunch * 1e3)
+        kms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if cuda else local / nlaunch * 1e3
+        # The measurement exists from here on. The two small collectives that turn it into the job's figure (max over ranks,
+        # every rank's time) are guarded: if the fabric fails NOW, rank 0 still prints what it measured itself, marked as such.
+        try:
+            barrier()
+            return local, shard.max_over_ranks(local, device=dev), shard.gather_scalars(local, device=dev), kms
+        except Exception as ex:     # noqa: BLE001 -- recorded under collectives.error, the line still prints
+            coll_err.append("timing collectives: " + repr(ex)[:300])
+            return local, local, [local], kms
 
+    coll_err = []      # collective failures after the timed region: recorded in the line, never fatal to it
     local, elapsed, per_rank_s, kern_ms = protocol()
     nsteps_done = args.warmup + args.steps
     loaded, precond = None, None
@@ -566,7 +576,7 @@ def main():
     # the same W + K pass is run a SECOND time behind >= 30 ms of the same step kernel on the same batch and reported
     # BESIDE the value of record, under `loaded_clocks` (compare loaded with loaded and first-pass with first-pass across
     # rounds). --no-precondition skips the second pass.
-    if not args.no_precondition and not args.dry_run and elapsed * (1 + args.warmup / max(1, args.steps)) < 25e-3:
+    if not args.no_precondition and not args.dry_run and not coll_err and elapsed * (1 + args.warmup / max(1, args.steps)) < 25e-3:
         P = int(np.ceil(30e-3 / (elapsed / args.steps)))
         t0 = time.perf_counter()
         mpc.rollout(P)
@@ -583,10 +593,15 @@ def main():
 
     # end-of-run trajectory statistics: the only exchange of the path (RCCL all_gather over xGMI,
     # outside the timed region; 2 floats per robot)
-    metric = shard.gather_stats(mpc.metrics(nsteps_done))
+    local_metric = mpc.metrics(nsteps_done)
+    try:
+        metric = shard.gather_stats(local_metric)
+    except Exception as ex:     # noqa: BLE001 -- the headline measurement is already taken: report it with rank 0's own statistics
+        coll_err.append("gather_stats: " + repr(ex)[:300])
+        metric = local_metric
     status = mpc.status
     nbad = int((~torch.isfinite(mpc.state)).sum().item())
-    if args.dry_run and rank == 0:
+    if args.dry_run and rank == 0 and not coll_err:
         # the gather returned every rank's block in global robot order
         assert metric.shape[1] == world * B and torch.equal(metric[0], torch.arange(world * B, dtype=metric.dtype))
 
@@ -599,9 +614,16 @@ def main():
         # committed rocprofv3 --pmc measurements of this kernel (profiles/), kept PER ROBOT-STEP and scaled to this
         # launch (B x steps-per-launch); used only when the kernel configuration is the profiled one
         traffic, traffic_src, valu_per_wave_step, valu_src = None, None, None, None
+        # ... and the KERNEL that ran (a batch <= 16 384 dispatches the quad form -- 16 robots per wavefront, other
+        # counters -- which has its own committed passes; any other kernel gets no traffic / VALU figure rather than the lane form's)
+        kname = mpc.kernel_name if not args.dry_run else None
+        quad_form = kname == "umpc_rollout_asm_quad_kernel"
+        robots_per_wave = 16 if quad_form else 64
         same_kernel = lambda j: (j is not None and j.get("dtype", "f32") == args.dtype and j.get("plant", "rk4") == args.plant
-                                 and j.get("max_iter", 50) == args.max_iter and j.get("nsub", 25) == args.nsub)
-        j = profile_json("pmc_config5_shard" if args.monte_carlo else "pmc_f3_gain_sweep" if args.gain_sweep else "pmc_traffic")
+                                 and j.get("max_iter", 50) == args.max_iter and j.get("nsub", 25) == args.nsub
+                                 and j.get("kernel") == kname)
+        j = profile_json("pmc_config5_shard" if args.monte_carlo else "pmc_f3_gain_sweep" if args.gain_sweep
+                         else "pmc_quad_B16384" if quad_form else "pmc_traffic")
         if j is not None and "per_unit_bytes" in j:
             j["per_robot_step_bytes"] = j["per_unit_bytes"]
         if same_kernel(j) and not (args.monte_carlo and args.gain_sweep):
@@ -616,7 +638,9 @@ def main():
             traffic = (per["read_corrected"] + per["written"]) * B * spl
             traffic_src = "%s: %.0f B read + %.0f B written per robot-step (rocprofv3 --pmc passes at B = %d, gfx950 correction " \
                           "applied) x %d robots x %d steps" % (j["_file"], per["read_corrected"], per["written"], j["batch"], B, spl)
-        j = profile_json("sq_counters")
+        j = profile_json("sq_counters_quad_B16384" if quad_form else "sq_counters")
+        if j is not None and quad_form:       # (tools/profile_summary_options.py writes the kernel and batch, not the options)
+            j.setdefault("dtype", "f32"); j.setdefault("plant", "rk4")
         if same_kernel(j):
             valu_per_wave_step = j["per_wave_step"]["valu_instructions"]
             valu_src = j["_file"]
@@ -634,7 +658,7 @@ def main():
                        "parallelism": "robots sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": mpc.kernel_name if not args.dry_run else None,   # what the handle's last launch dispatched
+                         "kernel": kname,   # what the handle's last launch dispatched
                          "kernel_ms": kern_ms, "steps_per_launch": spl, "alg_bytes_per_launch": bps * B * spl,
                          # SURVEY 8d asks for all three rooflines; the one that binds is vector issue
                          "flops": {"achieved": 1.1e5 * B * spl / (kern_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
@@ -642,7 +666,7 @@ def main():
                          "lds": {"achieved": (args.max_iter * 76 * 16 + 2 * 640) * B * spl / (kern_ms * 1e-3) / 1e9 if args.dtype == "f32" else None,
                                  "unit": "GB/s", "peak": 256 * 128 * 2.4,
                                  "note": "76 ds_read_b128 per ADMM iteration per lane (asmstep.py's loop) + hand-off; peak 128 B/clk/CU"},
-                         "valu_issue": valu_issue(valu_per_wave_step, B, spl, kern_ms, valu_src) if valu_per_wave_step else None,
+                         "valu_issue": valu_issue(valu_per_wave_step, B, spl, kern_ms, valu_src, robots_per_wave) if valu_per_wave_step else None,
                          "note": "path is VALU-issue bound, not HBM bound (DESIGN.md): ~1.1e5 flop per 1208 B"},
             "check": {"nonfinite_state_values": nbad,
                       "mean_pos_err_mm2": float(metric[0].mean().item()),
@@ -650,7 +674,10 @@ def main():
         }
         if args.dry_run:
             line["dry_run"] = True
-            line["value"] = line["ms_per_step"] = None     # no kernel ran: nothing was measured
+            # no kernel ran: nothing was measured. What the line WOULD carry (from the ranks' sleeps) is kept beside it so that
+            # the CPU tests can see that a failed collective does not cost the figure
+            line["dry_run_unmeasured"] = {"value": line["value"], "ms_per_step": line["ms_per_step"]}
+            line["value"] = line["ms_per_step"] = None
             line["roofline"] = None
         default_headline = (args.dtype == "f32" and B == 65536 and args.max_iter == 50 and args.nsub == 25
                             and args.plant == "rk4" and not args.monte_carlo and not args.gain_sweep)
@@ -663,10 +690,21 @@ def main():
         if dist.is_initialized():
             line["collectives"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                    "gathered_robots": int(metric.shape[1])}
+            if coll_err:
+                # `value` then is rank 0's own time over world x B robots (weak scaling: every rank ran the same launch)
+                line["collectives"]["error"] = coll_err
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            if not coll_err:
+                dist.barrier()
+            dist.destroy_process_group()
+        except Exception:       # noqa: BLE001 -- shutting down a broken group: the line is out, exit code below tells
+            pass
+    if any(e_.startswith("timing") for e_ in coll_err):
+        # the line was printed, but its value is ONE rank's time, not the maximum over ranks the protocol asks for: a
+        # non-zero code tells the launcher. (A failed statistics gather alone leaves the measurement whole: exit 0.)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -218,6 +218,12 @@ int umpcBatchSetWeights(umpc_batch_t *h, const void *weights);
  * run bit for bit -- a shard against the whole -- pins the form). fp64 has the same two forms of its assembly ADMM phase
  * (robobee3d_amd/asmquad64.py; automatic = the quad form for B <= 4 096, one workgroup per CU in one round). */
 int umpcBatchSetStepKernel(umpc_batch_t *h, int mode);
+/* The size of the WHOLE job this handle's batch is a block of (contiguous blocks of robots per rank; default
+ * = the handle's own B). The automatic choice between the lane and the quad form is made from THIS number, so that a
+ * shard runs the instruction stream the undivided batch would run and a sharded job equals the single-GPU job bit for
+ * bit whatever the partition (65 536 robots as 8 blocks of 8 192 stay on the lane form). global_B < B is refused. */
+int umpcBatchSetGlobalBatch(umpc_batch_t *h, long long global_B);
+long long umpcBatchGlobalBatch(const umpc_batch_t *h);
 
 /* Static facts */
 int umpcBatchSize(const umpc_batch_t *h);

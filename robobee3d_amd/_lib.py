@@ -24,7 +24,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease", "
            "umpcBatchDefaultParams", "umpcBatchCreate", "umpcBatchDestroy", "umpcBatchInitCtrl",
            "umpcBatchRollout", "umpcBatchUpdate", "umpcBatchPlant", "umpcBatchAssemble",
            "umpcBatchSize", "umpcBatchDtype", "umpcAxIdx", "umpcKKTPerm", "umpcNnzL",
-           "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchSetStepKernel", "umpcBatchReactive", "umpcBatchTaskReference",
+           "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchSetStepKernel", "umpcBatchSetGlobalBatch", "umpcBatchGlobalBatch", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "umpcBatchKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather", "umpcQPGatherUpdate",
            "umpcP5fStep", "umpcP5fStepU", "umpcP5fLinearise", "umpcNAssemble", "umpcNExtract"]
@@ -231,6 +231,9 @@ def lib():
         L.umpcBatchSetTask.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double]
         L.umpcBatchSetWeights.argtypes = [C.c_void_p, C.c_void_p]
         L.umpcBatchSetStepKernel.argtypes = [C.c_void_p, C.c_int]
+        L.umpcBatchSetGlobalBatch.argtypes = [C.c_void_p, C.c_longlong]
+        L.umpcBatchGlobalBatch.argtypes = [C.c_void_p]
+        L.umpcBatchGlobalBatch.restype = C.c_longlong
         L.umpcBatchTime.argtypes = [C.c_void_p]
         L.umpcBatchTime.restype = C.c_double
         L.umpcBatchModel.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4

@@ -47,7 +47,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # variants, tools/build_variant.py). Everything that matches these prefixes changes the emitted instruction streams;
 # the names below it are RUN-time diagnostics of the host side and do not.
 SWITCH_PREFIXES = ("UMPC_ASM_", "UMPC_ASM64_", "UMPC_QP_", "UMPC_X_")
-NOT_SWITCHES = ("UMPC_QP_KERNEL",)
+# RUN-time variables that happen to match a prefix (read with getenv() by the host code in csrc/, or by batchqp.py, when a
+# kernel is launched; they select among kernels that exist, they do not change an emitted stream).
+# tests/test_generated_headers.py greps csrc/ and keeps this list honest.
+NOT_SWITCHES = ("UMPC_QP_KERNEL", "UMPC_QP_NO_ASM", "UMPC_ASM_SKEW_US", "UMPC_ASM_SKEW_GROUPS")
 
 
 def generator_switches():

@@ -123,7 +123,10 @@ def hover_initial_conditions_device(B, seed, dtype=torch.float32, tilt=0.5, inde
 class BatchUprightMPC:
     """B independent uprightmpc2 controllers (+ plants), one GPU lane each."""
 
-    def __init__(self, B, dtype=torch.float32, device="cuda", **params):
+    def __init__(self, B, dtype=torch.float32, device="cuda", global_batch=None, **params):
+        """global_batch: the size of the whole job when this object holds one block of a sharded batch (shard.py,
+        SURVEY 8e). The automatic lane / quad choice of the step kernel is made from it, so every block runs the
+        instruction stream the undivided batch would and the partition cannot change a bit of the result."""
         if not torch.cuda.is_available():
             raise RuntimeError("BatchUprightMPC needs a HIP device; there is no CPU path")
         self.L = _lib.lib()
@@ -141,6 +144,8 @@ class BatchUprightMPC:
             self.h = self.L.umpcBatchCreate(C.byref(self.prm), self.B, _DT[dtype])
         if not self.h:
             raise RuntimeError(self.L.umpcLastError().decode())
+        if global_batch is not None:
+            self._check(self.L.umpcBatchSetGlobalBatch(self.h, int(global_batch)))
         z = lambda r, dt=dtype: torch.zeros((r, self.B), dtype=dt, device=self.device)
         self.state, self.ctrl, self.ref = z(_lib.STATE_ROWS), z(_lib.CTRL_ROWS), z(_lib.REF_ROWS)
         self.out, self.stats, self.info = z(_lib.OUT_ROWS), z(_lib.STAT_ROWS), z(2)
@@ -209,8 +214,8 @@ class BatchUprightMPC:
         """"auto" (default: the all-assembly fp32 kernel / the fp64 kernel with the assembly ADMM loop where they apply)
         or "cpp" (fp32: the C++ kernel around the assembly ADMM loop; fp64: the C++ loop): ablation and cross-checks.
         "lane" / "quad" pin the form of the assembly path (one lane / one lane quad per robot; "auto" takes the quad form for
-        B <= 16 384 in fp32, B <= 4 096 in fp64): equal up to rounding, so a run that must equal another batch size's bit for bit
-        -- a shard against the whole -- pins one."""
+        B <= 16 384 in fp32, B <= 4 096 in fp64, counted on `global_batch`, the size of the WHOLE job, so that a shard takes the
+        form the undivided batch takes): equal up to rounding, not bit for bit."""
         self._check(self.L.umpcBatchSetStepKernel(self.h, {"auto": 0, "cpp": 1, "lane": 2, "quad": 3}[mode]))
 
     M0_CA6 = (100.0, 100.0, 100.0, 3333.0, 3333.0, 1000.0)   # dynamicsTerms, template/ca6dynamics.py:5-10

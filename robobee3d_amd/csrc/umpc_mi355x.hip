@@ -357,6 +357,7 @@ DevParams<T> make_dev(const umpc_batch_params_t &p) {
 struct umpc_batch {
   umpc_batch_params_t prm;
   int B, dtype;
+  long long global_B = 0;        // size of the whole (sharded) job, umpcBatchSetGlobalBatch; the lane / quad choice is made from it
   int task = 0;
   double task_p[4] = {0, 0, 0, 0};
   double t_ms = 0;               // time of the next MPC step (advanced by every rollout)
@@ -444,7 +445,7 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
       static const int skew_us10 = [] { const char *e_ = getenv("UMPC_ASM_SKEW_US"); return e_ ? (int)(atof(e_) * 10) : 0; }();
       static const int skew_groups = [] { const char *e_ = getenv("UMPC_ASM_SKEW_GROUPS"); return e_ ? atoi(e_) : 4; }();
       const int skew_ticks = (h->B >= 32768 && K >= 2) ? skew_us10 * 10 : 0;
-      if (h->step_kernel == 3 || (h->step_kernel == 0 && h->B <= quad_max_b())) {
+      if (h->step_kernel == 3 || (h->step_kernel == 0 && h->global_B <= quad_max_b())) {
         hipLaunchKernelGGL(umpc_rollout_asm_quad_kernel, dim3((h->B + kBlock / 4 - 1) / (kBlock / 4)), dim3(kBlock), 0,
                            (hipStream_t)stream, p, h->B);
         h->last_kernel = "umpc_rollout_asm_quad_kernel";
@@ -477,7 +478,7 @@ static int launch_rollout(umpc_batch_t *h, int K, int nsub, void *state, void *c
       // config 2's 4 096 robots are then 256 waves instead of 64, each iteration ~0.55 of the one-lane loop's time
       // (asmquad64.py). UMPC_QUAD64=0 keeps the lane form, UMPC_QUAD64=<n> moves the switch-over batch size.
       static const int quad64_max_b = [] { const char *e_ = getenv("UMPC_QUAD64"); return e_ ? atoi(e_) : 4096; }();
-      const bool want_quad = h->step_kernel == 3 || (h->step_kernel == 0 && h->B <= quad64_max_b);
+      const bool want_quad = h->step_kernel == 3 || (h->step_kernel == 0 && h->global_B <= quad64_max_b);
       if (!no_asm64 && h->step_kernel != 1 && h->prm.maxIter >= 2 && fits && want_quad) {
         hipLaunchKernelGGL((umpc_rollout_kernel<T, true, true, true>), dim3((h->B + kBlock / 4 - 1) / (kBlock / 4)), dim3(kBlock), 0,
                            (hipStream_t)stream, a, K, (const T *)actualT0, 0);
@@ -567,7 +568,7 @@ umpc_batch_t *umpcBatchCreate(const umpc_batch_params_t *prm, int B, int dtype) 
     return nullptr;
   }
   umpc_batch *h = new umpc_batch;
-  h->prm = *prm; h->B = B; h->dtype = dtype; h->ws = nullptr;
+  h->prm = *prm; h->B = B; h->global_B = B; h->dtype = dtype; h->ws = nullptr;
   e = hipMalloc(&h->ws, (size_t)umpc::WS_ROWS * (size_t)B * (dtype == UMPC_F64 ? 8 : 4));
   if (e != hipSuccess) { fail(e, "umpcBatchCreate: workspace"); delete h; return nullptr; }
   return h;
@@ -608,6 +609,12 @@ int umpcBatchSetStepKernel(umpc_batch_t *h, int mode) {
   h->step_kernel = mode;
   return 0;
 }
+int umpcBatchSetGlobalBatch(umpc_batch_t *h, long long global_B) {
+  if (!h || global_B < (long long)h->B) { g_err = "umpcBatchSetGlobalBatch: bad argument (the whole job cannot be smaller than its block)"; return -1; }
+  h->global_B = global_B;
+  return 0;
+}
+long long umpcBatchGlobalBatch(const umpc_batch_t *h) { return h ? h->global_B : 0; }
 double umpcBatchTime(const umpc_batch_t *h) { return h->t_ms; }
 int umpcBatchSize(const umpc_batch_t *h) { return h->B; }
 int umpcBatchDtype(const umpc_batch_t *h) { return h->dtype; }
@@ -761,25 +768,46 @@ void release_locked(uint32_t id) {
 // equalities, so this runs on the general-structure solver (umpc_bqp.hip) with the controller's own warm start x, y, z,
 // T0 and thrust-row E. Device arrays in s.gbuf (floats): Pv 45 | q 45 | l 39 | u 39 | par 10 | Av 111 | cst 111 | E 39 |
 // sol_x 45 | sol_y 39 | info 6 | src 111 (int32).
-int compat_reject_step(Single &s, const UprightMPC_t *up) {
-  static_assert(umpcn3::N == N && umpcn3::NX == NX && umpcn3::NC == NC && umpcn3::NNZA == NNZA, "umpc_n3_general.h is the N = 3 structure");
-  constexpr int O_PV = 0, O_QV = O_PV + NX, O_LV = O_QV + NX, O_UV = O_LV + NC, O_PAR = O_UV + NC, O_AV = O_PAR + 10,
-                O_CST = O_AV + NNZA, O_E = O_CST + NNZA, O_SX = O_E + NC, O_SY = O_SX + NX, O_INF = O_SY + NC,
-                O_SRC = O_INF + 6, O_END = O_SRC + NNZA;
-  if (!s.gqp) {
-    umpcQPSettings st;
-    umpcQPDefaultSettings(&st);
-    st.max_iter = s.h->prm.maxIter;
-    s.gqp = umpcQPCreate(umpcn3::kBlob, umpcn3::BLOB_WORDS, 1, UMPC_F32, &st);
-    if (!s.gqp) return 1;
-    if (hipMalloc((void **)&s.gbuf, O_END * sizeof(float)) != hipSuccess) { umpcQPDestroy(s.gqp); s.gqp = nullptr; return 1; }
+namespace reject {
+constexpr int O_PV = 0, O_QV = O_PV + NX, O_LV = O_QV + NX, O_UV = O_LV + NC, O_PAR = O_UV + NC, O_AV = O_PAR + 10,
+              O_CST = O_AV + NNZA, O_E = O_CST + NNZA, O_SX = O_E + NC, O_SY = O_SX + NX, O_INF = O_SY + NC,
+              O_SRC = O_INF + 6, O_END = O_SRC + NNZA;
+}
+// The general-solver handle and the device arrays of the reject path. Created by umpcSetCompat (a set-up call), or by
+// the first rejected umpcUpdate of a controller whose switch came from UMPC_COMPAT in the environment. Nothing is kept
+// unless EVERYTHING succeeded (a failed table copy used to leave the handle set and later calls solved with
+// uninitialised tables).
+int compat_reject_init(Single &s) {
+  using namespace reject;
+  if (s.gqp && s.gbuf) return 0;
+  umpcQPSettings st;
+  umpcQPDefaultSettings(&st);
+  st.max_iter = s.h->prm.maxIter;
+  void *gqp = umpcQPCreate(umpcn3::kBlob, umpcn3::BLOB_WORDS, 1, UMPC_F32, &st);
+  if (!gqp) return 1;
+  float *gbuf = nullptr;
+  hipError_t e = hipMalloc((void **)&gbuf, O_END * sizeof(float));
+  if (e == hipSuccess) {
     float tmp[O_END];
     memset(tmp, 0, sizeof(tmp));
     for (int k = 0; k < NNZA; ++k) tmp[O_CST + k] = umpcn3::kIsDt[k] ? (float)s.h->prm.dt : umpcn3::kCst[k];
     for (int k = 0; k < NC; ++k) tmp[O_E + k] = 1.0f;
     memcpy(tmp + O_SRC, umpcn3::kSrc, NNZA * sizeof(int32_t));
-    if (hipMemcpy(s.gbuf, tmp, sizeof(tmp), hipMemcpyHostToDevice) != hipSuccess) return 1;
+    e = hipMemcpy(gbuf, tmp, sizeof(tmp), hipMemcpyHostToDevice);
   }
+  if (e != hipSuccess) {
+    fail(e, "umpcUpdate (compat bounds-reject path: tables)");
+    if (gbuf) (void)hipFree(gbuf);
+    umpcQPDestroy(gqp);
+    return 1;
+  }
+  s.gqp = gqp; s.gbuf = gbuf;
+  return 0;
+}
+int compat_reject_step(Single &s, const UprightMPC_t *up) {
+  static_assert(umpcn3::N == N && umpcn3::NX == NX && umpcn3::NC == NC && umpcn3::NNZA == NNZA, "umpc_n3_general.h is the N = 3 structure");
+  using namespace reject;
+  if (compat_reject_init(s)) return 1;
   float *g = s.gbuf, *d = s.hdev;
   umpcNParams np;
   const umpc_batch_params_t &bp = s.h->prm;
@@ -990,6 +1018,9 @@ int umpcSetCompat(UprightMPC_t *up, int flags) {
   if (it == g_single.end()) return -1;
   const int prev = it->second.compat;
   it->second.compat = flags;
+  // the reject path's solver handle and tables are set up HERE, not inside the first rejected umpcUpdate (a failure
+  // leaves the switch on and is retried, and reported, by that call)
+  if ((flags & UMPC_COMPAT_BOUNDS_REJECT) && it->second.h) (void)compat_reject_init(it->second);
   return prev;
 }
 void umpcRelease(UprightMPC_t *up) {

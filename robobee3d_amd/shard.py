@@ -25,8 +25,14 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def init(backend=None, device=None, force=False):
-    """force: initialise the process group even for world_size 1 (rehearsal of the RCCL path on a one-GPU box)"""
+INIT_TIMEOUT_S = float(os.environ.get("UMPC_DIST_TIMEOUT_S", "300"))
+
+
+def init(backend=None, device=None, force=False, timeout_s=None):
+    """force: initialise the process group even for world_size 1 (rehearsal of the RCCL path on a one-GPU box).
+    timeout_s: rendezvous AND collective timeout of the group (default INIT_TIMEOUT_S = 300 s, UMPC_DIST_TIMEOUT_S in the
+    environment): a rank that never arrives fails the job in minutes with an error instead of hanging it for the backend's
+    default half hour."""
     rank, ws, local_rank = world()
     if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -38,7 +44,8 @@ def init(backend=None, device=None, force=False):
                                    "--gpus N`, which picks a free port itself)")
             os.environ["MASTER_PORT"] = str(free_port())
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {}
+        import datetime
+        kw = {"timeout": datetime.timedelta(seconds=float(timeout_s if timeout_s is not None else INIT_TIMEOUT_S))}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=ws, **kw)
@@ -78,6 +85,10 @@ def gather_stats(stats):
     """stats [rows, B_local] on every rank -> [rows, sum B_local] in global robot order (all ranks)."""
     if not dist.is_initialized():
         return stats
+    if os.environ.get("UMPC_TEST_FAIL_GATHER") == "1":
+        # TEST ONLY (tests/test_shard_gloo.py): every rank fails here the way a broken RCCL gather would surface in
+        # Python, so that the CPU suite can check that bench.py still prints the measurement it has already taken
+        raise RuntimeError("injected gather failure (UMPC_TEST_FAIL_GATHER=1)")
     ws = dist.get_world_size()
     n = torch.tensor([stats.shape[1]], dtype=torch.int64, device=stats.device)
     sizes = [torch.zeros_like(n) for _ in range(ws)]

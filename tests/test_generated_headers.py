@@ -48,3 +48,21 @@ def test_build_refuses_generator_switches(monkeypatch):
     monkeypatch.setenv("UMPC_QP_KERNEL", "tables")       # a run-time diagnostic, not a generator switch
     monkeypatch.delenv("UMPC_ASM_LIMIT_FAST")
     assert asmgen.generator_switches() == {}
+
+
+def test_run_time_variables_of_the_host_code_are_not_generator_switches(monkeypatch):
+    """generator_switches() matches by prefix, so a RUN-time variable of the host code whose name starts like a
+    generator switch (UMPC_ASM_SKEW_US, UMPC_QP_NO_ASM ...) must be listed in NOT_SWITCHES, or setting it makes build()
+    refuse and the header test fail. Every getenv("UMPC_...") of csrc/ is checked against the list."""
+    import glob
+    import re
+    from robobee3d_amd import asmgen
+    names = set()
+    for path in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")):
+        names |= set(re.findall(r'getenv\("(UMPC_[A-Z0-9_]+)"\)', open(path).read()))
+    assert {"UMPC_ASM_SKEW_US", "UMPC_QP_NO_ASM", "UMPC_QUAD"} <= names
+    for n in sorted(names):
+        if n.startswith(asmgen.SWITCH_PREFIXES):
+            assert n in asmgen.NOT_SWITCHES, "%s is read at run time by csrc/ but counts as a generator switch" % n
+        monkeypatch.setenv(n, "1")
+    assert asmgen.generator_switches() == {}

@@ -1,10 +1,14 @@
 """GPU parity tests (run on the MI355X box: pytest -m gpu). Everything goes
 through the C ABI of libumpc_mi355x.so; the oracle is only the checker.
 
-Stated fp32 tolerance of the path (same start state, same 50 ADMM iterations):
-    |d thrust| <= 3e-5, |d moment| <= max(2e-2, 1e-3 |moment|), |d accdes| <= 3e-5
-(the fp32 reference itself is 0.9e-5 / 3.4e-3 / 0.9e-5 from the fp64 evaluation
-of the same algorithm on these vectors: tests/test_oracle_golden.py).
+Stated fp32 tolerance of the path (same start state, same ADMM iteration count):
+    |d thrust| <= 1e-5, |d moment| <= max(2e-2, 1e-3 |moment|), |d accdes| <= 1e-5
+asserted AS STATED against the reference's own converged fixtures (seq_iter50, seq_iter10: GOLDEN_TOL; achieved 8.9e-6 /
+9.2e-6 and 2.7e-6 / 3.0e-6 on the MI355X). 3e-5 (TOL_T, TOL_A) is kept only where something other than one converged
+step is compared, and each such place says why: iterates cut off after 1 or 2 iterations (not yet contracted: the fp32
+reference is itself 1.2e-4 / 1.4e-5 from fp64 there), multi-call sequences (errors of earlier calls feed later ones through
+the warm start), and comparisons against the FP64 oracle (the fp32 reference itself is 0.9e-5 / 3.4e-3 / 0.9e-5 from
+the fp64 evaluation of the same algorithm on these vectors: tests/test_oracle_golden.py).
 fp64 kernel vs fp64 oracle: 1e-9 relative.
 """
 import numpy as np
@@ -15,6 +19,8 @@ from conftest import golden, record_margin
 pytestmark = pytest.mark.gpu
 
 TOL_T, TOL_A = 3e-5, 3e-5
+# SURVEY 8(c)'s stated single-step bound, asserted on the reference fixtures that hold converged steps
+GOLDEN_TOL = {"seq_iter50.npz": 1e-5, "seq_iter10.npz": 1e-5}
 
 
 def tol_tau(ref):
@@ -77,7 +83,8 @@ def test_assembly_matches_reference(torch_cuda):
 FIXTURE_SCALE = {"seq_iter1.npz": 15.0}
 
 
-def _check_outputs(out, seq, n, label, scale=1.0, sel=None, tau_scale=None):
+def _check_outputs(out, seq, n, label, scale=1.0, sel=None, tau_scale=None, tol=None):
+    TOL_T, TOL_A = (tol, tol) if tol is not None else (globals()["TOL_T"], globals()["TOL_A"])
     sel = np.arange(n) if sel is None else sel
     uq, ac = out[:3].T[sel], out[3:].T[sel]
     ru, ra = seq["uquad"][:n].astype(np.float64)[sel], seq["accdes"][:n].astype(np.float64)[sel]
@@ -121,7 +128,7 @@ def test_single_step_matches_reference_golden(torch_cuda, structure, fname):
     torch.cuda.synchronize()
     out = mpc.out.cpu().numpy().astype(np.float64)
     sc = FIXTURE_SCALE.get(fname, 1.0)
-    _check_outputs(out, seq, n, fname, sc, tau_scale=1.0)
+    _check_outputs(out, seq, n, fname, sc, tau_scale=1.0, tol=GOLDEN_TOL.get(fname))
     ctrl = mpc.ctrl.cpu().numpy()
     # iterates: scaled x, y, z after the same number of iterations
     for name, sl in (("x", slice(0, 45)), ("y", slice(45, 84)), ("z", slice(84, 123))):
@@ -325,12 +332,12 @@ def test_full_size_hover_properties(torch_cuda):
     off, n = 1000, 4096
     st2, ref2 = hover_initial_conditions(n, 20201118, index_offset=off)
     np.testing.assert_array_equal(st2, st[:, off:off + n])
-    sub = BatchUprightMPC(n, torch.float32)
-    sub.set_step_kernel("lane")     # the whole batch ran the lane form of the stream; 4096 robots alone would take the quad form
+    sub = BatchUprightMPC(n, torch.float32, global_batch=B)   # a block of the B-robot job: it runs the form the whole runs
     sub.set_state(st2, ref2)
     sub.rollout(K)
     np.testing.assert_array_equal(sub.state.cpu().numpy(), mpc.state[:, off:off + n].cpu().numpy())
     np.testing.assert_array_equal(sub.stats.cpu().numpy(), mpc.stats[:, off:off + n].cpu().numpy())
+    assert sub.kernel_name == mpc.kernel_name == "umpc_rollout_asm_kernel"
 
 
 def test_ragged_and_tiny_batches(torch_cuda):

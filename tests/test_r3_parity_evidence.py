@@ -205,13 +205,22 @@ def test_reference_closed_loop_log_replayed_on_the_gpu(torch_cuda, margin):
     met = np.array([np.mean(np.sum(Y[:, :3] ** 2, axis=1)), np.mean(np.sum(U[:, 1:3] ** 2, axis=1))])
     margin(lab + "logMetric pair, relative", float(np.max(np.abs(met / g["metric"] - 1))), 2e-4)
     assert np.linalg.norm(Y[-1, :3]) < 0.02 and abs(Y[-1, 5] - 1) < 1e-4      # hover converges to the origin, upright
-    # (b), (c): the product's own harness at the recorded schedule, one precision throughout
-    # (fp32, B = 2: the quad form of the stream since round 4 -- 1.9e-4 on this trajectory where the lane form had 2.7e-5; against
-    # the fp64 oracle the two forms have the same error statistics, tests/test_asm_quad.py)
-    for tdt, name, bp, bs, bm in ((torch.float32, "fp32 harness: ", 1e-3, 1e-4, 5e-4), (torch.float64, "fp64 harness: ", 1e-3, 1e-4, 1.5e-4)):
+    # (b), (c): the product's own harness at the recorded schedule, one precision throughout. fp32 runs BOTH forms of the
+    # stream (B = 2 takes the quad form by default since round 4). The lane form keeps its round-3 bound on the logMetric pair
+    # (1.5e-4; achieved 2.7e-5). The quad form ends this ONE trajectory at 1.9e-4: not a property of the form -- over 1 024
+    # trajectories of the same length the two forms have the same error distribution against the fp64 oracle
+    # (tests/test_r5_evidence.py::test_lane_and_quad_forms_share_their_closed_loop_error_statistics, whose 95th percentile
+    # is what the quad bound here is taken from) -- a closed loop amplifies a different accumulation order differently
+    # along each trajectory.
+    for tdt, form, name, bp, bs, bm in ((torch.float32, "lane", "fp32 harness (lane form): ", 1e-3, 1e-4, 1.5e-4),
+                                        (torch.float32, "quad", "fp32 harness (quad form): ", 1e-3, 1e-4, 5e-4),
+                                        (torch.float64, "auto", "fp64 harness: ", 1e-3, 1e-4, 1.5e-4)):
         m = BatchUprightMPC(2, tdt, plant_mode=0)
+        m.set_step_kernel(form)
         m.set_state(np.repeat(st, 2, 1), np.repeat(ref, 2, 1))
         log = m.control_test_log(500.0, robots=(0, 1), fire=g["fire"])
+        if tdt == torch.float32:
+            assert m.kernel_name == ("umpc_rollout_asm_kernel" if form == "lane" else "umpc_rollout_asm_quad_kernel")
         for r in (0, 1):
             lg = log[r]
             assert lg["y"].shape == (Nt, 12)
@@ -443,8 +452,7 @@ def test_batch_beyond_the_old_31_bit_workspace_limit(torch_cuda):
     m.rollout(K)
     assert m.kernel_name == "umpc_rollout_asm_kernel"
     for lo in (0, B - 4096):
-        s = BatchUprightMPC(4096, torch.float32, plant_mode=1)
-        s.set_step_kernel("lane")          # the form the million-robot batch ran in (auto would take the quad form at 4096)
+        s = BatchUprightMPC(4096, torch.float32, plant_mode=1, global_batch=B)   # a block of the million-robot job
         st4, ref4, _ = hover_initial_conditions_device(4096, 20201118, torch.float32, index_offset=lo)
         s.set_state(st4, ref4)
         s.rollout(K)

@@ -123,3 +123,28 @@ def test_device_draws_equal_the_host_draws():
     std, refd, (a, b) = batch.hover_initial_conditions_device(3000, 20201118, torch.float64, index_offset=77, device="cpu")
     assert np.allclose(st, std.numpy(), rtol=0, atol=1e-15) and np.array_equal(ref, refd.numpy())
     assert np.abs(a.numpy()).max() <= 0.5 and np.abs(b.numpy()).max() <= 0.5
+
+
+def test_failed_statistics_gather_does_not_cost_the_measurement():
+    """the N > 1 path has never met two RCCL ranks, and the statistics gather sits between the timed
+    region and the print. A gather that raises (injected on every rank, the way a broken collective surfaces in Python)
+    must leave ONE line with the figure the ranks had already measured, the failure recorded under collectives.error, and
+    a clean exit (the timing itself went through its own collectives)."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "64", "--dry-run"], env={"UMPC_TEST_FAIL_GATHER": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and len(j["ms_per_step_per_rank"]) == 2
+    assert j["dry_run_unmeasured"]["value"] > 0 and j["dry_run_unmeasured"]["ms_per_step"] > 0     # what `value` would carry
+    assert j["collectives"]["world_size"] == 2 and "injected gather failure" in j["collectives"]["error"][0]
+    assert j["collectives"]["gathered_robots"] == 64          # rank 0's own block only
+
+
+def test_process_group_has_an_explicit_timeout():
+    """shard.init passes timeout= to init_process_group (the backend default is half an hour of silence)"""
+    import inspect
+    from robobee3d_amd import shard
+    src = inspect.getsource(shard.init)
+    assert "timeout" in src and shard.INIT_TIMEOUT_S <= 600
