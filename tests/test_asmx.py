@@ -1,12 +1,21 @@
-"""The two-lanes-per-robot ADMM iteration of the DESIGN.md 9.1 experiment (robobee3d_amd/asmx.py, not part of the
-library): the generated stream, interpreted on a lane pair, equals a numpy statement of the OSQP iteration
+"""The two-lanes-per-robot ADMM iteration of the closed experiment tools/asmx.py (outside the product package: measured,
+not built, DESIGN.md "Two lanes per robot"): the generated stream, interpreted on a lane pair, equals a numpy statement of the OSQP iteration
 (reference: osqp 0.6.0 src/osqp.c:osqp_solve loop body -- update_xz_tilde / update_x / update_z / update_y,
 auxil.c:64-140 -- with the LDL' solve of lin_sys/direct/qdldl/qdldl_interface.c:solve_linsys_qdldl)."""
+import os
+import sys
+
 import numpy as np
 
 
+def _asmx():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import asmx
+    return asmx
+
+
 def test_two_lane_iteration_equals_the_unsplit_one():
-    from robobee3d_amd import asmx
+    asmx = _asmx()
     from robobee3d_amd.asmgen import Emit
     p = asmx.Plan()
     s = p.s
@@ -41,7 +50,7 @@ def test_two_lane_stream_assembles():
     if not os.path.exists(mc):
         import pytest
         pytest.skip("llvm-mc not available")
-    from robobee3d_amd import asmx
+    asmx = _asmx()
     from robobee3d_amd.asmgen import Emit
     e = Emit()
     asmx.body(e, asmx.Plan())

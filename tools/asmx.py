@@ -1,4 +1,5 @@
-"""EXPERIMENT (not wired into the library): the ADMM iteration with TWO LANES PER ROBOT, so that two
+"""EXPERIMENT, CLOSED in round 5 (DESIGN.md "Two lanes per robot": measured, not built; this file lives in tools/, outside the
+product package): the ADMM iteration with TWO LANES PER ROBOT, so that two
 wavefronts fit on a SIMD (256 unified registers + 80 LDS words per lane; a robot's 561-word working set is split over
 a lane pair, no AGPR is needed) and the SIMD issues from two waves: measured 2.6 cycles per VOP2 SIMD-instruction
 instead of 5.2 for a lone wave, 3.5 per packed one, 3.7 per DPP-operand one (tools/microbench2.hip).
@@ -17,10 +18,12 @@ import os
 
 import numpy as np
 
-from . import asmgen, symbolic
-from .asmgen import Emit, pk, _sb, _vp, f32bits
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from robobee3d_amd import asmgen, symbolic              # noqa: E402
+from robobee3d_amd.asmgen import Emit, pk, _sb, _vp, f32bits     # noqa: E402
 
 # per-lane register map (v0 = robot offset, v1 = lane LDS address)
 VWX, VWZ, VX, VY, VZT, VDX, VDZ, VT3, VTMP, VL = 2, 26, 46, 70, 90, 92, 116, 136, 144, 160
@@ -453,7 +456,7 @@ def write_microbench(path=None):
     iteration at 4 waves per CU, same harness, registers filled with finite values, iterations timed by HIP events.
     Two more kernels bound what the exec-mask switches and the DPP operands cost (their results are NOT an ADMM
     iteration): X without the s_mov of exec, X with plain operands instead of DPP ones."""
-    path = path or os.path.join(os.path.dirname(HERE), "tools", "microbench_x.hip")
+    path = path or os.path.join(HERE, "microbench_x.hip")
     plan = Plan()
     s = plan.s
     streams = {}
@@ -496,7 +499,7 @@ def write_microbench(path=None):
   if (iters < 0) out[threadIdx.x] = 0;
 }
 '''
-    txt = '''// GENERATED by robobee3d_amd/asmx.py (experiment, DESIGN.md 9.1) -- do not edit.
+    txt = '''// GENERATED by tools/asmx.py (experiment, closed in round 5) -- do not edit.
 // Times one ADMM iteration: X = two lanes per robot, 8 waves per CU (two per SIMD), %d instructions per wave-iteration
 // of 32 robots (%d forward + %d backward solve instructions, %d LDS quads); O = the shipped one-lane middle iteration,
 // 4 waves per CU, %d instructions per wave-iteration of 64 robots. Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench_x tools/microbench_x.hip
