@@ -95,6 +95,17 @@ if OPT_RING == 6:
 OPT_LIMIT_FAST = os.environ.get("UMPC_ASM_LIMIT_FAST", "0") == "1"
 # ZSKIP: the right-hand side of entries whose q / l is structurally zero is formed without the AGPR read (asmgen.body)
 OPT_ZSKIP = os.environ.get("UMPC_ASM_ZSKIP", "1") == "1"
+# NT: the once-per-step STREAMING rows (state, ctrl, ref, out, stats: read in phase A, rewritten in phase C) carry the
+# non-temporal hint, so that the 85 workspace rows D, E, c a wave parks across its 50 iterations (21.7 KB per wave, 2.8 MB per
+# XCD against a 4-MB L2) are not evicted by them and need not round-trip through HBM. "1" (default, lane form): loads and
+# stores, "ld" / "st": one side, "0": off. Measured (tools/ab_nt.sh, profiles/r05_nt_ab.txt, one box, K = 500): read bytes per
+# robot-step 969 -> 616 (algorithmic 604), written 977 -> 980, 1.61x -> 1.32x algorithmic; 0.1208 -> 0.1216 ms per step. Either
+# side alone does nothing ("ld": 1071 read; "st": 964).
+OPT_NT = os.environ.get("UMPC_ASM_NT", "1")
+NT_PTRS = ("state", "ctrl", "ref", "out", "stats")
+# The ten AGPRs nobody owns (the loop: a0..a229, the weights: a230..a245) take c and the first nine D words across the loop
+# instead of workspace rows (lane form only: the quad entry composes words in AGPRs): 10 stores + 10 loads fewer per step
+A_SPARE, N_SPARE_D = 246, 9
 
 
 class Pool:
@@ -307,6 +318,9 @@ class StepGen:
         self.pool = Pool(self.e)
         self.lab = 20
         self.quad = quad
+        # the quad form serves batches whose whole working set lives in the eight L2s (0.14-0.44x algorithmic HBM traffic):
+        # there the state / ctrl rows are exactly what should stay cached, so the hint is a lane-form matter
+        self.nt = "0" if quad else OPT_NT
 
     # ---- small emit helpers -----------------------------------------------------------------------------
     def label(self):
@@ -349,7 +363,8 @@ class StepGen:
             voff = self.pool.get()
         self.rows_ptr(voff, first_row)
         for k, r in enumerate(regs):
-            self.e("global_load_dword", r if isinstance(r, str) else v(r), v(voff), sp(S_PTR[ptr]))
+            self.e("global_load_dword", r if isinstance(r, str) else v(r), v(voff), sp(S_PTR[ptr]),
+                   *(("nt",) if self.nt in ("1", "ld") and ptr in NT_PTRS else ()))
             if k + 1 < len(regs):
                 self.adv(voff)
         if own:
@@ -361,7 +376,8 @@ class StepGen:
             voff = self.pool.get()
         self.rows_ptr(voff, first_row)
         for k, r in enumerate(regs):
-            self.e("global_store_dword", v(voff), v(r), sp(S_PTR[ptr]))
+            self.e("global_store_dword", v(voff), v(r), sp(S_PTR[ptr]),
+                   *(("nt",) if self.nt in ("1", "st") and ptr in NT_PTRS else ()))
             if k + 1 < len(regs):
                 self.adv(voff)
         if own:
@@ -968,7 +984,8 @@ class StepGen:
         cinv, t, d, r = pool.get(), pool.get(), pool.get(), pool.get()
         self.rcp_nr(cinv, cs, t)
         voff = pool.get()
-        self.rows_ptr(voff, 0)     # the kernel's `ws` pointer is the workspace row WS_DS (host side): rows D 0.., E 45.., c 84
+        npark = 0 if self.quad else N_SPARE_D
+        self.rows_ptr(voff, npark)     # the kernel's `ws` pointer is the workspace row WS_DS (host side): rows D 0.., E 45.., c 84
         rows_of_col = {}
         for i in range(nc):
             rows_of_col.setdefault(st.unit[i][1], []).append(i)
@@ -981,8 +998,11 @@ class StepGen:
             e("v_mul_f32", v(d), v(IWV[st.weight_of(j)]), v(d))
             e("v_sqrt_f32", v(d), v(d))
             e("s_nop", 0)
-            e("global_store_dword", v(voff), v(d), sp(S_PTR["ws"]))
-            self.adv(voff)
+            if j < npark:
+                e("v_accvgpr_write_b32", "a%d" % (A_SPARE + j), v(d))
+            else:
+                e("global_store_dword", v(voff), v(d), sp(S_PTR["ws"]))
+                self.adv(voff)
             if j in rows_of_col:
                 e("v_rcp_f32", v(r), v(d))
                 e("s_nop", 0)
@@ -992,7 +1012,10 @@ class StepGen:
         for i in range(nc):
             e("global_store_dword", v(voff), v(RE(i)), sp(S_PTR["ws"]))
             self.adv(voff)
-        e("global_store_dword", v(voff), v(cs), sp(S_PTR["ws"]))
+        if npark:
+            e("v_accvgpr_write_b32", "a%d" % (A_SPARE + N_SPARE_D), v(cs))
+        else:
+            e("global_store_dword", v(voff), v(cs), sp(S_PTR["ws"]))
         self.store_rows("ctrl", nx + 2 * nc + 1, [RE(neq + k) for k in range(N)], voff)     # Eprev of the next step
         pool.free(cinv, d, r, voff, cs, *IWV.values())
         # scaled bounds from the LDS stash
@@ -1214,26 +1237,33 @@ class StepGen:
         DS, dblocks = slot_blocks(nx)
         DR = lambda j: DS(st.xs[j])
         cr, T0 = g_(), g_()
-        self.load_rows("ws", 0, [DR(j) for j in range(nx)], voff)
-        self.load_rows("ws", asmgen.WS_C - asmgen.WS_DS, [cr], voff)
+        npark = 0 if self.quad else N_SPARE_D
+        self.load_rows("ws", npark, [DR(j) for j in range(npark, nx)], voff)
+        if npark:
+            for j in range(npark):
+                e("v_accvgpr_read_b32", v(DR(j)), "a%d" % (A_SPARE + j))
+            e("v_accvgpr_read_b32", v(cr), "a%d" % (A_SPARE + N_SPARE_D))
+        else:
+            self.load_rows("ws", asmgen.WS_C - asmgen.WS_DS, [cr], voff)
         self.load_rows("ctrl", nx + 2 * nc, [T0], voff)
         e("v_mov_b32", v(DS(nx)), 0)
         # 2. the controller record goes back now (a cold start, if any, rewrites it below): x, y, z
         zt = [g_() for _ in range(4)]
+        NT_ST = ("nt",) if self.nt in ("1", "st") else ()
         self.rows_ptr(voff, 0)
         for r in range(nx):
-            e("global_store_dword", v(voff), v(XR(r)), sp(S_PTR["ctrl"]))
+            e("global_store_dword", v(voff), v(XR(r)), sp(S_PTR["ctrl"]), *NT_ST)
             self.adv(voff)
         for r in range(nc):
-            e("global_store_dword", v(voff), v(YR(r)), sp(S_PTR["ctrl"]))
+            e("global_store_dword", v(voff), v(YR(r)), sp(S_PTR["ctrl"]), *NT_ST)
             self.adv(voff)
         for r in range(nc):
             if r < neq:
                 t_ = zt[r % 4]
                 e("v_accvgpr_read_b32", v(t_), "a%d" % (A_LO + r))
-                e("global_store_dword", v(voff), v(t_), sp(S_PTR["ctrl"]))
+                e("global_store_dword", v(voff), v(t_), sp(S_PTR["ctrl"]), *NT_ST)
             else:
-                e("global_store_dword", v(voff), v(ZR(r)), sp(S_PTR["ctrl"]))
+                e("global_store_dword", v(voff), v(ZR(r)), sp(S_PTR["ctrl"]), *NT_ST)
             self.adv(voff)
         pool.free(*zt)
         e("s_waitcnt", "vmcnt(0)")
@@ -2126,7 +2156,7 @@ def fmt(t):
     if m.startswith("s_load_"):
         return "%s %s, %s, %s%s" % (m, a[0], a[1], ("0x%x" % t[3]) if isinstance(t[3], int) else t[3],
                                     (" " + t[4]) if len(t) > 4 else "")
-    if m.startswith("global_") and isinstance(t[-1], str) and (t[-1].startswith("offset:") or t[-1].startswith("sc0")):
+    if m.startswith("global_") and isinstance(t[-1], str) and (t[-1].startswith("offset:") or t[-1].startswith("sc0") or t[-1] == "nt"):
         return "%s %s %s" % (m, ", ".join(a[:-1]), t[-1])
     if m == "buffer_wbl2":
         return "buffer_wbl2 %s" % t[1]

@@ -219,5 +219,11 @@ def test_ruiz_and_plant_sections_reproduce_the_lane_stream_bit_for_bit(programs)
         asmstep.simulate(ins4, a4, dict(K=3, maxIter=1, nsub=25, plant=1), fl)
         sec = asmstep.simulate.last_quad_sections
         assert sec.get("admm", 0) == 0 and sec["ruiz"] > 0 and sec["plant"] > 0
-        for k in ("state", "out", "ctrl", "stats", "info", "status", "ws"):
+        for k in ("state", "out", "ctrl", "stats", "info", "status"):
             assert np.array_equal(a1[k], a4[k], equal_nan=True), (b, k)
+        # the parked scalings: the lane form keeps c and its first nine D words in spare AGPRs (round 5), the quad form in rows
+        parked = np.ones(asmgen.WS_ROWS, bool)
+        parked[:asmstep.N_SPARE_D] = False
+        parked[asmgen.WS_C - asmgen.WS_DS] = False
+        assert np.array_equal(a1["ws"][parked], a4["ws"][parked], equal_nan=True), b
+        assert not a1["ws"][~parked].any() and a4["ws"][~parked].all()
