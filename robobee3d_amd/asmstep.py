@@ -106,6 +106,12 @@ NT_PTRS = ("state", "ctrl", "ref", "out", "stats")
 # The ten AGPRs nobody owns (the loop: a0..a229, the weights: a230..a245) take c and the first nine D words across the loop
 # instead of workspace rows (lane form only: the quad entry composes words in AGPRs): 10 stores + 10 loads fewer per step
 A_SPARE, N_SPARE_D = 246, 9
+# Cache-policy bits on the workspace stores / loads of the parked D, E, c rows (lane form). Measured (tools/ab_ws.sh,
+# profiles/r05_nt_ab.txt, one box, on top of the streaming hint): plain 565 B read + 936 B written per robot-step = 1.24x
+# algorithmic; "nt" on both sides 502 + 779 = 1.06x, same ms per step (0.1206 / 0.1208); sc0 no change; sc1 / sc0 sc1
+# (write-through scopes) 805 read = 1.44x. Shipped: nt / nt.
+OPT_WS_ST = os.environ.get("UMPC_ASM_WS_ST", "nt")
+OPT_WS_LD = os.environ.get("UMPC_ASM_WS_LD", "nt")
 
 
 class Pool:
@@ -364,7 +370,7 @@ class StepGen:
         self.rows_ptr(voff, first_row)
         for k, r in enumerate(regs):
             self.e("global_load_dword", r if isinstance(r, str) else v(r), v(voff), sp(S_PTR[ptr]),
-                   *(("nt",) if self.nt in ("1", "ld") and ptr in NT_PTRS else ()))
+                   *(("nt",) if self.nt in ("1", "ld") and ptr in NT_PTRS else (OPT_WS_LD,) if ptr == "ws" and OPT_WS_LD and not self.quad else ()))
             if k + 1 < len(regs):
                 self.adv(voff)
         if own:
@@ -985,6 +991,7 @@ class StepGen:
         self.rcp_nr(cinv, cs, t)
         voff = pool.get()
         npark = 0 if self.quad else N_SPARE_D
+        WS_ST = (OPT_WS_ST,) if OPT_WS_ST and not self.quad else ()
         self.rows_ptr(voff, npark)     # the kernel's `ws` pointer is the workspace row WS_DS (host side): rows D 0.., E 45.., c 84
         rows_of_col = {}
         for i in range(nc):
@@ -1001,7 +1008,7 @@ class StepGen:
             if j < npark:
                 e("v_accvgpr_write_b32", "a%d" % (A_SPARE + j), v(d))
             else:
-                e("global_store_dword", v(voff), v(d), sp(S_PTR["ws"]))
+                e("global_store_dword", v(voff), v(d), sp(S_PTR["ws"]), *WS_ST)
                 self.adv(voff)
             if j in rows_of_col:
                 e("v_rcp_f32", v(r), v(d))
@@ -1010,7 +1017,7 @@ class StepGen:
                     e("v_mul_f32", v(RE(i)), "|%s|" % v(RA(st.unit[i][0])), v(r))       # E_i = |A_ip| / D_p
         assert asmgen.WS_ES == asmgen.WS_DS + nx and asmgen.WS_C == asmgen.WS_ES + nc
         for i in range(nc):
-            e("global_store_dword", v(voff), v(RE(i)), sp(S_PTR["ws"]))
+            e("global_store_dword", v(voff), v(RE(i)), sp(S_PTR["ws"]), *WS_ST)
             self.adv(voff)
         if npark:
             e("v_accvgpr_write_b32", "a%d" % (A_SPARE + N_SPARE_D), v(cs))
@@ -2156,7 +2163,7 @@ def fmt(t):
     if m.startswith("s_load_"):
         return "%s %s, %s, %s%s" % (m, a[0], a[1], ("0x%x" % t[3]) if isinstance(t[3], int) else t[3],
                                     (" " + t[4]) if len(t) > 4 else "")
-    if m.startswith("global_") and isinstance(t[-1], str) and (t[-1].startswith("offset:") or t[-1].startswith("sc0") or t[-1] == "nt"):
+    if m.startswith("global_") and isinstance(t[-1], str) and (t[-1].startswith("offset:") or t[-1].startswith("sc") or t[-1].startswith("nt")):
         return "%s %s %s" % (m, ", ".join(a[:-1]), t[-1])
     if m == "buffer_wbl2":
         return "buffer_wbl2 %s" % t[1]
