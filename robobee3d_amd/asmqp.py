@@ -253,6 +253,7 @@ MERGE_VM = int(os.environ.get("UMPC_QP_MERGE_VM", "150"))
 # generation-time experiment: the first NT_ITEMS landing items of an iteration are loaded with the non-temporal hint, so that
 # the rest of the stream (re-read every iteration) can stay in the XCD's L2 instead of the whole of it cycling through
 NT_ITEMS = int(os.environ.get("UMPC_QP_NT", "0"))
+NT_KINDS = tuple(k for k in os.environ.get("UMPC_QP_NT_KINDS", "").split(",") if k)     # "", "rows", "stream", "rows,stream"
 RING_AHEAD = int(os.environ.get("UMPC_QP_RING_AHEAD", "20"))   # ops of look-ahead for the LDS ring reads
 
 
@@ -1482,7 +1483,12 @@ def fmt(t):
     if m.startswith("ds_"):
         return "%s %s, %s offset:%s" % (m, a[0], a[1], a[2])
     if m.startswith("global_"):
-        return "%s %s, %s, %s offset:%s%s" % (m, a[0], a[1], a[2], a[3], " nt" if len(a) > 4 and a[4] == "nt" else "")
+        # cache policy (round 5, tools/ab_qp_nt.sh): "rows" = the caller's [row][B] arrays (lane offset v0: read or written once
+        # per tick), "stream" = the kernel's own per-workgroup stream blocks (written once, read once, by the same workgroup)
+        off = a[1] if m == "global_load_dword" else a[0]
+        kind = "rows" if off == "v0" else "stream"
+        nt = (len(a) > 4 and a[4] == "nt") or kind in NT_KINDS
+        return "%s %s, %s, %s offset:%s%s" % (m, a[0], a[1], a[2], a[3], " nt" if nt else "")
     if m == "s_waitcnt":
         return "s_waitcnt " + " ".join(a)
     return "%s %s" % (m, ", ".join(a))

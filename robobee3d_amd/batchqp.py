@@ -5,6 +5,7 @@ reference MPC formulations built on it:
                    usage of the reference's Python MPCs (template/genqp.py:206-209,157-158;
                    planar/mpc_osqp_p5f.py:131-147,172) with the embedded-C step of template/uprightmpc2/.
   PlanarP5fMPC     planar/mpc_osqp_p5f.py: stroke-plane MPC, nx = 7, nu = 1, N = 10 (config 4).
+  PlanarP5fStrokeMPC  planar/mpc_osqp_p5f_stroke.py: the stroke model, nx = 7, nu = 2, LTV blocks, N = 1 in the script.
   UprightMPCv1     template/genqp.py:43-168: the v1 template QP (nq = 6, nu = 3).
 
 torch is device memory / streams only; every computation is a kernel of libumpc_mi355x.so. Arrays are SoA
@@ -280,6 +281,144 @@ class PlanarP5fMPC:
                                      _ptr(lin) if lin is not None else None, stream)
         if rc != 0:
             raise RuntimeError(self.L.umpcLastError().decode())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# planar/mpc_osqp_p5f_stroke.py: the stroke model (two inputs (u, tf) per stroke, LTV blocks), SURVEY 8(f-4)
+# ---------------------------------------------------------------------------------------------------------
+STROKE_NPAR = 14        # per stage: tf0 | Ad[4,3] Ad[5,3] Ad[6,0] | u0 dx dz dphi | Bd[4,0] Bd[4,1] Bd[5,0] Bd[5,1] Bd[6,0] Bd[6,1]
+
+
+def stroke_getlin(u0, tf0, y):
+    """getLin of planar/mpc_osqp_p5f_stroke.py:38-86 for arrays u0, tf0 [B] and y [7, B] (y = (sigma, x, z, phi, dx, dz,
+    dphi)): the STROKE_NPAR entries of (Ad, Bd) that depend on the linearisation point, [14, B] float64 (host side:
+    the script evaluates it once per stage and tick; the structure's other entries are the constants 1 and -1)."""
+    u0, tf0, y = np.asarray(u0, np.float64), np.asarray(tf0, np.float64), np.asarray(y, np.float64)
+    sigma0, phi, dx, dz, dphi = y[0], y[3], y[4], y[5], y[6]
+    d, kaero2 = 2, 0.091875
+    u02, u03 = u0 ** 2, u0 ** 3
+    cphi, sphi, su0 = np.cos(phi), np.sin(phi), np.sign(u0)
+    one = np.ones_like(u0 * tf0 * phi)
+    return np.stack([
+        tf0 * one,
+        (tf0 * (-(cphi * kaero2 * u02) + kaero2 * sphi * su0 * u02)) / 100.,
+        (tf0 * (-(kaero2 * sphi * u02) - cphi * kaero2 * su0 * u02)) / 100.,
+        (kaero2 * tf0 * u02) / 7200. * one,
+        u0 * one, dx * one, dz * one, dphi * one,
+        (tf0 * (-2 * kaero2 * sphi * u0 - 2 * cphi * kaero2 * su0 * u0)) / 100.,
+        (-(kaero2 * sphi * u02) - cphi * kaero2 * su0 * u02) / 100.,
+        (tf0 * (2 * cphi * kaero2 * u0 - 2 * kaero2 * sphi * su0 * u0)) / 100.,
+        (-0.9800000000000001 + cphi * kaero2 * u02 - kaero2 * sphi * su0 * u02) / 100.,
+        (tf0 * (2 * d * kaero2 * su0 * u0 + 2 * kaero2 * u0 * (sigma0 + (tf0 * u0) / 2.) + (kaero2 * tf0 * u02) / 2.)) / 7200.,
+        (d * kaero2 * su0 * u02 + kaero2 * (sigma0 + (tf0 * u0) / 2.) * u02) / 7200. + (kaero2 * tf0 * u03) / 14400.])
+
+
+def p5f_stroke_structure(N=1):
+    """The QP of planar/mpc_osqp_p5f_stroke.py:139-193 with the LTV blocks of getCondensed :88-124: x = (y(0..N) [7 each],
+    (u, tf)(0..N-1)); rows = (N+1)*7 dynamics equalities (-I on the diagonal, stage k's Ad below it, its Bd in the input
+    columns) + identity box rows (states free, umin = (-10, 0.1), umax = (10, 100) :130-133). Returns dict(n, m, A_p, A_i,
+    P_cols, cst, src, Pv, q, l, u): A[k] = cst[k] (src < 0) or cst[k] * par[src[k]] with par [STROKE_NPAR * N, B] = the stages'
+    stroke_getlin rows. The pattern holds every entry getLin's expressions can make non-zero (13 of Ad, 11 of Bd); P is what
+    scipy's block_diag keeps of diag(Q .. QN, R) as non-zeros (Q = diag(0, 10, 10, 10, 0, 0, 0), R = 10 I :136-138)."""
+    nx, nu = 7, 2
+    n = (N + 1) * nx + N * nu
+    neq = (N + 1) * nx
+    m = neq + n
+    ent = {}
+    AD = ((0, 0, -1), (1, 1, -1), (1, 4, 0), (2, 2, -1), (2, 5, 0), (3, 3, -1), (3, 6, 0), (4, 3, 1), (4, 4, -1), (5, 3, 2),
+          (5, 5, -1), (6, 0, 3), (6, 6, -1))
+    BD = ((0, 0, 0), (0, 1, 4), (1, 1, 5), (2, 1, 6), (3, 1, 7), (4, 0, 8), (4, 1, 9), (5, 0, 10), (5, 1, 11), (6, 0, 12), (6, 1, 13))
+    for k in range(N + 1):
+        for i in range(nx):
+            ent[(k * nx + i, k * nx + i)] = (-1.0, -1)
+        if k > 0:
+            for (r, c, sidx) in AD:
+                ent[(k * nx + r, (k - 1) * nx + c)] = (1.0, -1 if sidx < 0 else STROKE_NPAR * (k - 1) + sidx)
+            for (r, c, sidx) in BD:
+                ent[(k * nx + r, neq + nu * (k - 1) + c)] = (1.0, STROKE_NPAR * (k - 1) + sidx)
+    for j in range(n):
+        ent[(neq + j, j)] = (1.0, -1)
+    A_p, A_i, cst, src = [0], [], [], []
+    for j in range(n):
+        for i in sorted(r for (r, c) in ent if c == j):
+            A_i.append(i)
+            cst.append(ent[(i, j)][0])
+            src.append(ent[(i, j)][1])
+        A_p.append(len(A_i))
+    Qd = np.array([0., 10., 10., 10., 0., 0., 0.])
+    Pfull = np.hstack([np.tile(Qd, N + 1), np.full(N * nu, 10.0)])
+    P_cols = [j for j in range(n) if Pfull[j] != 0.0]
+    yr = np.zeros(nx)                                                   # :143
+    q = np.hstack([np.tile(-Qd * yr, N + 1), np.zeros(N * nu)])
+    l = np.hstack([np.zeros(neq), np.full(neq, -OSQP_INFTY), np.tile([-10.0, 0.1], N)])
+    u = np.hstack([np.zeros(neq), np.full(neq, OSQP_INFTY), np.tile([10.0, 100.0], N)])
+    return dict(N=N, n=n, m=m, A_p=A_p, A_i=A_i, P_cols=P_cols, cst=np.array(cst), src=np.array(src, np.int32),
+                Pv=Pfull[P_cols], q=q, l=l, u=u, npar=STROKE_NPAR * N)
+
+
+def stroke_dense_A(st, par):
+    """dense A [m, n] of ONE robot from the structure and its parameter column (host side; the tests compare it with the
+    script's own getCondensed output)"""
+    A = np.zeros((st["m"], st["n"]))
+    for j in range(st["n"]):
+        for k in range(st["A_p"][j], st["A_p"][j + 1]):
+            A[st["A_i"][k], j] = st["cst"][k] * (1.0 if st["src"][k] < 0 else par[st["src"][k]])
+    return A
+
+
+class PlanarP5fStrokeMPC:
+    """B copies of the QP step of planar/mpc_osqp_p5f_stroke.py:204-225 on the general-structure solver: per tick the N stage
+    linearisations (stroke_getlin along the nominal alternating-stroke rollout, getCondensed :88-124) fill A through
+    umpcQPGather, the first seven bounds pin the initial state (l[:nx] = u[:nx] = -y0, :120-122) and the QP is solved with
+    the script's tolerances (eps 1e-2, :196) in pip-osqp termination semantics, or for a fixed iteration count."""
+
+    def __init__(self, B, dtype=torch.float64, device="cuda", N=1, **settings):
+        st = p5f_stroke_structure(N)
+        self.st, self.B, self.N, self.dtype = st, int(B), N, dtype
+        settings.setdefault("eps_abs", 1e-2)
+        settings.setdefault("eps_rel", 1e-2)
+        self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, **settings)
+        dev = self.qp.device
+        col = lambda v: torch.as_tensor(np.repeat(np.asarray(v, np.float64)[:, None], B, 1)).to(dev, dtype).contiguous()
+        self.Pv, self.q, self.l, self.u = col(st["Pv"]), col(st["q"]), col(st["l"]), col(st["u"])
+        self.cst = torch.as_tensor(st["cst"]).to(dev, dtype)
+        self.src = torch.as_tensor(st["src"]).to(dev)
+        self.par = torch.zeros((st["npar"], B), dtype=dtype, device=dev)
+        self.Av = torch.zeros((len(st["A_i"]), B), dtype=dtype, device=dev)
+        self.L = self.qp.L
+
+    def rollout_parameters(self, u0, tf0, y0):
+        """getCondensed's forward simulation (:97-112): stage j linearises about (u_j, tf0, y_j) with u_j alternating in sign
+        and y_{j+1} = Ad y_j + Bd (u_j, tf0). u0, tf0 [B], y0 [7, B] (host arrays) -> par [14 N, B]."""
+        u0, tf0 = np.asarray(u0, np.float64) * np.ones(self.B), np.asarray(tf0, np.float64) * np.ones(self.B)
+        y = np.array(y0, np.float64).reshape(7, -1) * np.ones((7, self.B))
+        rows, up = [], u0
+        for _ in range(self.N):
+            pr = stroke_getlin(up, tf0, y)
+            rows.append(pr)
+            tf, a43, a53, a60, bu, bdx, bdz, bdphi, b40, b41, b50, b51, b60, b61 = pr
+            y = np.stack([y[0] + tf * up + bu * tf0,                       # row 0: Ad = 1; Bd = (tf0, u0)
+                          y[1] + tf * y[4] + bdx * tf0, y[2] + tf * y[5] + bdz * tf0, y[3] + tf * y[6] + bdphi * tf0,
+                          a43 * y[3] + y[4] + b40 * up + b41 * tf0, a53 * y[3] + y[5] + b50 * up + b51 * tf0,
+                          a60 * y[0] + y[6] + b60 * up + b61 * tf0])
+            up = -up
+        return np.vstack(rows)
+
+    def update(self, par, y0):
+        """A <- gather(par), l[:7] = u[:7] = -y0; par [14 N, B], y0 [7, B] (host arrays or device tensors)"""
+        dev = self.qp.device
+        self.par.copy_(torch.as_tensor(np.asarray(par, np.float64) if not torch.is_tensor(par) else par).to(dev, self.dtype))
+        y0 = torch.as_tensor(np.asarray(y0, np.float64) if not torch.is_tensor(y0) else y0).to(dev, self.dtype)
+        self.l[:7] = -y0
+        self.u[:7] = -y0
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self.L.umpcQPGather(self.B, _DT[self.dtype], int(self.cst.numel()), _ptr(self.cst), _ptr(self.src), _ptr(self.par),
+                                 _ptr(self.Av), stream)
+        if rc != 0:
+            raise RuntimeError(self.L.umpcLastError().decode())
+
+    def solve(self, max_iter=None):
+        return self.qp.solve(self.Pv, self.Av, self.q, self.l, self.u, max_iter=max_iter)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -493,6 +493,77 @@ def planar_p5f():
 
 
 
+def planar_p5f_stroke():
+    """SURVEY 8(f-4)'s SECOND planar structure: planar/mpc_osqp_p5f_stroke.py (stroke model: nx = 7, nu = 2 inputs (u, tf),
+    N = 1 => n = 16, m = 30; LTV blocks from getLin :38-86; input box umin = (-10, 0.1), umax = (10, 100), states free). The
+    script needs pip `osqp` (absent) at import and solves with it (eps 1e-2, :196), so its solves are unpinnable; what it
+    COMPUTES without osqp is pinned here by executing its own statements where they lie, one at a time: getLin, the QP
+    data :139-193 (P through scipy.sparse.block_diag, which drops Q's zero diagonal entries), and for every tick of its loop
+    :204-221 the nominal-input bookkeeping, the open-loop state, and getCondensed's (A, l, u) -- the statements of the loop
+    body up to `prob.update`, in the script's own namespace (ympc is never advanced: the script's own update line :247 is
+    commented out). Skipped statements are recorded."""
+    import ast
+    import scipy as sp
+    import scipy.linalg  # noqa: F401
+    import scipy.sparse as sparse
+    path = "/root/reference/planar/mpc_osqp_p5f_stroke.py"
+    tree = ast.parse(open(path).read(), path)
+    ns = {"np": np, "sp": sp, "sparse": sparse, "sys": sys}
+    skipped, loop = [], None
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            continue
+        if isinstance(node, ast.For):
+            loop = node
+            break
+        try:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        except Exception as ex:
+            skipped.append("line %d: %s" % (node.lineno, type(ex).__name__))
+    assert loop is not None and len(skipped) == 2, skipped          # prob = osqp.OSQP(); prob.setup(...)
+    # the loop body up to (not including) the first statement that touches `prob`
+    body = []
+    for node in loop.body:
+        if "prob" in {n_.id for n_ in ast.walk(node) if isinstance(n_, ast.Name)}:
+            break
+        body.append(node)
+    assert isinstance(body[-1], ast.Assign) and "getCondensed(" in ast.unparse(body[-1])
+    rec = {k: [] for k in ("u0", "tf0", "y_prev", "ympc_prev", "y_ol", "A", "l", "u", "Ad0", "Bd0")}
+    for ti in ns["tvec"]:
+        ns["ti"] = ti
+        try:
+            for node in body:
+                if isinstance(node, ast.If) and ast.unparse(node.test) == "ti == 0":
+                    if ti == 0:
+                        raise StopIteration      # the script's `continue`
+                    continue
+                exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        except StopIteration:
+            continue
+        rec["u0"].append(float(ns["u0"])); rec["tf0"].append(float(ns["tf0"]))
+        rec["y_prev"].append(np.array(ns["y"][ti - 1], np.float64)); rec["ympc_prev"].append(np.array(ns["ympc"][ti - 1], np.float64))
+        rec["y_ol"].append(np.array(ns["y"][ti], np.float64).ravel())
+        rec["A"].append(np.asarray(ns["A"], np.float64)); rec["l"].append(np.array(ns["l"], np.float64)); rec["u"].append(np.array(ns["u"], np.float64))
+        rec["Ad0"].append(np.asarray(ns["Ad0"], np.float64)); rec["Bd0"].append(np.asarray(ns["Bd0"], np.float64))
+    # more getLin samples, away from the script's own trajectory (random inputs, both signs of u0, u0 = 0)
+    rng = np.random.default_rng(22)
+    lu0 = np.concatenate(([0.0, 5.0, -5.0], rng.normal(size=45) * 8))
+    ltf = np.concatenate(([0.0, 5.0, 5.0], rng.uniform(0.1, 20, 45)))
+    ly = rng.normal(size=(48, 7)) * np.array([10, 1, 1, 0.5, 1, 1, 1])
+    lAd, lBd = [], []
+    for a, b, c in zip(lu0, ltf, ly):
+        Ad, Bd = ns["getLin"](a, b, c)
+        lAd.append(np.asarray(Ad, np.float64)); lBd.append(np.asarray(Bd, np.float64))
+    P = ns["P"].tocsc()
+    np.savez_compressed(os.path.join(HERE, "planar_p5f_stroke.npz"), N=np.int32(ns["N"]), nx=np.int32(ns["nx"]), nu=np.int32(ns["nu"]),
+                        P_indices=P.indices, P_indptr=P.indptr, P_data=P.data, q=np.asarray(ns["q"], np.float64),
+                        umin=ns["umin"], umax=ns["umax"], A_setup=np.asarray(ns["A"].todense() if hasattr(ns["A"], "todense") else ns["A"], np.float64) if False else
+                        np.asarray(sparse.vstack([ns["Aeq"], ns["Aineq"]]).todense(), np.float64),
+                        lin_u0=lu0, lin_tf0=ltf, lin_y=ly, lin_Ad=np.stack(lAd), lin_Bd=np.stack(lBd),
+                        skipped=np.array(skipped), **{"tick_" + k: np.stack(v) for k, v in rec.items()})
+    print("planar_p5f_stroke.npz: %d ticks, A %s, P nnz %d, skipped %s" % (len(rec["A"]), rec["A"][0].shape, P.nnz, skipped))
+
+
 def planar_code():
     """The reference's SECOND generated controller, planar/code (emosqp of OSQP 0.5.0, EMBEDDED 1, DFLOAT, n = 46,
     m = 82, scaling 0, rho 5.694, check_termination 25, max_iter 50: planar/code/include/workspace.h:1068-1071; the output of
@@ -610,6 +681,10 @@ if __name__ == "__main__":
         assembly_fp64(import_reference_python(), 5, "assembly_fp64_N5.npz")
         v1_qp(import_reference_python())
         planar_p5f()
+        planar_p5f_stroke()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stroke":
+        planar_p5f_stroke()
         sys.exit(0)
     structure()
     sequence(20201117, 256, 50, "seq_iter50.npz")
@@ -625,6 +700,7 @@ if __name__ == "__main__":
     reactive(mods)
     v1_qp(mods)
     planar_p5f()
+    planar_p5f_stroke()
     nan_branch()
     bounds_reject()
     models()

@@ -1032,3 +1032,109 @@ def test_gpu_p5f_entries_reject_bad_arguments():
     assert L.umpcP5fLinearise(8, 0, None, 1.0, _ptr(mpc.y), _ptr(mpc.lin), nnz, _ptr(mpc.cst), _ptr(mpc.src), _ptr(mpc.Av), 0, None) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(mpc.Av).all() and torch.isfinite(mpc.lin).all()
+
+
+# ------------------------------------------------------------------------------------------------------
+# planar/mpc_osqp_p5f_stroke.py (SURVEY 8(f-4)'s second planar structure)
+# ------------------------------------------------------------------------------------------------------
+def test_stroke_structure_reproduces_the_script():
+    """tests/golden/planar_p5f_stroke.npz = what planar/mpc_osqp_p5f_stroke.py computes without osqp, executed where it lies
+    (make_golden.py::planar_p5f_stroke): getLin samples, the QP data, and (A, l, u) of every tick of its loop. The registered
+    structure + the host-side getLin restatement reproduce them: getLin to round-off, the assembled dense A of all 29 ticks
+    EXACTLY (same float64 expressions), P's non-zeros, q, and the bounds with the wrapper's +-1e30 for +-inf."""
+    from robobee3d_amd import batchqp as bq
+    g = golden("planar_p5f_stroke.npz")
+    N = int(g["N"])
+    st = bq.p5f_stroke_structure(N)
+    assert (st["n"], st["m"]) == g["tick_A"].shape[:0:-1] == (16, 30) and int(g["nx"]) == 7 and int(g["nu"]) == 2
+    par = bq.stroke_getlin(g["lin_u0"], g["lin_tf0"], g["lin_y"].T)
+    for b in range(len(g["lin_u0"])):
+        A = bq.stroke_dense_A(st, par[:, b])
+        assert np.abs(A[7:14, 0:7] - g["lin_Ad"][b]).max() < 1e-15 and np.abs(A[7:14, 14:16] - g["lin_Bd"][b]).max() < 1e-15
+    full = bq.stroke_dense_A(st, np.ones(st["npar"])) != 0
+    assert np.all((g["A_setup"] != 0) <= full)                       # the LTI matrix of prob.setup lies inside the pattern
+    for t in range(len(g["tick_u0"])):
+        par = bq.stroke_getlin(g["tick_u0"][t:t + 1], g["tick_tf0"][t:t + 1], g["tick_ympc_prev"][t][:, None])
+        A = bq.stroke_dense_A(st, par[:, 0])
+        assert np.array_equal(A, g["tick_A"][t]) and np.all((g["tick_A"][t] != 0) <= full)
+        l, u = st["l"].copy(), st["u"].copy()
+        l[:7] = u[:7] = -g["tick_ympc_prev"][t]
+        assert np.array_equal(l, np.clip(g["tick_l"][t], -bq.OSQP_INFTY, bq.OSQP_INFTY))
+        assert np.array_equal(u, np.clip(g["tick_u"][t], -bq.OSQP_INFTY, bq.OSQP_INFTY))
+        # the open-loop state of the script's own plant line (:218)
+        Ad0, Bd0 = g["tick_Ad0"][t], g["tick_Bd0"][t]
+        assert np.allclose(Ad0 @ g["tick_y_prev"][t] + Bd0 @ np.array([g["tick_u0"][t], g["tick_tf0"][t]]), g["tick_y_ol"][t], rtol=0, atol=1e-12)
+    # P: scipy's block_diag of dense blocks keeps explicit zeros (102 stored entries); its NON-ZEROS are the structure's
+    Pd = np.zeros(16)
+    for j in range(16):
+        for k in range(g["P_indptr"][j], g["P_indptr"][j + 1]):
+            if g["P_indices"][k] == j:
+                Pd[j] = g["P_data"][k]
+            else:
+                assert g["P_data"][k] == 0
+    assert [j for j in range(16) if Pd[j] != 0] == st["P_cols"] and np.array_equal(Pd[st["P_cols"]], st["Pv"])
+    assert np.array_equal(np.abs(g["q"]), np.abs(st["q"]))           # (-0. in the script, 0. here)
+
+
+@pytest.mark.gpu
+def test_gpu_stroke_structure_on_the_table_kernel(margin):
+    """The stroke structure has no build-time specialisation: `umpcQPSolve` takes it on the table-driven kernel (and the
+    wave kernel), fp64 and fp32, for the script's 29 ticks as ONE batch (robot t = tick t: its A through umpcQPGather from
+    the stroke_getlin parameters, l[:7] = u[:7] = -ympc), against oracle/osqp_table.py on the fixture's own A, l, u:
+    (i) 50 fixed iterations, iterates to 1e-9 (fp64); (ii) the script's solve semantics -- eps 1e-2 (:196), termination test
+    every 25 iterations -- same iteration counts and status words (every tick SOLVED after 25 iterations). The script's own
+    solve needs pip osqp and is unpinnable (and hands `prob.update(Ax=...)` a dense matrix, :222, hence its `FIXME: says primal
+    infeasible`, :228); what is pinned is the data it assembles and the solver that takes them."""
+    import torch
+    import osqp_table
+    from robobee3d_amd import batchqp as bq
+    g = golden("planar_p5f_stroke.npz")
+    T = len(g["tick_u0"])
+    st = bq.p5f_stroke_structure(1)
+    par = bq.stroke_getlin(g["tick_u0"], g["tick_tf0"], g["tick_ympc_prev"].T)
+    Av_ref = np.zeros((len(st["A_i"]), T))
+    for t in range(T):
+        k = 0
+        for j in range(st["n"]):
+            for p_ in range(st["A_p"][j], st["A_p"][j + 1]):
+                Av_ref[p_, t] = g["tick_A"][t][st["A_i"][p_], j]
+    l = np.clip(g["tick_l"].T, -bq.OSQP_INFTY, bq.OSQP_INFTY)
+    u = np.clip(g["tick_u"].T, -bq.OSQP_INFTY, bq.OSQP_INFTY)
+    rep = lambda v: np.repeat(np.asarray(v, np.float64)[:, None], T, 1)
+    z = lambda r: np.zeros((r, T))
+    for dtype, ndt, tol in ((torch.float64, np.float64, 1e-9), (torch.float32, np.float32, 2e-4)):
+        for kern in ("tables", "wave"):
+            mpc = bq.PlanarP5fStrokeMPC(T, dtype)
+            mpc.qp.set_kernel(kern)
+            mpc.update(par, g["tick_ympc_prev"].T)
+            torch.cuda.synchronize()
+            assert np.array_equal(mpc.Av.cpu().numpy().astype(np.float64), Av_ref.astype(ndt).astype(np.float64))
+            assert np.array_equal(mpc.l.cpu().numpy().astype(np.float64), l.astype(ndt).astype(np.float64))
+            # (i) fixed 50 iterations
+            mpc.qp.reset()
+            mpc.qp.set_termination(check_every=0, max_iter=50)
+            mpc.solve()
+            torch.cuda.synchronize()
+            r = osqp_table.solve(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], mpc.qp.s.perm, rep(st["Pv"]), Av_ref, rep(st["q"]),
+                                 l, u, z(16), z(30), z(30), np.ones((30, T)), osqp_table.Settings(max_iter=50, eps_abs=1e-2, eps_rel=1e-2),
+                                 dtype=ndt)
+            lab = "stroke %s %s: " % (kern, "fp64" if ndt is np.float64 else "fp32")
+            sc = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+            f = lambda t_: t_.cpu().numpy().astype(np.float64)
+            margin(lab + "iterates after 50 iterations |d| / max(1, |ref|)", max(sc(f(mpc.qp.x), r["x"]), sc(f(mpc.qp.y), r["y"]), sc(f(mpc.qp.z), r["z"])), tol)
+            if ndt is np.float64:
+                assert np.array_equal(f(mpc.qp.status), r["status"])
+            # (ii) the script's solve semantics
+            mpc.qp.reset()
+            mpc.qp.set_termination(check_every=25, max_iter=4000)
+            mpc.solve()
+            torch.cuda.synchronize()
+            r2 = osqp_table.solve(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], mpc.qp.s.perm, rep(st["Pv"]), Av_ref, rep(st["q"]),
+                                  l, u, z(16), z(30), z(30), np.ones((30, T)),
+                                  osqp_table.Settings(max_iter=4000, eps_abs=1e-2, eps_rel=1e-2, check_termination=25), dtype=ndt)
+            if ndt is np.float64:
+                assert np.array_equal(f(mpc.qp.status), r2["status"]) and np.array_equal(f(mpc.qp.info[4]).astype(np.int32), r2["iters"])
+                ok = r2["status"] > 0
+                margin(lab + "solution at eps 1e-2 |d| / max(1, |ref|)", sc(f(mpc.qp.sol_x)[:, ok], r2["sol_x"][:, ok]), 1e-8)
+            else:
+                margin(lab + "status words differing from the float32 oracle (of %d)" % T, int(np.count_nonzero(f(mpc.qp.status) != r2["status"])), 2)
