@@ -140,6 +140,24 @@ __global__ void umpc_dropin_debug_kernel(DevParams<float> dprm, const float *sta
   __hip_atomic_store(done1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Round 5: the same in ONE launch. The drop-in's step kernel is the quad stream on robot 0 = lanes 0..3 of one wavefront;
+// lane 4 -- outside the quad, it never enters the stream -- assembles the debug fields FIRST (the barrier is a convergence
+// point: its stores are issued before the stream starts), and the stream's own epilogue (s_waitcnt vmcnt(0), L2 write-back at
+// system scope, completion word) then releases them with the results: one launch, one completion word to poll.
+__global__ __launch_bounds__(kBlock) void umpc_dropin_quad_kernel(const umpcasm::StepParams prm, DevParams<float> dprm,
+                                                                  const float *state, const float *ref, const float *t0dbg,
+                                                                  float *l, float *u, float *q, float *Px, float *Ax) {
+  __shared__ float4 lds[(umpcasm::STEP_LDS_BYTES_PER_LANE / 16) * kBlock];
+  if (threadIdx.x == 4) assemble_rows<float>(dprm, 1, 0, state, nullptr, ref, nullptr, t0dbg, l, u, q, Px, Ax);
+  __syncthreads();
+  if (threadIdx.x >= 4) return;
+  const unsigned ldsaddr = (unsigned)(size_t)(&lds[threadIdx.x]);
+  const unsigned voff = 0u;           // robot 0 in all four lanes of the quad
+  (void)prm;
+  const void *pp = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  UMPC_STEP_ASM_QUAD(voff, ldsaddr, pp);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void umpc_plant_kernel(DevParams<T> prm, int B_, int nsub, T *state,
                                                             const T *u, const T *IbA, const T *gainA) {
@@ -946,14 +964,24 @@ int umpcUpdate(UprightMPC_t *up, float uquad[3], float accdes[6], const float p0
     umpcasm::StepParams p = make_step_params(s.h, 1, 0, d + O_STATE, s.ctrl, d + O_REF, d + O_AT0, nullptr, nullptr, d + O_OUT,
                                              nullptr, (int32_t *)(d + O_STATUS), d + O_INFO);
     p.done = d + O_DONE0; p.seq = (int)seq;
-    if (quad_max_b() >= 1)
-      hipLaunchKernelGGL(umpc_rollout_asm_quad_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1);
-    else
-      hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1, 0, 1);
-    hipLaunchKernelGGL(umpc_dropin_debug_kernel, dim3(1), dim3(64), 0, s.stream2, make_dev<float>(s.h->prm),
-                       (const float *)(d + O_STATE), (const float *)(d + O_REF), (const float *)(d + O_T0DBG), d + O_L, d + O_U,
-                       d + O_Q, d + O_PX, d + O_AX, (unsigned *)(d + O_DONE1), seq);
-    s.h->last_kernel = quad_max_b() >= 1 ? "umpc_rollout_asm_quad_kernel" : "umpc_rollout_asm_kernel";
+    // UMPC_DROPIN_TWO_STREAMS=1: round 4's form (step kernel + debug-field kernel on two streams, two completion words), A/B
+    static const bool two_streams = getenv("UMPC_DROPIN_TWO_STREAMS") != nullptr;
+    const bool one_launch = quad_max_b() >= 1 && !two_streams;
+    if (one_launch) {
+      hipLaunchKernelGGL(umpc_dropin_quad_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, make_dev<float>(s.h->prm),
+                         (const float *)(d + O_STATE), (const float *)(d + O_REF), (const float *)(d + O_T0DBG), d + O_L,
+                         d + O_U, d + O_Q, d + O_PX, d + O_AX);
+      *(unsigned *)(hb + O_DONE1) = seq;           // (one completion word in this form: the second one is the host's own)
+    } else {
+      if (quad_max_b() >= 1)
+        hipLaunchKernelGGL(umpc_rollout_asm_quad_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1);
+      else
+        hipLaunchKernelGGL(umpc_rollout_asm_kernel, dim3(1), dim3(kBlock), 0, s.stream, p, 1, 0, 1);
+      hipLaunchKernelGGL(umpc_dropin_debug_kernel, dim3(1), dim3(64), 0, s.stream2, make_dev<float>(s.h->prm),
+                         (const float *)(d + O_STATE), (const float *)(d + O_REF), (const float *)(d + O_T0DBG), d + O_L, d + O_U,
+                         d + O_Q, d + O_PX, d + O_AX, (unsigned *)(d + O_DONE1), seq);
+    }
+    s.h->last_kernel = one_launch ? "umpc_dropin_quad_kernel" : quad_max_b() >= 1 ? "umpc_rollout_asm_quad_kernel" : "umpc_rollout_asm_kernel";
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fail(e, "umpcUpdate"); return 1; }
     volatile unsigned *f0 = (volatile unsigned *)(hb + O_DONE0), *f1 = (volatile unsigned *)(hb + O_DONE1);
