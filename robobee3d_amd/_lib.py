@@ -197,7 +197,35 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=csrc, stderr=None if verbose else subprocess.DEVNULL)
+    build_ext(verbose=verbose)
     return SO_PATH
+
+
+EXT_SRC = os.path.join(HERE, "csrc", "uprightmpc2py_ext.cpp")
+
+
+def ext_path():
+    import sysconfig
+    return os.path.join(HERE, "_uprightmpc2py" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_ext(force=False, verbose=False):
+    """The compiled Python module of the drop-in boundary (csrc/uprightmpc2py_ext.cpp: pybind11 over the C ABI, the
+    counterpart of template/uprightmpc2/py/uprightmpc2py.cpp): host compiler only, linked against libumpc_mi355x.so next to
+    it (rpath $ORIGIN). In-tree, like the library, so that it travels to the GPU box."""
+    import sysconfig
+    import pybind11
+    out = ext_path()
+    hdr = os.path.join(ROOT, "include", "umpc_mi355x.h")
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in (EXT_SRC, hdr, SO_PATH)):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-I", pybind11.get_include(),
+           "-I", sysconfig.get_paths()["include"], "-I", os.path.join(ROOT, "include"), EXT_SRC, "-o", out,
+           "-L", HERE, "-l:libumpc_mi355x.so", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
 
 
 _lib = None

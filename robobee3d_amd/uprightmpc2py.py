@@ -10,8 +10,14 @@ C symbols, here executing on the MI355X).
 
 `actualT0` defaults to -1 because the reference's own harness calls update with
 six arguments (template/uprightmpc2.py:139).
+
+Two bindings of the same C symbols: the COMPILED module `_uprightmpc2py` (csrc/uprightmpc2py_ext.cpp, pybind11 like the
+reference's own extension; built in-tree by _lib.build()) is what `UprightMPC2C` / `WLCon` name when it is present; the
+ctypes classes below (`UprightMPC2C_ctypes`, `WLCon_ctypes`) are the portable binding and what is used under
+UMPC_LIB (A/B builds of the library) or UMPC_PY_BINDING=ctypes. `binding()` says which one is active.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -25,7 +31,7 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-class UprightMPC2C:
+class UprightMPC2C_ctypes:
     def __init__(self, dt, g, TtoWmax, ws, wds, wpr, wpf, wvr, wvf, wthrust, wmom, Ib, maxIter):
         self._L = _lib.lib()
         self.umpc = _lib.UprightMPC_t()
@@ -74,7 +80,7 @@ class UprightMPC2C:
         return rc
 
 
-class WLCon:
+class WLCon_ctypes:
     """Mirror of the pybind `WLCon` class (template/uprightmpc2/py/uprightmpc2py.cpp:54-68):
     WLCon(u0, umin, umax, dumax, Qw, controlRate, popts).update(h0, pdotdes) -> (u1[4], w0[6]),
     over the reference's own C symbols wlConInit / wlConUpdate (funapprox.h:43-45) in libumpc_mi355x.so."""
@@ -91,6 +97,21 @@ class WLCon:
         u1, w0 = np.zeros(4, np.float32), np.zeros(6, np.float32)
         self._L.wlConUpdate(C.byref(self.wl), _fp(u1), _fp(w0), _fp(f(h0)), _fp(f(pdotdes)))
         return u1, w0
+
+
+try:
+    if os.environ.get("UMPC_LIB") or os.environ.get("UMPC_PY_BINDING") == "ctypes":
+        raise ImportError("ctypes binding requested")
+    from . import _uprightmpc2py as _native
+except ImportError:
+    _native = None
+UprightMPC2C = _native.UprightMPC2C if _native is not None else UprightMPC2C_ctypes
+WLCon = _native.WLCon if _native is not None else WLCon_ctypes
+
+
+def binding():
+    """"pybind11" (the compiled module) or "ctypes": which binding `UprightMPC2C` / `WLCon` are"""
+    return "pybind11" if _native is not None else "ctypes"
 
 
 class UprightMPC2:

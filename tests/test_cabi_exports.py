@@ -86,13 +86,27 @@ from uprightmpc2py import UprightMPC2C # C version               (template/templ
 from uprightmpc2py import UprightMPC2C, WLCon                    # (template/robobee_test_controllers.py:9, verbatim)
 import inspect, uprightmpc2py, os
 assert os.path.dirname(os.path.abspath(uprightmpc2py.__file__)) == %(root)r
-sig = inspect.signature(UprightMPC2C.update)
+import re
+def params(f):
+    # a compiled (pybind11) method carries its signature in the first line of its docstring, a Python one in inspect
+    try:
+        sig = inspect.signature(f)
+        return list(sig.parameters)[1:], {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
+    except ValueError:
+        head = f.__doc__.splitlines()[0]
+        inner = head[head.index("(") + 1:head.rindex(") ->")]
+        # split on the commas that precede "name:" (annotations contain commas of their own)
+        parts = re.split(r", (?=[A-Za-z_0-9]+: )", inner)[1:]
+        names = [p_.split(":")[0] for p_ in parts]
+        dflt = {p_.split(":")[0]: float(p_.rsplit("=", 1)[1]) for p_ in parts if "=" in p_.rsplit("]", 1)[-1]}
+        return names, dflt
 # template/uprightmpc2.py:139 calls update with SIX arguments; template/uprightmpc2/py/uprightmpc2py.cpp:38 has seven
-assert list(sig.parameters)[1:] == ["p0", "R0", "dq0", "pdes", "dpdes", "sdes", "actualT0"]
-assert sig.parameters["actualT0"].default == -1.0
-assert list(inspect.signature(UprightMPC2C.__init__).parameters)[1:] == ["dt", "g", "TtoWmax", "ws", "wds", "wpr", "wpf",
-    "wvr", "wvf", "wthrust", "wmom", "Ib", "maxIter"]
-assert list(inspect.signature(WLCon.__init__).parameters)[1:] == ["u0", "umin", "umax", "dumax", "Qw", "controlRate", "popts"]
+names, dflt = params(UprightMPC2C.update)
+assert names == ["p0", "R0", "dq0", "pdes", "dpdes", "sdes", "actualT0"], names
+assert dflt == {"actualT0": -1.0}, dflt
+assert params(UprightMPC2C.__init__)[0] == ["dt", "g", "TtoWmax", "ws", "wds", "wpr", "wpf", "wvr", "wvf", "wthrust", "wmom",
+                                            "Ib", "maxIter"]
+assert params(WLCon.__init__)[0] == ["u0", "umin", "umax", "dumax", "Qw", "controlRate", "popts"]
 print("ok")
 """
 
@@ -105,3 +119,34 @@ def test_reference_import_lines_run_unchanged(lib):
     r = subprocess.run([sys.executable, "-c", _IMPORT_LINES % dict(root=ROOT)], capture_output=True, text=True,
                        cwd="/", env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+
+
+def test_compiled_python_module_is_built_and_mirrors_the_reference_classes(lib):
+    """The counterpart of the reference's pybind11 extension (template/uprightmpc2/py/uprightmpc2py.cpp:70-80: classes
+    UprightMPC2C(13 arguments).update / vectors / matrices and WLCon(7 arguments).update) exists as a COMPILED module
+    (csrc/uprightmpc2py_ext.cpp, built in-tree by _lib.build()), links the library next to it, and is what the top-level
+    `uprightmpc2py` names. No GPU call here: classes and signatures only (constructing a controller needs the device)."""
+    import subprocess
+    import sys
+    from robobee3d_amd import _lib
+    assert os.path.exists(_lib.ext_path()), "run __graft_entry__.build()"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import uprightmpc2py as m\n"
+            "from robobee3d_amd import uprightmpc2py as w, _uprightmpc2py as n\n"
+            "assert w.binding() == 'pybind11' and m.UprightMPC2C is n.UprightMPC2C and m.WLCon is n.WLCon\n"
+            "d = n.UprightMPC2C.update.__doc__\n"
+            "assert all(k in d for k in ('p0', 'R0', 'dq0', 'pdes', 'dpdes', 'sdes', 'actualT0')) and '= -1.0' in d\n"
+            "assert all(hasattr(n.UprightMPC2C, k) for k in ('update', 'vectors', 'matrices', 'status', 'set_compat'))\n"
+            "assert hasattr(n.WLCon, 'update')\n"
+            "print('ok')\n") % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "UMPC_LIB", "UMPC_PY_BINDING")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/", env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+    # ... and the ctypes binding stays selectable
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom robobee3d_amd import uprightmpc2py as w\n"
+                        "assert w.binding() == 'ctypes' and w.UprightMPC2C is w.UprightMPC2C_ctypes\nprint('ok')" % ROOT],
+                       capture_output=True, text=True, cwd="/", env=dict(env, UMPC_PY_BINDING="ctypes"))
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+    with open(os.path.join(ROOT, "robobee3d_amd", "csrc", "uprightmpc2py_ext.cpp")) as f:
+        src = f.read()
+    assert "umpcInit(" in src and "umpcUpdate(" in src and "wlConInit(" in src and "wlConUpdate(" in src
