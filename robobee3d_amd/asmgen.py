@@ -485,7 +485,7 @@ def despace(ops, window=int(os.environ.get("UMPC_ASM_WINDOW", "12"))):
     return out
 
 
-def body(e, s, first, capture, plan, lv=False, delta_in_w=False, qzero=frozenset(), lzero=frozenset()):
+def body(e, s, first, capture, plan, lv=False, delta_in_w=False, qzero=frozenset(), lzero=frozenset(), dy3_in_w=False):
     """delta_in_w (asmstep.py, the all-assembly step kernel): a capturing iteration leaves delta_x = x - x_prev in
     the x part of W and delta_y in the z part of W (registers) instead of writing x_prev / delta_y to the workspace.
     qzero / lzero: x indices whose q and dynamics rows whose l (= u) are STRUCTURALLY zero for this QP (asmstep.Struct:
@@ -697,6 +697,12 @@ def body(e, s, first, capture, plan, lv=False, delta_in_w=False, qzero=frozenset
             e("v_max_f32", t3, t3, v(V_AT + 2))
             e("v_min_f32", Z(i), t3, v(V_AT + 3))
             e("v_sub_f32", t2, t1, Z(i))
+        if dy3_in_w and not eq and not capture:
+            # (asmstep.py, round 5) the thrust rows' delta_y lands in their W register -- nu has been consumed above -- in EVERY
+            # iteration, at no cost, so that the last middle iteration can stand in for a capturing one
+            e("v_mul_f32", nu, rho, t2)
+            e("v_add_f32", Y(i), Y(i), nu)
+            continue
         e("v_mul_f32", t2, rho, t2)                       # delta_y
         e("v_add_f32", Y(i), Y(i), t2)
         if capture and delta_in_w:

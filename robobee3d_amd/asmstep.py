@@ -1200,22 +1200,45 @@ class StepGen:
 
 
     def _admm_rest(self, plan, zk):
-        e, s = self.e, self.s
+        """Iterations 2 .. maxIter: ONE body (round 5; rounds 2-4 carried a third, capturing copy of the 6.7-KB body for the
+        last iteration). What phase C needs of the last iteration -- delta_x, delta_y for the infeasibility certificates
+        (auxil.c:362-512) -- follows from what the plain body leaves behind: W still holds the KKT solution (x~ | nu), and
+        x_new = alpha x~ + (1 - alpha) x_prev gives delta_x = x_new - x_prev = k (x_new - x~) with k = alpha / (alpha - 1);
+        on the dynamics rows y_new = (1 - alpha) y_prev + alpha nu gives delta_y = k (y_new - nu);
+        the three thrust rows leave their delta_y in W themselves (asmgen.body dy3_in_w). 41 packed instructions once per
+        step instead of a body copy: the stream is 7 KB shorter and the default path's footprint fits the 64-KB
+        instruction cache. x, y, z are the plain body's, bit for bit; delta_x / delta_y differ from the captured
+        differences by rounding and feed only the certificate tests."""
+        e, s, st = self.e, self.s, self.st
+        import numpy as np
         for p_ in range(NVZ):      # the z registers of the dynamics rows take the L entries parked in a0..a35
             e("v_accvgpr_read_b32", v(V_Z + p_), "a%d" % (A_L + p_))
-        lab7, lab8, lab6 = self.label(), self.label(), self.label()
-        e("s_sub_i32", sg(S_CNT), sg(S_ITERS), 2)
+        lab7, lab6 = self.label(), self.label()
+        e("s_sub_i32", sg(S_CNT), sg(S_ITERS), 1)
         e("s_cmp_lt_i32", sg(S_CNT), 1)
-        e("s_cbranch_scc1", lab8 + "f")
+        e("s_cbranch_scc1", lab6 + "f")
         e("label", lab7)
-        asmgen.body(e, s, first=False, capture=False, plan=plan, lv=True, **zk)
+        asmgen.body(e, s, first=False, capture=False, plan=plan, lv=True, dy3_in_w=True, **zk)
         e("s_sub_i32", sg(S_CNT), sg(S_CNT), 1)
         e("s_cmp_gt_i32", sg(S_CNT), 0)
         e("s_cbranch_scc1", lab7 + "b")
-        e("label", lab8)
-        e("s_cmp_lt_i32", sg(S_ITERS), 2)
-        e("s_cbranch_scc1", lab6 + "f")
-        asmgen.body(e, s, first=False, capture=True, plan=plan, lv=True, delta_in_w=True, **zk)
+        # delta_x = x_new - x_prev with x_prev = (x_new - alpha x~) / (1 - alpha):  delta_x = k (x_new - x~),  k = alpha / (alpha - 1)
+        # delta_y (dynamics rows) = y_new - y_prev with y_new = (1 - alpha) y_prev + alpha nu:  delta_y = k (y_new - nu)
+        k = float(np.float32(1.6) / (np.float32(1.6) - np.float32(1.0)))
+        e("s_mov_b32", sg(S_TMP), f32bits(k))
+        nx, neq = s.nx, st.neq
+        for p_ in range(0, nx - 1, 2):
+            pk(e, "v_pk_add_f32", V_W + p_, [P2(V_X + p_), P2(V_W + p_)], [0, 1])
+        for p_ in range(0, nx - 1, 2):
+            pk(e, "v_pk_mul_f32", V_W + p_, [PS(S_TMP), P2(V_W + p_)])
+        if nx % 2:
+            jl = st.xinv[nx - 1]
+            e("v_sub_f32", v(V_W + st.xs[jl]), v(V_X + st.xs[jl]), v(V_W + st.xs[jl]))
+            e("v_mul_f32", v(V_W + st.xs[jl]), sg(S_TMP), v(V_W + st.xs[jl]))
+        for p_ in range(0, neq, 2):
+            pk(e, "v_pk_add_f32", V_WZ + p_, [P2(V_Y + p_), P2(V_WZ + p_)], [0, 1])
+        for p_ in range(0, neq, 2):
+            pk(e, "v_pk_mul_f32", V_WZ + p_, [PS(S_TMP), P2(V_WZ + p_)])
         e("label", lab6)
 
     # ---- phase C ------------------------------------------------------------------------------------------
