@@ -392,6 +392,16 @@ int umpcP5fStepU(int B, int dtype, int mode, double dt, double u, void *y, void 
  * rows (src[k] in 0..4). u [B] or NULL (then u_all is every robot's input); lin [5][B], Av [nnz][B] as above. */
 int umpcP5fLinearise(int B, int dtype, const void *u, double u_all, const void *y, void *lin, int nnz, const void *cst,
                      const int32_t *src, void *Av, int update, void *stream);
+/* One tick of planar/mpc_osqp_p5f.py:157-176 in ONE launch (round 5): umpcP5fLinearise (getLin at (unom, y[0], y[3]) -> lin and
+ * the state-dependent entries of Av) + umpcQPSolve + umpcP5fStepU(mode 1) (the plant tick y += (Ad y + Bd unom) dt), with the
+ * first and the last folded into the prologue of the QP kernel (they depend on the previous state only). Same arguments as
+ * umpcQPSolve, then the tick's: Av is rewritten in place where src[k] >= 0 (its constant entries must be there already: a
+ * first tick goes through umpcP5fLinearise), ystate [7][B] is advanced, lin [5][B] may be null. Only for a handle that
+ * dispatches the fp32 p5f10 assembly kernel; returns -2 (and does nothing) otherwise, so that a caller can fall back to the
+ * three calls. Results are the three calls' bit for bit. */
+int umpcP5fTick(void *h, const void *Pv, void *Av, const void *q, const void *l, const void *u, void *x, void *y, void *z,
+                void *Eprev, void *sol_x, void *sol_y, int32_t *status, void *info, double unom, double dt, void *ystate,
+                void *lin, int nnz, const void *cst, const int32_t *src, void *stream);
 /* UprightMPC2 at any horizon N (template/template_controllers.py:170-258; N = 3 is Parts 1-2's specialised path):
  * assembly (updateConstraint :65-125, updateObjective :127-143 = uprightmpc2.c:121-207) and extraction (update2 /
  * getAccDes :232-250 = uprightmpc2.c:253-269) around umpcQPSolve on the structure of initConstraint (:28-63).

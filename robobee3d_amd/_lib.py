@@ -27,7 +27,7 @@ EXPORTS = ["umpcInit", "umpcUpdate", "umpcS", "umpcLastStatus", "umpcRelease", "
            "umpcBatchSetTask", "umpcBatchTime", "umpcBatchSetWeights", "umpcBatchSetStepKernel", "umpcBatchSetGlobalBatch", "umpcBatchGlobalBatch", "umpcBatchReactive", "umpcBatchTaskReference",
            "umpcLastError", "umpcKernelName", "umpcBatchKernelName", "wlConInit", "wlConUpdate", "wlconS", "umpcBatchWLUpdate", "umpcBatchSetWL", "umpcBatchModel",
            "umpcQPDefaultSettings", "umpcQPCreate", "umpcQPDestroy", "umpcQPSetMaxIter", "umpcQPSetCheckTermination", "umpcQPSetAdaptiveRho", "umpcQPUseTables", "umpcQPSetKernel", "umpcQPKernelName", "umpcQPSolve", "umpcQPGather", "umpcQPGatherUpdate",
-           "umpcP5fStep", "umpcP5fStepU", "umpcP5fLinearise", "umpcNAssemble", "umpcNExtract"]
+           "umpcP5fStep", "umpcP5fStepU", "umpcP5fLinearise", "umpcP5fTick", "umpcNAssemble", "umpcNExtract"]
 
 
 class NParams(C.Structure):
@@ -286,6 +286,7 @@ def lib():
         L.umpcP5fStepU.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 3
         L.umpcP5fLinearise.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.umpcP5fTick.argtypes = [C.c_void_p] * 14 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.umpcNAssemble.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(NParams)] + [C.c_void_p] * 10
         L.umpcNExtract.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 5
         L.umpcLastStatus.restype = C.c_int

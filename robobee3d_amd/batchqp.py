@@ -236,6 +236,7 @@ class PlanarP5fMPC:
         self.y = torch.zeros((7, B), dtype=dtype, device=dev)
         self.u_nom = torch.zeros(B, dtype=dtype, device=dev)
         self._av_constants_written = False
+        self.fused = dtype == torch.float32 and not os.environ.get("UMPC_P5F_UNFUSED")   # tick(): try umpcP5fTick first
         self.L = self.qp.L
 
     def linearise(self, u):
@@ -255,6 +256,21 @@ class PlanarP5fMPC:
     def tick(self, t, solve=True):
         """One loop body of mpc_osqp_p5f.py:157-176 at time t (unom = 15 sin(2 pi 170 t), :157)."""
         unom = 15.0 * np.sin(2 * np.pi * 170 * t)
+        if solve and self.fused and self._av_constants_written:
+            # round 5: getLin, the A update and the plant tick are the prologue of the QP kernel (umpcP5fTick): one launch
+            # instead of three, the same numbers (tests/test_bqp.py::test_gpu_p5f_fused_tick_equals_the_three_launches)
+            qp = self.qp
+            stream = C.c_void_p(torch.cuda.current_stream(qp.device).cuda_stream)
+            rc = self.L.umpcP5fTick(qp.h, _ptr(self.Pv), _ptr(self.Av), _ptr(self.q), _ptr(self.l), _ptr(self.u), _ptr(qp.x),
+                                    _ptr(qp.y), _ptr(qp.z), _ptr(qp.Eprev), _ptr(qp.sol_x), _ptr(qp.sol_y), _ptr(qp.status),
+                                    _ptr(qp.info), float(unom), self.dt, _ptr(self.y), _ptr(self.lin), int(self.cst.numel()),
+                                    _ptr(self.cst), _ptr(self.src), stream)
+            if rc == 0:
+                self.u_nom_scalar = float(unom)
+                return self.y
+            if rc != -2:
+                raise RuntimeError(self.L.umpcLastError().decode())
+            self.fused = False          # this handle does not dispatch the assembly kernel: the three calls from now on
         self.linearise(unom)
         if solve:
             self.qp.solve(self.Pv, self.Av, self.q, self.l, self.u)

@@ -416,6 +416,30 @@ def emit_structure(name, s, asm=None):
         E("  const unsigned lane = threadIdx.x & 63u, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
         E("  const int b = blockIdx.x * 64 + (int)lane;")
         E("  if (b >= a.B) return;              // (the same lanes in every wavefront: none of them is left without a lane)")
+        if name == "p5f10":
+            # the planar-p5f tick as the kernel's prologue (umpcP5fTick): getLin at the previous state (every wavefront
+            # evaluates it for its lanes: the same function of the same numbers), then -- behind a barrier, because the
+            # plant tick overwrites the state the others read -- wavefront 0 writes lin and advances the plant while all
+            # four rewrite the state-dependent entries of A (a quarter each); a second barrier publishes A to the Ruiz
+            # block's loads. Two launches fewer per tick.
+            E("  if (a.tick_y) {")
+            E("    const size_t Bz = (size_t)a.B;")
+            E("    float o[5], yy[7];")
+            E("    for (int i = 0; i < 7; ++i) yy[i] = a.tick_y[(size_t)i * Bz + b];")
+            E("    p5f_getlin<float>(a.tick_u, yy[0], yy[3], o);")
+            E("    __syncthreads();")
+            E("    if (wv == 0u) {")
+            E("      if (a.tick_lin) for (int i = 0; i < 5; ++i) a.tick_lin[(size_t)i * Bz + b] = o[i];")
+            E("      p5f_plant_tick<float>(o, a.tick_u, a.tick_dt, yy);")
+            E("      for (int i = 0; i < 7; ++i) a.tick_y[(size_t)i * Bz + b] = yy[i];")
+            E("    }")
+            E("    float *Aw = const_cast<float *>(a.Av);")
+            E("    for (int k = (int)wv; k < a.tick_nnz; k += %d) {" % ASM_GROUP_WAVES)
+            E("      const int sidx = a.tick_src[k];      // (wave-uniform: scalar loads)")
+            E("      if (sidx >= 0) Aw[(size_t)k * Bz + b] = o[sidx] * a.tick_cst[k];")
+            E("    }")
+            E("    __syncthreads();")
+            E("  }")
         E("  bqp_fixed_%s_asm<float>(a, b, (int)blockIdx.x, lane, wv, (unsigned)(size_t)(&lds[lane]), reinterpret_cast<const float *>(lds) + 4 * lane);" % name)
         E("}")
         return "\n".join(o) + "\n"

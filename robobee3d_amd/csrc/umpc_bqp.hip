@@ -682,27 +682,8 @@ __global__ void bqp_gather_kernel(int B, int nnz, const T *__restrict__ cst, con
   }
 }
 
-// getLin, planar/mpc_osqp_p5f.py:45-85: (u, sigma, phi) -> the state-dependent entries of (Ad, Bd):
-// out rows = Ad[4][3], Ad[5][3], Bd[4], Bd[5], Bd[6]. Constants of the module (:33-43).
-template <typename T>
-__device__ __forceinline__ void p5f_getlin(T u, T sigma, T phi, T o[5]) {
-  const T CDmax = T(3.4), CLmax = T(1.8), CD0 = T(0.4), khinge0 = T(0.1), mb = T(100), kaero = T(1), d = T(5);
-  const T ib = T(1.) / T(12.) * mb * T(144);
-  const T kh = u < T(0) ? -khinge0 : khinge0;
-  const T uu = u * u;
-  const T ang = T(2) * kh * uu;
-  const T s2 = std::sin(ang), c2 = std::cos(ang), sp = std::sin(phi), cp = std::cos(phi);
-  const T CDs = CD0 + CDmax, CDd = CD0 - CDmax;
-  o[0] = -(kaero * u * (T(2) * CLmax * cp * s2 + (CDs + CDd * c2) * sp)) / (T(2.) * mb);
-  o[1] = (kaero * u * ((CDs + CDd * c2) * cp - T(2) * CLmax * s2 * sp)) / (T(2.) * mb);
-  o[2] = (kaero * (cp * (CDs + CDd * c2 - T(4) * CDd * kh * uu * s2) -
-                   T(2) * CLmax * (T(4) * kh * uu * c2 + s2) * sp)) / (T(2.) * mb);
-  o[3] = (kaero * (T(2) * CLmax * cp * s2 + (CDs - T(4) * CDd * kh * uu * s2) * sp +
-                   c2 * (T(8) * CLmax * kh * uu * cp + CDd * sp))) / (T(2.) * mb);
-  o[4] = (kaero * (-(d * (CDs + CDd * c2 - T(4) * CDd * kh * uu * s2)) +
-                   T(2) * CLmax * (T(4) * kh * uu * c2 + s2) * sigma)) / (T(2.) * ib);
-}
-
+// getLin and the plant tick of planar/mpc_osqp_p5f.py: p5f_getlin / p5f_plant_tick in umpc_bqp_common.h (shared with the
+// fused tick of the p5f10 assembly kernel)
 // mode 0: lin[5][B] <- getLin(u[b], y[0][b], y[3][b]) (the reference linearises about the PREVIOUS state, :165-167)
 // mode 1: the same, then the reference's plant tick y += (Ad y + Bd u) dt (:176)
 template <typename T>
@@ -716,9 +697,8 @@ __global__ void p5f_kernel(int B, int mode, T dt, const T *__restrict__ u, T u_a
   p5f_getlin(ub, yy[0], yy[3], o);
   if (lin) for (int i = 0; i < 5; ++i) lin[i * Bz + b] = o[i];
   if (mode == 1) {
-    // Ad rows: 1: y4, 2: y5, 3: y6, 4: Ad43 y3, 5: Ad53 y3; Bd = (1, 0, 0, 0, Bd4, Bd5, Bd6)
-    const T dy[7] = {ub, yy[4], yy[5], yy[6], o[0] * yy[3] + o[2] * ub, o[1] * yy[3] + o[3] * ub, o[4] * ub};
-    for (int i = 0; i < 7; ++i) y[i * Bz + b] = yy[i] + dy[i] * dt;
+    p5f_plant_tick(o, ub, dt, yy);
+    for (int i = 0; i < 7; ++i) y[i * Bz + b] = yy[i];
   }
 }
 
@@ -877,8 +857,12 @@ bool asm_active(const qp_batch *h) {
 template <typename T>
 int launch_solve(qp_batch *h, const void *Pv, const void *Av, const void *q, const void *l, const void *u, void *x,
                  void *y, void *z, void *Eprev, void *sol_x, void *sol_y, int32_t *status, void *info,
-                 hipStream_t s) {
+                 hipStream_t s, const QPArgs<T> *tick = nullptr) {
   QPArgs<T> a;
+  if (tick) {
+    a.tick_y = tick->tick_y; a.tick_lin = tick->tick_lin; a.tick_cst = tick->tick_cst; a.tick_src = tick->tick_src;
+    a.tick_nnz = tick->tick_nnz; a.tick_u = tick->tick_u; a.tick_dt = tick->tick_dt;
+  }
   a.tab = h->tab; a.B = h->B; a.W = (T *)h->W;
   a.Pv = (const T *)Pv; a.Av = (const T *)Av; a.q = (const T *)q; a.l = (const T *)l; a.u = (const T *)u;
   a.x = (T *)x; a.y = (T *)y; a.z = (T *)z; a.Eprev = (T *)Eprev; a.sol_x = (T *)sol_x; a.sol_y = (T *)sol_y;
@@ -1110,6 +1094,26 @@ int umpcQPSolve(void *hv, const void *Pv, const void *Av, const void *q, const v
   if (h->dtype == UMPC_F32) launch_solve<float>(h, Pv, Av, q, l, u, x, y, z, Eprev, sol_x, sol_y, status, info, s);
   else launch_solve<double>(h, Pv, Av, q, l, u, x, y, z, Eprev, sol_x, sol_y, status, info, s);
   return check_launch("umpcQPSolve");
+}
+
+int umpcP5fTick(void *hv, const void *Pv, void *Av, const void *q, const void *l, const void *u, void *x, void *y, void *z,
+                void *Eprev, void *sol_x, void *sol_y, int32_t *status, void *info, double unom, double dt, void *ystate,
+                void *lin, int nnz, const void *cst, const int32_t *src, void *stream) {
+  qp_batch *h = (qp_batch *)hv;
+  if (!h || !Av || !q || !l || !u || !x || !y || !z || !Eprev || !ystate || !cst || !src || nnz <= 0 || (h->nnzP > 0 && !Pv)) {
+    umpc_set_error("umpcP5fTick: bad argument");
+    return -1;
+  }
+  // the fused tick is the prologue of ONE kernel: the fp32 p5f10 assembly specialisation on its all-assembly route
+  if (!(asm_active(h) && std::string(kFixedKernels[h->fixed].name) == "p5f10" && nnz == h->nnzA)) {
+    umpc_set_error("umpcP5fTick: this handle does not dispatch the p5f10 assembly kernel (use umpcP5fLinearise + umpcQPSolve + umpcP5fStepU)");
+    return -2;
+  }
+  QPArgs<float> t;
+  t.tick_y = (float *)ystate; t.tick_lin = (float *)lin; t.tick_cst = (const float *)cst; t.tick_src = src; t.tick_nnz = nnz;
+  t.tick_u = (float)unom; t.tick_dt = (float)dt;
+  launch_solve<float>(h, Pv, Av, q, l, u, x, y, z, Eprev, sol_x, sol_y, status, info, (hipStream_t)stream, &t);
+  return check_launch("umpcP5fTick");
 }
 
 int umpcQPGather(int B, int dtype, int nnz, const void *cst, const int32_t *src, const void *par, void *out,

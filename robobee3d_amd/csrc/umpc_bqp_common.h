@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
 #include <limits>
 
 namespace umpcqp {
@@ -41,6 +42,14 @@ struct QPArgs {
                // loop's stream first, the residual stream behind it; allocated behind the workspace rows
   T oma, rinv_eq;  // 1 - alpha and 1 / rho_eq as the kernels compute them, evaluated on the host (assembly operands)
   T rinv0, rho_eq;  // 1 / rho and rho_eq likewise
+  // Planar-p5f tick fused into the p5f10 assembly kernel (umpcP5fTick; null tick_y = a plain QP solve): before the QP blocks
+  // the workgroup evaluates getLin of its 64 robots at (tick_u, y[0], y[3]), writes lin, rewrites the state-dependent entries
+  // of A (Av[k] = tick_cst[k] * lin[tick_src[k]] where tick_src[k] >= 0) and advances the plant, y += (Ad y + Bd u) dt
+  T *tick_y = nullptr, *tick_lin = nullptr;
+  const T *tick_cst = nullptr;
+  const int32_t *tick_src = nullptr;
+  int tick_nnz = 0;
+  T tick_u = T(0), tick_dt = T(0);
 };
 
 template <typename T> __device__ __forceinline__ T qabs(T v) { return v < T(0) ? -v : v; }
@@ -68,6 +77,35 @@ __device__ __forceinline__ void qp_classify(T ls, T us, T rho0, T rho_eq, T &r, 
   } else {
     r = rho0; ri = T(1. / (double)rho0);
   }
+}
+
+// getLin, planar/mpc_osqp_p5f.py:45-85: (u, sigma, phi) -> the state-dependent entries of (Ad, Bd):
+// out rows = Ad[4][3], Ad[5][3], Bd[4], Bd[5], Bd[6]. Constants of the module (:33-43).
+template <typename T>
+__device__ __forceinline__ void p5f_getlin(T u, T sigma, T phi, T o[5]) {
+  const T CDmax = T(3.4), CLmax = T(1.8), CD0 = T(0.4), khinge0 = T(0.1), mb = T(100), kaero = T(1), d = T(5);
+  const T ib = T(1.) / T(12.) * mb * T(144);
+  const T kh = u < T(0) ? -khinge0 : khinge0;
+  const T uu = u * u;
+  const T ang = T(2) * kh * uu;
+  const T s2 = std::sin(ang), c2 = std::cos(ang), sp = std::sin(phi), cp = std::cos(phi);
+  const T CDs = CD0 + CDmax, CDd = CD0 - CDmax;
+  o[0] = -(kaero * u * (T(2) * CLmax * cp * s2 + (CDs + CDd * c2) * sp)) / (T(2.) * mb);
+  o[1] = (kaero * u * ((CDs + CDd * c2) * cp - T(2) * CLmax * s2 * sp)) / (T(2.) * mb);
+  o[2] = (kaero * (cp * (CDs + CDd * c2 - T(4) * CDd * kh * uu * s2) -
+                   T(2) * CLmax * (T(4) * kh * uu * c2 + s2) * sp)) / (T(2.) * mb);
+  o[3] = (kaero * (T(2) * CLmax * cp * s2 + (CDs - T(4) * CDd * kh * uu * s2) * sp +
+                   c2 * (T(8) * CLmax * kh * uu * cp + CDd * sp))) / (T(2.) * mb);
+  o[4] = (kaero * (-(d * (CDs + CDd * c2 - T(4) * CDd * kh * uu * s2)) +
+                   T(2) * CLmax * (T(4) * kh * uu * c2 + s2) * sigma)) / (T(2.) * ib);
+}
+
+// the reference's plant tick (:176) from the getLin values: y += (Ad y + Bd u) dt with
+// Ad rows 1: y4, 2: y5, 3: y6, 4: Ad43 y3, 5: Ad53 y3; Bd = (1, 0, 0, 0, Bd4, Bd5, Bd6)
+template <typename T>
+__device__ __forceinline__ void p5f_plant_tick(const T o[5], T ub, T dt, T yy[7]) {
+  const T dy[7] = {ub, yy[4], yy[5], yy[6], o[0] * yy[3] + o[2] * ub, o[1] * yy[3] + o[3] * ub, o[4] * ub};
+  for (int i = 0; i < 7; ++i) yy[i] = yy[i] + dy[i] * dt;
 }
 
 }  // namespace umpcqp

@@ -1028,6 +1028,15 @@ def test_gpu_p5f_entries_reject_bad_arguments():
     assert L.umpcP5fStepU(8, 0, 2, 0.002, 1.0, _ptr(mpc.y), None, None) == -1
     assert b"umpcP5fStepU" in L.umpcLastError()
     assert L.umpcP5fStepU(8, 0, 0, 0.002, 1.0, _ptr(mpc.y), None, None) == -1          # mode 0 needs lin
+    qp = mpc.qp
+    tick = lambda ystate, n_: L.umpcP5fTick(qp.h, _ptr(mpc.Pv), _ptr(mpc.Av), _ptr(mpc.q), _ptr(mpc.l), _ptr(mpc.u), _ptr(qp.x), _ptr(qp.y),
+                                            _ptr(qp.z), _ptr(qp.Eprev), _ptr(qp.sol_x), _ptr(qp.sol_y), _ptr(qp.status), _ptr(qp.info), 1.0,
+                                            0.002, ystate, _ptr(mpc.lin), n_, _ptr(mpc.cst), _ptr(mpc.src), None)
+    assert tick(None, nnz) == -1 and b"umpcP5fTick" in L.umpcLastError()                # no state array
+    assert tick(_ptr(mpc.y), nnz - 1) == -2                                              # not this structure's A
+    qp.set_kernel("tables")
+    assert tick(_ptr(mpc.y), nnz) == -2 and b"does not dispatch" in L.umpcLastError()    # not the assembly kernel: nothing launched
+    qp.set_kernel("lane")
     # and the good calls still go through afterwards
     assert L.umpcP5fLinearise(8, 0, None, 1.0, _ptr(mpc.y), _ptr(mpc.lin), nnz, _ptr(mpc.cst), _ptr(mpc.src), _ptr(mpc.Av), 0, None) == 0
     torch.cuda.synchronize()
@@ -1138,3 +1147,44 @@ def test_gpu_stroke_structure_on_the_table_kernel(margin):
                 margin(lab + "solution at eps 1e-2 |d| / max(1, |ref|)", sc(f(mpc.qp.sol_x)[:, ok], r2["sol_x"][:, ok]), 1e-8)
             else:
                 margin(lab + "status words differing from the float32 oracle (of %d)" % T, int(np.count_nonzero(f(mpc.qp.status) != r2["status"])), 2)
+
+
+@pytest.mark.gpu
+def test_gpu_p5f_fused_tick_equals_the_three_launches():
+    """umpcP5fTick (round 5): getLin, the A update and the plant tick as the prologue of the p5f10 assembly kernel -- one
+    launch per tick of planar/mpc_osqp_p5f.py:157-176 instead of three. Same function of the same numbers: after 6 ticks a
+    fused and an unfused controller hold the same bits in every array (state, lin, A, iterates, solution, status), for a
+    ragged batch (B = 200: a last workgroup with 8 lanes) and for the benchmarked B = 16 384; with per-robot finite input
+    limits on half of the workgroups (the general variant of the loop block) as well."""
+    import torch
+    from robobee3d_amd.batchqp import PlanarP5fMPC
+    for B in (200, 16384):
+        rng = np.random.default_rng(20201119)
+        pert = rng.uniform(-0.1, 0.1, (2, B)).astype(np.float32)
+        pair = []
+        for fused in (True, False):
+            mpc = PlanarP5fMPC(B, torch.float32)
+            mpc.fused = fused
+            mpc.y[0] = torch.as_tensor(pert[0]).cuda()
+            mpc.y[3] = torch.as_tensor(pert[1]).cuda()
+            rows = [77 + t for t, j in enumerate(mpc.st["var_order"]) if j >= 77]
+            odd = torch.as_tensor(((np.arange(B) // 64) % 2) == 1).cuda()
+            for r in rows:
+                mpc.l[r][odd] = -4.0
+                mpc.u[r][odd] = 4.0
+            for ti in range(2, 8):
+                mpc.tick(0.002 * ti)
+            torch.cuda.synchronize()
+            assert mpc.fused == fused and mpc.qp.kernel_name == "p5f10+asm"
+            pair.append(mpc)
+        a, b = pair
+        for name in ("y", "lin", "Av"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (B, name)
+        for name in ("x", "y", "z", "sol_x", "sol_y", "status", "Eprev"):
+            assert torch.equal(getattr(a.qp, name), getattr(b.qp, name)), (B, name)
+        assert bool((a.qp.status > 0).all()) and bool(torch.isfinite(a.y).all())
+    # a handle that does not dispatch the assembly kernel refuses the fused entry and the front end falls back
+    m64 = PlanarP5fMPC(64, torch.float32)
+    m64.qp.set_kernel("tables")
+    m64.tick(0.004); m64.tick(0.006)
+    assert m64.fused is False and bool(torch.isfinite(m64.y).all())
