@@ -672,6 +672,23 @@ def fmt(t):
 PSEUDO = ("quad_begin", "quad_end")
 
 
+def used_registers(ins):
+    """(AGPR numbers, VGPR numbers) that appear in ANY operand of the instruction list: an over-approximation of what an
+    `asm volatile` block of it may write, for exact clobber lists"""
+    import re
+    A, V = set(), set()
+    for t in ins:
+        for x in t[1:]:
+            if not isinstance(x, str):
+                continue
+            for m_ in re.finditer(r"\b([av])\[(\d+):(\d+)\]|\b([av])(\d+)\b", x):
+                if m_.group(1):
+                    (A if m_.group(1) == "a" else V).update(range(int(m_.group(2)), int(m_.group(3)) + 1))
+                else:
+                    (A if m_.group(4) == "a" else V).add(int(m_.group(5)))
+    return A, V
+
+
 def write_quad(path=None, N=3, perm=None):
     """csrc/umpc_admm_asm64_quad.h: the ADMM phase with one robot per lane quad (asmquad64.py) as UMPC_ADMM_ASM64_QUAD, and
     csrc/umpc_quad64_tab.h, the constant table of per-lane coefficient addresses it reads through s[8:9]."""
@@ -700,8 +717,10 @@ def write_quad(path=None, N=3, perm=None):
     rins = [t for t in rins if t[0] not in PSEUDO]
     r27 = [k for k, t_ in enumerate(rins) if t_ == ("label", "27")][0]
     rend = [k for k, t_ in enumerate(rins) if t_[0] == "s_cbranch_scc1"][-1]
-    rclob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + \
+    # exact VGPR clobbers (round 5: the quad passes touch v2..v187 and no AGPR; what lives across them stays in registers)
+    rclob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in sorted(used_registers(rins)[1] - {0, 1})] + \
             ['"s%d"' % i for i in [S_CNT] + list(range(30, 42))]
+    assert not used_registers(rins)[0]
     out += ["// The Ruiz passes of the fp64 step on the lane quad (asmquad64.ruiz_program): %d instructions, %d per pass (one-lane"
             % (len(rins), rend - r27),
             "// block: 2 546 per pass). LDS words in and out as UMPC_RUIZ_ASM64; every lane's slice ends with the whole result.",
@@ -770,7 +789,9 @@ def write(path=None, N=3, perm=None):
     out.append("  : " + ", ".join(rclob) + ")")
     # the residual norms
     sins, _ = resid_program(N, perm)
-    sclob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in range(2, V_END)] + ['"a%d"' % i for i in range(256)] + \
+    # exact AGPR clobbers (round 5): the block touches 70 AGPRs; the compiler may keep what lives across it (state, weights,
+    # row pointers) in the other 186 -- v_accvgpr_write / read instead of scratch stores / loads around the block
+    sclob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % i for i in sorted(used_registers(sins)[1] - {0, 1})] + ['"a%d"' % i for i in sorted(used_registers(sins)[0])] + \
             ['"s%d"' % i for i in [S_P, S_P + 1]]
     out += ["// The residual norms of the fp64 step (auxil.c:243-307): %d instructions. LDS words in: x, y, z, D, E where the ADMM"
             % len(sins),
