@@ -676,7 +676,9 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     for (int k = 0; k < N; ++k) {
       lo3[k] = LRAW_(NEQ + k) * Es[NEQ + k];
       up3[k] = up3[k] * Es[NEQ + k];
-      Eprev3[k] = Es[NEQ + k];
+      // the thrust-row E of THIS call classifies the NEXT call's thrust rows (osqp.c:812-820): stored here, where it is
+      // formed, so that it does not live (in scratch, around the assembly blocks) until the end of the step
+      GLD(a.ctrl, NX + 2 * NC + 1 + k) = Es[NEQ + k];
       GLD(a.ws, FAC_M + k) = lo3[k];
       GLD(a.ws, FAC_M + N + k) = up3[k];
       GLD(a.ws, FAC_M + 2 * N + k) = rho3[k];
@@ -1046,8 +1048,6 @@ __device__ __forceinline__ void closed_loop_step(const StepIO<T> &a, const int b
     for (int i = 0; i < NC; ++i) { const T v = has_sol ? ZV(i) : T(0); GLD(a.ctrl, NX + NC + i) = v; }
   }
   GLD(a.ctrl, NX + 2 * NC) = T0next;
-#pragma unroll
-  for (int k = 0; k < N; ++k) GLD(a.ctrl, NX + 2 * NC + 1 + k) = Eprev3[k];
 #pragma unroll
   for (int i = 0; i < 3; ++i) GLD(a.out, i) = uq[i];
 #pragma unroll
