@@ -914,11 +914,16 @@ def simulate(ins, mem_ws, mem_ctrl, iters, lds, perm=None):
             pc, nq = asmquad64.simulate(ins, pc, V4, A4, L4, S, asmquad64.table(asmquad64.plan_for(s_)))
             nexec += nq
             simulate.last_quad_instructions = nq
+            # (words LW_END.. are scratch: the quad loop's compact coefficient array ends there; the C++ side writes what the
+            # residual block reads from them before it runs. The array's first words overlay the last words of L: whatever the
+            # exit does not rewrite there is per-lane data, dead -- the epilogue writes the thrust-row bounds over it --
+            # and poisoned here so that a read before that write shows up)
+            differ = np.zeros(LW_END, bool)
             for ln in range(1, 4):
-                # (words LW_END.. are scratch: the quad loop's per-lane address table ends there; the C++ side writes what
-                # the residual block reads from them before it runs)
-                assert np.array_equal(L4[ln, :LW_END], L4[0, :LW_END]), "LDS slices of the quad disagree"
+                differ |= ~((L4[ln, :LW_END] == L4[0, :LW_END]) | (np.isnan(L4[ln, :LW_END]) & np.isnan(L4[0, :LW_END])))
+            assert set(np.nonzero(differ)[0]) <= set(range(asmquad64.CW0, NNZL)), "LDS slices of the quad disagree"
             lds[:LW_END] = L4[0, :LW_END]
+            lds[:LW_END][differ] = np.nan
             lds[LW_END:] = np.nan
             keep = {0, 1, V_B1, V_B2} | set(range(V_C, V_RING))
             for r in range(256):

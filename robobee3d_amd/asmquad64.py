@@ -35,29 +35,42 @@ from .asmquad import IX_EQ, IX_T, qperm
 
 # ---- VGPR words (first register of the pair); the block may use v2..v245, v172..v201 are the one-lane thrust-row words
 QYT, QZT, QLO3, QUP3, QRHO3, QRINV3 = 118, 120, 122, 124, 126, 128
-T_AQ = [218, 222, 226]                 # address quads in flight (3 x ds_read_b128 of four coefficient addresses each)
-T_COEF = [230, 232, 234, 236, 238, 240]    # coefficient words in flight (ring of NRING)
+T_CQ = [218, 222, 226, 230, 234, 238]  # coefficient float4 in flight: two coefficients per ds_read_b128 (ring of six)
+T_COEF = [230, 232, 234, 236, 238, 240]    # coefficient words read from AGPRs in flight (ring of NRING; the first NAC instructions)
 T_SRC = [242, 244]                     # sources fetched from another lane
-T_A = [230, 232, 234, 236]             # AGPR read / update temporaries (outside the solves: the ring is idle there)
+T_A = [230, 232, 234, 236]             # AGPR read / update temporaries (outside the solves: the rings are idle there)
 T_X = [238, 240]
 NRING = 6
-RD_AHEAD = 5                           # coefficient reads run this many solve instructions ahead, address quads two quads ahead
-TAB_WORD = 214                         # the lane's LDS words 214..311 hold its 196 coefficient addresses during the loop (x, y
-                                       # live in registers then; the exit rewrites the words)
+RD_AHEAD = 5                           # coefficient reads run this many solve instructions ahead
 STAGE = 4                              # entry staging: the (idle) W words, v4..v59 = 14 float4
 AQ, AL = 0, 32                         # AGPRs: q (16 words), l (12 words)
 NTAB = 196                             # table row length (dwords): the 194 solve instructions + padding to whole dwordx4 loads
 ZERO_WORD = 319                        # this lane's LDS word that holds 0.0
 S_L0, S_L1, S_L2, S_EXEC, S_TAB = 30, 32, 34, 36, 8
-# Coefficients of the first NAC solve instructions live in AGPRs during the loop instead of being fetched from LDS every
-# iteration: a56..a167 hold nothing while the section runs (the one-lane block's 1/D copies, dead after the first iteration;
-# q and l took a0..a55, the right-hand-side homes a168.. stay), and a register is per-lane storage by nature -- lane l's
-# a[AC0 + 2 n] is ITS coefficient of instruction n, no per-lane address needed. Two v_accvgpr_read instead of a per-lane
-# ds_read_b64 plus a quarter of an address quad (an LDS instruction costs a lone wave ~6 ns).
-import os as _os
-NAC = int(_os.environ.get("UMPC_ASM64_QUAD_NAC", "56"))
-AC0 = 56
-assert NAC % 4 == 0 and AC0 + 2 * NAC <= 168
+# Where a lane's coefficient of solve instruction n lives during the loop (round 5). Every lane holds the whole factor in its
+# own LDS slice, and instruction n needs, in lane l, ONE of its words -- a per-lane choice (`table()`). Rounds 4 read it with a
+# per-lane address every iteration (ds_read_b64 + a quarter of an address float4: two LDS instructions per coefficient pair and
+# then some, and an LDS instruction costs a lone wave ~6 ns whatever its width). Now the entry GATHERS each lane's 194 words
+# ONCE per step -- addresses straight from the constant table, per-lane reads as before -- into storage that needs no
+# address in the loop:
+#   n < NAC       AGPR pairs (per-lane storage by nature): a56..a167 (dead 1/D copies of the one-lane block) and a200..a251
+#                 (the one-lane homes of q: composed into a0..a31 by the entry; the epilogue reads the l homes a168..a199 only)
+#   n >= NAC      a COMPACT array in the lane's LDS words CW0.., instruction n at word CW0 + n - NAC: ONE ds_read_b128 at a
+#                 uniform address fetches the coefficients of two instructions. The array overlays the words of x and y
+#                 (they live in registers during the loop; the exit rewrites them) and the last seven words of L, which the
+#                 gather therefore overwrites in its LAST round, after every source has been read.
+NAC1, NAC = 56, 82
+AC0, AC1 = 56, 200
+CW0 = 206
+assert NAC % 2 == 0 and CW0 % 2 == 0 and AC0 + 2 * NAC1 <= 168 and AC1 + 2 * (NAC - NAC1) <= 254 and CW0 + (194 - NAC) <= ZERO_WORD - 1
+
+
+def coef_agpr(n):
+    return AC0 + 2 * n if n < NAC1 else AC1 + 2 * (n - NAC1)
+
+
+def coef_word(n):
+    return CW0 + n - NAC
 
 
 def QW(ix):
@@ -193,41 +206,51 @@ def entry(e, plan, s):
                 e("v_mov_b32", v(dst), v(src))
                 e("v_mov_b32", v(dst + 1), v(src + 1))
         e("s_mov_b64", "exec", sp(S_EXEC))
-    # ---- the zero word, and the table: dword + lane LDS base -> this lane's LDS words TAB_WORD.. (four addresses per float4)
+    # ---- the zero word (lanes that have nothing to do in an instruction read it during the gather)
     e("v_mov_b32", v(T_A[0]), 0)
     e("v_mov_b32", v(T_A[0] + 1), 0)
     b_, off, half = g.lds_addr(ZERO_WORD)
     e("ds_write_b64", b_, vp(T_A[0]), off + 8 * half)
-    nld = NTAB // 4
-    for base in range(0, nld, 14):
-        n = min(14, nld - base)
-        for k in range(n):
-            e("global_load_dwordx4", "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), v(tb), sp(S_TAB), "offset:%d" % (16 * (base + k)))
+    e("s_waitcnt", "lgkmcnt(0)")
+    # ---- the gather: the lane's coefficient of every solve instruction -> its AGPR pair / its word of the compact array.
+    # Table groups of four instructions, up to four groups per round through the idle W words: addresses from the constant
+    # table (+ the lane's LDS base), one per-lane ds_read_b64 each, then the destination. The compact array shares its first
+    # words with the last words of L: the rounds that write BELOW word NNZL run last, in one round, behind all other reads.
+    nops = len(plan.fwd) + len(plan.bwd)
+    assert nops <= NTAB and nops % 2 == 0 and coef_word(nops - 1) < ZERO_WORD
+    ngrp = (nops + 3) // 4
+    last = [gq for gq in range(ngrp) if any(NAC <= n < nops and coef_word(n) < g.NNZL for n in range(4 * gq, 4 * gq + 4))]
+    first = [gq for gq in range(ngrp) if gq not in last and all(n < NAC for n in range(4 * gq, 4 * gq + 4))]
+    mid = [gq for gq in range(ngrp) if gq not in last and gq not in first]
+    assert len(last) <= 4 and all(coef_word(n) >= g.NNZL for gq in mid for n in range(4 * gq, 4 * gq + 4) if NAC <= n < nops)
+    rounds = [first[k:k + 4] for k in range(0, len(first), 4)] + [mid[k:k + 4] for k in range(0, len(mid), 4)] + [last]
+    for gqs in rounds:
+        for k, gq in enumerate(gqs):
+            e("global_load_dwordx4", "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), v(tb), sp(S_TAB), "offset:%d" % (16 * gq))
         e("s_waitcnt", "vmcnt(0)")
-        for k in range(n):
+        for k, gq in enumerate(gqs):
             for h in range(4):
                 e("v_add_u32", v(STAGE + 4 * k + h), v(STAGE + 4 * k + h), "v1")
-            b_, off, _ = g.lds_addr(TAB_WORD + 2 * (base + k))
-            e("ds_write_b128", b_, "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), off)
-    e("s_waitcnt", "lgkmcnt(0)")
-    e("s_nop", 4)
-    # ---- the coefficients of solve instructions 0 .. NAC-1 -> AGPRs (through the idle W words: four address quads at a time)
-    for g0 in range(0, NAC // 4, 4):
-        gqs = list(range(g0, min(NAC // 4, g0 + 4)))
-        for k, gq in enumerate(gqs):
-            b_, off, _ = g.lds_addr(TAB_WORD + 2 * gq)
-            e("ds_read_b128", "v[%d:%d]" % (STAGE + 4 * k, STAGE + 4 * k + 3), b_, off)
-        e("s_waitcnt", "lgkmcnt(0)")
         for k, gq in enumerate(gqs):
             for h in range(4):
                 e("ds_read_b64", vp(STAGE + 16 + 8 * k + 2 * h), v(STAGE + 4 * k + h), 0)
         e("s_waitcnt", "lgkmcnt(0)")
         for k, gq in enumerate(gqs):
-            for h in range(4):
+            for h in range(0, 4, 2):
                 n_ = 4 * gq + h
-                e("v_accvgpr_write_b32", "a%d" % (AC0 + 2 * n_), v(STAGE + 16 + 8 * k + 2 * h))
-                e("v_accvgpr_write_b32", "a%d" % (AC0 + 2 * n_ + 1), v(STAGE + 16 + 8 * k + 2 * h + 1))
-    e("s_nop", 1)
+                r = STAGE + 16 + 8 * k + 2 * h
+                if n_ >= nops:
+                    continue
+                if n_ < NAC:
+                    for d in range(2):
+                        e("v_accvgpr_write_b32", "a%d" % coef_agpr(n_ + d), v(r + 2 * d))
+                        e("v_accvgpr_write_b32", "a%d" % (coef_agpr(n_ + d) + 1), v(r + 2 * d + 1))
+                else:
+                    b_, off, half = g.lds_addr(coef_word(n_))
+                    assert half == 0
+                    e("ds_write_b128", b_, "v[%d:%d]" % (r, r + 3), off)
+    e("s_waitcnt", "lgkmcnt(0)")
+    e("s_nop", 4)
 
 
 def body(e, plan, s, capture):
@@ -256,40 +279,30 @@ def body(e, plan, s, capture):
 
     from . import asmgen64 as g
     nlds = [0]                      # LDS reads issued so far in this body (they complete in order)
-    aq_seq, co_seq = {}, {}         # address quad / coefficient read -> its issue number
+    co_seq = {}                     # solve instruction whose coefficient comes from LDS -> issue number of its read
 
     def wait_for(seq):
         e("s_waitcnt", "lgkmcnt(%d)" % min(15, nlds[0] - 1 - seq))
 
-    def aquad(gq):
-        """the four addresses of solve instructions 4 gq .. 4 gq + 3"""
-        if 4 * gq + 3 < NAC:
-            return                                      # (their coefficients are in AGPRs)
-        if 4 * gq < nops:
-            b_, off, _ = g.lds_addr(TAB_WORD + 2 * gq)
-            r = T_AQ[gq % 3]
-            e("ds_read_b128", "v[%d:%d]" % (r, r + 3), b_, off)
-            aq_seq[gq] = nlds[0]
-            nlds[0] += 1
+    def creg(n):
+        """first register of instruction n's coefficient word"""
+        if n < NAC:
+            return T_COEF[n % NRING]
+        return T_CQ[((n - NAC) // 2) % len(T_CQ)] + 2 * ((n - NAC) & 1)
 
     def read(n):
-        if n < nops:
-            q = seq[opsidx[n]][1]
-            if n % 4 == 0:
-                aquad(n // 4 + 2)                       # two quads ahead of the one about to be used
-            if q < NAC:
-                e("v_accvgpr_read_b32", v(T_COEF[n % NRING]), "a%d" % (AC0 + 2 * q))
-                e("v_accvgpr_read_b32", v(T_COEF[n % NRING] + 1), "a%d" % (AC0 + 2 * q + 1))
-                return
-            if aq_seq[q // 4] is not None:
-                wait_for(aq_seq[q // 4])
-                aq_seq[q // 4] = None                   # (arrived: later reads of this quad need no wait)
-            e("ds_read_b64", vp(T_COEF[n % NRING]), v(T_AQ[(q // 4) % 3] + q % 4), 0)
-            co_seq[n] = nlds[0]
+        if n >= nops:
+            return
+        if n < NAC:
+            e("v_accvgpr_read_b32", v(T_COEF[n % NRING]), "a%d" % coef_agpr(n))
+            e("v_accvgpr_read_b32", v(T_COEF[n % NRING] + 1), "a%d" % (coef_agpr(n) + 1))
+        elif (n - NAC) % 2 == 0:
+            b_, off, half = g.lds_addr(coef_word(n))
+            r = creg(n)
+            e("ds_read_b128", "v[%d:%d]" % (r, r + 3), b_, off)      # the coefficients of instructions n and n + 1
+            co_seq[n] = co_seq[n + 1] = nlds[0]
             nlds[0] += 1
     assert all(seq[opsidx[n]][1] == n for n in range(nops))     # running op number == coefficient index
-    aquad(0)
-    aquad(1)
     for n in range(RD_AHEAD):
         read(n)
     waited_co = [-1]
@@ -324,11 +337,10 @@ def body(e, plan, s, capture):
                 e("v_mov_b32_dpp", v(T_SRC[slot] + 1), v(sr + 1), qperm(ins["perm"]))
                 cached[slot] = key
                 src = T_SRC[slot]
-        if n in co_seq and (n % 2 == 0 or waited_co[0] < n):    # one wait per two coefficient reads (they return in order)
-            upto = n + 1 if n + 1 in co_seq else n
-            wait_for(co_seq[upto])
-            waited_co[0] = upto
-        e("v_fma_f64", vp(d), "-" + vp(T_COEF[n % NRING]), vp(src), vp(d))
+        if n in co_seq and waited_co[0] < co_seq[n]:            # one wait per float4 = two coefficients (reads return in order)
+            wait_for(co_seq[n])
+            waited_co[0] = co_seq[n]
+        e("v_fma_f64", vp(d), "-" + vp(creg(n)), vp(src), vp(d))
         lastw = [d, lastw[0]]
         cached = [None if (c is not None and c[0] == d) else c for c in cached]     # a fetched copy of d is stale now
     # ---- x <- alpha x~ + (1 - alpha) x; capturing: x_new into W (x stays x_prev)

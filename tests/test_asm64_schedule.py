@@ -109,7 +109,14 @@ def test_fp64_quad_iteration_size_and_table(prog_quad):
     assert not any(t[0] == "s_mov_b64" and t[1] == "exec" for t in body)
     plan = asmquad64.plan_for(s)
     tab = asmquad64.table(plan)
-    assert tab.shape == (4, asmquad64.NTAB) and plan.ncoef <= asmquad64.NTAB and asmquad64.TAB_WORD + asmquad64.NTAB // 2 <= asmquad64.ZERO_WORD
+    assert tab.shape == (4, asmquad64.NTAB) and plan.ncoef <= asmquad64.NTAB
+    # round 5: the per-lane coefficients are gathered ONCE per step: AGPR pairs for the first NAC instructions, a compact LDS
+    # array (uniform addresses, two coefficients per ds_read_b128) for the rest -- no per-lane address in the iterations
+    assert asmquad64.coef_word(plan.ncoef - 1) < asmquad64.ZERO_WORD and asmquad64.coef_word(asmquad64.NAC) % 2 == 0
+    lds_rd = [t for t in body if t[0].startswith("ds_read")]
+    assert all(t[0] == "ds_read_b128" for t in lds_rd) and len(lds_rd) == (plan.ncoef - asmquad64.NAC) // 2
+    assert not any(t[0].startswith("ds_write") or t[0].startswith("global_") for t in body)
+    assert len(body) <= 1010, len(body)
     assert (tab[3] == asmquad64.rel_addr(asmquad64.ZERO_WORD)).all()            # lane 3 of a quad idles on the zero word
     assert (tab % 8 == 0).all() and tab.max() < 160 * 1024 // 64 * 64
     # every entry of L is addressed exactly twice (once per solve direction), by the lane that owns its destination
