@@ -1,7 +1,8 @@
 """ONE ROBOT PER LANE QUAD, fp64: ADMM iterations 2..maxIter of the small-batch fp64 step (asmgen64.py, BASELINE config 2:
 B = 4 096) -- the fp64 counterpart of asmquad.py. 4 096 robots are 64 one-lane waves on 64 of the chip's 256 CUs; with
-four lanes per robot they are 256 waves, one per CU (the fp64 loop owns its CU's LDS), and each iteration is 1 125
-instructions with 314 fp64 operations instead of 1 483 with 786 (measured: 0.295 -> 0.224 ms per step; 0.185 with the Ruiz passes on the quad too, ruiz_program below).
+four lanes per robot they are 256 waves, one per CU (the fp64 loop owns its CU's LDS), and each iteration is 819
+instructions with 314 fp64 operations instead of 1 483 with 786 (measured: 0.295 -> 0.224 ms per step; 0.185 with the Ruiz
+passes on the quad too, ruiz_program below; 0.152 with the coefficients gathered once per step).
 
 Same idea as asmquad.py (its docstring has the reasoning): the phases around the loop run redundantly in the four lanes
 of a quad, the loop keeps a third of the unknowns in each of lanes 0..2, a triangular-solve operation runs in the lane
@@ -11,12 +12,12 @@ used unchanged). What differs for eight-byte words:
   * v_fma_f64 is VOP3: no DPP operand. A source that lives in another lane is fetched with two v_mov_b32_dpp (low, high
     word) into a temporary pair right before its consumer; consecutive consumers of one (register, selection) reuse it.
   * a lane owns 121 words of VGPRs: W, x, y, 1/D and the thrust-row words (92 words) leave no room for the 194
-    coefficient words. They are NOT moved at all: every lane already holds the whole factor in its own LDS slice
-    (phase A wrote it there for the one-lane first iteration), so instruction q reads, in lane l, the word of L that lane
-    needs -- ds_read_b64 with a PER-LANE address. The 194 addresses per lane class are a constant table
-    (`table()`, csrc/umpc_quad64_tab.h), added to the lane's LDS base once per step and parked in AGPRs; a lane with
-    nothing to do in an instruction reads a word that holds 0.0. Reading 8 bytes at a per-lane word of the
-    [quad][lane] layout is conflict-free (the bank is decided by the lane, not by the word).
+    coefficient words. Every lane already holds the whole factor in its own LDS slice (phase A wrote it there for the
+    one-lane first iteration) and instruction q needs, in lane l, ONE of its words -- a per-lane choice, a constant table
+    (`table()`, csrc/umpc_quad64_tab.h); a lane with nothing to do in an instruction gets a word that holds 0.0.
+    Rounds 3-4 read that word with a per-lane address EVERY iteration; since round 5 the entry gathers each lane's 194
+    words once per step into AGPR pairs and a compact LDS array read at uniform addresses (see NAC / CW0 below):
+    0.173 -> 0.152 ms per step (profiles/r05_quad64_gather_ab.txt).
   * q and l of the lane's unknowns sit in AGPR pairs (read once per iteration), composed from the one-lane homes.
 
 Exit: x, y, x_prev and delta_y of the capturing iteration go back to EVERY lane's LDS slice (two DPP moves + one
