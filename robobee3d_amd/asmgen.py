@@ -92,11 +92,74 @@ def f32bits(v):
     return struct.unpack("<I", struct.pack("<f", v))[0]
 
 
+def _vgprs(x):
+    """the VGPR numbers an operand string names ('v7', '-v7', '|v7|', 'v[4:7]'); empty for anything else"""
+    if not isinstance(x, str):
+        return set()
+    x = x.strip("-|")
+    if x.startswith("v[") and x.endswith("]"):
+        lo, hi = x[2:-1].split(":")
+        return set(range(int(lo), int(hi) + 1))
+    if x.startswith("v") and x[1:].isdigit():
+        return {int(x[1:])}
+    return set()
+
+
+WIDE_STORES = {"ds_write_b128": 2, "ds_write_b96": 2, "global_store_dwordx4": 2, "global_store_dwordx3": 2}   # mnemonic -> data operand
+WIDE_STORE_WAIT = 2     # wait states (gfx940 and later) before a VALU may overwrite the data registers of such a store
+
+
+def valu_dst(t):
+    """VGPRs a VALU instruction tuple writes"""
+    m = t[0]
+    if not m.startswith("v_") or m.startswith("v_cmp") or m in ("v_accvgpr_write_b32", "v_readfirstlane_b32", "v_readlane_b32"):
+        return set()
+    return _vgprs(t[1])
+
+
+def wide_store_hazards(ins):
+    """[(index of the store, index of the VALU)]: a store of more than 64 bits reads its data registers over several cycles; a
+    VALU instruction that overwrites one of them within WIDE_STORE_WAIT wait states races with it (the hardware does not
+    interlock this; hipcc's hazard recogniser inserts the nops for compiled code, nobody does for inline assembly)."""
+    out = []
+    for k, t in enumerate(ins):
+        if t[0] in WIDE_STORES:
+            data = _vgprs(t[WIDE_STORES[t[0]]])
+            ws, j = 0, k + 1
+            while j < len(ins) and ws < WIDE_STORE_WAIT:
+                u = ins[j]
+                if u[0] == "label":
+                    j += 1
+                    continue
+                if u[0] == "s_nop":
+                    ws += int(u[1]) + 1
+                elif valu_dst(u) & data:
+                    out.append((k, j))
+                    ws += 1
+                else:
+                    ws += 1
+                j += 1
+    return out
+
+
 class Emit:
+    """Collects instruction tuples. Keeps the one hazard of straight-line LDS / VMEM stores out of every generated stream: a VALU
+    write to the data registers of a store of more than 64 bits waits WIDE_STORE_WAIT states (wide_store_hazards)."""
+
     def __init__(self):
         self.ins = []  # tuples (mnemonic, operands..., [dict of VOP3P modifiers])
 
     def __call__(self, *t):
+        dst = valu_dst(t)
+        if dst:
+            ws = 0
+            for u in reversed(self.ins[-(WIDE_STORE_WAIT + 1):]):
+                if ws >= WIDE_STORE_WAIT or u[0] == "label":
+                    break            # (a label: whatever precedes it is not necessarily what ran before)
+                if u[0] in WIDE_STORES and _vgprs(u[WIDE_STORES[u[0]]]) & dst:
+                    self.ins.append(("s_nop", WIDE_STORE_WAIT - ws - 1))
+                    break
+                ws += int(u[1]) + 1 if u[0] == "s_nop" else 1
         self.ins.append(t)
 
 

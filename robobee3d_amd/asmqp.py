@@ -84,7 +84,14 @@ KNOB = dict(leafeq=os.environ.get("UMPC_QP_LEAFEQ", "V"), rinv_lds=os.environ.ge
 
 
 class Plan:
-    def __init__(self, s, eq_rows):
+    def __init__(self, s, eq_rows, pad=None):
+        if pad is None:
+            # one unused word between L and x or none: whichever parity of the x / y words lets more row pairs share packed
+            # instructions (a box row pair needs its y words AND its variables' W registers on aligned pairs)
+            best = max((Plan(s, eq_rows, q) for q in (0, 1)), key=lambda c: (len(c.pairs), len(c.eqpairs), -c.pad))
+            self.__dict__.update(best.__dict__)
+            return
+        self.pad = pad
         t = s.tables
         n, m, nk = s.n, s.m, s.nk
         self.s, self.n, self.m, self.nk = s, n, m, nk
@@ -113,7 +120,7 @@ class Plan:
         self.wreg = {k: xbase + j for j, k in enumerate(xk)}
         # ... and the unknowns of consecutive non-leaf EQUALITY rows (i, i + 1) whose y words are an aligned pair (LW_Y + i
         # even) on aligned register pairs too: their row updates and right-hand sides pack the same way
-        LW_Y_ = len(L_i) + n
+        LW_Y_ = len(L_i) + pad + n
         nl_eq = {r["i"]: r["k"] for r in self.rows if r["eq"] and not r["leaf"]}
         self.eqpairs, usede = [], set()
         for i in sorted(nl_eq):
@@ -160,7 +167,7 @@ class Plan:
         # Pairs of leaf inequality rows (i, i + 1) for the packed row updates of the loose variant: their y words are an
         # aligned pair when LW_Y + i is even, their variables' W registers (x_j, x_j+1 on consecutive registers) likewise;
         # their z words and L entries are PLACED on aligned pairs below (paired rows first in both orders).
-        self.LW_L, self.LW_X = 0, len(L_i)
+        self.LW_L, self.LW_X = 0, len(L_i) + pad
         self.LW_Y = self.LW_X + n
         cand = {r["i"]: r for r in self.rows if r["leaf"] and not r["eq"]}
         self.pairs, used = [], set()
@@ -188,7 +195,7 @@ class Plan:
         # inequality rows as LDS words are left (each is read twice per iteration: rhs and row update).
         self.once = {}                                         # item -> ('A', agpr) | ('L', lds word)
         free_a = list(range(nk, 256))
-        free_l = list(range(self.LW_END, LW_FLAGS))
+        free_l = list(range(self.LW_END, LW_XCH))
         for q, i in enumerate(self.leafeq):
             if KNOB["leafeq"] == "V":
                 self.once[("l", i)] = ("V", self.V_LEQ + q)
@@ -215,7 +222,7 @@ class Plan:
         self.y0_home = {}
         for j, i in zip(range(n), gen):
             self.y0_home[("q", j)] = self.LW_Y + i
-        spare = list(range(self.LW_END + self.LW_END % 2, LW_FLAGS))
+        spare = list(range(self.LW_END + self.LW_END % 2, LW_XCH))
         for (a_, b_) in self.eqpairs:
             if len(spare) >= 2:
                 self.y0_home[("l", a_)], self.y0_home[("l", b_)] = spare[0], spare[1]
@@ -260,10 +267,23 @@ RING_AHEAD = int(os.environ.get("UMPC_QP_RING_AHEAD", "20"))   # ops of look-ahe
 class Own:
     """Which variables, rows and KKT unknowns a wavefront's copy of the loop block works on (LoopSplit); ALL = one wave, all."""
 
-    def __init__(self, varw=None, roww=None, kw=None, wave=0, lhome=None):
+    def __init__(self, varw=None, roww=None, kw=None, wave=0, lhome=None, fkw=None, split=None, fvarw=None):
         self.varw, self.roww, self.kw, self.wave = varw, roww, kw, wave
         self.all = varw is None
         self.lhome = lhome or {}          # L entry (CSC index) -> VGPR that holds -L during the iterations (LoopSplit.own)
+        self.fkw = fkw if fkw is not None else kw          # who FACTORISES unknown k (a component cut in two: the wave of half A)
+        self.fvarw = fvarw if fvarw is not None else varw
+        # a component cut in two (LoopSplit): the solves of every wave of the workgroup meet at two barriers
+        self.xbar = split is not None
+        sp = split or {}
+        self.top = sp.get("top", set())          # unknowns of the separators this wave owns
+        self.cross = sp.get("cross", [])         # solve entries (r, c, j), c the partner's, r in `top`: this wave's forward solve applies them
+        self.xrecv_f = sp.get("xrecv_f", {})     # ... reading the partner's forward value of c from this LDS word
+        self.xsend_f = sp.get("xsend_f", {})     # unknown c -> LDS word this wave leaves its forward value in
+        self.xsend_b = sp.get("xsend_b", {})     # separator unknown r -> LDS word this wave leaves its solution in
+        self.xrecv_b = sp.get("xrecv_b", {})     # separator unknown r (the partner's) -> LDS word
+        self.hand_out = sp.get("hand_out", {})   # unknown k this wave factorises for its partner -> LDS word 1/D_k is handed over in
+        self.hand_in = sp.get("hand_in", {})     # unknown k of this wave that the partner factorises -> that word
 
     def var(self, j):
         return self.all or self.varw[j] == self.wave
@@ -274,6 +294,12 @@ class Own:
     def k(self, k):
         return self.all or self.kw[k] == self.wave
 
+    def fk(self, k):
+        return self.all or self.fkw[k] == self.wave
+
+    def fvar(self, j):
+        return self.all or self.fvarw[j] == self.wave
+
     def item(self, item):
         what, idx = item
         return self.var(idx) if what == "q" else self.row(idx)
@@ -281,42 +307,193 @@ class Own:
 
 ALL = Own()
 L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
+TREE_SPLIT = os.environ.get("UMPC_QP_TREE_SPLIT", "1") == "1"  # (A/B switch: LoopSplit cuts large components in two)
+N_XCH = 16                                                      # LDS words LW_XCH.. below the flags: the halves' exchange words
+LW_XCH = LW_FLAGS - N_XCH
 
 
 class LoopSplit:
     """A QP whose constraint graph falls into several connected components (qpstruct.qp_components) is several independent
     QPs: right-hand sides, LDL' factor, triangular solves, row and x updates of one component never touch another's words.
-    The loose loop block deals the components out to the wavefronts of the workgroup, largest first, each to the least loaded
-    (planar p5f: 118 + 112 + 8 + 7 of 251 unknowns on four wavefronts); they run their 50 iterations side by side on disjoint
-    LDS words of the SAME layout (Plan), without a barrier inside the loop. Words come out bit-identical to the one-wave block."""
+    The loop block deals the components out to the wavefronts of the workgroup, largest first, each to the least loaded; they
+    run their 50 iterations side by side on disjoint LDS words of the SAME layout (Plan). Words come out bit-identical to the
+    one-wave block.
 
-    def __init__(self, p, nw=4):
+    Round 5: a component larger than a wavefront's fair share whose elimination tree is two subtrees under a short top chain
+    (qpstruct.bisect_ordering makes the horizon chains of an MPC such trees) is cut in TWO units: half A with the top chain
+    (the separator), half B. Everything elementwise belongs to the owner of its unknown; the triangular solves meet twice:
+        forward   both halves eliminate their subtree; B leaves the forward values of its columns that reach into the separator
+                  in LDS -- barrier -- A applies those entries (the same fmac on the same operands, in the one-wave order: the
+                  ordering puts A's columns before B's), eliminates the separator columns, scales, solves them back
+        backward  A leaves the separator's solution in LDS -- barrier -- both halves walk their subtree back
+    Two barriers per iteration for every wavefront of the workgroup (a wavefront without a cut component just meets them).
+    The factorisation of a cut component stays with ONE wavefront (A's; it hands 1/D of B's unknowns over through LDS once).
+    planar p5f: 118 + 112 + 12 + 9 unknowns on four wavefronts became 63 + 60 + 64 + 64."""
+
+    def __init__(self, p, nw=4, tree=None):
         from . import qpstruct
         s = p.s
         self.p = p
+        tree = TREE_SPLIT if tree is None else tree
         vc, rc = qpstruct.qp_components(s.n, s.m, list(s.tables["A_p"]), list(s.tables["A_i"]))
         self.nw = nw
         ncomp = max(vc) + 1
-        # components (numbered by decreasing size) -> wavefronts: each to the least loaded so far (weight = KKT unknowns)
-        load, cw = [0] * min(nw, ncomp), {}
-        for c in range(ncomp):
-            w = min(range(len(load)), key=lambda w_: (load[w_], w_))
-            cw[c] = w
-            load[w] += sum(1 for x in vc if x == c) + sum(1 for x in rc if x == c)
-        self.active = len(load)
-        self.load = load
-        self.varw = [cw[c] for c in vc]
-        self.roww = [cw[c] for c in rc]
-        self.kw = [0] * s.nk
+        comp = [0] * s.nk
         for j in range(s.n):
-            self.kw[p.pinv[j]] = self.varw[j]
+            comp[p.pinv[j]] = vc[j]
         for i in range(s.m):
-            self.kw[p.pinv[s.n + i]] = self.roww[i]
+            comp[p.pinv[s.n + i]] = rc[i]
+        size = [sum(1 for x in comp if x == c) for c in range(ncomp)]
+        # units: whole components, or the two halves of a cut one
+        self.cut = {}
+        units = []
+        for c in range(ncomp):
+            cut = (self._given(comp, c) or self._cut(comp, c)) if tree and nw >= 2 and size[c] * nw > s.nk else None
+            if cut is None:
+                units.append((size[c], c, None))
+            else:
+                self.cut[c] = cut
+                units.append((len(cut["A"]) + len(cut["T"]), c, "A"))
+                units.append((len(cut["B"]), c, "B"))
+        units.sort(key=lambda u: (-u[0], u[1], u[2] or ""))
+        nact = min(nw, len(units))
+        load, uw = [0] * nact, {}
+        for (wt, c, half) in units:
+            other = uw.get((c, "A" if half == "B" else "B")) if half else None
+            w = min((w_ for w_ in range(nact) if w_ != other), key=lambda w_: (load[w_], w_))
+            uw[(c, half)] = w
+            load[w] += wt
+        self.active = nact
+        self.load = load
+        self.kw, self.fkw = [0] * s.nk, [0] * s.nk
+        for k in range(s.nk):
+            c = comp[k]
+            if c in self.cut:
+                self.kw[k] = uw[(c, "B")] if k in self.cut[c]["B"] else uw[(c, "A")]
+                self.fkw[k] = uw[(c, "A")]
+            else:
+                self.kw[k] = self.fkw[k] = uw[(c, None)]
+        self.varw = [self.kw[p.pinv[j]] for j in range(s.n)]
+        self.roww = [self.kw[p.pinv[s.n + i]] for i in range(s.m)]
         for r in p.rows:
             if r["leaf"]:
                 assert self.kw[r["r"]] == self.roww[r["i"]]
-        for (r_, c, j) in p.solve_entries:
-            assert self.kw[r_] == self.kw[c]
+        # exchange words and the entries that cross a cut
+        self.split = [dict(top=set(), cross=[], xrecv_f={}, xsend_f={}, xsend_b={}, xrecv_b={}, hand_out={}, hand_in={})
+                      for _ in range(nact)] if self.cut else None
+        self.fvarw = [self.fkw[p.pinv[j]] for j in range(s.n)]
+        # 1/D of half B's unknowns: from the factorising wave's AGPRs to B's through LDS words that held the component's A entries
+        A_p_ = list(s.tables["A_p"])
+        for a_ in range(nact if self.cut else 0):
+            words = [p.LW_X + q for j in range(s.n) if self.fvarw[j] == a_ for q in range(A_p_[j], A_p_[j + 1])]
+            ks = [k for k in range(s.nk) if self.fkw[k] == a_ and self.kw[k] != a_]
+            assert len(ks) <= len(words)
+            for k, word in zip(ks, words):
+                self.split[a_]["hand_out"][k] = word
+                self.split[self.kw[k]]["hand_in"][k] = word
+        quad = LW_XCH
+        for c in sorted(self.cut):
+            a_, b_ = uw[(c, "A")], uw[(c, "B")]
+            T = self.cut[c]["T"]
+            self.split[a_]["top"] |= T
+            cross = [(r_, c_, j) for (r_, c_, j) in p.solve_entries if self.kw[c_] == b_ and self.kw[r_] == a_]
+            assert all(r_ in T for (r_, _, _) in cross)
+            self.split[a_]["cross"] += cross
+            cols, tops = sorted({c_ for (_, c_, _) in cross}), sorted({r_ for (r_, _, _) in cross})
+            assert len(cols) <= 4 and len(tops) <= 4 and quad + 8 <= LW_FLAGS, (cols, tops, quad)
+            for q, c_ in enumerate(cols):          # (one float4 per direction and cut: one LDS read fetches it)
+                self.split[a_]["xrecv_f"][c_] = self.split[b_]["xsend_f"][c_] = quad + q
+            for q, r_ in enumerate(tops):
+                self.split[a_]["xsend_b"][r_] = self.split[b_]["xrecv_b"][r_] = quad + 4 + q
+            quad += 8
+        for (r_, c_, j) in p.solve_entries:
+            assert self.kw[r_] == self.kw[c_] or any((r_, c_, j) in sp_["cross"] for sp_ in self.split or [])
+
+    def _given(self, comp, c):
+        """the halves and the separator that the structure's ordering was made from (qpstruct.bisect_parts, tables["part"]), if it
+        carries them and they satisfy what the solves need (see _cut); a leaf row goes where its parent is"""
+        p = self.p
+        s = p.s
+        part = s.tables.get("part")
+        if part is None:
+            return None
+        K = [k for k in range(s.nk) if comp[k] == c]
+        of = {k: part[s.perm[k]] for k in K}
+        for r in p.rows:
+            if r["leaf"] and r["k"] in of:
+                of[r["k"]] = 0 if of[r["r"]] == 2 else of[r["r"]]
+        A, B, T = ({k for k in K if of[k] == h} for h in (0, 1, 2))
+        if not T or not B:
+            return None
+        seen_b = set()
+        for (r_, c_, j) in p.solve_entries:
+            if c_ not in of:
+                continue
+            if r_ in T:
+                if c_ in B:
+                    seen_b.add(r_)
+                elif c_ in A and r_ in seen_b:
+                    return None
+            if (c_ in A and r_ in B) or (c_ in B and r_ in A) or (c_ in T and r_ not in T):
+                return None
+        return dict(A=A, B=B, T=T)
+
+    def _cut(self, comp, c):
+        """component c as (half A, half B, top chain T) of its elimination tree, or None: T = the nodes from the root down while
+        one child's subtree is more than 55 % of the component; the subtrees under T are dealt to two bins, largest first; a
+        leaf row stays with its parent. Accepted when the smaller half is at least a quarter and, for every unknown of T, the
+        solve entries of A's columns come before those of B's columns (the one-wave order of the additions)."""
+        p = self.p
+        s = p.s
+        etree = list(s.etree)
+        K = [k for k in range(s.nk) if comp[k] == c]
+        kids = {k: [] for k in K}
+        roots = []
+        for k in K:
+            (kids[etree[k]] if etree[k] != -1 else roots).append(k)
+        if len(roots) != 1:
+            return None
+        sz = {}
+        for k in K:                               # (children have smaller indices than their parent)
+            sz[k] = 1 + sum(sz[x] for x in kids[k])
+        leafk = {r["k"] for r in p.rows if r["leaf"]}
+
+        def deal(T, frontier):
+            T = set(T)
+            bins = [set(), set()]
+            for k in sorted(frontier, key=lambda k: (-sz[k], k)):
+                sub, st = set(), [k]
+                while st:
+                    x = st.pop()
+                    sub.add(x)
+                    st += kids[x]
+                b = 0 if (k in leafk and etree[k] in T) else (0 if len(bins[0]) + len(T) <= len(bins[1]) else 1)
+                bins[b] |= sub
+            A, B = bins
+            if min(len(A) + len(T), len(B)) < 0.25 * len(K):
+                return None
+            seen_b = set()
+            for (r_, c_, j) in p.solve_entries:
+                if r_ in T:
+                    if c_ in B:
+                        seen_b.add(r_)
+                    elif c_ in A and r_ in seen_b:
+                        return None
+                if (c_ in A and r_ in B) or (c_ in B and r_ in A) or (c_ in T and r_ not in T):
+                    return None
+            return dict(A=A, B=B, T=T)
+        # every prefix of the chain root -> largest child -> ... (a few nodes) is a candidate top; the best balanced valid one wins
+        T, frontier, cands = [roots[0]], list(kids[roots[0]]), []
+        for _ in range(6):
+            c_ = deal(T, frontier)
+            if c_ is not None:
+                cands.append((max(len(c_["A"]) + len(c_["T"]), len(c_["B"])), len(T), c_))
+            if not frontier:
+                break
+            big = max(frontier, key=lambda k: (sz[k], k))
+            T = T + [big]
+            frontier = [k for k in frontier if k != big] + kids[big]
+        return min(cands, key=lambda c: c[:2])[2] if cands else None
 
     def own(self, wave):
         """... and the W registers of the OTHER wavefronts' unknowns, which this wavefront's copy of the block never touches, hold
@@ -324,9 +501,10 @@ class LoopSplit:
         instruction costs a lone wave ~6 ns whatever its width"""
         p = self.p
         pool = sorted(p.wreg[k] for k in p.nonleaf if self.kw[k] != wave)
-        mine = [j for (r_, c, j) in p.solve_entries if self.kw[c] == wave]
+        cross = set(self.split[wave]["cross"]) if self.split else set()
+        mine = [j for (r_, c, j) in p.solve_entries if self.kw[c] == wave or (r_, c, j) in cross]
         lhome = dict(zip(mine, pool)) if L_HOMES else {}
-        return Own(self.varw, self.roww, self.kw, wave, lhome)
+        return Own(self.varw, self.roww, self.kw, wave, lhome, self.fkw, self.split[wave] if self.split else None, self.fvarw)
 
 
 class Sched:
@@ -715,24 +893,61 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
         del ops[rhs_ops_start:]
     # ---- solves over the non-leaf unknowns (qdldl.c:250-293)
     lsrc_ = lambda j: ("V", own.lhome[j]) if j in own.lhome else ("L", p.lpos[j])
-    for (r_, c, j) in p.solve_entries:
-        if own.k(c):
-            op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
     kof = {reg: k for k, reg in p.wreg.items() if own.k(k)}
-    kdone = set()
-    for reg in sorted(kof) if pack else [p.wreg[k] for k in p.nonleaf if own.k(k)]:      # (by register when pairing: a pair is visited once)
-        k = kof[reg]
-        if k in kdone:
-            continue
-        if "2" in PACK_PARTS and pack and reg % 2 == 0 and reg + 1 in kof:
-            k1 = kof[reg + 1]
-            kdone.add(k1)
-            op([("A2", k, k1)], lambda g, reg=reg: _pk(e, "v_pk_mul_f32", reg, [VP(reg), VP(g[0])]))
-        else:
-            op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
-    for (r_, c, j) in reversed(p.solve_entries):
-        if own.k(c):
-            op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+
+    def scale(which):
+        """W <- W / D on this wave's unknowns selected by `which`; two per instruction where both registers of an aligned pair are"""
+        kdone = set()
+        for reg in sorted(kof) if pack else [p.wreg[k] for k in p.nonleaf if own.k(k)]:    # (by register when pairing: a pair is visited once)
+            k = kof[reg]
+            if k in kdone or not which(k):
+                continue
+            if "2" in PACK_PARTS and pack and reg % 2 == 0 and reg + 1 in kof and which(kof[reg + 1]):
+                k1 = kof[reg + 1]
+                kdone.add(k1)
+                op([("A2", k, k1)], lambda g, reg=reg: _pk(e, "v_pk_mul_f32", reg, [VP(reg), VP(g[0])]))
+            else:
+                op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
+
+    def meet():
+        op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
+        ops.append(dict(flush=True))              # (nothing is fetched across it: the partner's words are read behind the barrier)
+    if not own.xbar:
+        for (r_, c, j) in p.solve_entries:
+            if own.k(c):
+                op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
+        scale(lambda k: True)
+        for (r_, c, j) in reversed(p.solve_entries):
+            if own.k(c):
+                op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+    else:
+        # a component cut in two (LoopSplit): the subtrees of the elimination tree side by side, the separator between two barriers
+        top = own.top
+        for (r_, c, j) in p.solve_entries:
+            if own.k(c) and c not in top and own.k(r_):
+                op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
+        for c, word in sorted(own.xsend_f.items()):
+            op([], lambda g, c=c, word=word: sc.lds_write(word, p.wreg[c]))       # (the forward value: before the scaling below)
+        scale(lambda k: k not in top)
+        meet()
+        for (r_, c, j) in own.cross:
+            op([lsrc_(j), ("L", own.xrecv_f[c])], lambda g, r_=r_: e("v_fmac_f32", W(r_), v(g[0]), v(g[1])))
+        for (r_, c, j) in p.solve_entries:
+            if own.k(c) and c in top:
+                op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
+        scale(lambda k: k in top)
+        for (r_, c, j) in reversed(p.solve_entries):
+            if own.k(c) and c in top:
+                op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+        for r_, word in sorted(own.xsend_b.items()):
+            op([], lambda g, r_=r_, word=word: sc.lds_write(word, p.wreg[r_]))
+        meet()
+        for (r_, c, j) in reversed(p.solve_entries):
+            if own.k(c) and c not in top:
+                if own.k(r_):
+                    op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(c), v(g[0]), W(r_)))
+                else:
+                    op([lsrc_(j), ("L", own.xrecv_b[r_])], lambda g, c=c: e("v_fmac_f32", W(c), v(g[0]), v(g[1])))
     if capture and group:
         # x_prev and delta_y are written over the L words, ANY wave's: nobody writes them before everybody's last solve is done
         op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
@@ -1228,7 +1443,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     assert p.LW_X + s.nnzA <= 640
     G = V_END - V_W - (1 if y0check else 0)      # landing registers V_W ..; y0check keeps the last one as its accumulator
     A_p_ = list(s.tables["A_p"])
-    own_a = [k for j in range(s.n) if own.var(j) for k in range(A_p_[j], A_p_[j + 1])]
+    own_a = [k for j in range(s.n) if own.fvar(j) for k in range(A_p_[j], A_p_[j + 1])]      # (what this wave FACTORISES)
     for g in range(0, len(own_a), G):
         ks = own_a[g:g + G]
         for q, k in enumerate(ks):
@@ -1245,7 +1460,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     pool0 = v_rinv + len(gen)
     assert pool0 + 30 <= p.V_RING
     for j in sorted(res.it_p):
-        if own.var(j):
+        if own.fvar(j):
             sload(v_p + res.pidx[j], res.it_p[j])
     items = p.stream + p.extra
     for q, i in enumerate(gen):
@@ -1262,6 +1477,11 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING - 12)),
                 list(range(p.V_LAND, p.V_LAND + p.NLAND)) + list(range(p.V_RING - 12, p.V_RING)), v_fmin, own)
     _lstamp(e, own, 2)
+    for q, (k, word) in enumerate(sorted(own.hand_out.items())):       # a cut component: 1/D of the partner's half -> LDS
+        t = p.V_TT + q % 4                 # (V_TT + N_TT - 1 is the pivot accumulator)
+        e("v_accvgpr_read_b32", "v%d" % t, "a%d" % k)
+        base, off = lds_addr(word)
+        e("ds_write_b32", base, "v%d" % t, off)
     base, off = lds_addr(FAC_MIN)
     if group:
         # several waves: the A words above are the other waves' x, y words -- nobody loads its warm start before everybody
@@ -1272,6 +1492,17 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_barrier")
         e("ds_min_f32", base, "v%d" % v_fmin, off)
+        if own.xbar:
+            # ... and the other half takes its 1/D from there into its own AGPRs; nobody's warm start overwrites the words before
+            hin = sorted(own.hand_in.items())
+            assert len(hin) <= G
+            for q, (k, word) in enumerate(hin):
+                base_, off_ = lds_addr(word)
+                e("ds_read_b32", "v%d" % (V_W + q), base_, off_)
+            e("s_waitcnt", "lgkmcnt(0)")
+            for q, (k, word) in enumerate(hin):
+                e("v_accvgpr_write_b32", "a%d" % k, "v%d" % (V_W + q))
+            e("s_barrier")
     else:
         e("ds_write_b32", base, "v%d" % v_fmin, off)
     e("s_waitcnt", "lgkmcnt(0)")
@@ -1450,6 +1681,7 @@ def loop_group_program(s, eq_rows, res, nw=4, loose=True):
     other inputs as program(...) with the fast start. Returns (instructions, plan, split)."""
     p = Plan(s, eq_rows)
     sp = LoopSplit(p, nw)
+    assert not sp.cut or sp.active == nw      # (a cut component puts barriers inside the loop: every wavefront runs a copy of it)
     e = Emit()
     for w in range(nw):
         if w < nw - 1:
@@ -2819,7 +3051,7 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
     t = s.tables
     pidx = list(t["pidx"])
     v = lambda r: "v%d" % r
-    fops = [op_ for op_ in s.factor_ops if own.k(op_["k"])]      # (components factorise independently: LoopSplit)
+    fops = [op_ for op_ in s.factor_ops if own.fk(op_["k"])]     # (components factorise independently: LoopSplit)
     reused = sorted({j for op_ in fops for (_, upd, _) in op_["elim"] for (j, _) in upd})
     assert len(reused) <= len(v_pin), (len(reused), len(v_pin))
     pin = {j: v_pin[q] for q, j in enumerate(reused)}

@@ -141,7 +141,34 @@ def p5f_analysis(N=10):
     """(p5f_structure(N, grouped=True), its qpstruct.analyse_qp): what PlanarP5fMPC and the build-time specialisation
     (codegen_qp) both use"""
     st = p5f_structure(N, grouped=True)
-    return st, qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"])
+    # elimination order: the two horizon chains cut in the middle (qpstruct.bisect_ordering: an elimination tree of two halves
+    # under a two-vertex separator instead of one spine; +14 entries of L at N = 10) -- asmqp.LoopSplit gives the halves to two
+    # wavefronts. UMPC_QP_ORDERING=minfill: the plain min-fill order of rounds 2-4.
+    if os.environ.get("UMPC_QP_ORDERING") == "minfill":
+        from . import symbolic
+        perm = symbolic.min_fill_ordering(qpstruct.kkt_adjacency(st["n"], st["m"], st["A_p"], st["A_i"]), hold=st["hold"])
+        return st, qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], perm=perm)
+    perm = qpstruct.bisect_ordering(st["n"], st["m"], st["A_p"], st["A_i"], parts=st["parts"], hold=st["hold"])
+    return st, qpstruct.analyse_qp(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], perm=perm, parts=st["parts"])
+
+
+def p5f_hold(st):
+    """symbolic.min_fill_ordering's tie-break for the p5f QP: a variable WITHOUT a cost term waits (among candidates of equal
+    fill) for one of the dynamics rows that carry it with a constant unit coefficient. Eliminated before all of them its pivot
+    is sigma + 1/rho_min^-1 = 2e-6 and its column of L 5e5: still an exact factorisation, but in fp32 the solves lose five
+    digits (measured on the reference's linearisations: 7.6e-2 of the iterates against 7.5e-7 with the tie-break; plain
+    min-fill on the script's labelling happens to walk the horizon forwards and never does it -- any ordering that walks a
+    stretch of the horizon backwards does)."""
+    n, m = st["n"], st["m"]
+    neq = m - n
+    costless = set(range(n)) - set(int(j) for j in st["P_cols"])
+    hold = {}
+    for j in sorted(costless):
+        rows = {n + st["A_i"][q] for q in range(st["A_p"][j], st["A_p"][j + 1])
+                if st["A_i"][q] < neq and st["src"][q] < 0 and abs(abs(float(st["cst"][q])) - 1.0) < 1e-12}
+        if rows:
+            hold[j] = rows
+    return hold
 
 
 def p5f_structure(N=10, grouped=False):
@@ -159,8 +186,14 @@ def p5f_structure(N=10, grouped=False):
         n, m = st["n"], st["m"]
         neq = m - n
         vc, rc = qp_components(n, m, st["A_p"], st["A_i"])
-        var_order = sorted(range(n), key=lambda j: (vc[j], j))
-        row_order = sorted(range(neq), key=lambda i: (rc[i], i)) + [neq + j for j in var_order]
+        # ... and inside a large component, the two halves that qpstruct.bisect_ordering's separator cuts it into (the separator
+        # itself with the first): a wavefront that owns a half owns a contiguous stretch of variables and rows (aligned pairs
+        # of neighbours stay whole)
+        hold0 = p5f_hold(st)
+        parts = qpstruct.bisect_parts(n, m, st["A_p"], st["A_i"], hold=hold0)
+        half = [0 if h == 2 else h for h in parts]
+        var_order = sorted(range(n), key=lambda j: (vc[j], half[j], j))
+        row_order = sorted(range(neq), key=lambda i: (rc[i], half[n + i], i)) + [neq + j for j in var_order]
         vnew = {j: t for t, j in enumerate(var_order)}
         rnew = {i: t for t, i in enumerate(row_order)}
         A_p, A_i, cst, src = [0], [], [], []
@@ -177,7 +210,9 @@ def p5f_structure(N=10, grouped=False):
         P_cols = [j for j in range(n) if Pfull[j] != 0.0]
         return dict(N=N, n=n, m=m, A_p=A_p, A_i=A_i, P_cols=P_cols, cst=np.array(cst), src=np.array(src, np.int32),
                     Pv=Pfull[P_cols], q=st["q"][var_order], l=st["l"][row_order], u=st["u"][row_order],
-                    var_order=np.array(var_order), row_order=np.array(row_order))
+                    var_order=np.array(var_order), row_order=np.array(row_order),
+                    parts=[parts[j] for j in var_order] + [parts[n + i] for i in row_order],
+                    hold={vnew[j]: {n + rnew[r - n] for r in rows} for j, rows in hold0.items()})
     nx, nu = 7, 1
     n = (N + 1) * nx + N * nu
     neq = (N + 1) * nx
@@ -220,9 +255,9 @@ class PlanarP5fMPC:
     reference's plant tick y += (Ad y + Bd unom) dt."""
 
     def __init__(self, B, dtype=torch.float32, device="cuda", N=10, dt=0.002, **settings):
-        st = p5f_structure(N, grouped=True)
+        st, s = p5f_analysis(N)           # (the labelling AND the elimination order the build-time specialisation was made for)
         self.st, self.B, self.dt, self.dtype = st, int(B), float(dt), dtype
-        self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, **settings)
+        self.qp = BatchQP(st["n"], st["m"], st["A_p"], st["A_i"], st["P_cols"], B, dtype, device, perm=s.perm, **settings)
         if not os.environ.get("UMPC_QP_KERNEL") and dtype != torch.float32:
             self.qp.set_kernel("wave")     # fp64: 10.8 ms per tick (fp32 figure) against 13.0 ms for the C++ lane specialisation;
             # fp32 keeps the default "lane": the specialisation with its middle iterations in assembly (asmqp.py)

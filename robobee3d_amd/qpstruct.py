@@ -34,6 +34,15 @@ _TABLES = ["pinv", "pidx", "A_p", "A_i", "Ar_p", "Ar_j", "Ar_k", "fi_p", "fi_b",
 HEADER_WORDS = 64
 
 
+def kkt_adjacency(n, m, A_p, A_i):
+    adj = [set() for _ in range(n + m)]
+    for j in range(n):
+        for q in range(A_p[j], A_p[j + 1]):
+            adj[j].add(n + A_i[q])
+            adj[n + A_i[q]].add(j)
+    return adj
+
+
 def analyse_pattern(nx, nc, A_p, A_i, perm=None):
     """The structure-only part shared with symbolic.analyse: permuted upper-triangular KKT, etree, L pattern
     and the recorded up-looking factorisation schedule. Every column has a diagonal entry ('P', j) (= P_jj +
@@ -124,9 +133,11 @@ def analyse_pattern(nx, nc, A_p, A_i, perm=None):
     return perm, pinv, K_p, K_i, K_src, etree, L_p, L_i, ops
 
 
-def analyse_qp(n, m, A_p, A_i, P_cols, perm=None):
+def analyse_qp(n, m, A_p, A_i, P_cols, perm=None, parts=None):
     """n, m: sizes; (A_p, A_i): CSC pattern of A (row indices ascending within a column); P_cols: sorted list of
-    the columns j that carry a diagonal P entry (value index k = position in this list)."""
+    the columns j that carry a diagonal P entry (value index k = position in this list).
+    parts: bisect_parts' labels that `perm` (bisect_ordering) was made from; kept as tables["part"] (not part of the blob:
+    a generator's hint -- asmqp.LoopSplit deals the halves of a cut component to two wavefronts)."""
     A_p = [int(v) for v in A_p]
     A_i = [int(v) for v in A_i]
     P_cols = [int(v) for v in P_cols]
@@ -231,6 +242,8 @@ def analyse_qp(n, m, A_p, A_i, P_cols, perm=None):
                   l_ksrc=l_ksrc, l_col=ent_col, ft_p=ft_p, ft_a=ft_a, ft_b=ft_b, ft_j=ft_j, fd_p=fd_p, fd_a=fd_a, fd_j=fd_j)
     # blob: [HEADER_WORDS header | tables]; header = sizes, nrows, then (table offset) x len(_TABLES), then row offsets
     hdr = [n, m, nk, nnzP, nnzA, nnzL, nrows, nlev]
+    if parts is not None:
+        tables["part"] = [int(v) for v in parts]
     body, offs = [], []
     pos = HEADER_WORDS
     for name in _TABLES:
@@ -255,6 +268,135 @@ def csc_pattern(dense_mask):
         A_i += [int(i) for i in np.nonzero(dense_mask[:, j])[0]]
         A_p.append(len(A_i))
     return A_p, A_i
+
+
+_PARTS_CACHE = {}
+
+
+def bisect_parts(n, m, A_p, A_i, min_size=64, max_sep=2, hold=None):
+    key = (n, m, tuple(A_p), tuple(A_i), min_size, max_sep, tuple(sorted((k, tuple(sorted(v))) for k, v in (hold or {}).items())))
+    if key not in _PARTS_CACHE:
+        _PARTS_CACHE[key] = _bisect_parts(n, m, A_p, A_i, min_size, max_sep, hold)
+    return list(_PARTS_CACHE[key])
+
+
+def _bisect_parts(n, m, A_p, A_i, min_size, max_sep, hold=None):
+    """For every KKT vertex (variables, then rows): 0 / 1 = half A / half B of its component, 2 = the separator, for the
+    components of >= min_size unknowns that a separator of <= max_sep vertices cuts into two balanced halves (all such
+    separators are tried; the one with the lightest heavier side wins); 0 everywhere else. An unknown that hangs off one
+    other unknown (a box row on its variable) travels with it, the ones of a separator vertex with half A."""
+    import itertools
+    nk = n + m
+    adj = [set() for _ in range(nk)]
+    for j in range(n):
+        for q in range(A_p[j], A_p[j + 1]):
+            adj[j].add(n + A_i[q])
+            adj[n + A_i[q]].add(j)
+    vc, rc = qp_components(n, m, A_p, A_i)
+    comp = list(vc) + list(rc)
+    part = [0] * nk
+    for c in range(max(comp) + 1):
+        V = [v for v in range(nk) if comp[v] == c]
+        core = [v for v in V if len(adj[v]) > 1]
+        wt = {v: 1 + sum(1 for u in adj[v] if len(adj[u]) == 1) for v in core}
+        if len(V) < min_size or len(core) < 4:
+            continue
+
+        def pieces(S):
+            seen, out = set(S), []
+            for v in core:
+                if v in seen:
+                    continue
+                st, piece = [v], []
+                seen.add(v)
+                while st:
+                    x = st.pop()
+                    piece.append(x)
+                    for u in adj[x]:
+                        if u in wt and u not in seen:
+                            seen.add(u)
+                            st.append(u)
+                out.append(piece)
+            return sorted(out, key=lambda pc: (-sum(wt[v] for v in pc), pc[0]))
+        cands = []
+        for size in range(1, max_sep + 1):
+            for S in itertools.combinations(core, size):
+                pcs = pieces(S)
+                if len(pcs) < 2:
+                    continue
+                bins, load = [[], []], [sum(wt[v] for v in S), 0]          # (the separator is half A's work)
+                for pc in pcs:
+                    b_ = 0 if load[0] <= load[1] else 1
+                    bins[b_].append(pc)
+                    load[b_] += sum(wt[v] for v in pc)
+                cands.append((max(load), size, S, bins))
+        if not cands:
+            continue
+        # among the (nearly) best balanced: the one whose half B reaches into the separator through the fewest entries of L
+        # (each is an exchange between the two wavefronts), then the least fill
+        lightest = min(c_[0] for c_ in cands)
+        best = None
+        loc = {v: q for q, v in enumerate(V)}
+        sub_c = [{loc[u] for u in adj[v]} for v in V]         # (the component alone, renumbered: min-fill is quadratic)
+        hold_c = {loc[v]: {loc[u] for u in us} for v, us in (hold or {}).items() if v in loc}
+        for (ld, size, S, bins) in cands:
+            if ld > lightest + 2:
+                continue
+            inB = {v for pc in bins[1] for v in pc}
+            order = [V[q] for q in symbolic.min_fill_ordering(sub_c, last=[loc[v] for v in S], hold=hold_c)]
+            g = {v: set(adj[v]) for v in V}
+            done, nnz, cross = set(), 0, 0
+            for v in order:
+                nb = [u for u in g[v] if u not in done]
+                nnz += len(nb)
+                if v in inB:
+                    cross += sum(1 for u in nb if u in S)
+                for a_ in nb:
+                    g[a_].update(x for x in nb if x != a_)
+                done.add(v)
+            key = (cross, nnz, ld, size, S)
+            if best is None or key < best[0]:
+                best = (key, S, bins)
+        if best is None:
+            continue
+        _, S, bins = best
+        for b_, bin_ in enumerate(bins):
+            for pc in bin_:
+                for v in pc:
+                    part[v] = b_
+                    for u in adj[v]:
+                        if len(adj[u]) == 1:
+                            part[u] = b_
+        for v in S:
+            part[v] = 2
+    return part
+
+
+def bisect_ordering(n, m, A_p, A_i, min_size=64, max_sep=2, parts=None, hold=None):
+    """Elimination ordering for a QP whose large components are CHAINS (an MPC horizon): min-fill walks a chain from one end
+    to the other -- an elimination tree that is one long spine, nothing for two wavefronts to share. Here every large
+    component is cut in two by a small vertex separator S (bisect_parts), both halves are ordered by min-fill with S held
+    back, and the result is laid out half A, half B, S: the fill of a chain eliminated from both ends, an elimination tree of
+    two subtrees under S. (asmqp.LoopSplit gives the subtrees to two wavefronts; they meet twice per solve.)
+    hold: symbolic.min_fill_ordering's numerical tie-break.
+    Returns perm (position -> KKT index: variables, then rows)."""
+    nk = n + m
+    adj = [set() for _ in range(nk)]
+    for j in range(n):
+        for q in range(A_p[j], A_p[j + 1]):
+            adj[j].add(n + A_i[q])
+            adj[n + A_i[q]].add(j)
+    vc, rc = qp_components(n, m, A_p, A_i)
+    comp = list(vc) + list(rc)
+    part = bisect_parts(n, m, A_p, A_i, min_size, max_sep, hold) if parts is None else list(parts)
+    perm = []
+    for c in range(max(comp) + 1):
+        S = [v for v in range(nk) if comp[v] == c and part[v] == 2]
+        sub = [v for v in symbolic.min_fill_ordering([adj[v] if comp[v] == c else set() for v in range(nk)], last=S, hold=hold)
+               if comp[v] == c]
+        perm += sorted(sub, key=lambda v: part[v])             # (stable: min-fill order inside each part)
+    assert sorted(perm) == list(range(nk))
+    return perm
 
 
 def qp_components(n, m, A_p, A_i):

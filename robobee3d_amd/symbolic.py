@@ -98,22 +98,29 @@ def kkt_graph(N, A_p, A_i):
     return adj
 
 
-def min_fill_ordering(adj0):
-    """Greedy minimum-fill elimination ordering, ties -> (degree, index)."""
+def min_fill_ordering(adj0, last=(), hold=None):
+    """Greedy minimum-fill elimination ordering, ties -> (held back, degree, index). last: vertices that are eliminated only
+    after every other one (a separator held back: qpstruct.bisect_ordering). hold: {vertex: set of vertices} -- among
+    candidates of EQUAL fill, a vertex is passed over while none of hold[vertex] has been eliminated (a numerical hint, no
+    effect on the fill: a variable without a cost term eliminated before any constraint row that carries it with a unit
+    coefficient gets the pivot sigma -- 1e-6 -- and multipliers of 5e5; batchqp.p5f_analysis)."""
     n = len(adj0)
     adj = [set(s) for s in adj0]
     alive = set(range(n))
+    last = set(last)
+    hold = hold or {}
     perm = []
     while alive:
         best, bkey = None, None
-        for v in sorted(alive):
+        for v in sorted(alive - last or alive):
             nb = [u for u in adj[v] if u in alive]
             fill = 0
             for a_i, a in enumerate(nb):
                 for b in nb[a_i + 1:]:
                     if b not in adj[a]:
                         fill += 1
-            key = (fill, len(nb), v)
+            held = 1 if (hold.get(v) and all(u in alive for u in hold[v])) else 0
+            key = (fill, held, len(nb), v)
             if bkey is None or key < bkey:
                 best, bkey = v, key
         nb = [u for u in adj[best] if u in alive]

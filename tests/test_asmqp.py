@@ -602,7 +602,9 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
     res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
     one, _ = asmqp.program(s, eq, res, loose=True)
     grp, pg, sp = asmqp.loop_group_program(s, eq, res, 4)
-    assert sp.active == 4 and sp.load == [118, 112, 12, 9]          # KKT unknowns per wavefront: two chains, small pieces
+    # KKT unknowns per wavefront: the two horizon chains (118 and 112 unknowns) are each cut in two halves under a two-vertex
+    # separator (qpstruct.bisect_ordering / LoopSplit), the small pieces fill up the lighter wavefronts
+    assert sp.active == 4 and sp.load == [64, 63, 62, 62] and sorted(len(c["T"]) for c in sp.cut.values()) == [1, 2]
     f = lambda a: a.astype(np.float32).astype(np.float64)
     gen = [i for i in range(p.m) if i not in set(eq)]
     rng = np.random.default_rng(3)
@@ -638,9 +640,12 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
                           sgpr={asmqp.S_FAST: 1}, count=n1)
     lds4, counts, nbar = asmqp.simulate_group(grp, 4, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, asmqp.S_LWAVE,
                                               regions=regs(), sgpr={asmqp.S_FAST: 1})
-    assert nbar == 4
+    # barriers: after the factorisation + the 1/D hand-over of the cut components, two per solve (iters + 1 bodies), two in the
+    # capturing iteration, one at the end
+    assert nbar == 5 + 2 * (iters + 1), nbar
     assert np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
-    assert max(counts) < 0.6 * n1[0] and counts[2] < 0.2 * n1[0] and counts[3] < 0.2 * n1[0], (counts, n1)
+    # (the factorisation of a cut component stays with one wavefront: 41 % of the one-wave block with no middle iteration, less with more)
+    assert max(counts) < 0.42 * n1[0], (counts, n1)
 
 
 @pytest.mark.parametrize("iters", [0, 2])
@@ -676,5 +681,30 @@ def test_general_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog,
                           sgpr={asmqp.S_FAST: 1}, count=n1)
     lds4, counts, nbar = asmqp.simulate_group(grp, 4, np.full(p.R_END, np.nan, np.float32), S.copy(), iters, consts, asmqp.S_LWAVE,
                                               regions=regs(), sgpr={asmqp.S_FAST: 1})
-    assert nbar == 4 and np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
-    assert max(counts) < 0.6 * n1[0], (counts, n1)
+    assert nbar == 5 + 2 * (iters + 1) and np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
+    assert max(counts) < 0.45 * n1[0], (counts, n1)
+
+
+def test_no_wide_store_data_hazard_in_any_p5f_block(prog):
+    """A store of more than 64 bits (ds_write_b128) reads its data registers over several cycles: a VALU instruction that
+    overwrites one of them within two wait states races with it on gfx940 and later, and nothing inserts the nops for inline
+    assembly (asmgen.Emit does, at emission). Round 5 found one such pair in the cut loop block -- the interpreter cannot see
+    it, the GPU can."""
+    from robobee3d_amd import asmgen, codegen_qp
+    asmqp, _, p = prog
+    s = p.s
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
+    rp = asmqp.RuizPlan(s)
+    blocks = [asmqp.loop_group_program(s, eq, res, 4)[0], asmqp.loop_group_program(s, eq, res, 4, loose=False)[0],
+              asmqp.program(s, eq, res, loose=True)[0], asmqp.ruiz_group_program(s, res, 4)[0],
+              asmqp.res_group_program(s, eq, p, res, 4)[0], asmqp.glue_group_program(s, eq, p, res, rp, 4)]
+    for ins in blocks:
+        assert len(ins) > 100 and asmgen.wide_store_hazards(ins) == []
+    # the checker sees a planted one, and the emitter repairs it
+    bad = [("ds_write_b128", "v1", "v[8:11]", 0), ("v_mov_b32", "v9", 0)]
+    assert asmgen.wide_store_hazards(bad) == [(0, 1)]
+    e = asmgen.Emit()
+    for t in bad:
+        e(*t)
+    assert e.ins == [bad[0], ("s_nop", 1), bad[1]] and asmgen.wide_store_hazards(e.ins) == []

@@ -192,6 +192,47 @@ def test_table_oracle_converges_on_v1_and_p5f():
         assert np.all(Ax >= g["l"][kk] - 1e-5) and np.all(Ax <= g["u"][kk] + 1e-5)
 
 
+def test_p5f_elimination_order_keeps_fp32_accurate_and_cuts_the_chains():
+    """The order PlanarP5fMPC and the build-time specialisation eliminate in (batchqp.p5f_analysis: each horizon chain cut in two
+    halves under a small separator, min-fill inside, variables without a cost term held back behind a unit-coefficient
+    dynamics row): (1) no more fill than plain min-fill, (2) an elimination tree of two balanced subtrees per chain, (3) fp32
+    stays fp32 -- the float32 table oracle within 5e-6 of the float64 one on the reference's own linearisations
+    (planar_p5f.npz: getLin at 64 random states), after 3 and after 50 iterations. Without the hold-back the same check reads
+    7.6e-2 (five digits lost to pivots of 2e-6: the GPU caught it, the interpreter's random data cannot)."""
+    import osqp_table
+    from robobee3d_amd import batchqp, qpstruct, symbolic
+    g = golden("planar_p5f.npz")
+    st, s = batchqp.p5f_analysis(10)
+    n, m = st["n"], st["m"]
+    plain = qpstruct.analyse_qp(n, m, st["A_p"], st["A_i"], st["P_cols"])
+    assert s.nnzL == 264 <= plain.nnzL
+    from robobee3d_amd import asmqp, codegen_qp
+    sp = asmqp.LoopSplit(asmqp.Plan(s, codegen_qp.ASM_STRUCTURES["p5f10"]), 4)
+    assert sorted(sp.cut) == [0, 1] and max(sp.load) <= 64 and min(sp.load) >= 61          # (118 + 112 + 12 + 9 unknowns before)
+    for cut in sp.cut.values():
+        assert len(cut["T"]) <= 2 and min(len(cut["A"]), len(cut["B"])) >= 54
+    assert sum(len(sp.own(w).cross) for w in range(4)) <= 6          # entries of L that reach from a half B into a separator
+    col = lambda v: np.asarray(v, np.float64)[:, None]
+    z = lambda r: np.zeros((r, 1))
+    cst, src = np.asarray(st["cst"], float), np.asarray(st["src"])
+
+    def worst(perm, samples):
+        w = 0.0
+        for k in samples:
+            lin = np.array([g["lin_Ad"][k][4, 3], g["lin_Ad"][k][5, 3], g["lin_Bd"][k][4], g["lin_Bd"][k][5], g["lin_Bd"][k][6]])
+            Av = np.where(src >= 0, cst * lin[np.maximum(src, 0)], cst)[:, None]
+            for iters in (3, 50):
+                out = [osqp_table.solve(n, m, st["A_p"], st["A_i"], st["P_cols"], perm, col(st["Pv"]), Av, col(st["q"]), col(st["l"]),
+                                        col(st["u"]), z(n), z(m), z(m), np.ones((m, 1)), osqp_table.Settings(max_iter=iters), dtype=dt)
+                       for dt in (np.float64, np.float32)]
+                d = np.abs(out[1]["x"].astype(np.float64) - out[0]["x"]) / np.maximum(1.0, np.abs(out[0]["x"]))
+                w = max(w, float(d.max()))
+        return w
+    assert worst(s.perm, range(0, 64, 5)) <= 5e-6
+    unheld = qpstruct.bisect_ordering(n, m, st["A_p"], st["A_i"], parts=st["parts"])
+    assert worst(unheld, [17]) >= 1e-2
+
+
 def _tiny_infeasible_qps():
     """(name, n, m, A_p, A_i, P_cols, Pv, Av, q, l, u, expected status): primal infeasible -- x0 >= 1 and x0 <= 0;
     dual infeasible -- min -x1 with x1 >= 0 only and no curvature in x1 (auxil.c:362-512)."""
@@ -569,6 +610,7 @@ def test_gpu_p5f_full_size_properties():
     from robobee3d_amd.batchqp import PlanarP5fMPC
     B = 16384
     mpc = PlanarP5fMPC(B, torch.float32)
+    assert mpc.qp.kernel_name == "p5f10+asm"          # (the build-time specialisation is found by the hash of the structure's tables)
     rng = np.random.default_rng(20201119)
     pert = rng.uniform(-0.1, 0.1, (2, B // 2)).astype(np.float32)
     pert = np.concatenate((pert, pert[:, ::-1]), 1)                  # robot b and robot B-1-b are twins
