@@ -308,6 +308,7 @@ class Own:
 ALL = Own()
 L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
 TREE_SPLIT = os.environ.get("UMPC_QP_TREE_SPLIT", "1") == "1"  # (A/B switch: LoopSplit cuts large components in two)
+SCALE_LATE = os.environ.get("UMPC_QP_SCALE_LATE", "1") == "1"  # (A/B switch: where a cut component's W / D sits between the barriers)
 N_XCH = 16                                                      # LDS words LW_XCH.. below the flags: the halves' exchange words
 LW_XCH = LW_FLAGS - N_XCH
 
@@ -928,8 +929,14 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 op([lsrc_(j)], lambda g, r_=r_, c=c: e("v_fmac_f32", W(r_), v(g[0]), W(c)))
         for c, word in sorted(own.xsend_f.items()):
             op([], lambda g, c=c, word=word: sc.lds_write(word, p.wreg[c]))       # (the forward value: before the scaling below)
-        scale(lambda k: k not in top)
+        # W / D of the subtree: a wave that only waits between the two barriers (half B, a whole small component) does it there;
+        # the wave with the separator after the second barrier, while its partner's read of the separator's solution is in flight
+        late = bool(top) and SCALE_LATE
+        if not SCALE_LATE:
+            scale(lambda k: k not in top)
         meet()
+        if SCALE_LATE and not late:
+            scale(lambda k: True)
         for (r_, c, j) in own.cross:
             op([lsrc_(j), ("L", own.xrecv_f[c])], lambda g, r_=r_: e("v_fmac_f32", W(r_), v(g[0]), v(g[1])))
         for (r_, c, j) in p.solve_entries:
@@ -942,6 +949,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
         for r_, word in sorted(own.xsend_b.items()):
             op([], lambda g, r_=r_, word=word: sc.lds_write(word, p.wreg[r_]))
         meet()
+        if late:
+            scale(lambda k: k not in top)
         for (r_, c, j) in reversed(p.solve_entries):
             if own.k(c) and c not in top:
                 if own.k(r_):
