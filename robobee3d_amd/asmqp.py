@@ -271,6 +271,7 @@ class Own:
         self.varw, self.roww, self.kw, self.wave = varw, roww, kw, wave
         self.all = varw is None
         self.lhome = lhome or {}          # L entry (CSC index) -> VGPR that holds -L during the iterations (LoopSplit.own)
+        self.chome, self.yhome = {}, {}   # LDS word of a loop constant -> VGPR: leaf entries of L (every variant); q, l (y0 bodies)
         self.fkw = fkw if fkw is not None else kw          # who FACTORISES unknown k (a component cut in two: the wave of half A)
         self.fvarw = fvarw if fvarw is not None else varw
         # a component cut in two (LoopSplit): the solves of every wave of the workgroup meet at two barriers
@@ -307,6 +308,7 @@ class Own:
 
 ALL = Own()
 L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
+C_HOMES = os.environ.get("UMPC_QP_C_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the loop's other constants in VGPRs)
 TREE_SPLIT = os.environ.get("UMPC_QP_TREE_SPLIT", "1") == "1"  # (A/B switch: LoopSplit cuts large components in two)
 SCALE_LATE = os.environ.get("UMPC_QP_SCALE_LATE", "1") == "1"  # (A/B switch: where a cut component's W / D sits between the barriers)
 N_XCH = 16                                                      # LDS words LW_XCH.. below the flags: the halves' exchange words
@@ -505,7 +507,38 @@ class LoopSplit:
         cross = set(self.split[wave]["cross"]) if self.split else set()
         mine = [j for (r_, c, j) in p.solve_entries if self.kw[c] == wave or (r_, c, j) in cross]
         lhome = dict(zip(mine, pool)) if L_HOMES else {}
-        return Own(self.varw, self.roww, self.kw, wave, lhome, self.fkw, self.split[wave] if self.split else None, self.fvarw)
+        o = Own(self.varw, self.roww, self.kw, wave, lhome, self.fkw, self.split[wave] if self.split else None, self.fvarw)
+        if C_HOMES and L_HOMES:
+            # ... and what is left of them the wave's other loop constants, which the bodies read from LDS every iteration (with all
+            # four wavefronts at work the LDS pipe is the second bottleneck: 1 KB per instruction, 128 B per clock): the leaf rows'
+            # entries of L, then (y0 bodies) q and l of the equality rows. A pair of words that the packed operations read as a
+            # pair gets an aligned register pair.
+            free = [r_ for r_ in pool if r_ not in set(lhome.values())]
+            lw = [p.lpos[r["j"]] for r in p.rows if r["leaf"] and self.roww[r["i"]] == wave]
+            qw = [h for (what, j), h in sorted(p.y0_home.items(), key=lambda kv: kv[1] if isinstance(kv[1], int) else -1)
+                  if what == "q" and isinstance(h, int) and self.varw[j] == wave]
+            ew = [h for (what, i), h in sorted(p.y0_home.items(), key=lambda kv: kv[1] if isinstance(kv[1], int) else -1)
+                  if what == "l" and isinstance(h, int) and self.roww[i] == wave]
+            for words, dst in ((lw, o.chome), (qw, o.yhome), (ew, o.yhome)):
+                ws = set(words)
+                for w_ in sorted(ws):
+                    if w_ in dst:
+                        continue
+                    if w_ % 2 == 0 and w_ + 1 in ws:
+                        base = next((r_ for r_ in free if r_ % 2 == 0 and r_ + 1 in free), None)
+                        if base is None:
+                            continue              # (no aligned pair left: these two stay in LDS)
+                        free.remove(base)
+                        free.remove(base + 1)
+                        dst[w_], dst[w_ + 1] = base, base + 1
+                    elif not (w_ % 2 == 1 and w_ - 1 in ws):
+                        odd = [r_ for r_ in free if not (r_ % 2 == 0 and r_ + 1 in free) and not (r_ % 2 == 1 and r_ - 1 in free)]
+                        if not (odd or free):
+                            continue
+                        r_ = (odd or free)[0]     # (singles first into registers that cannot form an aligned pair)
+                        free.remove(r_)
+                        dst[w_] = r_
+        return o
 
 
 class Sched:
@@ -731,6 +764,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     T = lambda q: p.V_TT + q
     assert loose or not y0
     homes = p.y0_home if y0 else {}
+    # a loop constant: its VGPR home if this wave keeps one (Own.chome: leaf entries of L; Own.yhome, y0 bodies: q, l), else its LDS word
+    C = lambda word: ("V", own.chome[word]) if word in own.chome else ("V", own.yhome[word]) if (y0 and word in own.yhome) else ("L", word)
     pre_items = [it for it in p.stream[p.n_land:] if it not in homes and own.item(it)]
     npre = len(pre_items)
     own_land = None if own.all else [q for q, it in enumerate(p.stream[:p.n_land]) if own.item(it)]
@@ -764,11 +799,11 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             continue
         if qh is not None and "1" in PACK_PARTS and xpair(j) and qh % 2 == 0 and homes.get(("q", j + 1)) == qh + 1:
             jskip.add(j + 1)
-            op([("L", p.LW_X + j), ("L", qh)], lambda r, j=j: _pk(e, "v_pk_fma_f32", p.wreg[p.pinv[j]],
+            op([("L", p.LW_X + j), C(qh)], lambda r, j=j: _pk(e, "v_pk_fma_f32", p.wreg[p.pinv[j]],
                                                                   [SB(S_SIGMA, S_SIGMA % 2), VP(r[0]), VP(r[1])], [0, 0, 1]))
             continue
         if qh is not None:
-            op([("L", p.LW_X + j), ("L", qh)], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
+            op([("L", p.LW_X + j), C(qh)], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
             continue
         if "1" in PACK_PARTS and xpair(j) and ("q", j + 1) not in homes:
             jskip.add(j + 1)
@@ -830,16 +865,16 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 wr = p.wreg[r["r"]]
                 _pk(e, "v_pk_fma_f32", wr, [VP(g[2]), VP(t), VP(wr)])                           # W(x_j) += (-L) rhs
             if y0:       # y == 0: the rhs is z
-                op([("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])],
+                op([("L", p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])],
                    lambda g, r=r: _pk(e, "v_pk_fma_f32", p.wreg[r["r"]], [VP(g[1]), VP(g[0]), VP(p.wreg[r["r"]])]))
                 continue
-            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])], f2)
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])], f2)
             continue
         if pack and "4" in PACK_PARTS and i in eqskip:
             continue
         lh = homes.get(("l", i))
         lh1 = homes.get(("l", i + 1))
-        lsrc = lambda h: h if isinstance(h, tuple) else ("L", h)
+        lsrc = lambda h: h if isinstance(h, tuple) else C(h)
         if pack and "4" in PACK_PARTS and i in eqfirst and isinstance(lh, tuple) and isinstance(lh1, tuple):
             eqskip.add(i + 1)           # both bounds in AGPR homes: read as a pair
             op([("L", p.LW_Y + i), ("A2", lh[1], lh1[1])], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
@@ -855,7 +890,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 wait_pre(wr + 1)
                 _pk(e, "v_pk_fma_f32", wr, [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(wr)], [1, 0, 0])
             if lh is not None:       # l from its LDS home
-                op([("L", p.LW_Y + i), ("L", lh)], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
+                op([("L", p.LW_Y + i), C(lh)], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
                                                                        [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0]))
             else:
                 op([("L", p.LW_Y + i)], f2e)
@@ -869,25 +904,25 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             else:
                 op([("L", p.LW_Y + i)], f)
         elif r["eq"]:
-            op([("L", p.LW_Y + i), ("L", p.lpos[r["j"]]), src_of(("l", i))],
+            op([("L", p.LW_Y + i), C(p.lpos[r["j"]]), src_of(("l", i))],
                lambda g, r=r, i=i: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
                                     e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0)))))
         elif y0 and not r["leaf"]:
             op([("L", p.LW_Z + p.zpos[i])], lambda g, k=k: e("v_mov_b32", W(k), v(g[0])))
         elif y0:
-            op([("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])], lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0])))
+            op([("L", p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])], lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0])))
         elif loose and not r["leaf"]:
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i])],
                lambda g, k=k: e("v_fma_f32", W(k), "-s%d" % S_RIMIN, v(g[0]), v(g[1])))
         elif loose:
-            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), ("L", p.lpos[r["j"]])],
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])],
                lambda g, r=r: (e("v_fma_f32", v(T(0)), "-s%d" % S_RIMIN, v(g[0]), v(g[1])),
                                e("v_fmac_f32", W(r["r"]), v(g[2]), v(T(0)))))
         elif not r["leaf"]:
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), src_of(("rinv", i))],
                lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[2]), v(g[0]), v(g[1])))
         else:
-            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), src_of(("rinv", i)), ("L", p.lpos[r["j"]])],
+            op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), src_of(("rinv", i)), C(p.lpos[r["j"]])],
                lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[2]), v(g[0]), v(g[1])),
                                e("v_fmac_f32", W(r["r"]), v(g[3]), v(T(0)))))
     if not rhs:                  # (the definitions above are needed below; the operations are not)
@@ -1055,7 +1090,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 _pk(e, "v_pk_fma_f32", wr, [L_, VP(a_), VP(wr)])                 # ... + (-L) z_new  (y == 0)
                 if zw not in fzc1:
                     npk[0] += 1
-            rop(B_PAIR, [("L", zw), ("L", p.lpos[r["j"]]), ("L", p.LW_X + j), ("L", homes[("q", j)])], ffused)
+            rop(B_PAIR, [("L", zw), C(p.lpos[r["j"]]), ("L", p.LW_X + j), C(homes[("q", j)])], ffused)
             continue
         if i in paired:
             if paired[i] is None:
@@ -1105,12 +1140,12 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 if zw not in zc1:
                     npk[0] += 1
             if y0:
-                rop(B_OTHER, [("L", zw), ("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
+                rop(B_OTHER, [("L", zw), C(p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
                 if fuse:          # the pair's pushes into the next rhs: after the x updates
-                    B_PUSH.append(dict(srcs=[("L", zw), ("L", p.lpos[r["j"]])],
+                    B_PUSH.append(dict(srcs=[("L", zw), C(p.lpos[r["j"]])],
                                        emit=lambda g, r=r: _pk(e, "v_pk_fma_f32", p.wreg[r["r"]], [VP(g[1]), VP(g[0]), VP(p.wreg[r["r"]])])))
             else:
-                op([("L", yw), ("L", zw), ("L", p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
+                op([("L", yw), ("L", zw), C(p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
             continue
         if r["eq"]:
             if r["leaf"]:
@@ -1122,9 +1157,9 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                     store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
                     e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
                     sc.lds_write(yw, T(1))
-                rop(B_EQ, [("L", yw), ("L", p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
+                rop(B_EQ, [("L", yw), C(p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
                 if fuse:          # its push into the next rhs (the classic operation), after the x updates
-                    B_PUSH.append(dict(srcs=[("L", yw), ("L", p.lpos[r["j"]]), src_of(("l", i))],
+                    B_PUSH.append(dict(srcs=[("L", yw), C(p.lpos[r["j"]]), src_of(("l", i))],
                                        emit=lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
                                                             e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0))))))
             elif pack and "4" in PACK_PARTS and i in eqskip2:
@@ -1147,7 +1182,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                         npk[0] += 1
                 lh_, lh1_ = homes.get(("l", i)), homes.get(("l", i + 1))
                 if fuse:
-                    lsrc2 = ("A2", lh_[1], lh1_[1]) if isinstance(lh_, tuple) and isinstance(lh1_, tuple) else ("L", lh_)
+                    lsrc2 = ("A2", lh_[1], lh1_[1]) if isinstance(lh_, tuple) and isinstance(lh1_, tuple) else C(lh_)
                     assert isinstance(lh_, tuple) == isinstance(lh1_, tuple) and (isinstance(lh_, tuple) or (lh_ % 2 == 0 and lh1_ == lh_ + 1))
                     rop(B_EQ, [("L", yw), lsrc2], f2u)
                 else:
@@ -1162,7 +1197,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                         e("v_fma_f32", W(k), "-" + v(T(1)), sRe, v(g[1]))
                 if fuse:
                     lh_ = homes[("l", i)]
-                    rop(B_EQ, [("L", yw), lh_ if isinstance(lh_, tuple) else ("L", lh_)], f)
+                    rop(B_EQ, [("L", yw), lh_ if isinstance(lh_, tuple) else C(lh_)], f)
                 else:
                     op([("L", yw)], f)
             continue
@@ -1185,9 +1220,9 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 sc.lds_write(zw, T(3))
                 if fuse and not r["leaf"]:
                     e("v_mov_b32", W(k), tt)                                  # next rhs of the row: z_new (y == 0)
-            rop(B_OTHER, [("L", zw)] + ([("L", p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A", k)]) if r["leaf"] else []), f0)
+            rop(B_OTHER, [("L", zw)] + ([C(p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A", k)]) if r["leaf"] else []), f0)
             if fuse and r["leaf"]:
-                B_PUSH.append(dict(srcs=[("L", zw), ("L", p.lpos[r["j"]])],
+                B_PUSH.append(dict(srcs=[("L", zw), C(p.lpos[r["j"]])],
                                    emit=lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0]))))
             continue
         if loose:
@@ -1199,7 +1234,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 srcs.append(src_of(("rho", i)))
                 nfix = 6
         if r["leaf"]:
-            srcs += [("L", p.lpos[r["j"]]), ("A", k)]
+            srcs += [C(p.lpos[r["j"]]), ("A", k)]
 
         def f(g, r=r, k=k, yw=yw, zw=zw, nfix=nfix):
             if loose:
@@ -1276,7 +1311,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             if fuse and not (isinstance(qh_, int) and qh_ % 2 == 0 and homes.get(("q", j + 1)) == qh_ + 1):
                 jskip.discard(j + 1)          # (no aligned q pair: the two variables go one at a time below)
             else:
-                op([("L", p.LW_X + j)] + ([("L", qh_)] if fuse else []), fx2)
+                op([("L", p.LW_X + j)] + ([C(qh_)] if fuse else []), fx2)
                 continue
 
         def f(g, k=k, j=j):
@@ -1289,7 +1324,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             if fuse:
                 e("v_fma_f32", W(k), sS, v(t), "-" + v(g[1]))
         qh_ = homes.get(("q", j))
-        op([("L", p.LW_X + j)] + ([qh_ if isinstance(qh_, tuple) else ("L", qh_)] if fuse else []), f)
+        op([("L", p.LW_X + j)] + ([qh_ if isinstance(qh_, tuple) else C(qh_)] if fuse else []), f)
     if fuse:
         ops.append(dict(flush=True))          # the pushes read words this body has written
         ops.extend(B_PUSH)
@@ -1545,12 +1580,16 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     prologue_tail(e, p, loose, own=own)
 
 
-def l_homes_fill(e, p, own):
-    """-L of the wave's solve entries: LDS (where the factorisation left them) -> their VGPR homes, once per block"""
-    if not own.lhome:
-        return
-    quads = sorted(set(p.lpos[j] >> 2 for j in own.lhome))
+def l_homes_fill(e, p, own, y0=False):
+    """-L of the wave's solve entries (and its other resident constants: Own.chome; y0 path: Own.yhome): LDS -> their VGPR homes,
+    once per block"""
     byword = {p.lpos[j]: reg for j, reg in own.lhome.items()}
+    byword.update(own.chome)
+    if y0:
+        byword.update(own.yhome)
+    if not byword:
+        return
+    quads = sorted(set(w_ >> 2 for w_ in byword))
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")         # (the preloads into W registers have landed: the ring registers are free)
     for g in range(0, len(quads), NRING):
         grp = quads[g:g + NRING]
@@ -1608,7 +1647,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
                 e("v_readfirstlane_b32", "s%d" % S_DLEAF, "v%d" % v_or)
             y0_fill(e, p, own)
             prologue_tail(e, p, True, p.y0_home, own)
-            l_homes_fill(e, p, own)
+            l_homes_fill(e, p, own, y0=True)
             _lstamp(e, own, 5)
             if not Y0_FUSE:
                 loop(y0=True)
