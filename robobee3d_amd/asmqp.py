@@ -1,5 +1,5 @@
 """Generated gfx950 assembly for the MIDDLE ADMM iterations of a build-time-known, chain-structured batch QP (BASELINE
-config 4: planar p5f, n = 87, m = 164, nnz(L) = 264), fp32, one lane per robot, ONE wave per CU (B <= 16 384).
+config 4: planar p5f, n = 87, m = 164, nnz(L) = 264), fp32, one lane per robot, one workgroup per CU (B <= 16 384).
 
 Why: the straight-line C++ specialisation (codegen_qp.py) keeps ~3 000 words per robot in compiler-managed storage; a
 lone wave per CU walks them as a chain of exposed scratch round trips -- 0.21 ms per iteration, 10.5 of the 12.4 ms tick
@@ -32,9 +32,17 @@ solve(); the iteration is the build's).
 
 Round 4: the kernel's workgroup is FOUR wavefronts (one per SIMD of the CU) that own the same 64 robots and LDS slots and
 divide every block's instructions -- RuizSplit / ruiz_group_program (stretches of columns), glue_group_program (rows),
-LoopSplit / loop_group_program and res_group_program (the QP's connected components: independent QPs, no barrier inside the
-loop). Same layouts, every word bit-identical to the one-wavefront blocks; simulate_group() runs the wavefronts barrier phase
-by barrier phase on one LDS image and rejects a word written by one and touched by another between two barriers."""
+LoopSplit / loop_group_program (the QP's connected components: independent QPs) and res_group_program (quarters of the rows
+and columns). Same layouts, every word bit-identical to the one-wavefront blocks; simulate_group() runs the wavefronts barrier
+phase by barrier phase on one LDS image and rejects a word written by one and touched by another between two barriers.
+
+Round 5: two of the four wavefronts were nearly idle in the loop (the QP is two long chains and five crumbs). A chain is now CUT
+IN TWO (LoopSplit; the elimination order comes bisected from qpstruct.bisect_ordering): each half's subtree of the elimination
+tree is one wavefront's, the separator (one or two unknowns) goes with half A, the solves meet at two barriers per iteration.
+The W registers a wavefront no longer needs hold its entries of L and its other loop constants (Own.lhome / chome / yhome): with
+four wavefronts at work the CU's one LDS pipe is the second bottleneck. Still bit-identical to the one-wavefront block. And
+asmgen.Emit keeps the one hazard nobody checks for inline assembly out of every stream (a VALU write to the data registers of a
+ds_write_b128 within two wait states)."""
 import os
 import struct
 
@@ -285,6 +293,7 @@ class Own:
         self.xrecv_b = sp.get("xrecv_b", {})     # separator unknown r (the partner's) -> LDS word
         self.hand_out = sp.get("hand_out", {})   # unknown k this wave factorises for its partner -> LDS word 1/D_k is handed over in
         self.hand_in = sp.get("hand_in", {})     # unknown k of this wave that the partner factorises -> that word
+        self.ftop = sp.get("ftop", set())        # separator unknowns this wave factorises AFTER its partner's subtree (FACTOR_SPLIT)
 
     def var(self, j):
         return self.all or self.varw[j] == self.wave
@@ -308,6 +317,7 @@ class Own:
 
 ALL = Own()
 L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
+FACTOR_SPLIT = os.environ.get("UMPC_QP_FACTOR_SPLIT", "1") == "1"   # (A/B switch: a cut component's halves factorise their own subtrees)
 C_HOMES = os.environ.get("UMPC_QP_C_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the loop's other constants in VGPRs)
 TREE_SPLIT = os.environ.get("UMPC_QP_TREE_SPLIT", "1") == "1"  # (A/B switch: LoopSplit cuts large components in two)
 SCALE_LATE = os.environ.get("UMPC_QP_SCALE_LATE", "1") == "1"  # (A/B switch: where a cut component's W / D sits between the barriers)
@@ -373,7 +383,7 @@ class LoopSplit:
             c = comp[k]
             if c in self.cut:
                 self.kw[k] = uw[(c, "B")] if k in self.cut[c]["B"] else uw[(c, "A")]
-                self.fkw[k] = uw[(c, "A")]
+                self.fkw[k] = self.kw[k] if FACTOR_SPLIT else uw[(c, "A")]
             else:
                 self.kw[k] = self.fkw[k] = uw[(c, None)]
         self.varw = [self.kw[p.pinv[j]] for j in range(s.n)]
@@ -385,7 +395,9 @@ class LoopSplit:
         self.split = [dict(top=set(), cross=[], xrecv_f={}, xsend_f={}, xsend_b={}, xrecv_b={}, hand_out={}, hand_in={})
                       for _ in range(nact)] if self.cut else None
         self.fvarw = [self.fkw[p.pinv[j]] for j in range(s.n)]
-        # 1/D of half B's unknowns: from the factorising wave's AGPRs to B's through LDS words that held the component's A entries
+        # 1/D that changes hands once per tick. One wave factorises the whole of a cut component (FACTOR_SPLIT off): 1/D of half B's
+        # unknowns goes from its AGPRs to B's through LDS words that held the component's A entries. The halves factorise their own
+        # subtrees (default): only 1/D of B's columns that reach into the separator goes to A, through the exchange words.
         A_p_ = list(s.tables["A_p"])
         for a_ in range(nact if self.cut else 0):
             words = [p.LW_X + q for j in range(s.n) if self.fvarw[j] == a_ for q in range(A_p_[j], A_p_[j + 1])]
@@ -408,6 +420,10 @@ class LoopSplit:
                 self.split[a_]["xrecv_f"][c_] = self.split[b_]["xsend_f"][c_] = quad + q
             for q, r_ in enumerate(tops):
                 self.split[a_]["xsend_b"][r_] = self.split[b_]["xrecv_b"][r_] = quad + 4 + q
+            if FACTOR_SPLIT:
+                for q, c_ in enumerate(cols):       # (the forward words of the solves, idle during the factorisation)
+                    self.split[b_]["hand_out"][c_] = self.split[a_]["hand_in"][c_] = quad + q
+                self.split[a_]["ftop"] = self.split[a_].get("ftop", set()) | T
             quad += 8
         for (r_, c_, j) in p.solve_entries:
             assert self.kw[r_] == self.kw[c_] or any((r_, c_, j) in sp_["cross"] for sp_ in self.split or [])
@@ -1521,7 +1537,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
     factor_emit(e, s, p, p.LW_X, v_p, v_rinv, dict(p.zpos), S_SIGMA, S_RINVEQ, list(range(pool0, p.V_RING - 12)),
                 list(range(p.V_LAND, p.V_LAND + p.NLAND)) + list(range(p.V_RING - 12, p.V_RING)), v_fmin, own)
     _lstamp(e, own, 2)
-    for q, (k, word) in enumerate(sorted(own.hand_out.items())):       # a cut component: 1/D of the partner's half -> LDS
+    for q, (k, word) in enumerate(sorted(own.hand_out.items()) if not FACTOR_SPLIT else []):   # a cut component: 1/D of the partner's half -> LDS
         t = p.V_TT + q % 4                 # (V_TT + N_TT - 1 is the pivot accumulator)
         e("v_accvgpr_read_b32", "v%d" % t, "a%d" % k)
         base, off = lds_addr(word)
@@ -1536,7 +1552,7 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_barrier")
         e("ds_min_f32", base, "v%d" % v_fmin, off)
-        if own.xbar:
+        if own.xbar and not FACTOR_SPLIT:
             # ... and the other half takes its 1/D from there into its own AGPRs; nobody's warm start overwrites the words before
             hin = sorted(own.hand_in.items())
             assert len(hin) <= G
@@ -3115,8 +3131,31 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
 
     def op(srcs, fn):
         ops.append(dict(srcs=srcs, emit=fn))
+    split = own.xbar and FACTOR_SPLIT
+    met = [not split]
+
+    def meet():
+        """a cut component whose halves factorise their own subtrees: before the separator's rows the waves meet once -- half B
+        has left 1/D of its columns that reach into the separator in LDS, and its entries of L that the separator's rows
+        multiply again are where every entry of L goes"""
+        for k_, word in sorted(own.hand_out.items()):
+            def fo(g, k_=k_, word=word):
+                sc.lds_write(word, g[0])
+            op([("A", k_)], fo)
+        op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
+        ops.append(dict(flush=True))
+        for k_, word in sorted(own.hand_in.items()):
+            op([("L", word)], lambda g, k_=k_: e("v_accvgpr_write_b32", "a%d" % k_, v(g[0])))
+        mine = {op_["k"] for op_ in fops}
+        theirs = sorted(j for j in pin if not any(new == j for op_ in fops for (_, _, new) in op_["elim"]))
+        for j in theirs:
+            op([("L", p.LW_L + p.lpos[j])], lambda g, j=j: e("v_mov_b32", v(pin[j]), v(g[0])))
+        met[0] = True
+    fops = [op_ for op_ in fops if op_["k"] not in own.ftop] + [op_ for op_ in fops if op_["k"] in own.ftop]
     for op_ in fops:
         k = op_["k"]
+        if not met[0] and k in own.ftop:
+            meet()
         yv = {}
         for (bb, pk) in op_["init"]:
             reg = free.pop()
@@ -3159,6 +3198,8 @@ def factor_emit(e, s, p, lw_a, v_p, v_rinv, gen_pos, s_sigma, s_rinveq, v_pool, 
             e("v_accvgpr_write_b32", "a%d" % k, v(T_LV))
             e("v_min_f32", v(v_fmax), v(v_fmax), "|" + v(T_DK) + "|")
         op([], fin)
+    if not met[0]:
+        meet()
     sc.run(ops)
     e("s_waitcnt", "lgkmcnt(0)")
 

@@ -644,8 +644,8 @@ def test_loose_loop_shared_by_the_workgroup_is_bit_identical_to_one_wave(prog, i
     # capturing iteration, one at the end
     assert nbar == 5 + 2 * (iters + 1), nbar
     assert np.isfinite(words(lds1)).all() and np.array_equal(words(lds1), words(lds4))
-    # (the factorisation of a cut component stays with one wavefront: 41 % of the one-wave block with no middle iteration, less with more)
-    assert max(counts) < 0.42 * n1[0], (counts, n1)
+    # (the halves of a cut component factorise their own subtrees too: every wavefront executes about 28 % of the one-wave block)
+    assert max(counts) < 0.33 * n1[0], (counts, n1)
 
 
 @pytest.mark.parametrize("iters", [0, 2])
