@@ -2017,6 +2017,8 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
             SG["vcc"] = int(fval(t[2]) > fval(t[3]))
         elif m == "v_cmp_eq_f32":
             SG["vcc"] = int(fval(t[2]) == fval(t[3]))
+        elif m == "v_cmp_neq_f32":
+            SG["vcc"] = int(not (fval(t[2]) == fval(t[3])))
         elif m == "v_cndmask_b32_e64":
             bits = lambda x: f32bits(x) if isinstance(x, float) else x if isinstance(x, int) else int(V[int(x[1:])])
             V[int(t[1][1:])] = bits(t[3]) if SG["vcc"] else bits(t[2])
@@ -2075,6 +2077,11 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
             V[int(t[1][1:])] = int(V[int(t[2][1:])]) | int(V[int(t[3][1:])])
         elif m == "v_cmp_ne_u32":
             SG["vcc"] = int(t[2] != int(V[int(t[3][1:])]))
+        elif m == "s_cbranch_vccz":
+            if not SG["vcc"]:
+                lab, d = t[1][:-1], t[1][-1]
+                cands = labels[lab]
+                pc = min(c for c in cands if c > pc) if d == "f" else max(c for c in cands if c < pc)
         elif m == "s_cbranch_vccnz":
             if SG["vcc"]:
                 lab, d = t[1][:-1], t[1][-1]
@@ -3236,6 +3243,7 @@ def _f32_strict_bounds():
 
 
 S_GWAVE = 28                       # glue_group_program: s28 = the wave's index in its workgroup
+GLUE_TWO_PASS = os.environ.get("UMPC_QP_GLUE_TWO_PASS", "1") == "1"   # (A/B switch: glue_program, shared blocks)
 
 
 def glue_program(s, eq_rows, p, res, rp, split=None):
@@ -3309,6 +3317,11 @@ def glue_program(s, eq_rows, p, res, rp, split=None):
         e("v_cndmask_b32", v(V_FLAG), 0, v(V_FLAG), "vcc")
     nrow = 0
     put_items = []
+    # A shared block decides FIRST whether the 64 robots take the loose loop (every inequality row of every robot a loose row:
+    # the reference's problem) and then leaves the per-row items of those rows -- 1/rho, l, u, rho: what only the general loop
+    # and the C++ routes read -- unwritten: 5 of the 7 stores of such a row, 1.7 kB per robot-tick (GLUE_TWO_PASS; the C++
+    # residual phase forms l E, u E of those rows itself: codegen_qp.emit_fast_route_reload). One chunk of rows per wave.
+    two_pass = split is not None and GLUE_TWO_PASS and len(my_rows) <= R
     for c00 in range(0, len(my_rows), R):
         rows = my_rows[c00:c00 + R]
         c0 = rows[0]
@@ -3323,44 +3336,82 @@ def glue_program(s, eq_rows, p, res, rp, split=None):
                 last = i
                 e("global_load_dword", v(v0_ + i - c0), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
         e("s_waitcnt", "vmcnt(0)")
-        sc = Sched(e, pl, 0)
-        ops = []
-        for i in rows:
-            def f(g, i=i, k=nrow):
-                T = lambda q: V_T + 8 * (k % NSET) + q
-                l_, u_, e_, z_ = V_L + i - c0, V_U + i - c0, V_E + i - c0, V_Z + i - c0
-                le, ue, d, t, rho, rinv, ls, us = (T(q) for q in range(8))
-                e("v_mul_f32", v(le), v(l_), v(e_))
-                e("v_mul_f32", v(ue), v(u_), v(e_))
-                e("v_sub_f32", v(d), v(ue), v(le))
-                e("v_mov_b32", v(rho), v(GV_RHO0))
-                e("v_mov_b32", v(rinv), v(GV_RINV0))
-                e("v_cmp_gt_f32", "vcc", v(V_TOL), v(d))                        # u - l < RHO_TOL: an equality row
-                e("v_cndmask_b32", v(rho), v(rho), v(GV_RHOEQ), "vcc")
-                e("v_cndmask_b32", v(rinv), v(rinv), v(GV_RINVEQ), "vcc")
-                e("v_cmp_lt_f32", "vcc", v(V_F), v(ue))                         # both bounds infinite: a loose row
-                e("v_cndmask_b32", v(t), 0, v(le), "vcc")
-                e("v_cmp_gt_f32", "vcc", v(V_NF), v(t))
-                e("v_cndmask_b32", v(rho), v(rho), v(V_RMIN), "vcc")
-                e("v_cndmask_b32", v(rinv), v(rinv), v(V_RIMIN), "vcc")
-                e("v_mul_f32", v(ls), v(l_), v(g[0]))
-                e("v_mul_f32", v(us), v(u_), v(g[0]))
-                if i in eq:
-                    check(rho, GV_RHOEQ)
-                    check(ls, us)
-                    check(z_, ls)
-                    for q in pos[("l", i)]:
-                        put(q, ls)
-                    put(res.it_ls[i], ls)
-                else:
-                    e("v_cmp_eq_f32", "vcc", v(rho), v(V_RMIN))                 # a loose row? (the loose loop variant)
+
+        def classify(i, T):
+            """rho, 1/rho of row i from its bounds scaled by the previous E (auxil.c:103-145) -> T(4), T(5); T(0), T(1) = l E', u E'"""
+            l_, u_, e_ = V_L + i - c0, V_U + i - c0, V_E + i - c0
+            le, ue, d, t, rho, rinv = (T(q) for q in range(6))
+            e("v_mul_f32", v(le), v(l_), v(e_))
+            e("v_mul_f32", v(ue), v(u_), v(e_))
+            e("v_sub_f32", v(d), v(ue), v(le))
+            e("v_mov_b32", v(rho), v(GV_RHO0))
+            e("v_mov_b32", v(rinv), v(GV_RINV0))
+            e("v_cmp_gt_f32", "vcc", v(V_TOL), v(d))                        # u - l < RHO_TOL: an equality row
+            e("v_cndmask_b32", v(rho), v(rho), v(GV_RHOEQ), "vcc")
+            e("v_cndmask_b32", v(rinv), v(rinv), v(GV_RINVEQ), "vcc")
+            e("v_cmp_lt_f32", "vcc", v(V_F), v(ue))                         # both bounds infinite: a loose row
+            e("v_cndmask_b32", v(t), 0, v(le), "vcc")
+            e("v_cmp_gt_f32", "vcc", v(V_NF), v(t))
+            e("v_cndmask_b32", v(rho), v(rho), v(V_RMIN), "vcc")
+            e("v_cndmask_b32", v(rinv), v(rinv), v(V_RIMIN), "vcc")
+        if two_pass:
+            for i in rows:
+                if i not in eq:
+                    classify(i, lambda q: V_T + q)
+                    e("v_cmp_eq_f32", "vcc", v(V_T + 4), v(V_RMIN))
                     e("v_cndmask_b32", v(V_LFLAG), 0, v(V_LFLAG), "vcc")
-                    for what, reg in (("rinv", rinv), ("l", ls), ("u", us), ("rho", rho)):
-                        for q in pos.get((what, i), []):
-                            put(q, reg)
-            ops.append(dict(srcs=[("L", rp.LW_EV + i)], emit=f))
-            nrow += 1
-        sc.run(ops)
+            base, off = lds_addr(LOOSE_FLAG)
+            e("ds_min_f32", base, v(V_LFLAG), off)
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("s_barrier")
+            e("ds_read_b32", v(V_T), base, off)
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("v_cmp_neq_f32", "vcc", 1.0, v(V_T))                          # lanes whose robot is NOT all loose
+            e("s_cbranch_vccz", "31f")
+
+        def rows_pass(lean, nrow0):
+            sc = Sched(e, pl, 0)
+            ops = []
+            for k_, i in enumerate(rows):
+                def f(g, i=i, k=nrow0 + k_):
+                    T = lambda q: V_T + 8 * (k % NSET) + q
+                    l_, u_, z_ = V_L + i - c0, V_U + i - c0, V_Z + i - c0
+                    rho, rinv, ls, us = (T(q) for q in range(4, 8))
+                    classify(i, T)
+                    e("v_mul_f32", v(ls), v(l_), v(g[0]))
+                    e("v_mul_f32", v(us), v(u_), v(g[0]))
+                    if i in eq:
+                        check(rho, GV_RHOEQ)
+                        check(ls, us)
+                        check(z_, ls)
+                        for q in pos[("l", i)]:
+                            put(q, ls)
+                        put(res.it_ls[i], ls)
+                    else:
+                        e("v_cmp_eq_f32", "vcc", v(rho), v(V_RMIN))                 # a loose row? (the loose loop variant)
+                        e("v_cndmask_b32", v(V_LFLAG), 0, v(V_LFLAG), "vcc")
+                        if not lean:
+                            for what, reg in (("rinv", rinv), ("l", ls), ("u", us), ("rho", rho)):
+                                for q in pos.get((what, i), []):
+                                    put(q, reg)
+                if lean and i not in eq:
+                    continue              # (nothing of such a row is stored, and its verdict is in already)
+                ops.append(dict(srcs=[("L", rp.LW_EV + i)], emit=f))
+            sc.run(ops)
+        if two_pass:
+            mark = len(put_items)
+            rows_pass(False, nrow)
+            e("s_branch", "32f")
+            e("label", "31")
+            n_full = len(put_items)
+            rows_pass(True, nrow)
+            del put_items[n_full:]        # (the items of a wave are what its full pass writes)
+            for q_ in ptrs:               # (the two passes leave different block pointers behind)
+                q_[1] = None
+            e("label", "32")
+        else:
+            rows_pass(False, nrow)
+        nrow += len(rows)
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")        # the landing registers are loaded again by the next chunk
     sc = Sched(e, pl, 0)
     ops = []
@@ -3371,6 +3422,8 @@ def glue_program(s, eq_rows, p, res, rp, split=None):
         ops.append(dict(srcs=[("L", rp.LW_Q + j)], emit=fq))
     sc.run(ops)
     for word, reg in ((GLUE_FLAG, V_FLAG), (LOOSE_FLAG, V_LFLAG)):
+        if word == LOOSE_FLAG and two_pass:
+            continue                  # (folded in before the rows were stored; the waves are reading the word by now)
         base, off = lds_addr(word)
         e("ds_min_f32" if split is not None else "ds_write_b32", base, v(reg), off)
     e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")

@@ -535,7 +535,8 @@ def emit_fast_route_reload(E, name, s, P):
         if i in res.eq:
             E("    ls[%d] = us[%d] = SB(%d);" % (i, i, res.it_ls[i]))
         else:
-            E("    ls[%d] = SB(%d); us[%d] = SB(%d);" % (i, pos[("l", i)], i, pos[("u", i)]))
+            # (l E, u E as the glue block forms them: it leaves these items of a wave that takes the loose loop unwritten)
+            E("    ls[%d] = IN(a.l, %d) * Ev[%d]; us[%d] = IN(a.u, %d) * Ev[%d];" % (i, i, i, i, i, i))
     E("    c = SB(%d); cinv = T(1.0) / c;" % res.it_c)
     E("#undef SB")
     E("#define LDSQ(w) ldsf[((w) >> 2) * 256 + ((w) & 3)]")
