@@ -1842,6 +1842,7 @@ def simulate_group(ins, nw, W, S, iters, consts, wave_sgpr, **kw):
         gens.append(_simulate(ins, W, S, iters, consts, **dict(kw, sgpr=sg, lds_shared=lds, access_log=logs[w], count=counts[w])))
     live = [True] * nw
     nbar = 0
+    hist = []                           # per barrier phase: the words each wave wrote
     while any(live):
         for w in range(nw):
             if live[w]:
@@ -1857,6 +1858,12 @@ def simulate_group(ins, nw, W, S, iters, consts, wave_sgpr, **kw):
                             (logs[a_].get("a", set()) & logs[b_]["r"])
                     assert not clash, ("LDS race before barrier %d: words written by wave %d and touched by wave %d" % (nbar, a_, b_),
                                        sorted(clash)[:8], {k_: sorted(clash & v_)[:4] for k_, v_ in logs[b_].items()})
+        hist.append([set(lg["w"]) | set(lg.get("a", set())) for lg in logs])
+        for b_ in range(nw):
+            for (ph, word) in logs[b_].get("late", set()):
+                for a_ in range(nw):
+                    assert a_ == b_ or ph >= len(hist) or word not in hist[ph][a_], \
+                        ("LDS race: word %d fetched by wave %d in phase %d (looked at later) was written by wave %d in that phase" % (word, b_, ph, a_))
         for lg in logs:
             for st_ in lg.values():
                 st_.clear()
@@ -1882,6 +1889,9 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
     log_w = access_log["w"] if access_log is not None else set()
     log_a = access_log.setdefault("a", set()) if access_log is not None else set()
     src_word = {}
+    src_phase = {}                      # register -> barrier phase in which its LDS read executed
+    phase = [0]
+    log_late = access_log.setdefault("late", set()) if access_log is not None else set()
     for k, t in enumerate(ins):
         if t[0] == "label":
             labels.setdefault(t[1], []).append(k)
@@ -1992,7 +2002,10 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
                     src_word.pop(r_, None)    # that is overwritten no longer stands for the word)
                 for r_ in used - wr_only:
                     if r_ in src_word:
-                        log_r.add(src_word[r_])
+                        if src_phase.get(r_, phase[0]) == phase[0]:
+                            log_r.add(src_word[r_])
+                        else:                 # fetched before a barrier, looked at behind it: the access belongs to THAT phase
+                            log_late.add((src_phase[r_], src_word[r_]))
             if m in ("ds_read_b128", "ds_read_b32"):
                 pend["lgkmcnt"].append(regs_of(t[1]))
             elif m.startswith("ds_write") or m == "ds_min_f32":
@@ -2006,6 +2019,7 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
         elif m == "s_barrier":
             assert not pend["lgkmcnt"], ("s_barrier with LDS operations in flight: another wave may not see them", pc)
             yield pc
+            phase[0] += 1
         elif m == "v_mov_b32":
             V[int(t[1][1:])] = (t[2] if isinstance(t[2], int) else f32bits(t[2]) if isinstance(t[2], float)
                                 else SG[int(t[2][1:])] if t[2][0] == "s" else V[int(t[2][1:])])
@@ -2105,10 +2119,12 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
             for h in range(4):
                 V[lo + h] = f32bits(float(lds[w + h]))
                 src_word[("v", lo + h)] = w + h
+                src_phase[("v", lo + h)] = phase[0]
         elif m == "ds_read_b32":
             w = ldsword(t[2], t[3])
             V[int(t[1][1:])] = f32bits(float(lds[w]))
             src_word[("v", int(t[1][1:]))] = w
+            src_phase[("v", int(t[1][1:]))] = phase[0]
         elif m == "ds_write_b128":
             lo = int(t[2][2:t[2].index(":")])
             w = ldsword(t[1], t[3])
