@@ -2179,6 +2179,8 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
             setf(t[1], max(fval(t[2]), fval(t[3])))
         elif m == "v_min_f32":
             setf(t[1], min(fval(t[2]), fval(t[3])))
+        elif m == "v_max3_f32":
+            setf(t[1], max(fval(t[2]), fval(t[3]), fval(t[4])))
         else:
             raise ValueError("unknown instruction %r" % (t,))
         pc += 1
@@ -2385,6 +2387,7 @@ S_RSB, V_RLANE = 24, 210           # Ruiz block with a residual stream: s[24:25]
 S_RMIN, S_RMAX = 20, 21            # 1e-4, 1e4 (float bits, set by the block)
 RUIZ_STAMPS = os.environ.get("UMPC_QP_RUIZ_STAMPS") == "1"     # (diagnostics: see ruiz_program)
 RUIZ_HOMES = os.environ.get("UMPC_QP_RUIZ_HOMES", "1") == "1"   # (A/B switch: ruiz_program, shared blocks)
+RUIZ_LEAN = os.environ.get("UMPC_QP_RUIZ_LEAN", "1") == "1"     # (A/B switch: in-place operations on the register homes, v_max3_f32)
 LOOP_STAMPS = os.environ.get("UMPC_QP_LOOP_STAMPS") == "1"     # (diagnostics: see program(); the residual block copies the items)
 STAMP_ITEM0 = 2040                 # spare items at the end of a wave's stream block (codegen_qp.ASM_STREAM_ITEMS = 2048)
 
@@ -2539,21 +2542,51 @@ def ruiz_program(s, res=None, split=None, wave=0):
     touched = set()
     for j in cols:
         ents = list(range(p.A_p[j], p.A_p[j + 1]))
-        if p.pidx[j] >= 0:
-            op([asrc(p.A_P + p.pidx[j])], lambda g: e("v_max_f32", v(T(0)), ab(v(g[0])), ab(v(g[0]))))
+        if RUIZ_LEAN and all(q in RA for q in ents) and (p.pidx[j] < 0 or p.A_P + p.pidx[j] in HV):
+            # every operand of the column's norm in a register (shared blocks): up to three per v_max3_f32 (max is exact and
+            # order-free: the same bits as the chain of v_max_f32 below), the row norms as before
+            def fcol(g, j=j, ents=ents, firsts=tuple(p.A_i[q] not in touched for q in ents)):
+                opnds = ([HV[p.A_P + p.pidx[j]]] if p.pidx[j] >= 0 else []) + [RA[q] for q in ents]
+                if not opnds:
+                    e("v_mov_b32", v(T(0)), 0)
+                head, rest = opnds[:3], opnds[3:]
+                if len(head) == 3:
+                    e("v_max3_f32", v(T(0)), ab(v(head[0])), ab(v(head[1])), ab(v(head[2])))
+                elif head:
+                    e("v_max_f32", v(T(0)), ab(v(head[0])), ab(v(head[-1])))
+                while rest:
+                    if len(rest) >= 2:
+                        e("v_max3_f32", v(T(0)), v(T(0)), ab(v(rest[0])), ab(v(rest[1])))
+                        rest = rest[2:]
+                    else:
+                        e("v_max_f32", v(T(0)), v(T(0)), ab(v(rest[0])))
+                        rest = rest[1:]
+                for q, first in zip(ents, firsts):
+                    i = p.A_i[q]
+                    e("v_max_f32", ET(i), ab(v(RA[q])) if first else ET(i), ab(v(RA[q])))
+            op([], fcol)
+            touched.update(p.A_i[q] for q in ents)
         else:
-            op([], lambda g: e("v_mov_b32", v(T(0)), 0))
-        for q in ents:
-            i = p.A_i[q]
+            if p.pidx[j] >= 0:
+                op([asrc(p.A_P + p.pidx[j])], lambda g: e("v_max_f32", v(T(0)), ab(v(g[0])), ab(v(g[0]))))
+            else:
+                op([], lambda g: e("v_mov_b32", v(T(0)), 0))
+            for q in ents:
+                i = p.A_i[q]
 
-            def f(g, i=i, first=i not in touched):
-                e("v_max_f32", v(T(0)), v(T(0)), ab(v(g[0])))
-                e("v_max_f32", ET(i), ab(v(g[0])) if first else ET(i), ab(v(g[0])))
-            op([("V", RA[q]) if q in RA else ("L", p.LW_A + q)], f)
-            touched.add(i)
+                def f(g, i=i, first=i not in touched):
+                    e("v_max_f32", v(T(0)), v(T(0)), ab(v(g[0])))
+                    e("v_max_f32", ET(i), ab(v(g[0])) if first else ET(i), ab(v(g[0])))
+                op([("V", RA[q]) if q in RA else ("L", p.LW_A + q)], f)
+                touched.add(i)
 
         def fin(g, j=j):
             limit(T(0), T(1))
+            if RUIZ_LEAN and p.A_DT + j in HV:
+                # straight into the column scaling's register home: no copy, and no wait state either (the next VALU
+                # instruction starts the next column and does not read it)
+                e("v_rsq_f32", v(HV[p.A_DT + j]), v(T(0)))
+                return
             rsqrt(T(1), T(0), T(2))
             awrite(p.A_DT + j, T(1))
         op([], fin)
@@ -2579,12 +2612,17 @@ def ruiz_program(s, res=None, split=None, wave=0):
     op([], lambda g: stamp(3))
     op([], lambda g: (e("v_mov_b32", v(T(4)), 0), e("v_mov_b32", v(T(5)), 0)))
     for j in cols:
-        op([asrc(p.A_DT + j)], lambda g: e("v_mov_b32", v(T(7)), v(g[0])))
+        lean = RUIZ_LEAN and p.A_DT + j in HV
+        DTJ = HV[p.A_DT + j] if lean else T(7)       # dt of the column: its register home itself (shared blocks), else a copy
+        if not lean:
+            op([asrc(p.A_DT + j)], lambda g: e("v_mov_b32", v(T(7)), v(g[0])))
         if p.pidx[j] >= 0:
-            def fp(g, k=p.pidx[j]):
+            def fp(g, k=p.pidx[j], DTJ=DTJ, lean=lean):
                 t = T(6) if sp is None else T(8 + k % 4)
-                e("v_mul_f32", v(t), v(g[0]), v(T(7)))
-                e("v_mul_f32", v(t), v(t), v(T(7)))
+                if lean and p.A_P + k in HV:
+                    t = HV[p.A_P + k]             # in place (the same two products)
+                e("v_mul_f32", v(t), v(g[0]), v(DTJ))
+                e("v_mul_f32", v(t), v(t), v(DTJ))
                 awrite(p.A_P + k, t)
                 if sp is None:
                     e("v_add_f32", v(T(4)), v(T(4)), ab(v(t)))
@@ -2592,29 +2630,30 @@ def ruiz_program(s, res=None, split=None, wave=0):
                     sc.lds_write(sp.PX[k], t)       # (every wave sums all of them in the reference's order below)
             op([asrc(p.A_P + p.pidx[j])], fp)
         for q in range(p.A_p[j], p.A_p[j + 1]):
-            def fa(g, q=q, i=p.A_i[q]):
+            def fa(g, q=q, i=p.A_i[q], DTJ=DTJ):
                 if q in RA:                   # in place, in its register home
                     e("v_mul_f32", v(RA[q]), v(RA[q]), ET(i))
-                    e("v_mul_f32", v(RA[q]), v(RA[q]), v(T(7)))
+                    e("v_mul_f32", v(RA[q]), v(RA[q]), v(DTJ))
                     return
                 t = wqa.reg(p.LW_A + q) if p.WQ else T(8 + q % 4)
                 e("v_mul_f32", v(t), v(g[0]), ET(i))
-                e("v_mul_f32", v(t), v(t), v(T(7)))
+                e("v_mul_f32", v(t), v(t), v(DTJ))
                 if p.WQ:
                     wqa.done(p.LW_A + q, q + 1 not in aq_set)
                 else:
                     sc.lds_write(p.LW_A + q, t)
             op([("V", RA[q]) if q in RA else ("L", p.LW_A + q)], fa)
 
-        def fq(g, j=j):
-            e("v_mul_f32", v(T(6)), v(g[0]), v(T(7)))
-            awrite(p.A_Q + j, T(6))
-            e("v_max_f32", v(T(5)), ab(v(T(6))), v(T(5)))
+        def fq(g, j=j, DTJ=DTJ, lean=lean):
+            tq = HV[p.A_Q + j] if (lean and p.A_Q + j in HV) else T(6)         # (in place in its register home)
+            e("v_mul_f32", v(tq), v(g[0]), v(DTJ))
+            awrite(p.A_Q + j, tq)
+            e("v_max_f32", v(T(5)), ab(v(tq)), v(T(5)))
             if j in RD:
-                e("v_mul_f32", v(RD[j]), v(T(7)), v(RD[j]))
+                e("v_mul_f32", v(RD[j]), v(DTJ), v(RD[j]))
                 return
             t = wqd.reg(p.LW_D + j) if p.WQ else T(12)
-            e("v_mul_f32", v(t), v(T(7)), v(g[1]))
+            e("v_mul_f32", v(t), v(DTJ), v(g[1]))
             if p.WQ:
                 wqd.done(p.LW_D + j, not (j + 1 < n and own_col(j + 1)))
             else:
