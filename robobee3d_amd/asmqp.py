@@ -2181,6 +2181,8 @@ def _simulate(ins, W, S, iters, consts, regions=None, sgpr=None, lds0=None, ret_
             setf(t[1], min(fval(t[2]), fval(t[3])))
         elif m == "v_max3_f32":
             setf(t[1], max(fval(t[2]), fval(t[3]), fval(t[4])))
+        elif m == "v_min3_f32":
+            setf(t[1], min(fval(t[2]), fval(t[3]), fval(t[4])))
         else:
             raise ValueError("unknown instruction %r" % (t,))
         pc += 1
@@ -2387,6 +2389,7 @@ S_RSB, V_RLANE = 24, 210           # Ruiz block with a residual stream: s[24:25]
 S_RMIN, S_RMAX = 20, 21            # 1e-4, 1e4 (float bits, set by the block)
 RUIZ_STAMPS = os.environ.get("UMPC_QP_RUIZ_STAMPS") == "1"     # (diagnostics: see ruiz_program)
 RUIZ_HOMES = os.environ.get("UMPC_QP_RUIZ_HOMES", "1") == "1"   # (A/B switch: ruiz_program, shared blocks)
+RUIZ_FAST_LIMIT = os.environ.get("UMPC_QP_RUIZ_FAST_LIMIT", "1") == "1"   # (A/B switch: one wave-wide limit_scaling test per pass)
 RUIZ_LEAN = os.environ.get("UMPC_QP_RUIZ_LEAN", "1") == "1"     # (A/B switch: in-place operations on the register homes, v_max3_f32)
 LOOP_STAMPS = os.environ.get("UMPC_QP_LOOP_STAMPS") == "1"     # (diagnostics: see program(); the residual block copies the items)
 STAMP_ITEM0 = 2040                 # spare items at the end of a wave's stream block (codegen_qp.ASM_STREAM_ITEMS = 2048)
@@ -2540,6 +2543,7 @@ def ruiz_program(s, res=None, split=None, wave=0):
     op([], lambda g: stamp(2))
     # ---- norms: columns in order; the row norms accumulate in the Et registers
     touched = set()
+    fast_cols = []                       # register homes that hold column NORMS until the wave-wide limit test below
     for j in cols:
         ents = list(range(p.A_p[j], p.A_p[j + 1]))
         if RUIZ_LEAN and all(q in RA for q in ents) and (p.pidx[j] < 0 or p.A_P + p.pidx[j] in HV):
@@ -2547,25 +2551,29 @@ def ruiz_program(s, res=None, split=None, wave=0):
             # order-free: the same bits as the chain of v_max_f32 below), the row norms as before
             def fcol(g, j=j, ents=ents, firsts=tuple(p.A_i[q] not in touched for q in ents)):
                 opnds = ([HV[p.A_P + p.pidx[j]]] if p.pidx[j] >= 0 else []) + [RA[q] for q in ents]
-                if not opnds:
-                    e("v_mov_b32", v(T(0)), 0)
                 head, rest = opnds[:3], opnds[3:]
+                nrm = HV[p.A_DT + j] if (RUIZ_FAST_LIMIT and p.A_DT + j in HV) else T(0)      # (limited wave-wide below)
+                if not opnds:
+                    e("v_mov_b32", v(nrm), 0)
                 if len(head) == 3:
-                    e("v_max3_f32", v(T(0)), ab(v(head[0])), ab(v(head[1])), ab(v(head[2])))
+                    e("v_max3_f32", v(nrm), ab(v(head[0])), ab(v(head[1])), ab(v(head[2])))
                 elif head:
-                    e("v_max_f32", v(T(0)), ab(v(head[0])), ab(v(head[-1])))
+                    e("v_max_f32", v(nrm), ab(v(head[0])), ab(v(head[-1])))
                 while rest:
                     if len(rest) >= 2:
-                        e("v_max3_f32", v(T(0)), v(T(0)), ab(v(rest[0])), ab(v(rest[1])))
+                        e("v_max3_f32", v(nrm), v(nrm), ab(v(rest[0])), ab(v(rest[1])))
                         rest = rest[2:]
                     else:
-                        e("v_max_f32", v(T(0)), v(T(0)), ab(v(rest[0])))
+                        e("v_max_f32", v(nrm), v(nrm), ab(v(rest[0])))
                         rest = rest[1:]
                 for q, first in zip(ents, firsts):
                     i = p.A_i[q]
                     e("v_max_f32", ET(i), ab(v(RA[q])) if first else ET(i), ab(v(RA[q])))
             op([], fcol)
             touched.update(p.A_i[q] for q in ents)
+            if RUIZ_FAST_LIMIT and p.A_DT + j in HV:
+                fast_cols.append(HV[p.A_DT + j])
+                continue
         else:
             if p.pidx[j] >= 0:
                 op([asrc(p.A_P + p.pidx[j])], lambda g: e("v_max_f32", v(T(0)), ab(v(g[0])), ab(v(g[0]))))
@@ -2602,11 +2610,38 @@ def ruiz_program(s, res=None, split=None, wave=0):
         for i in mine:
             for w2 in sorted(sp.touch[i] - {wave}):
                 op([("L", sp.X[(i, w2)])], lambda g, i=i: e("v_max_f32", ET(i), ET(i), v(g[0])))
-    for i in sorted(touched):
-        def fe(g, i=i):
-            limit(p.V_ET + i, T(1))
-            e("v_rsq_f32", ET(i), ET(i))        # in place; the next VALU instruction (the next row's compare, or the
-        op([], fe)                               # csum initialisation) does not read it: no trans-use wait state needed
+    if fast_cols:
+        # limit_scaling + 1/sqrt of all the wave's norms at once (as asmstep.Step.limit): running v_min3 / v_max3 over them
+        # decide wave-wide whether ANY value of ANY robot needs limiting -- it never does once the data is equilibrated -- and
+        # the exact compare / min / select sequence runs only then. Same values either way.
+        def flim(g, regs=tuple(fast_cols + [p.V_ET + i for i in sorted(touched)])):
+            regs = list(regs)
+            mn, mx = T(0), T(2)
+            take = (regs + [regs[0], regs[0]])[:3]
+            e("v_min3_f32", v(mn), v(take[0]), v(take[1]), v(take[2]))
+            e("v_max3_f32", v(mx), v(take[0]), v(take[1]), v(take[2]))
+            for q in range(3, len(regs), 2):
+                a_, b_ = regs[q], regs[min(q + 1, len(regs) - 1)]
+                e("v_min3_f32", v(mn), v(mn), v(a_), v(b_))
+                e("v_max3_f32", v(mx), v(mx), v(a_), v(b_))
+            e("v_cmp_gt_f32", "vcc", sMIN, v(mn))
+            e("s_cbranch_vccnz", "33f")
+            e("v_cmp_lt_f32", "vcc", sMAX, v(mx))
+            e("s_cbranch_vccz", "34f")
+            e("label", "33")
+            for r_ in regs:
+                limit(r_, T(1))
+            e("label", "34")
+            for r_ in regs:
+                e("v_rsq_f32", v(r_), v(r_))
+            e("s_nop", 0)
+        op([], flim)
+    else:
+        for i in sorted(touched):
+            def fe(g, i=i):
+                limit(p.V_ET + i, T(1))
+                e("v_rsq_f32", ET(i), ET(i))        # in place; the next VALU instruction (the next row's compare, or the
+            op([], fe)                               # csum initialisation) does not read it: no trans-use wait state needed
     # ---- apply; csum in T(4), qn in T(5), dt of the column in T(7)
     wqa, wqd, wqe = (QuadWriter(sc, p.V_WQ + 4 * z) for z in range(3))
     op([], lambda g: stamp(3))
