@@ -3334,6 +3334,7 @@ def _f32_strict_bounds():
 
 S_GWAVE = 28                       # glue_group_program: s28 = the wave's index in its workgroup
 GLUE_TWO_PASS = os.environ.get("UMPC_QP_GLUE_TWO_PASS", "1") == "1"   # (A/B switch: glue_program, shared blocks)
+GLUE_BALANCE = os.environ.get("UMPC_QP_GLUE_BALANCE", "1") == "1"     # (A/B switch: equality and other rows dealt out separately)
 
 
 def glue_program(s, eq_rows, p, res, rp, split=None):
@@ -3344,6 +3345,12 @@ def glue_program(s, eq_rows, p, res, rp, split=None):
     n, m = s.n, s.m
     wave, nw = split if split is not None else (0, 1)
     my_rows = [i for i in range(m) if i * nw // m == wave]
+    if split is not None and GLUE_TWO_PASS and GLUE_BALANCE:
+        # a quarter of the equality rows AND a quarter of the other rows each: when the robots take the loose loop nothing of the
+        # other rows is stored, and the equality rows -- all of the work that is left -- must not sit on two of the four waves
+        eqr, ineqr = [i for i in range(m) if i in set(int(i_) for i_ in eq_rows)], [i for i in range(m) if i not in set(int(i_) for i_ in eq_rows)]
+        my_rows = sorted([i for q_, i in enumerate(eqr) if q_ * nw // len(eqr) == wave] +
+                         [i for q_, i in enumerate(ineqr) if q_ * nw // len(ineqr) == wave]) if eqr and ineqr else my_rows
     my_cols = [j for j in range(n) if j * nw // n == wave]
     eq = set(int(i) for i in eq_rows)
     pos = {}
@@ -3415,7 +3422,7 @@ def glue_program(s, eq_rows, p, res, rp, split=None):
     for c00 in range(0, len(my_rows), R):
         rows = my_rows[c00:c00 + R]
         c0 = rows[0]
-        assert rows == list(range(c0, c0 + len(rows)))
+        slot = {i: q_ for q_, i in enumerate(rows)}          # row -> its place in the chunk's register arrays
         for base_s, v0_, sel in ((S_LR, V_L, rows), (S_UR, V_U, rows), (S_ER, V_E, rows), (S_ZR, V_Z, [i for i in rows if i in eq])):
             last = None
             for i in sel:
@@ -3424,12 +3431,12 @@ def glue_program(s, eq_rows, p, res, rp, split=None):
                 else:
                     _adv(e, S_P)
                 last = i
-                e("global_load_dword", v(v0_ + i - c0), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
+                e("global_load_dword", v(v0_ + slot[i]), "v0", "s[%d:%d]" % (S_P, S_P + 1), 0)
         e("s_waitcnt", "vmcnt(0)")
 
         def classify(i, T):
             """rho, 1/rho of row i from its bounds scaled by the previous E (auxil.c:103-145) -> T(4), T(5); T(0), T(1) = l E', u E'"""
-            l_, u_, e_ = V_L + i - c0, V_U + i - c0, V_E + i - c0
+            l_, u_, e_ = V_L + slot[i], V_U + slot[i], V_E + slot[i]
             le, ue, d, t, rho, rinv = (T(q) for q in range(6))
             e("v_mul_f32", v(le), v(l_), v(e_))
             e("v_mul_f32", v(ue), v(u_), v(e_))
@@ -3465,7 +3472,7 @@ def glue_program(s, eq_rows, p, res, rp, split=None):
             for k_, i in enumerate(rows):
                 def f(g, i=i, k=nrow0 + k_):
                     T = lambda q: V_T + 8 * (k % NSET) + q
-                    l_, u_, z_ = V_L + i - c0, V_U + i - c0, V_Z + i - c0
+                    l_, u_, z_ = V_L + slot[i], V_U + slot[i], V_Z + slot[i]
                     rho, rinv, ls, us = (T(q) for q in range(4, 8))
                     classify(i, T)
                     e("v_mul_f32", v(ls), v(l_), v(g[0]))
