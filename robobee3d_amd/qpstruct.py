@@ -339,9 +339,8 @@ def _bisect_parts(n, m, A_p, A_i, min_size, max_sep, hold=None):
         loc = {v: q for q, v in enumerate(V)}
         sub_c = [{loc[u] for u in adj[v]} for v in V]         # (the component alone, renumbered: min-fill is quadratic)
         hold_c = {loc[v]: {loc[u] for u in us} for v, us in (hold or {}).items() if v in loc}
-        for (ld, size, S, bins) in cands:
-            if ld > lightest + 2:
-                continue
+        short = sorted((c_ for c_ in cands if c_[0] <= lightest + 2), key=lambda c_: c_[:3])[:max(32, 24000 // len(V))]     # (each costs a min-fill run: quadratic in the component)
+        for (ld, size, S, bins) in short:
             inB = {v for pc in bins[1] for v in pc}
             order = [V[q] for q in symbolic.min_fill_ordering(sub_c, last=[loc[v] for v in S], hold=hold_c)]
             g = {v: set(adj[v]) for v in V}
