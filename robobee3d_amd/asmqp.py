@@ -106,6 +106,7 @@ class Plan:
         pinv, L_p, L_i, Lr_p = list(t["pinv"]), list(t["L_p"]), list(t["L_i"]), list(t["Lr_p"])
         self.pinv, self.L_p, self.L_i = pinv, L_p, L_i
         eq = set(int(i) for i in eq_rows)
+        self.eq_rows_set = eq
         self.rows = []
         leafk = set()
         for i in range(m):
@@ -280,6 +281,7 @@ class Own:
         self.all = varw is None
         self.lhome = lhome or {}          # L entry (CSC index) -> VGPR that holds -L during the iterations (LoopSplit.own)
         self.chome, self.yhome = {}, {}   # LDS word of a loop constant -> VGPR: leaf entries of L (every variant); q, l (y0 bodies)
+        self.ahome, self.shome = {}, {}   # fused y0 bodies (S_HOMES): LDS word of a constant -> AGPR; of the wave's x / y / z -> VGPR
         self.fkw = fkw if fkw is not None else kw          # who FACTORISES unknown k (a component cut in two: the wave of half A)
         self.fvarw = fvarw if fvarw is not None else varw
         # a component cut in two (LoopSplit): the solves of every wave of the workgroup meet at two barriers
@@ -318,6 +320,7 @@ class Own:
 ALL = Own()
 L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
 FACTOR_SPLIT = os.environ.get("UMPC_QP_FACTOR_SPLIT", "1") == "1"   # (A/B switch: a cut component's halves factorise their own subtrees)
+S_HOMES = os.environ.get("UMPC_QP_S_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the iterates in VGPRs, the constants in AGPRs)
 C_HOMES = os.environ.get("UMPC_QP_C_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the loop's other constants in VGPRs)
 TREE_SPLIT = os.environ.get("UMPC_QP_TREE_SPLIT", "1") == "1"  # (A/B switch: LoopSplit cuts large components in two)
 SCALE_LATE = os.environ.get("UMPC_QP_SCALE_LATE", "1") == "1"  # (A/B switch: where a cut component's W / D sits between the barriers)
@@ -554,6 +557,42 @@ class LoopSplit:
                         r_ = (odd or free)[0]     # (singles first into registers that cannot form an aligned pair)
                         free.remove(r_)
                         dst[w_] = r_
+            if S_HOMES and self.split:
+                # The fused y0 bodies (the reference's problem: every iteration but the last) go one step further: the constants
+                # move on into AGPRs that this wave's 1/D does not use (a v_accvgpr_read costs a VALU slot and no LDS cycle), and
+                # the registers they held -- filled only on this path -- keep the wave's x, z and equality-row y words: no LDS
+                # access at all for them between the first and the last iteration.
+                topall = self.split[wave]["topall"] if "topall" in self.split[wave] else self.split[wave]["top"]
+                apool = [k for k in p.nonleaf if self.kw[k] != wave and k not in topall and k not in self.split[wave]["hand_in"]]
+                consts = sorted(set(lw) | set(qw) | set(ew))
+                eqs = set(int(i) for i in p.eq_rows_set)
+                sw = sorted([p.LW_X + j for j in range(p.n) if self.varw[j] == wave] +
+                            [p.LW_Z + p.zpos[i] for i in p.zpos if self.roww[i] == wave] +
+                            [p.LW_Y + i for i in range(p.m) if i in eqs and self.roww[i] == wave])
+                free2 = [r_ for r_ in pool if r_ not in set(lhome.values())]
+                sh, ok = {}, len(consts) <= len(apool)
+                for w_ in sw:
+                    if w_ in sh:
+                        continue
+                    if w_ % 2 == 0 and w_ + 1 in sw:
+                        base = next((r_ for r_ in free2 if r_ % 2 == 0 and r_ + 1 in free2), None)
+                        if base is None:
+                            ok = False
+                            break
+                        free2.remove(base)
+                        free2.remove(base + 1)
+                        sh[w_], sh[w_ + 1] = base, base + 1
+                    elif not (w_ % 2 == 1 and w_ - 1 in sw):
+                        odd = [r_ for r_ in free2 if not (r_ % 2 == 0 and r_ + 1 in free2) and not (r_ % 2 == 1 and r_ - 1 in free2)]
+                        if not (odd or free2):
+                            ok = False
+                            break
+                        r_ = (odd or free2)[0]
+                        free2.remove(r_)
+                        sh[w_] = r_
+                if ok:                # (all or nothing: a body either finds every word of the wave resident or none)
+                    o.shome = sh
+                    o.ahome = dict(zip(consts, apool))
         return o
 
 
@@ -780,12 +819,25 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     T = lambda q: p.V_TT + q
     assert loose or not y0
     homes = p.y0_home if y0 else {}
-    # a loop constant: its VGPR home if this wave keeps one (Own.chome: leaf entries of L; Own.yhome, y0 bodies: q, l), else its LDS word
-    C = lambda word: ("V", own.chome[word]) if word in own.chome else ("V", own.yhome[word]) if (y0 and word in own.yhome) else ("L", word)
+    # Where this body finds a loop constant (C: one word, C2: an aligned pair of words) and a word of x / y / z (S, S2):
+    #   fused y0 bodies of a wave with resident iterates (Own.shome): constants in AGPRs (Own.ahome), x / y / z in VGPRs;
+    #   the capturing body behind them: everything from LDS (the iterates are written back first, the registers are theirs);
+    #   every other body: the constants' VGPR homes (Own.chome: leaf entries of L; Own.yhome, y0 bodies: q, l), iterates in LDS
+    yreg = y0 and bool(own.shome)
+    yfuse = yreg and fuse
+    sh = own.shome if yfuse else {}
+    if yfuse:
+        C = lambda word: ("A", own.ahome[word]) if word in own.ahome else ("L", word)
+        C2 = lambda word: ("A2", own.ahome[word], own.ahome[word + 1]) if (word in own.ahome and word + 1 in own.ahome) else ("L", word)
+    elif yreg:
+        C = C2 = lambda word: ("L", word)
+    else:
+        C = C2 = lambda word: ("V", own.chome[word]) if word in own.chome else ("V", own.yhome[word]) if (y0 and word in own.yhome) else ("L", word)
+    S = S2 = lambda word: ("V", sh[word]) if word in sh else ("L", word)
     pre_items = [it for it in p.stream[p.n_land:] if it not in homes and own.item(it)]
     npre = len(pre_items)
     own_land = None if own.all else [q for q, it in enumerate(p.stream[:p.n_land]) if own.item(it)]
-    sc = Sched(e, p, npre, land_map=own_land)
+    sc = Sched(e, p, npre, la=1 if yfuse else 3, land_map=own_land)     # (constants in AGPRs: up to six fetches per operation, eight temporaries)
     e("s_mov_b64", "s[%d:%d]" % (S_SP, S_SP + 1), "s[%d:%d]" % (S_S, S_S + 1))
     ops = []
 
@@ -811,15 +863,15 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             continue
         qh = homes.get(("q", j))
         if isinstance(qh, tuple):
-            op([("L", p.LW_X + j), qh], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
+            op([S(p.LW_X + j), qh], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
             continue
         if qh is not None and "1" in PACK_PARTS and xpair(j) and qh % 2 == 0 and homes.get(("q", j + 1)) == qh + 1:
             jskip.add(j + 1)
-            op([("L", p.LW_X + j), C(qh)], lambda r, j=j: _pk(e, "v_pk_fma_f32", p.wreg[p.pinv[j]],
+            op([S2(p.LW_X + j), C2(qh)], lambda r, j=j: _pk(e, "v_pk_fma_f32", p.wreg[p.pinv[j]],
                                                                   [SB(S_SIGMA, S_SIGMA % 2), VP(r[0]), VP(r[1])], [0, 0, 1]))
             continue
         if qh is not None:
-            op([("L", p.LW_X + j), C(qh)], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
+            op([S(p.LW_X + j), C(qh)], lambda r, k=k: e("v_fma_f32", W(k), sS, v(r[0]), "-" + v(r[1])))
             continue
         if "1" in PACK_PARTS and xpair(j) and ("q", j + 1) not in homes:
             jskip.add(j + 1)
@@ -881,7 +933,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 wr = p.wreg[r["r"]]
                 _pk(e, "v_pk_fma_f32", wr, [VP(g[2]), VP(t), VP(wr)])                           # W(x_j) += (-L) rhs
             if y0:       # y == 0: the rhs is z
-                op([("L", p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])],
+                op([S2(p.LW_Z + p.zpos[i]), C2(p.lpos[r["j"]])],
                    lambda g, r=r: _pk(e, "v_pk_fma_f32", p.wreg[r["r"]], [VP(g[1]), VP(g[0]), VP(p.wreg[r["r"]])]))
                 continue
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])], f2)
@@ -893,7 +945,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
         lsrc = lambda h: h if isinstance(h, tuple) else C(h)
         if pack and "4" in PACK_PARTS and i in eqfirst and isinstance(lh, tuple) and isinstance(lh1, tuple):
             eqskip.add(i + 1)           # both bounds in AGPR homes: read as a pair
-            op([("L", p.LW_Y + i), ("A2", lh[1], lh1[1])], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
+            op([S2(p.LW_Y + i), ("A2", lh[1], lh1[1])], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
                                                                            [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0]))
             continue
         if pack and "4" in PACK_PARTS and i in eqfirst and not isinstance(lh, tuple) and not isinstance(lh1, tuple) and \
@@ -906,7 +958,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 wait_pre(wr + 1)
                 _pk(e, "v_pk_fma_f32", wr, [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(wr)], [1, 0, 0])
             if lh is not None:       # l from its LDS home
-                op([("L", p.LW_Y + i), C(lh)], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
+                op([S2(p.LW_Y + i), C2(lh)], lambda g, k=k: _pk(e, "v_pk_fma_f32", p.wreg[k],
                                                                        [VP(g[0]), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0]))
             else:
                 op([("L", p.LW_Y + i)], f2e)
@@ -916,17 +968,17 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 wait_pre(p.wreg[k])
                 e("v_fma_f32", W(k), "-" + v(g[0]), sRe, W(k))
             if lh is not None:
-                op([("L", p.LW_Y + i), lsrc(lh)], lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[0]), sRe, v(g[1])))
+                op([S(p.LW_Y + i), lsrc(lh)], lambda g, k=k: e("v_fma_f32", W(k), "-" + v(g[0]), sRe, v(g[1])))
             else:
                 op([("L", p.LW_Y + i)], f)
         elif r["eq"]:
-            op([("L", p.LW_Y + i), C(p.lpos[r["j"]]), src_of(("l", i))],
+            op([S(p.LW_Y + i), C(p.lpos[r["j"]]), src_of(("l", i))],
                lambda g, r=r, i=i: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
                                     e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0)))))
         elif y0 and not r["leaf"]:
-            op([("L", p.LW_Z + p.zpos[i])], lambda g, k=k: e("v_mov_b32", W(k), v(g[0])))
+            op([S(p.LW_Z + p.zpos[i])], lambda g, k=k: e("v_mov_b32", W(k), v(g[0])))
         elif y0:
-            op([("L", p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])], lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0])))
+            op([S(p.LW_Z + p.zpos[i]), C(p.lpos[r["j"]])], lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0])))
         elif loose and not r["leaf"]:
             op([("L", p.LW_Y + i), ("L", p.LW_Z + p.zpos[i])],
                lambda g, k=k: e("v_fma_f32", W(k), "-s%d" % S_RIMIN, v(g[0]), v(g[1])))
@@ -1027,11 +1079,11 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     if pack and PAIR_QUADS:
         assert (p.V_LAND + 8) % 2 == 0
         if y0:
-            zc1, zc2 = couples([p.LW_Z + p.zpos[r["i"]] for r in p.rows if paired.get(r["i"]) is not None])
+            zc1, zc2 = couples([p.LW_Z + p.zpos[r["i"]] for r in p.rows if paired.get(r["i"]) is not None and p.LW_Z + p.zpos[r["i"]] not in sh])
         if "4" in PACK_PARTS:
-            yc1, yc2 = couples([p.LW_Y + i for i in sorted(eqfirst)])
+            yc1, yc2 = couples([p.LW_Y + i for i in sorted(eqfirst) if p.LW_Y + i not in sh])
         if "3" in PACK_PARTS:
-            xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j)])
+            xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j) and p.LW_X + j not in sh])
     assert not fuse or (y0 and pack and not capture and PAIR_QUADS and Y0_DLEAF)
     # fuse: the updates run eq rows, then the inequality rows that are not part of a fused pair, then the box-row pairs together with
     # the x update of their two variables (a variable's W register is rewritten there: every row that reads it as x~ went before),
@@ -1057,14 +1109,15 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
         return j
     fpairs = [(r, paired[r["i"]], fusable(r, paired[r["i"]])) for r in p.rows if fuse and paired.get(r["i"]) is not None]
     fpairs = [(r, rb, j) for (r, rb, j) in fpairs if j is not None]
-    fzc1, fzc2 = couples([p.LW_Z + p.zpos[r["i"]] for (r, _, _) in fpairs]) if fuse else (set(), set())
-    fxc1, fxc2 = couples([p.LW_X + j for (_, _, j) in fpairs]) if fuse else (set(), set())
+    fzc1, fzc2 = couples([p.LW_Z + p.zpos[r["i"]] for (r, _, _) in fpairs if p.LW_Z + p.zpos[r["i"]] not in sh]) if fuse else (set(), set())
+    fxc1, fxc2 = couples([p.LW_X + j for (_, _, j) in fpairs if p.LW_X + j not in sh]) if fuse else (set(), set())
     fused_rows = {r["i"] for (r, _, _) in fpairs} | {rb["i"] for (_, rb, _) in fpairs}
     for (_, _, j) in fpairs:
         fused_x.update((j, j + 1))
     if fuse:      # the remaining pairs couple among themselves
-        zc1, zc2 = couples([p.LW_Z + p.zpos[r["i"]] for r in p.rows if paired.get(r["i"]) is not None and r["i"] not in fused_rows])
-        xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j) and j not in fused_x])
+        zc1, zc2 = couples([p.LW_Z + p.zpos[r["i"]] for r in p.rows if paired.get(r["i"]) is not None and r["i"] not in fused_rows
+                            and p.LW_Z + p.zpos[r["i"]] not in sh])
+        xc1, xc2 = couples([p.LW_X + j for j in range(0, n, 2) if xpair(j) and j not in fused_x and p.LW_X + j not in sh])
     for r in p.rows:
         i, k = r["i"], r["k"]
         if not own.row(i):
@@ -1091,22 +1144,28 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 _pk(e, "v_pk_fma_f32", b_, [L_, VP(wr), VP(b_)])                 # ... + (-L) x~_j
                 _pk(e, "v_pk_fma_f32", a_, [rinv, VP(b_), z])                    # z~
                 _pk(e, "v_pk_mul_f32", b_, [SB(S_OMA, S_OMA % 2), z])            # (1 - alpha) z
-                _pk(e, "v_pk_fma_f32", a_, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new
-                if zw in fzc2:
+                zn = sh.get(zw, a_)                 # (a word with a register home: the last operation writes it there)
+                _pk(e, "v_pk_fma_f32", zn, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new
+                if zw in sh:
+                    pass
+                elif zw in fzc2:
                     sc.lds_write4(zw - 2, TPK(c, 4))
                 elif zw not in fzc1:
                     sc.lds_write2(zw, a_)
+                xn = sh.get(xw, xt)
                 _pk(e, "v_pk_mul_f32", xt, [SB(S_OMA, S_OMA % 2), xq])           # x update of the two variables
-                _pk(e, "v_pk_fma_f32", xt, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(xt)])
-                if xw in fxc2:
+                _pk(e, "v_pk_fma_f32", xn, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(xt)])
+                if xw in sh:
+                    pass
+                elif xw in fxc2:
                     sc.lds_write4(xw - 2, T(0))
                 elif xw not in fxc1:
                     sc.lds_write2(xw, xt)
-                _pk(e, "v_pk_fma_f32", wr, [SB(S_SIGMA, S_SIGMA % 2), VP(xt), qq], [0, 0, 1])   # next rhs: sigma x_new - q ...
-                _pk(e, "v_pk_fma_f32", wr, [L_, VP(a_), VP(wr)])                 # ... + (-L) z_new  (y == 0)
+                _pk(e, "v_pk_fma_f32", wr, [SB(S_SIGMA, S_SIGMA % 2), VP(xn), qq], [0, 0, 1])   # next rhs: sigma x_new - q ...
+                _pk(e, "v_pk_fma_f32", wr, [L_, VP(zn), VP(wr)])                 # ... + (-L) z_new  (y == 0)
                 if zw not in fzc1:
                     npk[0] += 1
-            rop(B_PAIR, [("L", zw), C(p.lpos[r["j"]]), ("L", p.LW_X + j), C(homes[("q", j)])], ffused)
+            rop(B_PAIR, [S2(zw), C2(p.lpos[r["j"]]), S2(p.LW_X + j), C2(homes[("q", j)])], ffused)
             continue
         if i in paired:
             if paired[i] is None:
@@ -1148,17 +1207,19 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 _pk(e, "v_pk_fma_f32", b_, [L_, VP(wr), VP(b_)])                 # ... + (-L) x~_j
                 _pk(e, "v_pk_fma_f32", a_, [rinv, VP(b_), z])                    # z~
                 _pk(e, "v_pk_mul_f32", b_, [SB(S_OMA, S_OMA % 2), z])            # (1 - alpha) z
-                _pk(e, "v_pk_fma_f32", a_, [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new = alpha z~ + (1 - alpha) z
-                if zw in zc2:
+                _pk(e, "v_pk_fma_f32", sh.get(zw, a_), [SB(S_ALPHA, S_ALPHA % 2), VP(a_), VP(b_)])      # z_new = alpha z~ + (1 - alpha) z
+                if zw in sh:
+                    pass
+                elif zw in zc2:
                     sc.lds_write4(zw - 2, TPK(npk[0], 4))
                 elif zw not in zc1:
                     sc.lds_write2(zw, a_)
                 if zw not in zc1:
                     npk[0] += 1
             if y0:
-                rop(B_OTHER, [("L", zw), C(p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
+                rop(B_OTHER, [S2(zw), C2(p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A2", k, rb["k"])]), fp0)
                 if fuse:          # the pair's pushes into the next rhs: after the x updates
-                    B_PUSH.append(dict(srcs=[("L", zw), C(p.lpos[r["j"]])],
+                    B_PUSH.append(dict(srcs=[S2(zw), C2(p.lpos[r["j"]])],
                                        emit=lambda g, r=r: _pk(e, "v_pk_fma_f32", p.wreg[r["r"]], [VP(g[1]), VP(g[0]), VP(p.wreg[r["r"]])])))
             else:
                 op([("L", yw), ("L", zw), C(p.lpos[r["j"]]), ("A2", k, rb["k"])], fp)
@@ -1171,11 +1232,12 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                     e("v_fmac_f32", v(T(0)), v(g[1]), W(r["r"]))          # nu
                     e("v_sub_f32", v(T(1)), v(T(0)), v(g[0]))
                     store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
-                    e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
-                    sc.lds_write(yw, T(1))
-                rop(B_EQ, [("L", yw), C(p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
+                    e("v_fma_f32", v(sh.get(yw, T(1))), sA, v(T(1)), v(g[0]))
+                    if yw not in sh:
+                        sc.lds_write(yw, T(1))
+                rop(B_EQ, [S(yw), C(p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
                 if fuse:          # its push into the next rhs (the classic operation), after the x updates
-                    B_PUSH.append(dict(srcs=[("L", yw), C(p.lpos[r["j"]]), src_of(("l", i))],
+                    B_PUSH.append(dict(srcs=[S(yw), C(p.lpos[r["j"]]), src_of(("l", i))],
                                        emit=lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
                                                             e("v_fmac_f32", W(r["r"]), v(g[1]), v(T(0))))))
             elif pack and "4" in PACK_PARTS and i in eqskip2:
@@ -1187,33 +1249,38 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                     t = TPK(npk[0], 4 if yw in yc1 else 6 if yw in yc2 else 0)
                     wr = p.wreg[k]
                     _pk(e, "v_pk_add_f32", t, [VP(wr), VP(g[0])], [0, 1])                  # nu - y
-                    _pk(e, "v_pk_fma_f32", t, [SB(S_ALPHA, S_ALPHA % 2), VP(t), VP(g[0])])  # y + alpha (nu - y)
-                    if yw in yc2:
+                    yn = sh.get(yw, t)
+                    _pk(e, "v_pk_fma_f32", yn, [SB(S_ALPHA, S_ALPHA % 2), VP(t), VP(g[0])])  # y + alpha (nu - y)
+                    if yw in sh:
+                        pass
+                    elif yw in yc2:
                         sc.lds_write4(yw - 2, TPK(npk[0], 4))
                     elif yw not in yc1:
                         sc.lds_write2(yw, t)
                     if fuse:          # next rhs: l - y_new / rho_eq (the solution words in W are consumed)
-                        _pk(e, "v_pk_fma_f32", wr, [VP(t), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0])
+                        _pk(e, "v_pk_fma_f32", wr, [VP(yn), SB(S_RINVEQ, S_RINVEQ % 2), VP(g[1])], [1, 0, 0])
                     if yw not in yc1:
                         npk[0] += 1
                 lh_, lh1_ = homes.get(("l", i)), homes.get(("l", i + 1))
                 if fuse:
                     lsrc2 = ("A2", lh_[1], lh1_[1]) if isinstance(lh_, tuple) and isinstance(lh1_, tuple) else C(lh_)
                     assert isinstance(lh_, tuple) == isinstance(lh1_, tuple) and (isinstance(lh_, tuple) or (lh_ % 2 == 0 and lh1_ == lh_ + 1))
-                    rop(B_EQ, [("L", yw), lsrc2], f2u)
+                    rop(B_EQ, [S2(yw), C2(lh_) if lsrc2[0] != "A2" else lsrc2], f2u)
                 else:
                     op([("L", yw)], f2u)
             else:
                 def f(g, k=k, yw=yw, i=i):
                     e("v_sub_f32", v(T(1)), W(k), v(g[0]))
                     store_dy(i, lambda: e("v_mul_f32", v(T(2)), sA, v(T(1))), T(2))
-                    e("v_fma_f32", v(T(1)), sA, v(T(1)), v(g[0]))
-                    sc.lds_write(yw, T(1))
+                    yn = sh.get(yw, T(1))
+                    e("v_fma_f32", v(yn), sA, v(T(1)), v(g[0]))
+                    if yw not in sh:
+                        sc.lds_write(yw, T(1))
                     if fuse:
-                        e("v_fma_f32", W(k), "-" + v(T(1)), sRe, v(g[1]))
+                        e("v_fma_f32", W(k), "-" + v(yn), sRe, v(g[1]))
                 if fuse:
                     lh_ = homes[("l", i)]
-                    rop(B_EQ, [("L", yw), lh_ if isinstance(lh_, tuple) else C(lh_)], f)
+                    rop(B_EQ, [S(yw), lh_ if isinstance(lh_, tuple) else C(lh_)], f)
                 else:
                     op([("L", yw)], f)
             continue
@@ -1229,16 +1296,19 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                     nu = W(k)
                 e("v_fma_f32", t3, "s%d" % S_RIMIN, nu, z)                    # z~
                 e("v_mul_f32", t2, sO, z)
+                if zw in sh:
+                    tt = v(sh[zw])
                 e("v_fma_f32", tt, sA, t3, t2)                                # z_new = alpha z~ + (1 - alpha) z
                 if capture:
                     e("v_mov_b32", v(T(5)), 0)                                # delta_y = rho (t - z_new) = 0
                     store_dy(r["i"], lambda: None, T(5))
-                sc.lds_write(zw, T(3))
+                if zw not in sh:
+                    sc.lds_write(zw, T(3))
                 if fuse and not r["leaf"]:
                     e("v_mov_b32", W(k), tt)                                  # next rhs of the row: z_new (y == 0)
-            rop(B_OTHER, [("L", zw)] + ([C(p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A", k)]) if r["leaf"] else []), f0)
+            rop(B_OTHER, [S(zw)] + ([C(p.lpos[r["j"]])] + ([] if Y0_DLEAF else [("A", k)]) if r["leaf"] else []), f0)
             if fuse and r["leaf"]:
-                B_PUSH.append(dict(srcs=[("L", zw), C(p.lpos[r["j"]])],
+                B_PUSH.append(dict(srcs=[S(zw), C(p.lpos[r["j"]])],
                                    emit=lambda g, r=r: e("v_fmac_f32", W(r["r"]), v(g[1]), v(g[0]))))
             continue
         if loose:
@@ -1315,32 +1385,37 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                 xw = p.LW_X + j
                 t = TPK(xw // 4, 4) if xw in xc1 else TPK(xw // 4, 6) if xw in xc2 else TPK(j // 2, 6)     # (a couple = one float4 of x words)
                 wr = p.wreg[p.pinv[j]]
+                xn = sh.get(xw, t)
                 _pk(e, "v_pk_mul_f32", t, [SB(S_OMA, S_OMA % 2), VP(g[0])])
-                _pk(e, "v_pk_fma_f32", t, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(t)])
-                if xw in xc2:
+                _pk(e, "v_pk_fma_f32", xn, [SB(S_ALPHA, S_ALPHA % 2), VP(wr), VP(t)])
+                if xw in sh:
+                    pass
+                elif xw in xc2:
                     sc.lds_write4(xw - 2, TPK(xw // 4, 4))
                 elif xw not in xc1:
                     sc.lds_write2(xw, t)
                 if fuse:          # next rhs: sigma x_new - q
-                    _pk(e, "v_pk_fma_f32", wr, [SB(S_SIGMA, S_SIGMA % 2), VP(t), VP(g[1])], [0, 0, 1])
+                    _pk(e, "v_pk_fma_f32", wr, [SB(S_SIGMA, S_SIGMA % 2), VP(xn), VP(g[1])], [0, 0, 1])
             qh_ = homes.get(("q", j))
             if fuse and not (isinstance(qh_, int) and qh_ % 2 == 0 and homes.get(("q", j + 1)) == qh_ + 1):
                 jskip.discard(j + 1)          # (no aligned q pair: the two variables go one at a time below)
             else:
-                op([("L", p.LW_X + j)] + ([C(qh_)] if fuse else []), fx2)
+                op([S2(p.LW_X + j)] + ([C2(qh_)] if fuse else []), fx2)
                 continue
 
         def f(g, k=k, j=j):
             t = T(6 + j % 2)
             if capture:
                 sc.lds_write(p.LW_XP + j, g[0])      # x_prev (every L word is dead by now)
+            xn = sh.get(p.LW_X + j, t)
             e("v_mul_f32", v(t), sO, v(g[0]))
-            e("v_fma_f32", v(t), sA, W(k), v(t))
-            sc.lds_write(p.LW_X + j, t)
+            e("v_fma_f32", v(xn), sA, W(k), v(t))
+            if p.LW_X + j not in sh:
+                sc.lds_write(p.LW_X + j, t)
             if fuse:
-                e("v_fma_f32", W(k), sS, v(t), "-" + v(g[1]))
+                e("v_fma_f32", W(k), sS, v(xn), "-" + v(g[1]))
         qh_ = homes.get(("q", j))
-        op([("L", p.LW_X + j)] + ([qh_ if isinstance(qh_, tuple) else C(qh_)] if fuse else []), f)
+        op([S(p.LW_X + j)] + ([qh_ if isinstance(qh_, tuple) else C(qh_)] if fuse else []), f)
     if fuse:
         ops.append(dict(flush=True))          # the pushes read words this body has written
         ops.extend(B_PUSH)
@@ -1597,12 +1672,18 @@ def prologue_fast(e, p, res, loose=False, y0check=False, own=ALL, group=False):
 
 
 def l_homes_fill(e, p, own, y0=False):
-    """-L of the wave's solve entries (and its other resident constants: Own.chome; y0 path: Own.yhome): LDS -> their VGPR homes,
-    once per block"""
-    byword = {p.lpos[j]: reg for j, reg in own.lhome.items()}
-    byword.update(own.chome)
-    if y0:
-        byword.update(own.yhome)
+    """-L of the wave's solve entries and its other resident words: LDS -> their register homes, once per block. Every path:
+    Own.lhome; a path without resident iterates: the constants' VGPR homes (Own.chome; y0: Own.yhome); the y0 path of a wave
+    with resident iterates (Own.shome): the constants into AGPRs (Own.ahome), x / y / z into the VGPRs"""
+    yreg = y0 and bool(own.shome)
+    byword = {p.lpos[j]: ("v", reg) for j, reg in own.lhome.items()}
+    if yreg:
+        byword.update({w_: ("a", a_) for w_, a_ in own.ahome.items()})
+        byword.update({w_: ("v", r_) for w_, r_ in own.shome.items()})
+    else:
+        byword.update({w_: ("v", r_) for w_, r_ in own.chome.items()})
+        if y0:
+            byword.update({w_: ("v", r_) for w_, r_ in own.yhome.items()})
     if not byword:
         return
     quads = sorted(set(w_ >> 2 for w_ in byword))
@@ -1616,7 +1697,30 @@ def l_homes_fill(e, p, own, y0=False):
         for q, qd in enumerate(grp):
             for h in range(4):
                 if 4 * qd + h in byword:
-                    e("v_mov_b32", "v%d" % byword[4 * qd + h], "v%d" % (p.V_RING + 4 * q + h))
+                    kind, reg = byword[4 * qd + h]
+                    if kind == "v":
+                        e("v_mov_b32", "v%d" % reg, "v%d" % (p.V_RING + 4 * q + h))
+                    else:
+                        e("v_accvgpr_write_b32", "a%d" % reg, "v%d" % (p.V_RING + 4 * q + h))
+
+
+def state_writeback(e, p, own):
+    """x / y / z of a wave with resident iterates (Own.shome) go back to their LDS words: the capturing iteration, the residual
+    block and the C++ side read them there"""
+    done = set()
+    for w_ in sorted(own.shome):
+        if w_ in done:
+            continue
+        base, off = lds_addr(w_)
+        r_ = own.shome[w_]
+        if w_ % 2 == 0 and own.shome.get(w_ + 1) == r_ + 1 and r_ % 2 == 0:
+            e("ds_write_b64", base, "v[%d:%d]" % (r_, r_ + 1), off)
+            done.update((w_, w_ + 1))
+        else:
+            e("ds_write_b32", base, "v%d" % r_, off)
+            done.add(w_)
+    if own.shome:
+        e("s_waitcnt", "lgkmcnt(0)")
 
 
 def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
@@ -1683,6 +1787,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
                 e("s_cmp_gt_i32", "s%d" % S_CNT, 0)
                 e("s_cbranch_scc1", "7b")
                 e("label", "8")
+                state_writeback(e, p, own)
                 body(e, p, capture=True, loose=True, y0=True, rhs=False, own=own, group=group)
                 e("s_branch", "31f")
                 e("label", "30")
