@@ -282,6 +282,7 @@ class Own:
         self.lhome = lhome or {}          # L entry (CSC index) -> VGPR that holds -L during the iterations (LoopSplit.own)
         self.chome, self.yhome = {}, {}   # LDS word of a loop constant -> VGPR: leaf entries of L (every variant); q, l (y0 bodies)
         self.ahome, self.shome = {}, {}   # fused y0 bodies (S_HOMES): LDS word of a constant -> AGPR; of the wave's x / y / z -> VGPR
+        self.dhome = {}                   # ... and 1/D of own unknowns -> VGPR (registers that are idle in those bodies)
         self.fkw = fkw if fkw is not None else kw          # who FACTORISES unknown k (a component cut in two: the wave of half A)
         self.fvarw = fvarw if fvarw is not None else varw
         # a component cut in two (LoopSplit): the solves of every wave of the workgroup meet at two barriers
@@ -320,6 +321,8 @@ class Own:
 ALL = Own()
 L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
 FACTOR_SPLIT = os.environ.get("UMPC_QP_FACTOR_SPLIT", "1") == "1"   # (A/B switch: a cut component's halves factorise their own subtrees)
+D_HOMES = os.environ.get("UMPC_QP_D_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, 1/D of own unknowns in idle VGPRs)
+Y_NRING = 2                                                     # ring slots the fused y0 bodies of such a wave may use
 S_HOMES = os.environ.get("UMPC_QP_S_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the iterates in VGPRs, the constants in AGPRs)
 C_HOMES = os.environ.get("UMPC_QP_C_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the loop's other constants in VGPRs)
 TREE_SPLIT = os.environ.get("UMPC_QP_TREE_SPLIT", "1") == "1"  # (A/B switch: LoopSplit cuts large components in two)
@@ -593,6 +596,28 @@ class LoopSplit:
                 if ok:                # (all or nothing: a body either finds every word of the wave resident or none)
                     o.shome = sh
                     o.ahome = dict(zip(consts, apool))
+                    if D_HOMES:
+                        # what is idle in those bodies -- the registers left over, four of the six ring slots (the only LDS reads
+                        # are the exchange words), the AGPR temporaries of the unpacked bodies -- keeps 1/D of the wave's own
+                        # unknowns, pair for pair as the packed scaling reads them
+                        spare = sorted(free2 + list(range(p.V_RING + 4 * Y_NRING, p.V_RING + 4 * NRING)) + list(range(p.V_AT, p.V_AT + N_AT)))
+                        mine_k = sorted((p.wreg[k], k) for k in p.nonleaf if self.kw[k] == wave)
+                        regk = dict(mine_k)
+                        for reg, k in mine_k:
+                            if k in o.dhome:
+                                continue
+                            if reg % 2 == 0 and reg + 1 in regk:
+                                base = next((r_ for r_ in spare if r_ % 2 == 0 and r_ + 1 in spare), None)
+                                if base is not None:
+                                    spare.remove(base)
+                                    spare.remove(base + 1)
+                                    o.dhome[k], o.dhome[regk[reg + 1]] = base, base + 1
+                            elif not (reg % 2 == 1 and reg - 1 in regk):
+                                odd = [r_ for r_ in spare if not (r_ % 2 == 0 and r_ + 1 in spare) and not (r_ % 2 == 1 and r_ - 1 in spare)]
+                                if odd or spare:
+                                    r_ = (odd or spare)[0]
+                                    spare.remove(r_)
+                                    o.dhome[k] = r_
         return o
 
 
@@ -615,6 +640,7 @@ class Sched:
         self.lds_at, self.vm_at = {}, {}    # issue position -> instruction index (for merging waits, see MERGE_*)
         self.vm_done = -1                   # VMEM loads up to this issue index are known to have arrived
         self.at_base, self.n_at = getattr(plan, "V_AT", None), N_AT      # temporaries of the AGPR reads (even base for 'A2')
+        self.nring = NRING                  # ring slots this run may use (the rest may hold something else: Own.dhome)
 
     def vm_wait(self, pos):
         """the VMEM load with issue index `pos` must have arrived (loads arrive in order): emits a wait unless an earlier one
@@ -667,10 +693,11 @@ class Sched:
         e, p = self.e, self.p
         n = len(ops)
         # ---- static LDS ring analysis (a 'flush' op ends every residency: later reads see the words written since)
-        insts, slots, inst_of = [], [None] * NRING, {}
+        NR = self.nring
+        insts, slots, inst_of = [], [None] * NR, {}
         for i, op in enumerate(ops):
             if op.get("flush"):
-                slots = [None] * NRING
+                slots = [None] * NR
                 continue
             for q, src in enumerate(op["srcs"]):
                 if src[0] != "L":
@@ -681,14 +708,14 @@ class Sched:
                     insts[hit[0]]["last"] = i
                     inst_of[(i, q)] = hit[0]
                     continue
-                free = [sl for sl in range(NRING) if slots[sl] is None]
+                free = [sl for sl in range(NR) if slots[sl] is None]
                 if free:
                     sl, prev = free[0], None
                     # a slot emptied by a flush still holds an older instance's registers until its last use
                     olds = [k for k, it in enumerate(insts) if it["slot"] == sl]
                     prev = olds[-1] if olds else None
                 else:
-                    sl = min(range(NRING), key=lambda z: insts[slots[z]]["last"])
+                    sl = min(range(NR), key=lambda z: insts[slots[z]]["last"])
                     prev = slots[sl]
                 insts.append(dict(quad=qd, first=i, last=i, slot=sl, prev=prev, issued=None))
                 slots[sl] = len(insts) - 1
@@ -834,10 +861,15 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     else:
         C = C2 = lambda word: ("V", own.chome[word]) if word in own.chome else ("V", own.yhome[word]) if (y0 and word in own.yhome) else ("L", word)
     S = S2 = lambda word: ("V", sh[word]) if word in sh else ("L", word)
+    dh = own.dhome if yfuse else {}          # 1/D of own unknowns in VGPRs (registers idle in these bodies, ring slots among them)
+    DI = lambda k: ("V", dh[k]) if k in dh else ("A", k)
+    DI2 = lambda k, k1: ("V", dh[k]) if (k in dh and dh.get(k1) == dh[k] + 1 and dh[k] % 2 == 0) else ("A2", k, k1)
     pre_items = [it for it in p.stream[p.n_land:] if it not in homes and own.item(it)]
     npre = len(pre_items)
     own_land = None if own.all else [q for q, it in enumerate(p.stream[:p.n_land]) if own.item(it)]
     sc = Sched(e, p, npre, la=1 if yfuse else 3, land_map=own_land)     # (constants in AGPRs: up to six fetches per operation, eight temporaries)
+    if dh:
+        sc.nring = Y_NRING
     e("s_mov_b64", "s[%d:%d]" % (S_SP, S_SP + 1), "s[%d:%d]" % (S_S, S_S + 1))
     ops = []
 
@@ -1009,9 +1041,9 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             if "2" in PACK_PARTS and pack and reg % 2 == 0 and reg + 1 in kof and which(kof[reg + 1]):
                 k1 = kof[reg + 1]
                 kdone.add(k1)
-                op([("A2", k, k1)], lambda g, reg=reg: _pk(e, "v_pk_mul_f32", reg, [VP(reg), VP(g[0])]))
+                op([DI2(k, k1)], lambda g, reg=reg: _pk(e, "v_pk_mul_f32", reg, [VP(reg), VP(g[0])]))
             else:
-                op([("A", k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
+                op([DI(k)], lambda g, k=k: e("v_mul_f32", W(k), W(k), v(g[0])))
 
     def meet():
         op([], lambda g: (e("s_waitcnt", "lgkmcnt(0)"), e("s_barrier")))
@@ -1235,7 +1267,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
                     e("v_fma_f32", v(sh.get(yw, T(1))), sA, v(T(1)), v(g[0]))
                     if yw not in sh:
                         sc.lds_write(yw, T(1))
-                rop(B_EQ, [S(yw), C(p.lpos[r["j"]]), ("A", k), src_of(("l", i))], f)
+                rop(B_EQ, [S(yw), C(p.lpos[r["j"]]), DI(k), src_of(("l", i))], f)
                 if fuse:          # its push into the next rhs (the classic operation), after the x updates
                     B_PUSH.append(dict(srcs=[S(yw), C(p.lpos[r["j"]]), src_of(("l", i))],
                                        emit=lambda g, r=r: (e("v_fma_f32", v(T(0)), "-" + v(g[0]), sRe, v(g[2])),
@@ -1419,6 +1451,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     if fuse:
         ops.append(dict(flush=True))          # the pushes read words this body has written
         ops.extend(B_PUSH)
+    assert not dh or all(len({s_[1] >> 2 for s_ in o_.get("srcs", []) if s_[0] == "L"}) <= 1 for o_ in ops)
     sc.run(ops)
     if not capture:
         preloads(e, p, homes, own)
@@ -1702,6 +1735,9 @@ def l_homes_fill(e, p, own, y0=False):
                         e("v_mov_b32", "v%d" % reg, "v%d" % (p.V_RING + 4 * q + h))
                     else:
                         e("v_accvgpr_write_b32", "a%d" % reg, "v%d" % (p.V_RING + 4 * q + h))
+    if yreg:                          # (last: some of these registers are ring slots, the staging area above)
+        for k, reg in sorted(own.dhome.items()):
+            e("v_accvgpr_read_b32", "v%d" % reg, "a%d" % k)
 
 
 def state_writeback(e, p, own):
