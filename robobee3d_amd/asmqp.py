@@ -1451,7 +1451,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     if fuse:
         ops.append(dict(flush=True))          # the pushes read words this body has written
         ops.extend(B_PUSH)
-    assert not dh or all(len({s_[1] >> 2 for s_ in o_.get("srcs", []) if s_[0] == "L"}) <= 1 for o_ in ops)
+    # (Own.dhome sits in ring slots and in the AGPR temporaries of the unpacked bodies: these bodies must need neither)
+    assert not dh or (pack and all(len({s_[1] >> 2 for s_ in o_.get("srcs", []) if s_[0] == "L"}) <= 1 for o_ in ops))
     sc.run(ops)
     if not capture:
         preloads(e, p, homes, own)
