@@ -714,3 +714,40 @@ def test_no_wide_store_data_hazard_in_any_p5f_block(prog):
     for t in bad:
         e(*t)
     assert e.ins == [bad[0], ("s_nop", 1), bad[1]] and asmgen.wide_store_hazards(e.ins) == []
+
+
+def test_register_homes_of_the_cut_loop_are_disjoint(prog):
+    """LoopSplit.own(): what a wavefront of the cut loop keeps resident through the fused y0 iterations -- its solve entries of L
+    (lhome), its x / z / equality-row y words (shome) and 1/D of its own unknowns (dhome) in VGPRs, its other constants in AGPRs
+    (ahome) -- must not overlap each other, the W registers the wave computes in, or the AGPRs that hold its 1/D, the once-only
+    items and the y0 homes; the registers of the other regime (chome / yhome: bodies without resident iterates) are filled on
+    the other path only and may coincide with shome."""
+    from robobee3d_amd import codegen_qp
+    asmqp, _, p = prog
+    sp = asmqp.LoopSplit(p, 4)
+    assert sp.cut
+    for w in range(4):
+        o = sp.own(w)
+        assert len(o.shome) >= 60 and len(o.ahome) >= 40 and len(o.dhome) >= 25 and len(o.lhome) >= 40
+        wregs = {p.wreg[k] for k in p.nonleaf if o.k(k)} | {p.wreg[k] for k in o.top}
+        groups = [set(o.lhome.values()), set(o.shome.values()), set(o.dhome.values()), wregs]
+        for a_ in range(len(groups)):
+            assert len(groups[a_]) == [len(o.lhome), len(o.shome), len(o.dhome), len(wregs)][a_]
+            for b_ in range(a_ + 1, len(groups)):
+                assert not groups[a_] & groups[b_], (w, a_, b_)
+        # the other regime shares registers with shome only
+        other = set(o.chome.values()) | set(o.yhome.values())
+        assert not other & (set(o.lhome.values()) | wregs)
+        # pairs the packed operations read as pairs sit on aligned register pairs
+        for home in (o.shome, o.chome, o.yhome):
+            for w_, r_ in home.items():
+                if w_ % 2 == 0 and w_ + 1 in home:
+                    assert r_ % 2 == 0 and home[w_ + 1] == r_ + 1
+        # 1/D homes: left-over registers, ring slots 2..5, the unpacked bodies' AGPR temporaries -- nothing the fused bodies use
+        allowed = set(range(asmqp.V_W, asmqp.V_W + len(p.nonleaf))) | set(range(p.V_RING + 4 * asmqp.Y_NRING, p.V_RING + 4 * asmqp.NRING)) | \
+            set(range(p.V_AT, p.V_AT + asmqp.N_AT))
+        assert set(o.dhome.values()) <= allowed
+        # AGPRs: constants vs 1/D of the unknowns this wave uses, handed-over 1/D, once-only items, y0 homes
+        agpr_used = {k for k in range(p.nk) if o.k(k)} | set(o.hand_in) | {h[1] for h in p.once.values() if h[0] == "A"} | \
+            {h[1] for h in p.y0_home.values() if isinstance(h, tuple)}
+        assert len(set(o.ahome.values())) == len(o.ahome) and not set(o.ahome.values()) & agpr_used
