@@ -283,6 +283,7 @@ class Own:
         self.chome, self.yhome = {}, {}   # LDS word of a loop constant -> VGPR: leaf entries of L (every variant); q, l (y0 bodies)
         self.ahome, self.shome = {}, {}   # fused y0 bodies (S_HOMES): LDS word of a constant -> AGPR; of the wave's x / y / z -> VGPR
         self.dhome = {}                   # ... and 1/D of own unknowns -> VGPR (registers that are idle in those bodies)
+        self.ghome = {}                   # bodies that are not y0 (G_HOMES): stream item -> AGPR (what they loaded every iteration)
         self.fkw = fkw if fkw is not None else kw          # who FACTORISES unknown k (a component cut in two: the wave of half A)
         self.fvarw = fvarw if fvarw is not None else varw
         # a component cut in two (LoopSplit): the solves of every wave of the workgroup meet at two barriers
@@ -321,6 +322,7 @@ class Own:
 ALL = Own()
 L_HOMES = os.environ.get("UMPC_QP_L_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own)
 FACTOR_SPLIT = os.environ.get("UMPC_QP_FACTOR_SPLIT", "1") == "1"   # (A/B switch: a cut component's halves factorise their own subtrees)
+G_HOMES = os.environ.get("UMPC_QP_G_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the general loop's stream items in AGPRs)
 D_HOMES = os.environ.get("UMPC_QP_D_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, 1/D of own unknowns in idle VGPRs)
 Y_NRING = 2                                                     # ring slots the fused y0 bodies of such a wave may use
 S_HOMES = os.environ.get("UMPC_QP_S_HOMES", "1") == "1"        # (A/B switch: LoopSplit.own, the iterates in VGPRs, the constants in AGPRs)
@@ -530,6 +532,18 @@ class LoopSplit:
         mine = [j for (r_, c, j) in p.solve_entries if self.kw[c] == wave or (r_, c, j) in cross]
         lhome = dict(zip(mine, pool)) if L_HOMES else {}
         o = Own(self.varw, self.roww, self.kw, wave, lhome, self.fkw, self.split[wave] if self.split else None, self.fvarw)
+        if G_HOMES and self.split:
+            # The bodies of the GENERAL loop (finite bounds) and of the loose loop with non-zero multipliers loaded their read-only
+            # items -- l, u, 1/rho, rho of the wave's inequality rows, q, l of its equality rows -- from the stream EVERY iteration
+            # (150 VMEM instructions per wavefront-iteration). A wave of a cut workgroup uses a quarter of the 251 AGPR indices for
+            # its 1/D: the items go into the others once per tick.
+            mine = [it for it in p.stream if o.item(it) and it not in p.once]
+            mine = list(dict.fromkeys(mine))
+            taken = {k for k in range(p.nk) if self.kw[k] == wave} | set(self.split[wave]["hand_in"]) | \
+                {h[1] for h in p.once.values() if h[0] == "A"} | set(self.split[wave].get("top", set()))
+            apool_g = [k for k in range(256) if k not in taken]
+            if len(mine) <= len(apool_g):
+                o.ghome = dict(zip(mine, apool_g))
         if C_HOMES and L_HOMES:
             # ... and what is left of them the wave's other loop constants, which the bodies read from LDS every iteration (with all
             # four wavefronts at work the LDS pipe is the second bottleneck: 4 array cycles per float4 read, 13 per float4 write): the leaf rows'
@@ -845,7 +859,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     W = lambda k: v(p.wreg[k])
     T = lambda q: p.V_TT + q
     assert loose or not y0
-    homes = p.y0_home if y0 else {}
+    gh = {} if y0 else own.ghome             # (bodies that are not y0: the stream items of the wave in AGPRs, filled once per tick)
+    homes = p.y0_home if y0 else {it: ("A", a_) for it, a_ in gh.items() if it in set(p.stream[p.n_land:])}
     # Where this body finds a loop constant (C: one word, C2: an aligned pair of words) and a word of x / y / z (S, S2):
     #   fused y0 bodies of a wave with resident iterates (Own.shome): constants in AGPRs (Own.ahome), x / y / z in VGPRs;
     #   the capturing body behind them: everything from LDS (the iterates are written back first, the registers are theirs);
@@ -866,10 +881,12 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
     DI2 = lambda k, k1: ("V", dh[k]) if (k in dh and dh.get(k1) == dh[k] + 1 and dh[k] % 2 == 0) else ("A2", k, k1)
     pre_items = [it for it in p.stream[p.n_land:] if it not in homes and own.item(it)]
     npre = len(pre_items)
-    own_land = None if own.all else [q for q, it in enumerate(p.stream[:p.n_land]) if own.item(it)]
+    own_land = None if own.all else [q for q, it in enumerate(p.stream[:p.n_land]) if own.item(it) and it not in gh]
     sc = Sched(e, p, npre, la=1 if yfuse else 3, land_map=own_land)     # (constants in AGPRs: up to six fetches per operation, eight temporaries)
     if dh:
         sc.nring = Y_NRING
+    if gh:                                   # (up to five AGPR operands per row update; the landing registers are idle: nothing lands)
+        sc.la, sc.at_base, sc.n_at = 1, p.V_LAND, 8
     e("s_mov_b64", "s[%d:%d]" % (S_SP, S_SP + 1), "s[%d:%d]" % (S_S, S_S + 1))
     ops = []
 
@@ -927,6 +944,8 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
         """a constant word: its on-chip home (Plan.once) or the next landing item"""
         if item in p.once:
             return p.once[item]
+        if item in gh:
+            return ("A", gh[item])
         assert p.stream[land[0] if own_land is None else own_land[land[0]]] == item, (item, land[0])
         land[0] += 1
         return ("S", land[0] - 1)
@@ -1396,7 +1415,7 @@ def body(e, p, capture=False, loose=False, y0=False, rhs=True, fuse=False, own=A
             sc.lds_write(zw, T(4))
             sc.lds_write(yw, T(5))
         op(srcs, f)
-    assert land[0] == (0 if loose else p.n_land if own_land is None else len(own_land))
+    assert land[0] == (0 if (loose or gh) else p.n_land if own_land is None else len(own_land))
     # ---- x <- alpha x~ + (1 - alpha) x
     if fuse:
         ops.extend(B_EQ + B_OTHER + B_PAIR)
@@ -1570,7 +1589,25 @@ def prologue_tail(e, p, loose=False, homes=(), own=ALL):
         e("v_mov_b32", "v%d" % p.V_RHO0, "s%d" % S_RHO0)
         e("v_mov_b32", "v%d" % p.V_RHOEQ, "s%d" % S_RHOEQ)
         e("v_mov_b32", "v%d" % p.V_RHOMIN, f32bits(float(np.float32(RHO_MIN_F32))))
+    if not homes and own.ghome:
+        homes = {it: ("A", a_) for it, a_ in own.ghome.items()}
     preloads(e, p, homes, own)
+
+
+def g_homes_fill(e, p, own):
+    """bodies that are not y0 (the general loop; the loose loop with non-zero multipliers): the wave's read-only stream items ->
+    the AGPRs they are read from in every iteration (Own.ghome), one load each per tick"""
+    items = p.stream + p.extra
+    blk = None
+    for item, a_ in sorted(own.ghome.items(), key=lambda kv: items.index(kv[0])):
+        idx = items.index(item)
+        if idx // BLOCK != blk:
+            blk = idx // BLOCK
+            e("s_add_u32", "s%d" % S_SP, "s%d" % S_S, blk * BLOCK * 256)
+            e("s_addc_u32", "s%d" % (S_SP + 1), "s%d" % (S_S + 1), 0)
+        e("global_load_dword", "a%d" % a_, "v%d" % V_LANE, "s[%d:%d]" % (S_SP, S_SP + 1), (idx % BLOCK) * 256)
+    if own.ghome:
+        e("s_waitcnt", "vmcnt(0)")
 
 
 def epilogue(e, p):
@@ -1833,6 +1870,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
             y0_restore(e, p, own)
             e("s_branch", "29f")
             e("label", "20")
+            g_homes_fill(e, p, own)
             prologue_tail(e, p, True, own=own)
             l_homes_fill(e, p, own)
             _lstamp(e, own, 5)
@@ -1854,6 +1892,7 @@ def program(s, eq_rows, res=None, loose=False, own=ALL, group=False):
             return e.ins, p
     elif group:
         prologue_fast(e, p, res, own=own, group=True)          # (a shared block always factorises itself: the fast start)
+        g_homes_fill(e, p, own)
         l_homes_fill(e, p, own)
     else:
         if res is not None:
