@@ -751,3 +751,32 @@ def test_register_homes_of_the_cut_loop_are_disjoint(prog):
         agpr_used = {k for k in range(p.nk) if o.k(k)} | set(o.hand_in) | {h[1] for h in p.once.values() if h[0] == "A"} | \
             {h[1] for h in p.y0_home.values() if isinstance(h, tuple)}
         assert len(set(o.ahome.values())) == len(o.ahome) and not set(o.ahome.values()) & agpr_used
+
+
+def test_no_memory_instruction_inside_the_iterations_of_the_cut_loop(prog):
+    """What round 5 ends with: between the first and the last iteration of a tick no wavefront of the cut loop issues a VMEM
+    instruction -- on the loose route (the reference's problem) nor on the general one (finite bounds: its read-only items sit in
+    AGPRs, Own.ghome) -- and on the loose route the only LDS instructions left are the halves' exchange words."""
+    from robobee3d_amd import codegen_qp
+    asmqp, _, p = prog
+    s = p.s
+    eq = codegen_qp.ASM_STRUCTURES["p5f10"]
+    res = asmqp.ResPlan(s, eq, codegen_qp.ASM_RES_ITEM0)
+    for loose in (True, False):
+        ins = asmqp.loop_group_program(s, eq, res, 4, loose=loose)[0]
+        bodies, k = [], 0
+        while k < len(ins):
+            if ins[k] == ("label", "7"):
+                j = next(q for q in range(k, len(ins)) if ins[q][0].startswith("s_cbranch") and ins[q][1] == "7b")
+                bodies.append(ins[k:j])
+                k = j
+            k += 1
+        assert len(bodies) == (8 if loose else 4)         # (loose: the fused y0 body and the non-zero-multiplier body of each wavefront)
+        for body in bodies:
+            assert not any(t[0].startswith("global_") for t in body)
+            assert sum(t[0] == "s_barrier" for t in body) == 2
+        if loose:
+            fused = bodies[0::2]
+            for body in fused:
+                lds = [t for t in body if t[0].startswith("ds_")]
+                assert len(lds) <= 4 and len(body) <= 380, (len(lds), len(body))
